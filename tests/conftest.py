@@ -1,0 +1,38 @@
+"""pytest configuration: the ``gpu`` marker and import paths.
+
+``-m "not gpu"`` runs on a CPU-only box: oracle vs golden fixtures, host logic,
+C-ABI symbol table, gloo data-parallel path.  ``-m gpu`` are the parity tests
+proper; they call the HIP kernels through the C-ABI on a real MI355X.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "speech-tranformer-pytorch_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
