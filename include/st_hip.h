@@ -1,0 +1,122 @@
+/* st_hip.h - C ABI of libst_hip.so, the MI355X (gfx950) kernels behind the
+ * speech-transformer training step.
+ *
+ * The reference (ZhengkunTian/Speech-Tranformer-Pytorch) has no FFI: its hot
+ * path is the nn.Module surface of transformer/{Attention,SubLayers,Layers,
+ * Embedding,Models}.py.  The drop-in keeps those Python names (package
+ * speech-tranformer-pytorch_amd/transformer) and binds THIS library through
+ * ctypes (speech-tranformer-pytorch_amd/st_amd/native.py); INTEGRATION.md shows
+ * the stub.  Every entry point below names the reference lines it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers;
+ *  - every call is asynchronous on `stream` (hipStream_t passed as void*),
+ *    holds no global state and never synchronises the device (it is called
+ *    from the autograd engine thread as well as the main thread);
+ *  - return 0 on success, a positive hipError_t if the launch failed, a
+ *    negative value for an argument the kernels do not support (the Python
+ *    wrapper raises RuntimeError / ValueError);
+ *  - "bf16" buffers are IEEE bfloat16 (uint16 storage); activations are row
+ *    matrices [rows, ld]; utterance b owns rows off[b] .. off[b]+len[b]-1
+ *    (packed or padded - the kernels only see offsets and lengths);
+ *  - leading dimensions are in ELEMENTS and must be multiples of 8.
+ */
+#ifndef ST_HIP_H
+#define ST_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* st_stream_t; /* hipStream_t */
+
+/* Library ABI version (bumped on any signature change). */
+int st_version(void);
+
+/* Epilogue selector of st_gemm. */
+enum {
+  ST_EPI_BF16 = 0,       /* D(bf16) = acc (+ bias)                                   */
+  ST_EPI_BF16_RELU = 1,  /* D(bf16) = relu(acc + bias)      SubLayers.py:25          */
+  ST_EPI_F32 = 2,        /* D(f32)  = acc (+ bias)          Models.py:151 (logits)   */
+  ST_EPI_BF16_MASK = 3,  /* D(bf16) = acc * (aux > 0)       ReLU backward            */
+  ST_EPI_BF16_ADD = 4,   /* D(bf16) = acc + aux             residual-gradient add    */
+  ST_EPI_F32_ATOMIC = 5  /* D(f32) += acc (atomic, split-K) weight gradients         */
+};
+
+/* D[i][j] = sum_c X(i,c) * Y(j,c), bf16 operands, fp32 accumulate (MFMA).
+ * x_cmajor / y_cmajor: operand stored [c][rows] instead of [rows][c].
+ * Replaces the three GEMMs of every nn.Linear on the path
+ * (Attention.py:74-76,92; SubLayers.py:25-26; Models.py:145,151 and their
+ * autograd backward): forward (0,0), dgrad (0,1), wgrad (1,1).
+ * M rows of X, N rows of Y, Kc contraction length; `splits` > 1 only with
+ * ST_EPI_F32_ATOMIC. */
+int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy, void* D,
+            int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi, int splits);
+
+/* out = LayerNorm(act(X W^T + bias) + res) * gamma + beta (+ pe[pos[row]]),
+ * N = d_model in {128, 256, 512}.  Replaces output_linear + residual +
+ * layernorm (Attention.py:92-94), fc2 + residual + layernorm
+ * (SubLayers.py:26-27) and, with relu=1 and the PE add, the encoder front-end
+ * (Models.py:28-33,42-44).  Saves xhat (bf16 [M,N]) and rstd (f32 [M]) for the
+ * backward; `pre` (optional) receives the pre-LN value (front-end ReLU mask). */
+int st_gemm_ln(st_stream_t stream, const void* X, int ldx, const void* W, int M, int N, int K, const float* bias,
+               const void* res, int ldres, const float* gamma, const float* beta, float eps, int relu,
+               const float* pe, const int* pos, void* out, int ldo, void* xhat, float* rstd, void* pre);
+
+/* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
+ * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).
+ * mask (optional bf16 [M,N]): dx is zeroed where mask <= 0 (front-end ReLU,
+ * Models.py:28-33). */
+int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, const float* rstd, const float* gamma,
+              const void* mask, void* dx, int lddx, float* dgamma, float* dbeta, float* dbias, int M, int N);
+
+/* Fused masked attention forward: softmax(Q K^T * scale, keys >= k_len[b]
+ * and (causal) keys > query masked) V, per head; replaces Attention.py:82-90
+ * and the dense masks of Utils.py:41-70.  lse (f32 [H, q_rows_total], log2
+ * domain) is saved for the backward.  d_k in {32, 64}. */
+int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
+                int H, int d_k, int max_q, int q_rows_total, int causal, float scale);
+
+/* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
+ * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch. */
+int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
+                void* dK, int lddk, void* dV, int lddv, const int* q_off, const int* q_len, const int* k_off,
+                const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
+                float scale);
+
+/* out[N] (f32) += column sums of x (bf16 [M, N]) - bias gradients. */
+int st_colsum(st_stream_t stream, const void* x, int ld, int M, int N, float* out);
+
+/* row_pos[off[b]+t] = t (and row_seq[...] = b if non-null), t < len[b]:
+ * the per-row position the PE add needs (Embedding.py:21-29). */
+int st_row_index(st_stream_t stream, const int* off, const int* len, int B, int max_len, int* row_pos, int* row_seq);
+
+/* Padded fp32 features [B,T,F] -> bf16 row matrix (train.py:33, Models.py:42). */
+int st_pack_rows(st_stream_t stream, const float* x, int B, int T, int F, const int* off, const int* len, void* out);
+/* bf16 row matrix -> padded fp32 [B,T,D], zero past len[b] (Encoder/Decoder return value). */
+int st_unpack_rows(st_stream_t stream, const void* x, int ld, int B, int T, int D, const int* off, const int* len,
+                   float* out);
+/* Backward of st_unpack_rows: padded fp32 gradient -> bf16 row matrix. */
+int st_pack_grad(st_stream_t stream, const float* g, int B, int T, int D, const int* off, const int* len, void* out,
+                 int ld);
+
+/* Decoder input: out[off[b]+t] = emb[tok[b,t]] + pe[t]  (Models.py:84,87 with repair R3). */
+int st_embed_pe_fwd(st_stream_t stream, const long long* tok, int B, int L, const float* emb, const float* pe, int D,
+                    const int* off, const int* len, void* out);
+/* demb[tok] += dy (f32 atomics); row pad_idx receives nothing (Models.py:74). */
+int st_embed_bwd(st_stream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
+                 const int* off, const int* len, int pad_idx, float* demb);
+
+/* fp32 master parameters -> bf16 shadow, n a multiple of 8. */
+int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);
+
+/* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
+int st_probe_tr16(st_stream_t stream, const void* in, void* out);
+int st_probe_mfma(st_stream_t stream, const void* A, const void* Bt, float* D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST_HIP_H */

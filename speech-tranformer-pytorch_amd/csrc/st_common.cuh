@@ -1,0 +1,106 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) speech-transformer kernels.
+//
+// Conventions used by every kernel in this directory
+//   * wavefront = 64 lanes; workgroups are 256 threads = 4 waves (one per SIMD).
+//   * matrix core op: v_mfma_f32_32x32x16_bf16.  For D = A*B with A[32 x 16], B[16 x 32]:
+//       A operand, lane l : row  i = l & 31, k = (l >> 5) * 8 + 0..7   (8 bf16 = 4 VGPRs)
+//       B operand, lane l : col  j = l & 31, k = (l >> 5) * 8 + 0..7
+//       C/D,       lane l : col  j = l & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), r = 0..15
+//     Both operands are therefore "row fragments": 8 consecutive contraction
+//     elements of one row.  We always put the operand whose rows we want to be
+//     LANE-LOCAL in the output on the B side, so that per-row statistics
+//     (softmax max/sum, LayerNorm mean/var) and 8-byte row stores need no
+//     cross-lane traffic beyond one exchange with lane ^ 32.
+//   * an operand stored contraction-major in LDS ([c][row], row contiguous) is read
+//     with ds_read_b64_tr_b16 (frag_tr below), so no tile is ever transposed in
+//     registers or re-written transposed to HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define ST_WAVE 64
+#define ST_LDS __attribute__((address_space(3)))
+
+#define ST_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+__device__ __forceinline__ bf16x8 zero_bf8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+  return z;
+}
+
+// Row of accumulator register r for the lane half `hi` (C/D layout above).
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// 16-byte global load of 8 bf16 (predicated, zero fill).
+__device__ __forceinline__ bf16x8 gload8(const bf16* p, bool ok) {
+  if (ok) return *reinterpret_cast<const bf16x8*>(p);
+  return zero_bf8();
+}
+
+// Natural row fragment from an LDS tile stored [row][c] with `stride` elements
+// per row: 8 bf16 at (row, c0 .. c0+7).  One ds_read_b128.
+__device__ __forceinline__ bf16x8 frag_nat(const bf16* tile, int stride, int row, int c0) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * stride + c0);
+}
+
+// Transposing fragment read from an LDS tile stored contraction-major
+// [c][row] (`stride` elements per c-row).  Returns, for this lane's row
+// `row0 + (lane & 31)`, the 8 elements c = ca + 0..3 and cb + 0..3.
+// ds_read_b64_tr_b16 semantics (per 16-lane group): lane t supplies the address
+// of 4 consecutive bf16 of row (t >> 2), chunk (t & 3); lane t receives, for
+// j = 0..3, element (t & 3) of the chunk addressed by lane 4 * j + (t >> 2),
+// i.e. column t of the 4 x 16 block.  (Verified on hardware by tests/test_probe_gpu.py.)
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int stride, int row0, int ca, int cb) {
+  const int l = threadIdx.x & 63;
+  const int t = l & 15;
+  const int colblk = ((l >> 4) & 1) * 16;
+  const bf16* pa = tile + (ca + (t >> 2)) * stride + row0 + colblk + 4 * (t & 3);
+  const bf16* pb = tile + (cb + (t >> 2)) * stride + row0 + colblk + 4 * (t & 3);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pa));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pb));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+// Pack 8 consecutive accumulator registers (r0 .. r0+7) of one lane into the
+// B-operand fragment for the follow-up MFMA whose contraction index is this
+// accumulator's ROW index.  k-slot (hi, j) <-> row r0/8*16 + 8*(j>>2) + 4*hi + (j&3)
+// relative to the 32-row block; the matching A operand must gather the same rows
+// (frag_tr with ca = base + 4*hi, cb = base + 8 + 4*hi).
+__device__ __forceinline__ bf16x8 pack_acc8(const f32x16& a, int r0) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16)a[r0 + j];
+  return f;
+}
+
+__device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }

@@ -1,0 +1,384 @@
+// bf16 MFMA GEMMs for the speech-transformer training step (gfx950).
+//
+//   D[i][j] = sum_c X(i,c) * Y(j,c)            fp32 accumulate
+//
+// Each operand is either "natural" ([rows][c], c contiguous) or "contraction-major"
+// ([c][rows], rows contiguous; read from LDS with ds_read_b64_tr_b16).  That one
+// kernel family covers the three GEMMs of every nn.Linear in the reference
+// (transformer/Attention.py:74-76,92, transformer/SubLayers.py:25-26,
+// transformer/Models.py:28-33,145):
+//   forward  y  = x W^T      : X = x  [M,K] natural,      Y = W  [N,K] natural
+//   dgrad    dx = dy W       : X = dy [M,N] natural,      Y = W  [N,K] contraction-major (c = n)
+//   wgrad    dW = dy^T x     : X = dy [M,N] contr.-major, Y = x  [M,K] contraction-major (c = m)
+// so no transposed copy of a weight or an activation is ever written to HBM.
+//
+// Tile: 128 x 128 x 32, 256 threads = 2 x 2 waves, each wave 64 x 64 = 2 x 2
+// v_mfma_f32_32x32x16_bf16 tiles.  The accumulator is kept TRANSPOSED (the
+// X-row index i is the lane, the Y-row index j runs over registers) so the
+// epilogue owns whole output rows per lane: 8-byte packed bf16 row stores and
+// lane-local LayerNorm statistics (st_gemm_ln).
+#include "st_common.cuh"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NAT_STRIDE = BK + 8;  // 80 B rows: conflict-free ds_read_b128 for 16 consecutive rows
+
+__host__ __device__ constexpr int cm_stride(int rows) { return rows >= 64 ? rows + 32 : rows; }
+
+enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_BF16_ADD = 4, EPI_F32_ATOMIC = 5 };
+
+// ---- global -> register staging of one operand tile -----------------------------------------
+// natural: tile [ROWS][BK]; contraction-major: tile [BK][ROWS].
+template <int ROWS, bool CM>
+struct Stage {
+  static constexpr int CHUNKS = ROWS * BK / 8;
+  static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
+  bf16x8 v[PER_THREAD];
+
+  __device__ __forceinline__ void load(const bf16* __restrict__ base, int ld, int row0, int nrows, int c0, int c_end) {
+#pragma unroll
+    for (int p = 0; p < PER_THREAD; ++p) {
+      const int id = threadIdx.x + p * 256;
+      if (CHUNKS % 256 != 0 && id >= CHUNKS) { v[p] = zero_bf8(); continue; }
+      if (!CM) {
+        const int r = id / (BK / 8), ch = id % (BK / 8);
+        const int row = row0 + r, c = c0 + ch * 8;
+        v[p] = gload8(base + (size_t)row * ld + c, row < nrows && c < c_end);
+      } else {
+        const int cr = id / (ROWS / 8), ch = id % (ROWS / 8);
+        const int c = c0 + cr, row = row0 + ch * 8;
+        v[p] = gload8(base + (size_t)c * ld + row, c < c_end && row < nrows);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(bf16* tile) const {
+#pragma unroll
+    for (int p = 0; p < PER_THREAD; ++p) {
+      const int id = threadIdx.x + p * 256;
+      if (CHUNKS % 256 != 0 && id >= CHUNKS) continue;
+      if (!CM) {
+        const int r = id / (BK / 8), ch = id % (BK / 8);
+        *reinterpret_cast<bf16x8*>(tile + r * NAT_STRIDE + ch * 8) = v[p];
+      } else {
+        const int cr = id / (ROWS / 8), ch = id % (ROWS / 8);
+        *reinterpret_cast<bf16x8*>(tile + cr * cm_stride(ROWS) + ch * 8) = v[p];
+      }
+    }
+  }
+};
+
+template <int ROWS, bool CM>
+__host__ __device__ constexpr int tile_elems() { return CM ? BK * cm_stride(ROWS) : ROWS * NAT_STRIDE; }
+
+template <int ROWS, bool CM>
+__device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int kk) {
+  const int l = threadIdx.x & 63, hi = l >> 5;
+  if (!CM) return frag_nat(tile, NAT_STRIDE, blk_row0 + (l & 31), kk * 16 + hi * 8);
+  return frag_tr(tile, cm_stride(ROWS), blk_row0, kk * 16 + hi * 8, kk * 16 + hi * 8 + 4);
+}
+
+struct GemmArgs {
+  const bf16* X; int ldx;
+  const bf16* Y; int ldy;
+  void* D; int ldd;
+  int M, N, Kc;
+  const float* bias;      // [N] or null
+  const bf16* aux; int ldaux;  // mask source (EPI_BF16_MASK) or addend (EPI_BF16_ADD)
+  int epi;
+  int c_per_split;        // contraction elements per blockIdx.z
+};
+
+template <bool XT, bool YT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (tile_elems<BM, XT>() + tile_elems<BN, YT>())];
+  constexpr int XE = tile_elems<BM, XT>(), YE = tile_elems<BN, YT>();
+  auto xs = [&](int buf) { return smem + buf * (XE + YE); };
+  auto ys = [&](int buf) { return smem + buf * (XE + YE) + XE; };
+
+  const int j0 = blockIdx.x * BN, i0 = blockIdx.y * BM;
+  const int c_begin = blockIdx.z * a.c_per_split;
+  const int c_end = min(a.Kc, c_begin + a.c_per_split);
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+
+  Stage<BM, XT> sx;
+  Stage<BN, YT> sy;
+  const int nk = (c_end - c_begin + BK - 1) / BK;
+  if (nk > 0) {
+    sx.load(a.X, a.ldx, i0, a.M, c_begin, c_end);
+    sy.load(a.Y, a.ldy, j0, a.N, c_begin, c_end);
+    sx.store(xs(0));
+    sy.store(ys(0));
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      sx.load(a.X, a.ldx, i0, a.M, c_begin + (kt + 1) * BK, c_end);
+      sy.load(a.Y, a.ldy, j0, a.N, c_begin + (kt + 1) * BK, c_end);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 xf[2], yf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        xf[t] = read_frag<BM, XT>(xs(cur), (wm * 2 + t) * 32, kk);
+        yf[t] = read_frag<BN, YT>(ys(cur), (wn * 2 + t) * 32, kk);
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
+    }
+    if (kt + 1 < nk) {
+      sx.store(xs(cur ^ 1));
+      sy.store(ys(cur ^ 1));
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns row i, registers run over j ------------------------------------
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int i = i0 + (wm * 2 + x) * 32 + (l & 31);
+    if (i >= a.M) continue;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = j0 + (wn * 2 + y) * 32 + 8 * g + 4 * hi;
+        if (j >= a.N) continue;   // N is a multiple of 4 for every caller (8 for bf16 outputs)
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[x][y][4 * g + e];
+        if (a.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if (a.epi == EPI_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j) = o;
+        } else if (a.epi == EPI_F32_ATOMIC) {
+          float* d = reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(d + e, v[e]);
+        } else {
+          if (a.epi == EPI_BF16_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (a.epi == EPI_BF16_MASK) {
+            const bf16x4 m = *reinterpret_cast<const bf16x4*>(a.aux + (size_t)i * a.ldaux + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((float)m[e] > 0.f) ? v[e] : 0.f;
+          } else if (a.epi == EPI_BF16_ADD) {
+            const bf16x4 m = *reinterpret_cast<const bf16x4*>(a.aux + (size_t)i * a.ldaux + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)m[e];
+          }
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---- GEMM + bias (+ReLU) (+residual) + LayerNorm (+positional-encoding add) -------------------
+// out = LN(act(x W^T + b) + res) * gamma + beta (+ pe[pos[i]])      N = d_model, full rows per workgroup
+struct GemmLnArgs {
+  const bf16* X; int ldx;     // [M,K] natural
+  const bf16* W;              // [N,K] natural, ld = K
+  int M, K;
+  const float* bias;          // [N]
+  const bf16* res; int ldres; // residual [M,N] or null
+  const float* gamma; const float* beta;
+  float eps;
+  int relu;                   // ReLU before LN (front-end, Models.py:28-33)
+  const float* pe; const int* pos;  // optional PE table [max_len,N] and per-row position (Models.py:43-44)
+  bf16* out; int ldo;         // LN output (+PE)
+  bf16* xhat;                 // normalised value (saved for backward), ld = N
+  float* rstd;                // [M]
+  bf16* pre;                  // optional: pre-LN value (front-end ReLU mask), ld = N
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void gemm_ln_kernel(GemmLnArgs a) {
+  constexpr int WN = N / 128, WM = 4 / WN, BM = 32 * WM;
+  static_assert(N == 128 || N == 256 || N == 512, "d_model must be 128, 256 or 512");
+  constexpr int XE = tile_elems<BM, false>(), YE = tile_elems<N, false>();
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (XE + YE)];
+  __shared__ float red[2][WM][WN][32];
+  auto xs = [&](int buf) { return smem + buf * (XE + YE); };
+  auto ys = [&](int buf) { return smem + buf * (XE + YE) + XE; };
+
+  const int i0 = blockIdx.x * BM;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = zero16();
+
+  Stage<BM, false> sx;
+  Stage<N, false> sy;
+  const int nk = (a.K + BK - 1) / BK;
+  sx.load(a.X, a.ldx, i0, a.M, 0, a.K);
+  sy.load(a.W, a.K, 0, N, 0, a.K);
+  sx.store(xs(0));
+  sy.store(ys(0));
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      sx.load(a.X, a.ldx, i0, a.M, (kt + 1) * BK, a.K);
+      sy.load(a.W, a.K, 0, N, (kt + 1) * BK, a.K);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const bf16x8 xf = read_frag<BM, false>(xs(cur), wm * 32, kk);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bf16x8 yf = read_frag<N, false>(ys(cur), wn * 128 + b * 32, kk);
+        acc[b] = mfma32(yf, xf, acc[b]);
+      }
+    }
+    if (kt + 1 < nk) {
+      sx.store(xs(cur ^ 1));
+      sy.store(ys(cur ^ 1));
+    }
+    __syncthreads();
+  }
+
+  const int i = i0 + wm * 32 + (l & 31);
+  const bool row_ok = i < a.M;
+  // v = act(acc + bias) + residual ; column of (b, r): wn*128 + b*32 + acc_row(r, hi)
+  float sum = 0.f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j = wn * 128 + b * 32 + 8 * g + 4 * hi;
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + j);
+      bf16x4 rr = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      if (a.res && row_ok) rr = *reinterpret_cast<const bf16x4*>(a.res + (size_t)i * a.ldres + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[b][4 * g + e] + bb[e];
+        if (a.relu) v = fmaxf(v, 0.f);
+        v += (float)rr[e];
+        acc[b][4 * g + e] = v;
+        sum += v;
+      }
+    }
+  }
+  sum += wave_xor32(sum);
+  if (WN > 1) {
+    if (hi == 0) red[0][wm][wn][l & 31] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WN; ++w) sum += red[0][wm][w][l & 31];
+  }
+  const float mean = sum * (1.f / N);
+  float sq = 0.f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc[b][r] - mean;
+      sq += d * d;
+    }
+  sq += wave_xor32(sq);
+  if (WN > 1) {
+    if (hi == 0) red[1][wm][wn][l & 31] = sq;
+    __syncthreads();
+    sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < WN; ++w) sq += red[1][wm][w][l & 31];
+  }
+  const float rstd = rsqrtf(sq * (1.f / N) + a.eps);
+  if (!row_ok) return;
+  if (a.rstd && wn == 0 && hi == 0) a.rstd[i] = rstd;
+  const float* perow = (a.pe != nullptr) ? a.pe + (size_t)a.pos[i] * N : nullptr;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j = wn * 128 + b * 32 + 8 * g + 4 * hi;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + j);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + j);
+      f32x4 pe = {0.f, 0.f, 0.f, 0.f};
+      if (perow) pe = *reinterpret_cast<const f32x4*>(perow + j);
+      bf16x4 xh, yo, pr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[b][4 * g + e];
+        const float h = (v - mean) * rstd;
+        xh[e] = (bf16)h;
+        yo[e] = (bf16)(h * gm[e] + bt[e] + pe[e]);
+        pr[e] = (bf16)v;
+      }
+      *reinterpret_cast<bf16x4*>(a.out + (size_t)i * a.ldo + j) = yo;
+      if (a.xhat) *reinterpret_cast<bf16x4*>(a.xhat + (size_t)i * N + j) = xh;
+      if (a.pre) *reinterpret_cast<bf16x4*>(a.pre + (size_t)i * N + j) = pr;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
+                       void* D, int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi,
+                       int splits) {
+  if (M <= 0 || N <= 0 || Kc <= 0) return 0;
+  if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 5) return -1;
+  if (x_cmajor && !y_cmajor) return -2;  // not needed by any caller
+  // contraction-major operands are read in 8-row chunks: the caller guarantees the buffer is
+  // padded (ld >= round_up(rows, 8)); rows beyond M / N only feed outputs that are never stored.
+  if ((x_cmajor && ldx < ((M + 7) & ~7)) || (y_cmajor && ldy < ((N + 7) & ~7))) return -3;
+  if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && (ldd & 3)) return -4;
+  if (splits < 1) splits = 1;
+  if (epi != EPI_F32_ATOMIC) splits = 1;
+  GemmArgs a;
+  a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
+  a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux; a.epi = epi;
+  int per = (Kc + splits - 1) / splits;
+  per = (per + BK - 1) / BK * BK;
+  splits = (Kc + per - 1) / per;
+  a.c_per_split = per;
+  dim3 grid((N + 127) / 128, (M + 127) / 128, splits), block(256);
+  if (!x_cmajor && !y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, a);
+  else if (!x_cmajor && y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, a);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void* W, int M, int N, int K,
+                          const float* bias, const void* res, int ldres, const float* gamma, const float* beta,
+                          float eps, int relu, const float* pe, const int* pos, void* out, int ldo, void* xhat,
+                          float* rstd, void* pre) {
+  if (M <= 0) return 0;
+  if ((ldx & 7) || (K & 7) || !bias || !gamma || !beta || !out) return -1;
+  if (pe && !pos) return -2;
+  GemmLnArgs a;
+  a.X = (const bf16*)X; a.ldx = ldx; a.W = (const bf16*)W; a.M = M; a.K = K; a.bias = bias;
+  a.res = (const bf16*)res; a.ldres = ldres; a.gamma = gamma; a.beta = beta; a.eps = eps; a.relu = relu;
+  a.pe = pe; a.pos = pos; a.out = (bf16*)out; a.ldo = ldo; a.xhat = (bf16*)xhat; a.rstd = rstd; a.pre = (bf16*)pre;
+  dim3 block(256);
+  if (N == 128) hipLaunchKernelGGL((gemm_ln_kernel<128>), dim3((M + 127) / 128), block, 0, stream, a);
+  else if (N == 256) hipLaunchKernelGGL((gemm_ln_kernel<256>), dim3((M + 63) / 64), block, 0, stream, a);
+  else if (N == 512) hipLaunchKernelGGL((gemm_ln_kernel<512>), dim3((M + 31) / 32), block, 0, stream, a);
+  else return -3;
+  ST_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,320 @@
+// HBM-bound companions of the MFMA kernels (gfx950): LayerNorm backward, column sums
+// (bias gradients), embedding + positional encoding, ragged pack / unpack, fp32 -> bf16
+// parameter shadow.  All of them stream rows with >= 8-byte per-lane accesses along the
+// feature axis (coalesced 256-512 B per wave per row).
+#include "st_common.cuh"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward (nn.LayerNorm(d, eps=1e-6) of Attention.py:62,94 / SubLayers.py:18,27 /
+// Models.py:32).  With g = dy * gamma:
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+//   dgamma += sum_rows dy * xhat,  dbeta += sum_rows dy,  dbias += sum_rows dx
+// (dbias is the bias gradient of the Linear that feeds the LN: same column sum, free here.)
+// `mask` (optional, bf16 [M,N]): dx is zeroed where mask <= 0 - the ReLU that sits between the
+// Linear and the LN in the encoder front-end (Models.py:28-33).
+// One wave per row; each lane owns VPL = N/64 consecutive columns.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, int lddy,
+                                                     const bf16* __restrict__ xhat, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const bf16* __restrict__ mask,
+                                                     bf16* __restrict__ dx, int lddx, float* dgamma, float* dbeta,
+                                                     float* dbias, int M) {
+  constexpr int VPL = N / 64;
+  typedef bf16 vec_t __attribute__((ext_vector_type(VPL)));
+  __shared__ float red[3][4][N];
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int c0 = l * VPL;
+  float gm[VPL], ag[VPL], ab[VPL], ax[VPL];
+#pragma unroll
+  for (int e = 0; e < VPL; ++e) { gm[e] = gamma[c0 + e]; ag[e] = ab[e] = ax[e] = 0.f; }
+
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const vec_t vdy = *reinterpret_cast<const vec_t*>(dy + (size_t)row * lddy + c0);
+    const vec_t vxh = *reinterpret_cast<const vec_t*>(xhat + (size_t)row * N + c0);
+    float g[VPL], xh[VPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) {
+      const float d = (float)vdy[e];
+      xh[e] = (float)vxh[e];
+      g[e] = d * gm[e];
+      s1 += g[e];
+      s2 += g[e] * xh[e];
+      ag[e] += d * xh[e];
+      ab[e] += d;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      s1 += __shfl_xor(s1, o, 64);
+      s2 += __shfl_xor(s2, o, 64);
+    }
+    const float rs = rstd[row], m1 = s1 * (1.f / N), m2 = s2 * (1.f / N);
+    vec_t out, mk;
+    if (mask) mk = *reinterpret_cast<const vec_t*>(mask + (size_t)row * N + c0);
+#pragma unroll
+    for (int e = 0; e < VPL; ++e) {
+      float v = rs * (g[e] - m1 - xh[e] * m2);
+      if (mask && !((float)mk[e] > 0.f)) v = 0.f;   // ReLU in front of the LN (encoder front-end)
+      out[e] = (bf16)v;
+      ax[e] += v;
+    }
+    *reinterpret_cast<vec_t*>(dx + (size_t)row * lddx + c0) = out;
+  }
+#pragma unroll
+  for (int e = 0; e < VPL; ++e) {
+    red[0][wave][c0 + e] = ag[e];
+    red[1][wave][c0 + e] = ab[e];
+    red[2][wave][c0 + e] = ax[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < N; c += 256) {
+    const float g4 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float b4 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    const float x4 = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+    if (dgamma) atomicAdd(dgamma + c, g4);
+    if (dbeta) atomicAdd(dbeta + c, b4);
+    if (dbias) atomicAdd(dbias + c, x4);
+  }
+}
+
+// Column sums of a bf16 [M, N] matrix accumulated into fp32 out[N] (bias gradients).
+// Optional ReLU mask source: rows are multiplied by (mask > 0) - not needed when the
+// producer already applied it.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int ld, int M, int N, float* out,
+                                                     int rows_per_block) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= N) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const bf16x2 v = *reinterpret_cast<const bf16x2*>(x + (size_t)r * ld + c);
+    a0 += (float)v[0];
+    a1 += (float)v[1];
+  }
+  atomicAdd(out + c, a0);
+  atomicAdd(out + c + 1, a1);
+}
+
+// row_pos[off[b] + t] = t, row_seq[off[b] + t] = b  for t < len[b]
+__global__ void row_index_kernel(const int* off, const int* len, int* row_pos, int* row_seq) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < len[b]) {
+    row_pos[off[b] + t] = t;
+    if (row_seq) row_seq[off[b] + t] = b;
+  }
+}
+
+// Ragged pack: padded fp32 [B, T, F] -> row matrix bf16 [rows, F] (Models.py:42 input, train.py:33).
+__global__ void pack_rows_kernel(const float* __restrict__ x, int T, int F, const int* off, const int* len,
+                                 bf16* __restrict__ out) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  if (t >= len[b]) return;
+  const float* src = x + ((size_t)b * T + t) * F;
+  bf16* dst = out + (size_t)(off[b] + t) * F;
+  for (int f = threadIdx.x * 4; f < F; f += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + f);
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(dst + f) = o;
+  }
+}
+
+// Ragged unpack: bf16 row matrix [rows, D] -> padded fp32 [B, T, D], zero past len[b].
+__global__ void unpack_rows_kernel(const bf16* __restrict__ x, int ld, int T, int D, const int* off, const int* len,
+                                   float* __restrict__ out) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  const bool ok = t < len[b];
+  const bf16* src = x + (size_t)(off[b] + (ok ? t : 0)) * ld;
+  float* dst = out + ((size_t)b * T + t) * D;
+  for (int f = threadIdx.x * 4; f < D; f += blockDim.x * 4) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + f);
+      o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    }
+    *reinterpret_cast<f32x4*>(dst + f) = o;
+  }
+}
+
+// Ragged gather of a padded fp32 gradient [B, T, D] into a bf16 row matrix (backward of unpack).
+__global__ void pack_grad_kernel(const float* __restrict__ g, int T, int D, const int* off, const int* len,
+                                 bf16* __restrict__ out, int ld) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  if (t >= len[b]) return;
+  const float* src = g + ((size_t)b * T + t) * D;
+  bf16* dst = out + (size_t)(off[b] + t) * ld;
+  for (int f = threadIdx.x * 4; f < D; f += blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + f);
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(dst + f) = o;
+  }
+}
+
+// Decoder input: out[off[b]+t] = E[tok[b,t]] + PE[t]   (Models.py:84 + repair R3; Embedding.py:26)
+__global__ void embed_pe_fwd_kernel(const long long* __restrict__ tok, int L, const float* __restrict__ emb,
+                                    const float* __restrict__ pe, int D, const int* off, const int* len,
+                                    bf16* __restrict__ out) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  if (t >= len[b]) return;
+  const long long id = tok[(size_t)b * L + t];
+  const float* e = emb + (size_t)id * D;
+  const float* p = pe + (size_t)t * D;
+  bf16* dst = out + (size_t)(off[b] + t) * D;
+  for (int f = threadIdx.x * 4; f < D; f += blockDim.x * 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(e + f);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p + f);
+    bf16x4 o = {(bf16)(a[0] + c[0]), (bf16)(a[1] + c[1]), (bf16)(a[2] + c[2]), (bf16)(a[3] + c[3])};
+    *reinterpret_cast<bf16x4*>(dst + f) = o;
+  }
+}
+
+// dE[tok] += dy ; the padding_idx row (Models.py:74, Constants.PAD) never receives gradient.
+__global__ void embed_bwd_kernel(const long long* __restrict__ tok, int L, const bf16* __restrict__ dy, int ld, int D,
+                                 const int* off, const int* len, int pad_idx, float* demb) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  if (t >= len[b]) return;
+  const long long id = tok[(size_t)b * L + t];
+  if (id == pad_idx) return;
+  const bf16* src = dy + (size_t)(off[b] + t) * ld;
+  float* dst = demb + (size_t)id * D;
+  for (int f = threadIdx.x; f < D; f += blockDim.x) atomicAdd(dst + f, (float)src[f]);
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n8) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+    bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+    *reinterpret_cast<bf16x8*>(dst + i * 8) = o;
+  }
+}
+
+// ---- hardware probes (tests/test_probe_gpu.py): pin the fragment layouts the kernels rely on -------
+__global__ void probe_tr16_kernel(const bf16* in, bf16* out) {
+  __shared__ __attribute__((aligned(16))) bf16 tile[16 * 64];
+  for (int i = threadIdx.x; i < 16 * 64; i += 64) tile[i] = in[i];
+  __syncthreads();
+  const int l = threadIdx.x;
+  // natural-order fragment: c = hi*8 .. hi*8+7 of operand row (l & 31), tile stored [c][row], stride 64
+  const bf16x8 f = frag_tr(tile, 64, 0, (l >> 5) * 8, (l >> 5) * 8 + 4);
+  *reinterpret_cast<bf16x8*>(out + l * 8) = f;
+}
+
+__global__ void probe_mfma_kernel(const bf16* A, const bf16* Bt, float* D) {
+  // A [32][16] row-major, Bt [32][16] row-major (= B^T); D[i][j] written row-major [32][32]
+  const int l = threadIdx.x, hi = l >> 5;
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (l & 31) * 16 + hi * 8);
+  const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bt + (l & 31) * 16 + hi * 8);
+  const f32x16 c = mfma32(a, b, zero16());
+  for (int r = 0; r < 16; ++r) D[acc_row(r, hi) * 32 + (l & 31)] = c[r];
+}
+
+}  // namespace
+
+extern "C" int st_ln_bwd(hipStream_t stream, const void* dy, int lddy, const void* xhat, const float* rstd,
+                         const float* gamma, const void* mask, void* dx, int lddx, float* dgamma, float* dbeta,
+                         float* dbias, int M, int N) {
+  if (M <= 0) return 0;
+  if ((lddy & 7) || (lddx & 7)) return -1;
+  int blocks = (M + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+#define ST_LN_BWD(NN)                                                                                         \
+  hipLaunchKernelGGL((ln_bwd_kernel<NN>), dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, lddy,          \
+                     (const bf16*)xhat, rstd, gamma, (const bf16*)mask, (bf16*)dx, lddx, dgamma, dbeta, dbias, M)
+  if (N == 128) ST_LN_BWD(128);
+  else if (N == 256) ST_LN_BWD(256);
+  else if (N == 512) ST_LN_BWD(512);
+  else return -2;
+#undef ST_LN_BWD
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_colsum(hipStream_t stream, const void* x, int ld, int M, int N, float* out) {
+  if (M <= 0 || N <= 0) return 0;
+  if ((ld & 1) || (N & 1)) return -1;
+  const int rpb = 256;
+  dim3 grid((N / 2 + 255) / 256, (M + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, (const bf16*)x, ld, M, N, out, rpb);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_row_index(hipStream_t stream, const int* off, const int* len, int B, int max_len, int* row_pos,
+                            int* row_seq) {
+  if (B <= 0 || max_len <= 0) return 0;
+  hipLaunchKernelGGL(row_index_kernel, dim3((max_len + 255) / 256, B), dim3(256), 0, stream, off, len, row_pos, row_seq);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_pack_rows(hipStream_t stream, const float* x, int B, int T, int F, const int* off, const int* len,
+                            void* out) {
+  if (B <= 0 || T <= 0) return 0;
+  if (F & 3) return -1;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(1, T, B), dim3(64), 0, stream, x, T, F, off, len, (bf16*)out);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_unpack_rows(hipStream_t stream, const void* x, int ld, int B, int T, int D, const int* off,
+                              const int* len, float* out) {
+  if (B <= 0 || T <= 0) return 0;
+  if ((D & 3) || (ld & 3)) return -1;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(1, T, B), dim3(64), 0, stream, (const bf16*)x, ld, T, D, off, len, out);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_pack_grad(hipStream_t stream, const float* g, int B, int T, int D, const int* off, const int* len,
+                            void* out, int ld) {
+  if (B <= 0 || T <= 0) return 0;
+  if ((D & 3) || (ld & 3)) return -1;
+  hipLaunchKernelGGL(pack_grad_kernel, dim3(1, T, B), dim3(64), 0, stream, g, T, D, off, len, (bf16*)out, ld);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_embed_pe_fwd(hipStream_t stream, const long long* tok, int B, int L, const float* emb,
+                               const float* pe, int D, const int* off, const int* len, void* out) {
+  if (B <= 0 || L <= 0) return 0;
+  if (D & 3) return -1;
+  hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(1, L, B), dim3(64), 0, stream, tok, L, emb, pe, D, off, len, (bf16*)out);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_embed_bwd(hipStream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
+                            const int* off, const int* len, int pad_idx, float* demb) {
+  if (B <= 0 || L <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(1, L, B), dim3(64), 0, stream, tok, L, (const bf16*)dy, ld, D, off, len,
+                     pad_idx, demb);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_cast_bf16(hipStream_t stream, const float* src, void* dst, long long n) {
+  if (n <= 0) return 0;
+  if (n & 7) return -1;
+  const size_t n8 = (size_t)n / 8;
+  int blocks = (int)((n8 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, stream, src, (bf16*)dst, n8);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_probe_tr16(hipStream_t stream, const void* in, void* out) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, stream, (const bf16*)in, (bf16*)out);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_probe_mfma(hipStream_t stream, const void* A, const void* Bt, float* D) {
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, stream, (const bf16*)A, (const bf16*)Bt, D);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_version(void) { return 1; }

@@ -1,0 +1,44 @@
+"""Build libst_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build
+container; the resulting .so travels to the GPU box with the source tree.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
+LIB = os.path.join(LIBDIR, "libst_hip.so")
+SOURCES = ["st_gemm.hip", "st_attn.hip", "st_misc.hip"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-shared",
+         "-Wno-unused-result"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """Compile the library if it is missing or older than its sources."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libst_hip.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

@@ -1,0 +1,326 @@
+"""torch.autograd.Functions composed from the C-ABI HIP kernels.
+
+One Function per reference sub-layer (forward + hand-written backward):
+
+  MhaFn       MultiHeadAttention.forward      transformer/Attention.py:64-96
+  FfnFn       PositionwiseFeedForward.forward transformer/SubLayers.py:24-28
+  FrontendFn  Encoder.input_proj + PE add     transformer/Models.py:28-33,42-44
+  EmbedFn     tgt_word_emb + PE add           transformer/Models.py:84,87 (repair R3)
+  VocabFn     tgt_word_proj                   transformer/Models.py:145,151
+  Pack/Unpack padded [B,T,*] <-> ragged row matrix (train.py:31-35 trimming)
+
+Activations are bf16 row matrices [rows, d]; parameter gradients are written
+straight into the arena's fp32 gradient buffer (atomic accumulate), which is
+what ``param.grad`` views - the Functions therefore return ``None`` for their
+parameter anchor (the Megatron "main_grad" idiom).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import native as nv
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+LN_EPS = 1e-6  # Attention.py:62, SubLayers.py:18, Models.py:32
+
+
+class Rows:
+    """How utterances map onto the rows of an activation matrix."""
+
+    __slots__ = ("B", "off", "len", "max_len", "total", "_pos", "lens_host", "dense")
+
+    def __init__(self, off, length, max_len, total, lens_host=None, dense=True):
+        self.dense = dense  # every row of the matrix belongs to some utterance (no padding rows)
+        self.B = off.numel()
+        self.off, self.len = off, length
+        self.max_len, self.total = int(max_len), int(total)
+        self._pos = None
+        self.lens_host = lens_host
+
+    @staticmethod
+    def packed(lengths: torch.Tensor, device) -> "Rows":
+        """Ragged layout: utterance b owns rows cumsum(len)[b-1] ... (no padding rows)."""
+        host = lengths.detach().to("cpu", torch.int64)  # one D2H copy if the lengths live on the GPU
+        off = torch.zeros_like(host)
+        off[1:] = torch.cumsum(host, 0)[:-1]
+        return Rows(off.to(device=device, dtype=I32), host.to(device=device, dtype=I32), int(host.max()),
+                    int(host.sum()), host)
+
+    @staticmethod
+    def padded(B: int, T: int, device, lengths: Optional[torch.Tensor] = None) -> "Rows":
+        """Padded layout: utterance b owns rows b*T ... b*T+len[b]-1 (len = T when not given)."""
+        off = torch.arange(B, dtype=I32, device=device) * T
+        if lengths is None:
+            ln = torch.full((B,), T, dtype=I32, device=device)
+            host = None
+        else:
+            host = lengths.detach().to("cpu", torch.int64)
+            ln = host.to(device=device, dtype=I32)
+        return Rows(off, ln, T, B * T, host, dense=lengths is None)
+
+    @property
+    def pos(self) -> torch.Tensor:
+        if self._pos is None:
+            p = torch.zeros(self.total, dtype=I32, device=self.off.device)
+            nv.row_index(self.off, self.len, self.max_len, p)
+            self._pos = p
+        return self._pos
+
+
+def _splits(M: int, N: int, K: int) -> int:
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    return max(1, min((M + 255) // 256, (512 + tiles - 1) // tiles))
+
+
+def wgrad(dY, X, gW, rows=None):
+    """gW[n][k] += sum_m dY[m][n] X[m][k]   (both operands contraction-major)."""
+    N = dY.shape[1] if rows is None else rows
+    nv.gemm(dY, X, gW, epi=nv.EPI_F32_ATOMIC, x_cmajor=True, y_cmajor=True, splits=_splits(dY.shape[0], N, X.shape[1]),
+            m=N)
+
+
+def dgrad(dY, W, out, epi=nv.EPI_BF16, aux=None, kc=None):
+    """out[m][k] = sum_n dY[m][n] W[n][k]  (+ aux | masked by aux > 0)."""
+    return nv.gemm(dY, W, out, epi=epi, aux=aux, y_cmajor=True, kc=kc)
+
+
+def _empty(rows, cols, like, dtype=BF16):
+    return torch.empty(rows, cols, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------
+class MhaFn(torch.autograd.Function):
+    """out = LN(attn(x_q W_q, x_kv W_k, x_kv W_v) W_o + b_o + x_q)   (Attention.py:64-96, R2)."""
+
+    @staticmethod
+    def forward(ctx, x_q, x_kv, anchor, mod, q_rows: Rows, k_rows: Rows, causal: bool, want_attn: bool):
+        s = mod._st
+        d, H = s.d_model, s.n_head
+        Mq = x_q.shape[0]
+        self_attn = x_kv is None
+        if self_attn:
+            qkv = _empty(Mq, 3 * d, x_q)
+            nv.gemm(x_q, s.w_qkv, qkv, bias=s.b_qkv)
+            Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            kvbuf = None
+        else:
+            qkv = _empty(Mq, d, x_q)
+            nv.gemm(x_q, s.w_q, qkv, bias=s.b_q)
+            kvbuf = _empty(x_kv.shape[0], 2 * d, x_q)
+            nv.gemm(x_kv, s.w_kv, kvbuf, bias=s.b_kv)
+            Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
+        attn_ctx = _empty(Mq, d, x_q)
+        lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
+        scale = 1.0 / math.sqrt(d // H)
+        nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
+                    scale)
+        out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
+        rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
+        nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
+        ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd)
+        ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd = ctx.saved_tensors
+        mod, q_rows, k_rows = ctx.mod, ctx.q_rows, ctx.k_rows
+        s, arena = mod._st, mod._st_arena
+        d, H = s.d_model, s.n_head
+        Mq = x_q.shape[0]
+        dout = dout.contiguous()
+        arena.attach_grads(s.params, s.lo, s.hi)
+        ds = _empty(Mq, d, x_q)
+        nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b_o)
+        wgrad(ds, attn_ctx, s.g_w_o)
+        dctx = _empty(Mq, d, x_q)
+        dgrad(ds, s.w_o, dctx)
+        delta = torch.empty(H * Mq, dtype=F32, device=x_q.device)
+        if x_kv is None:
+            Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            # key rows past k_len (padded layout only) get no gradient: they must read as zeros
+            dqkv = _empty(Mq, 3 * d, x_q) if k_rows.dense else torch.zeros(Mq, 3 * d, dtype=BF16, device=x_q.device)
+            dQ, dK, dV = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        else:
+            Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
+            dqkv = _empty(Mq, d, x_q)
+            dkv = _empty(x_kv.shape[0], 2 * d, x_q) if k_rows.dense else \
+                torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
+            dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
+        nv.attn_bwd(Q, K, V, attn_ctx, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
+                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale)
+        dx_q = _empty(Mq, d, x_q)
+        dx_kv = None
+        if x_kv is None:
+            wgrad(dqkv, x_q, s.g_w_qkv)
+            nv.colsum(dqkv, s.g_b_qkv)
+            dgrad(dqkv, s.w_qkv, dx_q, epi=nv.EPI_BF16_ADD, aux=ds)
+        else:
+            wgrad(dqkv, x_q, s.g_w_q)
+            nv.colsum(dqkv, s.g_b_q)
+            dgrad(dqkv, s.w_q, dx_q, epi=nv.EPI_BF16_ADD, aux=ds)
+            wgrad(dkv, x_kv, s.g_w_kv)
+            nv.colsum(dkv, s.g_b_kv)
+            dx_kv = _empty(x_kv.shape[0], d, x_q)
+            dgrad(dkv, s.w_kv, dx_kv)
+        arena.grads_ready(s.lo, s.hi)
+        return dx_q, dx_kv, None, None, None, None, None, None
+
+
+class FfnFn(torch.autograd.Function):
+    """out = LN(x + fc2(relu(fc1(x))))   (SubLayers.py:24-28)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, mod):
+        s = mod._st
+        M, d = x.shape
+        h = _empty(M, s.d_ff, x)
+        nv.gemm(x, s.w1, h, bias=s.b1, epi=nv.EPI_BF16_RELU)
+        out, xhat = _empty(M, d, x), _empty(M, d, x)
+        rstd = torch.empty(M, dtype=F32, device=x.device)
+        nv.gemm_ln(h, s.w2, s.b2, x, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
+        ctx.save_for_backward(x, h, xhat, rstd)
+        ctx.mod = mod
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, xhat, rstd = ctx.saved_tensors
+        mod = ctx.mod
+        s, arena = mod._st, mod._st_arena
+        M, d = x.shape
+        dout = dout.contiguous()
+        arena.attach_grads(s.params, s.lo, s.hi)
+        ds = _empty(M, d, x)
+        nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b2)
+        wgrad(ds, h, s.g_w2)
+        dh = _empty(M, s.d_ff, x)
+        dgrad(ds, s.w2, dh, epi=nv.EPI_BF16_MASK, aux=h)
+        wgrad(dh, x, s.g_w1)
+        nv.colsum(dh, s.g_b1)
+        dx = _empty(M, d, x)
+        dgrad(dh, s.w1, dx, epi=nv.EPI_BF16_ADD, aux=ds)
+        arena.grads_ready(s.lo, s.hi)
+        return dx, None, None
+
+
+class FrontendFn(torch.autograd.Function):
+    """e = LN(relu(x W_in^T + b_in)) + PE[pos]   (Models.py:28-33 eval-mode, 42-44)."""
+
+    @staticmethod
+    def forward(ctx, xp, anchor, mod, rows: Rows):
+        s = mod._st
+        M = xp.shape[0]
+        d = s.d_model
+        out, xhat, pre = _empty(M, d, xp), _empty(M, d, xp), _empty(M, d, xp)
+        rstd = torch.empty(M, dtype=F32, device=xp.device)
+        nv.gemm_ln(xp, s.w_in, s.b_in, None, s.gamma_in, s.beta_in, out, xhat, rstd, eps=LN_EPS, relu=True, pe=s.pe,
+                   pos=rows.pos, pre=pre)
+        ctx.save_for_backward(xp, xhat, rstd, pre)
+        ctx.mod = mod
+        ctx.need_dx = xp.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xp, xhat, rstd, pre = ctx.saved_tensors
+        mod = ctx.mod
+        s, arena = mod._st, mod._st_arena
+        M, d = xhat.shape
+        dout = dout.contiguous()
+        arena.attach_grads(s.front_params, s.front_lo, s.front_hi)
+        dz = _empty(M, d, xp)
+        nv.ln_bwd(dout, xhat, rstd, s.gamma_in, dz, s.g_gamma_in, s.g_beta_in, s.g_b_in, mask=pre)
+        wgrad(dz, xp, s.g_w_in)
+        dxp = None
+        if ctx.need_dx:
+            dxp = _empty(M, xp.shape[1], xp)
+            dgrad(dz, s.w_in, dxp)
+        arena.grads_ready(s.front_lo, s.front_hi)
+        return dxp, None, None, None
+
+
+class EmbedFn(torch.autograd.Function):
+    """y = Emb(tokens) + PE[pos]   (Models.py:84,87 with repair R3; padding_idx row gets no grad)."""
+
+    @staticmethod
+    def forward(ctx, anchor, mod, tokens, rows: Rows):
+        s = mod._st
+        out = torch.empty(rows.total, s.d_model, dtype=BF16, device=tokens.device)
+        nv.embed_pe_fwd(tokens, s.emb, s.pe, rows.off, rows.len, out)
+        ctx.mod, ctx.rows = mod, rows
+        ctx.save_for_backward(tokens)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        mod = ctx.mod
+        s, arena = mod._st, mod._st_arena
+        arena.attach_grads(s.emb_params, s.emb_lo, s.emb_hi)
+        nv.embed_bwd(tokens, dout.contiguous(), ctx.rows.off, ctx.rows.len, s.pad_idx, s.g_emb)
+        arena.grads_ready(s.emb_lo, s.emb_hi)
+        return None, None, None, None
+
+
+class VocabFn(torch.autograd.Function):
+    """logits = dec W_vocab^T, fp32, columns padded to a multiple of 8 (Models.py:145,151)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, mod):
+        s = mod._st
+        logits = torch.empty(x.shape[0], s.v_pad, dtype=F32, device=x.device)
+        nv.gemm(x, s.w_vocab, logits, epi=nv.EPI_F32)
+        ctx.save_for_backward(x)
+        ctx.mod = mod
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        (x,) = ctx.saved_tensors
+        mod = ctx.mod
+        s, arena = mod._st, mod._st_arena
+        arena.attach_grads(s.vocab_params, s.vocab_lo, s.vocab_hi)
+        dl = dlogits.to(BF16)
+        wgrad(dl, x, s.g_w_vocab)
+        dx = _empty(x.shape[0], x.shape[1], x)
+        dgrad(dl, s.w_vocab, dx)
+        arena.grads_ready(s.vocab_lo, s.vocab_hi)
+        return dx, None, None
+
+
+class PackFn(torch.autograd.Function):
+    """Padded fp32 [B, T, D] -> bf16 row matrix [rows.total, D]."""
+
+    @staticmethod
+    def forward(ctx, x, rows: Rows):
+        out = torch.zeros(rows.total, x.shape[2], dtype=BF16, device=x.device)
+        nv.pack_rows(x.contiguous(), rows.off, rows.len, out)
+        ctx.rows, ctx.shape = rows, x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = torch.empty(ctx.shape, dtype=F32, device=dout.device)
+        nv.unpack_rows(dout.contiguous(), ctx.rows.off, ctx.rows.len, g)
+        return g, None
+
+
+class UnpackFn(torch.autograd.Function):
+    """bf16 row matrix -> padded fp32 [B, T, D] (zeros past each length)."""
+
+    @staticmethod
+    def forward(ctx, x, rows: Rows, T: int):
+        out = torch.empty(rows.B, T, x.shape[1], dtype=F32, device=x.device)
+        nv.unpack_rows(x, rows.off, rows.len, out)
+        ctx.rows, ctx.n = rows, x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out = torch.zeros(ctx.n, dtype=BF16, device=g.device)
+        nv.pack_grad(g.contiguous(), ctx.rows.off, ctx.rows.len, out)
+        return out, None, None

@@ -1,0 +1,296 @@
+"""ctypes binding of libst_hip.so - the C-ABI declared in include/st_hip.h.
+
+Each Python wrapper validates tensor dtype / layout on the host (the kernels
+themselves only see raw pointers), passes ``torch.cuda.current_stream()`` and
+raises on a non-zero status.  There is deliberately NO fallback: if the library
+is missing, or a tensor is not on a GPU, the call raises.
+
+Tensor conventions: activations are 2-D row matrices with ``stride(1) == 1``;
+column slices of a wider matrix (``qkv[:, :d]``) are fine - the leading
+dimension is taken from ``stride(0)``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+from . import build as _build
+
+EPI_BF16, EPI_BF16_RELU, EPI_F32, EPI_BF16_MASK, EPI_BF16_ADD, EPI_F32_ATOMIC = range(6)
+
+_c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
+
+# name -> argtypes (restype is int everywhere); must mirror include/st_hip.h exactly.
+SIGNATURES = {
+    "st_version": [],
+    "st_gemm": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
+                _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int],
+    "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
+                   _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                   _c_void_p, _c_void_p],
+    "st_ln_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
+                  _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int],
+    "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                    _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                    _c_float],
+    "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                    _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                    _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                    _c_float],
+    "st_colsum": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
+    "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
+    "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "st_unpack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "st_pack_grad": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int],
+    "st_embed_pe_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                        _c_void_p],
+    "st_embed_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
+                     _c_void_p],
+    "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
+    "st_probe_tr16": [_c_void_p, _c_void_p, _c_void_p],
+    "st_probe_mfma": [_c_void_p, _c_void_p, _c_void_p, _c_void_p],
+}
+
+_LIB = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """dlopen libst_hip.so (building it first if hipcc is available)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError("libst_hip.so not built: run `python __graft_entry__.py` (build())")
+        _build.build_lib()
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    _LIB = lib
+    return lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ValueError("%s: unsupported argument (code %d) - see include/st_hip.h" % (what, rc))
+    raise RuntimeError("%s: HIP launch failed (hipError_t %d)" % (what, rc))
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: the HIP path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s: expected %s, got %s" % (name, dtype, t.dtype))
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("%s: expected a 2-D row matrix with unit column stride, got shape %s stride %s"
+                         % (name, tuple(t.shape), t.stride()))
+
+
+def _vec(t: Optional[torch.Tensor], dtype, n: int, name: str) -> None:
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous() or t.numel() < n:
+        raise ValueError("%s: expected contiguous %s[%d] on the GPU" % (name, dtype, n))
+
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1,
+         m=None, n=None, kc=None):
+    """out[i][j] (+)= sum_c X(i,c) Y(j,c).  ``*_cmajor``: that tensor is stored [c, rows]."""
+    _mat(X, BF16, "X"), _mat(Y, BF16, "Y")
+    _mat(out, F32 if epi in (EPI_F32, EPI_F32_ATOMIC) else BF16, "out")
+    M = m if m is not None else (X.shape[1] if x_cmajor else X.shape[0])
+    N = n if n is not None else (Y.shape[1] if y_cmajor else Y.shape[0])
+    Kc = kc if kc is not None else (X.shape[0] if x_cmajor else X.shape[1])
+    if out.shape[0] < M or out.shape[1] < N:
+        raise ValueError("gemm: out %s too small for %dx%d" % (tuple(out.shape), M, N))
+    _vec(bias, F32, N, "bias")
+    ldaux = 0
+    if epi in (EPI_BF16_MASK, EPI_BF16_ADD):
+        _mat(aux, BF16, "aux")
+        ldaux = aux.stride(0)
+    rc = load().st_gemm(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0),
+                        out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux, epi, splits)
+    _check(rc, "st_gemm")
+    return out
+
+
+def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None):
+    _mat(X, BF16, "X"), _mat(W, BF16, "W"), _mat(out, BF16, "out")
+    M, K = X.shape
+    N = W.shape[0]
+    if W.stride(0) != K or W.shape[1] != K:
+        raise ValueError("gemm_ln: W must be a contiguous [N, K] matrix")
+    _vec(bias, F32, N, "bias"), _vec(gamma, F32, N, "gamma"), _vec(beta, F32, N, "beta")
+    if res is not None:
+        _mat(res, BF16, "res")
+    if xhat is not None:
+        _mat(xhat, BF16, "xhat")
+        assert xhat.stride(0) == N
+    if pre is not None:
+        _mat(pre, BF16, "pre")
+        assert pre.stride(0) == N
+    _vec(rstd, F32, M, "rstd")
+    if pe is not None:
+        _mat(pe, F32, "pe")
+        assert pe.stride(0) == N
+        _vec(pos, I32, M, "pos")
+    rc = load().st_gemm_ln(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), M, N, K, bias.data_ptr(), _p(res),
+                           0 if res is None else res.stride(0), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                           int(relu), _p(pe), _p(pos), out.data_ptr(), out.stride(0), _p(xhat), _p(rstd), _p(pre))
+    _check(rc, "st_gemm_ln")
+    return out
+
+
+def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None):
+    _mat(dy, BF16, "dy"), _mat(xhat, BF16, "xhat"), _mat(dx, BF16, "dx")
+    M, N = dy.shape
+    assert xhat.stride(0) == N
+    if mask is not None:
+        _mat(mask, BF16, "mask")
+        assert mask.stride(0) == N
+    _vec(rstd, F32, M, "rstd"), _vec(gamma, F32, N, "gamma")
+    _vec(dgamma, F32, N, "dgamma"), _vec(dbeta, F32, N, "dbeta"), _vec(dbias, F32, N, "dbias")
+    rc = load().st_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                          _p(mask), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias), M, N)
+    _check(rc, "st_ln_bwd")
+    return dx
+
+
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale):
+    for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
+        _mat(t, BF16, nm)
+    B = q_off.numel()
+    d_k = Q.shape[1] // n_head
+    for t, nm in ((q_off, "q_off"), (q_len, "q_len"), (k_off, "k_off"), (k_len, "k_len")):
+        _vec(t, I32, B, nm)
+    rows = Q.shape[0]
+    _vec(lse, F32, n_head * rows, "lse")
+    rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
+                            O.data_ptr(), O.stride(0), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
+                            k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), rows, int(causal),
+                            float(scale))
+    _check(rc, "st_attn_fwd")
+    return O
+
+
+def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale):
+    for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
+        _mat(t, BF16, nm)
+    B = q_off.numel()
+    d_k = Q.shape[1] // n_head
+    rows = Q.shape[0]
+    _vec(lse, F32, n_head * rows, "lse"), _vec(delta, F32, n_head * rows, "delta")
+    rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
+                            O.data_ptr(), O.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(), delta.data_ptr(),
+                            dQ.data_ptr(), dQ.stride(0), dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0),
+                            q_off.data_ptr(), q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k,
+                            int(max_q), int(max_k), rows, int(causal), float(scale))
+    _check(rc, "st_attn_bwd")
+
+
+def colsum(x, out):
+    _mat(x, BF16, "x")
+    M, N = x.shape
+    _vec(out, F32, N, "out")
+    _check(load().st_colsum(_stream(), x.data_ptr(), x.stride(0), M, N, out.data_ptr()), "st_colsum")
+    return out
+
+
+def row_index(off, length, max_len, row_pos, row_seq=None):
+    B = off.numel()
+    _vec(off, I32, B, "off"), _vec(length, I32, B, "len")
+    _check(load().st_row_index(_stream(), off.data_ptr(), length.data_ptr(), B, int(max_len), row_pos.data_ptr(),
+                               _p(row_seq)), "st_row_index")
+    return row_pos
+
+
+def pack_rows(x, off, length, out):
+    if not (x.is_cuda and x.dtype == F32 and x.is_contiguous() and x.dim() == 3):
+        raise ValueError("pack_rows: x must be a contiguous fp32 [B, T, F] GPU tensor")
+    B, T, Fd = x.shape
+    _mat(out, BF16, "out")
+    assert out.stride(0) == Fd
+    _check(load().st_pack_rows(_stream(), x.data_ptr(), B, T, Fd, off.data_ptr(), length.data_ptr(), out.data_ptr()),
+           "st_pack_rows")
+    return out
+
+
+def unpack_rows(x, off, length, out):
+    _mat(x, BF16, "x")
+    B, T, D = out.shape
+    assert out.dtype == F32 and out.is_contiguous() and out.is_cuda
+    _check(load().st_unpack_rows(_stream(), x.data_ptr(), x.stride(0), B, T, D, off.data_ptr(), length.data_ptr(),
+                                 out.data_ptr()), "st_unpack_rows")
+    return out
+
+
+def pack_grad(g, off, length, out):
+    assert g.is_cuda and g.dtype == F32 and g.is_contiguous() and g.dim() == 3
+    B, T, D = g.shape
+    _mat(out, BF16, "out")
+    _check(load().st_pack_grad(_stream(), g.data_ptr(), B, T, D, off.data_ptr(), length.data_ptr(), out.data_ptr(),
+                               out.stride(0)), "st_pack_grad")
+    return out
+
+
+def embed_pe_fwd(tok, emb, pe, off, length, out):
+    assert tok.is_cuda and tok.dtype == I64 and tok.is_contiguous() and tok.dim() == 2
+    B, L = tok.shape
+    _mat(emb, F32, "emb"), _mat(pe, F32, "pe"), _mat(out, BF16, "out")
+    D = emb.shape[1]
+    assert emb.stride(0) == D and pe.stride(0) == D and out.stride(0) == D and pe.shape[0] >= L
+    _check(load().st_embed_pe_fwd(_stream(), tok.data_ptr(), B, L, emb.data_ptr(), pe.data_ptr(), D, off.data_ptr(),
+                                  length.data_ptr(), out.data_ptr()), "st_embed_pe_fwd")
+    return out
+
+
+def embed_bwd(tok, dy, off, length, pad_idx, demb):
+    assert tok.is_cuda and tok.dtype == I64 and tok.is_contiguous()
+    B, L = tok.shape
+    _mat(dy, BF16, "dy"), _mat(demb, F32, "demb")
+    D = demb.shape[1]
+    assert demb.stride(0) == D
+    _check(load().st_embed_bwd(_stream(), tok.data_ptr(), B, L, dy.data_ptr(), dy.stride(0), D, off.data_ptr(),
+                               length.data_ptr(), int(pad_idx), demb.data_ptr()), "st_embed_bwd")
+    return demb
+
+
+def cast_bf16(src, dst):
+    assert src.is_cuda and dst.is_cuda and src.dtype == F32 and dst.dtype == BF16
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    _check(load().st_cast_bf16(_stream(), src.data_ptr(), dst.data_ptr(), src.numel()), "st_cast_bf16")
+    return dst
+
+
+def probe_tr16(inp, out):
+    _check(load().st_probe_tr16(_stream(), inp.data_ptr(), out.data_ptr()), "st_probe_tr16")
+    return out
+
+
+def probe_mfma(A, Bt, D):
+    _check(load().st_probe_mfma(_stream(), A.data_ptr(), Bt.data_ptr(), D.data_ptr()), "st_probe_mfma")
+    return D

@@ -1,0 +1,118 @@
+"""Multi-head attention sub-layer backed by the fused gfx950 kernels.
+
+Drop-in for reference transformer/Attention.py:40-96 - same constructor,
+``forward(q, k, v, mask=None) -> (out, attns)`` and ``state_dict`` keys.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from st_amd import functional as F_
+from st_amd.arena import arena_of, bundle
+from transformer.Utils import LengthMask, lengths_from_mask
+
+
+class MultiHeadAttention(nn.Module):
+    """q/k/v projections, masked scaled-dot-product attention per head, output
+    projection, residual add and LayerNorm(eps=1e-6).
+
+    Differences from the reference, all documented in DESIGN.md:
+      * the residual is ``q`` (the reference writes ``+ v``, identical for
+        self-attention and ill-formed otherwise - repair R2);
+      * ``attns`` is ``None`` unless ``self.return_attn`` is set (the fused
+        kernel never materialises the [B, h, Lq, Lk] tensor; every caller in the
+        reference discards it, train.py:39);
+      * ``mask`` may be a :class:`LengthMask`; a dense mask is analysed back
+        into lengths (slow path);
+      * training-mode dropout (p > 0) is not implemented yet and raises.
+    """
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1):
+        super(MultiHeadAttention, self).__init__()
+        assert d_model % n_head == 0
+        assert d_k == d_model // n_head and d_v == d_model // n_head
+        self.n_head, self.d_model, self.d_k, self.d_v = n_head, d_model, d_k, d_v
+        self.scaled = math.sqrt(d_k)
+        self.linear_q = nn.Linear(d_model, n_head * d_k)
+        self.linear_k = nn.Linear(d_model, n_head * d_k)
+        self.linear_v = nn.Linear(d_model, n_head * d_v)
+        self.softmax = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.output_linear = nn.Linear(d_model, d_model)
+        self.layernorm = nn.LayerNorm(d_model, eps=1e-6)
+        self.return_attn = False
+
+    # ---- arena plumbing ----------------------------------------------------------------------
+    def _st_param_order(self):
+        return [self.linear_q.weight, self.linear_k.weight, self.linear_v.weight,
+                self.linear_q.bias, self.linear_k.bias, self.linear_v.bias,
+                self.output_linear.weight, self.output_linear.bias,
+                self.layernorm.weight, self.layernorm.bias]
+
+    def _st_bind(self, a):
+        d = self.d_model
+        if d % 64 != 0:
+            raise NotImplementedError("HIP path: d_model must be a multiple of 64")
+        q, k, o, ln = self.linear_q, self.linear_k, self.output_linear, self.layernorm
+        params = self._st_param_order()
+        lo, hi = a.span(params)
+        return bundle(
+            d_model=d, n_head=self.n_head, params=params, lo=lo, hi=hi,
+            w_qkv=a.bf16(q.weight, 3 * d), b_qkv=a.master(q.bias, 3 * d),
+            w_q=a.bf16(q.weight), b_q=a.master(q.bias),
+            w_kv=a.bf16(k.weight, 2 * d), b_kv=a.master(k.bias, 2 * d),
+            w_o=a.bf16(o.weight), b_o=a.master(o.bias), gamma=a.master(ln.weight), beta=a.master(ln.bias),
+            g_w_qkv=a.grad_view(q.weight, 3 * d), g_b_qkv=a.grad_view(q.bias, 3 * d),
+            g_w_q=a.grad_view(q.weight), g_b_q=a.grad_view(q.bias),
+            g_w_kv=a.grad_view(k.weight, 2 * d), g_b_kv=a.grad_view(k.bias, 2 * d),
+            g_w_o=a.grad_view(o.weight), g_b_o=a.grad_view(o.bias),
+            g_gamma=a.grad_view(ln.weight), g_beta=a.grad_view(ln.bias))
+
+    def _check_dropout(self):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("HIP path: training-mode dropout is not implemented yet; "
+                                      "build the model with dropout=0 or call .eval()")
+
+    # ---- fast path: bf16 row matrices ----------------------------------------------------------
+    def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal):
+        """x_q [Mq, d] (and x_kv [Mk, d] for cross-attention, else None) bf16 row matrices."""
+        self._check_dropout()
+        arena = arena_of(self)
+        with arena.scope():
+            return F_.MhaFn.apply(x_q, x_kv, self.linear_q.weight, self, q_rows, k_rows, bool(causal), False)
+
+    # ---- reference API -------------------------------------------------------------------------
+    def forward(self, q, k, v, mask=None):
+        if k is not v:
+            raise NotImplementedError("HIP path: key and value must be the same tensor (as in every reference call site)")
+        B, Lq, d = q.shape
+        Lk = k.shape[1]
+        dev = q.device
+        if mask is None:
+            k_len, causal = None, False
+        elif isinstance(mask, LengthMask):
+            k_len, causal = mask.k_len, mask.causal
+        else:
+            k_len, causal = lengths_from_mask(mask)
+        q_rows = F_.Rows.padded(B, Lq, dev)
+        k_rows = F_.Rows.padded(B, Lk, dev, k_len)
+        xq = q.reshape(B * Lq, d).to(torch.bfloat16)
+        xkv = None if k is q else k.reshape(B * Lk, d).to(torch.bfloat16)
+        out = self.forward_rows(xq, xkv, q_rows, k_rows, causal)
+        attns = self._dense_attn(q, k, k_rows, causal) if self.return_attn else None
+        return out.to(q.dtype).view(B, Lq, d), attns
+
+    @torch.no_grad()
+    def _dense_attn(self, q, k, k_rows, causal):
+        """Materialise the attention probabilities with plain torch ops on the GPU
+        (debug / visualisation only; not used by the training step)."""
+        B, Lq, _ = q.shape
+        Lk = k.shape[1]
+        qh = self.linear_q(q.float()).view(B, Lq, self.n_head, self.d_k).transpose(1, 2)
+        kh = self.linear_k(k.float()).view(B, Lk, self.n_head, self.d_k).transpose(1, 2)
+        s = torch.matmul(qh, kh.transpose(2, 3)) / self.scaled
+        dead = torch.arange(Lk, device=q.device).view(1, 1, 1, -1) >= k_rows.len.view(-1, 1, 1, 1)
+        if causal:
+            dead = dead | torch.ones(Lq, Lk, dtype=torch.bool, device=q.device).triu(1)
+        return torch.softmax(s.masked_fill(dead, float('-inf')), dim=-1)

@@ -1,0 +1,175 @@
+"""Encoder / Decoder / Transformer assembly (drop-in for reference transformer/Models.py).
+
+Same class names, constructor arguments, forward signatures, return arity and
+``state_dict`` keys as the reference; inside, utterances are packed into ragged
+bf16 row matrices once at the front-end and stay packed through every layer (no
+padded frame is ever multiplied), lengths replace the dense masks, and the
+positional-encoding add is fused into the front-end / embedding kernels.
+
+Decoder semantics follow the documented minimal repairs R3/R4 of the reference's
+unfinished ``Decoder.forward`` (embeddings PLUS positional
+encoding; masks from the length vectors; 2-tuple unpack).
+"""
+import torch
+import torch.nn as nn
+
+import transformer.Constants as Constants
+from st_amd import functional as F_
+from st_amd.arena import arena_of, bundle
+from transformer.Embedding import PositionalEncoding
+from transformer.Layers import EncoderLayer, DecoderLayer
+
+
+def _check_lengths(lengths, limit, what):
+    if int(lengths.min()) < 1:
+        raise ValueError("%s: every utterance needs length >= 1 (a fully masked softmax row is NaN in the reference)" % what)
+    if int(lengths.max()) > limit:
+        raise ValueError("%s: length %d exceeds the positional-encoding table (%d)" % (what, int(lengths.max()), limit))
+
+
+class Encoder(nn.Module):
+    """Linear+ReLU+Dropout+LayerNorm front-end, += PE, N x EncoderLayer (Models.py:14-56)."""
+
+    def __init__(self, input_size, n_max_seq, n_layers=6, n_head=8, d_k=64, d_v=64,
+                 d_model=512, d_inner_hid=1024, dropout=0.1, emb_scale=1):
+        super(Encoder, self).__init__()
+        self.n_max_seq, self.d_model, self.emb_scale = n_max_seq, d_model, emb_scale
+        self.position_enc = PositionalEncoding(dropout, d_model, self.n_max_seq)
+        # nn.Dropout() here is p=0.5 whatever the config says (reference Models.py:31)
+        self.input_proj = nn.Sequential(nn.Linear(input_size, d_model, bias=True), nn.ReLU(), nn.Dropout(),
+                                        nn.LayerNorm(d_model, eps=1e-6))
+        self.layer_stack = nn.ModuleList([
+            EncoderLayer(d_model, d_inner_hid, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
+
+    def _st_bind(self, a):
+        lin, ln = self.input_proj[0], self.input_proj[3]
+        params = [lin.weight, lin.bias, ln.weight, ln.bias]
+        lo, hi = a.span(params)
+        return bundle(d_model=self.d_model, front_params=params, front_lo=lo, front_hi=hi,
+                      pe=self.position_enc.pe[0],
+                      w_in=a.bf16(lin.weight), b_in=a.master(lin.bias), gamma_in=a.master(ln.weight),
+                      beta_in=a.master(ln.bias), g_w_in=a.grad_view(lin.weight), g_b_in=a.grad_view(lin.bias),
+                      g_gamma_in=a.grad_view(ln.weight), g_beta_in=a.grad_view(ln.bias))
+
+    def forward_rows(self, inputs, inputs_length):
+        """inputs [B, T, F] fp32 (zero past each length) -> (packed bf16 [sum(len), d], Rows)."""
+        if self.training:
+            raise NotImplementedError("HIP path: the front-end Dropout(p=0.5) of training mode (Models.py:31) is not "
+                                      "implemented yet; call .eval() (autograd still works - the parity mode)")
+        _check_lengths(inputs_length, min(self.n_max_seq, inputs.shape[1]), "Encoder")
+        arena = arena_of(self)
+        with arena.scope():
+            rows = F_.Rows.packed(inputs_length, inputs.device)
+            xp = F_.PackFn.apply(inputs.float(), rows)
+            e = F_.FrontendFn.apply(xp, self.input_proj[0].weight, self, rows)
+            for layer in self.layer_stack:
+                e = layer.forward_rows(e, rows)
+        return e, rows
+
+    def forward(self, inputs, inputs_length, return_attns=False):
+        if return_attns:
+            raise NotImplementedError("HIP path: attention maps are not materialised (return_attns must be falsy)")
+        e, rows = self.forward_rows(inputs, inputs_length)
+        return F_.UnpackFn.apply(e, rows, inputs.shape[1]), []
+
+
+class Decoder(nn.Module):
+    """Embedding + PE, N x DecoderLayer (Models.py:59-111 with repairs R3/R4)."""
+
+    def __init__(self, vocab_size, n_max_seq, n_layers=6, n_head=8, d_k=64, d_v=64,
+                 d_model=512, d_inner_hid=1024, dropout=0.1, emb_scale=1):
+        super(Decoder, self).__init__()
+        self.n_max_seq, self.output_dim, self.d_model, self.emb_scale = n_max_seq, vocab_size, d_model, emb_scale
+        self.position_enc = PositionalEncoding(dropout, d_model, self.n_max_seq)
+        self.tgt_word_emb = nn.Embedding(vocab_size, d_model, Constants.PAD)
+        self.layer_stack = nn.ModuleList([
+            DecoderLayer(d_model, d_inner_hid, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
+
+    def _st_bind(self, a):
+        emb = self.tgt_word_emb.weight
+        lo, hi = a.span([emb])
+        return bundle(d_model=self.d_model, pad_idx=Constants.PAD, emb_params=[emb], emb_lo=lo, emb_hi=hi,
+                      emb=a.master(emb), g_emb=a.grad_view(emb), pe=self.position_enc.pe[0])
+
+    def forward_rows(self, tokens, tgt_len, enc_rows_mat, in_rows):
+        _check_lengths(tgt_len, min(self.n_max_seq, tokens.shape[1]), "Decoder")
+        arena = arena_of(self)
+        with arena.scope():
+            t_rows = F_.Rows.packed(tgt_len, tokens.device)
+            y = F_.EmbedFn.apply(self.tgt_word_emb.weight, self, tokens.contiguous(), t_rows)
+            for layer in self.layer_stack:
+                y = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows)
+        return y, t_rows
+
+    def forward(self, outputs_data, outputs_pos, input_pos, enc_output, return_attns=False):
+        """outputs_data [B, L] tokens, outputs_pos [B] target lengths, input_pos [B]
+        input lengths, enc_output [B, T, d] -> (dec_output [B, L, d], [], [])."""
+        if return_attns:
+            raise NotImplementedError("HIP path: attention maps are not materialised (return_attns must be falsy)")
+        in_rows = F_.Rows.packed(input_pos, enc_output.device)
+        enc = F_.PackFn.apply(enc_output.float(), in_rows)
+        y, t_rows = self.forward_rows(outputs_data, outputs_pos, enc, in_rows)
+        return F_.UnpackFn.apply(y, t_rows, outputs_data.shape[1]), [], []
+
+
+class Transformer(nn.Module):
+    """encoder -> decoder -> bias-free vocabulary projection (Models.py:114-153).
+
+    ``config`` is attribute-style with the reference's keys (Models.py:120-143):
+    feature_dim, max_inputs_length (``max_input_length`` - the spelling the shipped
+    YAML uses - is accepted too), max_target_length, num_enc_layer, num_dec_layer,
+    n_heads, d_k, d_v, d_model, d_inner_hid, dropout, vocab_size, [emb_scale],
+    [return_attns].  Missing required keys raise instead of silently reading None.
+    """
+
+    def __init__(self, config):
+        super(Transformer, self).__init__()
+
+        def need(*names):
+            for n in names:
+                v = getattr(config, n, None) if not isinstance(config, dict) else config.get(n)
+                if v is not None:
+                    return v
+            raise KeyError("Transformer(config): missing required key %s" % "/".join(names))
+
+        def opt(name, default):
+            v = getattr(config, name, None) if not isinstance(config, dict) else config.get(name)
+            return default if v is None else v
+
+        self.return_attns = opt('return_attns', None)
+        common = dict(n_head=need('n_heads'), d_k=need('d_k'), d_v=need('d_v'), d_model=need('d_model'),
+                      d_inner_hid=need('d_inner_hid'), dropout=need('dropout'), emb_scale=opt('emb_scale', 1))
+        self.vocab_size, self.d_model = need('vocab_size'), common['d_model']
+        self.encoder = Encoder(input_size=need('feature_dim'), n_max_seq=need('max_inputs_length', 'max_input_length'),
+                               n_layers=need('num_enc_layer'), **common)
+        self.decoder = Decoder(vocab_size=self.vocab_size, n_max_seq=need('max_target_length'),
+                               n_layers=need('num_dec_layer'), **common)
+        self.tgt_word_proj = nn.Linear(self.d_model, self.vocab_size, bias=False)
+
+    def _st_row_padding(self):
+        return [(self.tgt_word_proj.weight, (self.vocab_size + 7) // 8 * 8)]
+
+    def _st_bind(self, a):
+        w = self.tgt_word_proj.weight
+        v_pad = (self.vocab_size + 7) // 8 * 8
+        lo, hi = a.span([w])
+        return bundle(v_pad=v_pad, vocab_params=[w], vocab_lo=lo, vocab_hi=hi,
+                      w_vocab=a.bf16(w, v_pad), g_w_vocab=a.grad_view(w, v_pad))
+
+    def forward(self, inputs, inputs_pos, targets=None, targets_pos=None):
+        """inputs [B, T, F]; inputs_pos [B] input lengths; targets [B, L] tokens;
+        targets_pos [B] target lengths (the current train.py:39 calling convention)
+        -> (seq_logit [B, L, V] fp32, ([], [], []))."""
+        if self.return_attns:
+            raise NotImplementedError("HIP path: attention maps are not materialised (config.return_attns must be falsy)")
+        arena = arena_of(self)
+        with arena.scope():
+            enc, in_rows = self.encoder.forward_rows(inputs, inputs_pos)
+            dec, t_rows = self.decoder.forward_rows(targets, targets_pos, enc, in_rows)
+            logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self)       # [sum(tgt_len), v_pad]
+        B, L = targets.shape
+        # scatter the ragged rows back to the padded [B, L, V] layout train.py:40 expects
+        seq = torch.repeat_interleave(torch.arange(B), t_rows.lens_host)
+        flat_idx = (seq * L + torch.cat([torch.arange(int(n)) for n in t_rows.lens_host])).to(logits.device)
+        padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, flat_idx, logits)
+        return padded.view(B, L, -1)[:, :, :self.vocab_size], ([], [], [])

@@ -1,0 +1,199 @@
+"""TEST-ONLY torch emulation of the C-ABI kernels (st_amd.native).
+
+The container that builds this repo has no GPU, so the *composition* of the
+kernels (st_amd.functional: which buffer feeds which GEMM, which gradient lands
+in which arena slot) is checked on CPU by swapping every native entry point for
+a plain-torch emulation with the same signature and the same bf16 storage
+rounding.  Nothing in the product imports this file; on a GPU box the real
+kernels run and are compared with the oracle directly (-m gpu tests).
+"""
+import contextlib
+import math
+
+import torch
+
+from st_amd import arena as st_arena
+from st_amd import native as nv
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1, m=None, n=None,
+         kc=None):
+    Xl = (X.t() if x_cmajor else X).float()      # logical [M, Kc]
+    Yl = (Y.t() if y_cmajor else Y).float()      # logical [N, Kc]
+    M = m if m is not None else Xl.shape[0]
+    N = n if n is not None else Yl.shape[0]
+    Kc = kc if kc is not None else Xl.shape[1]
+    Xl = torch.nn.functional.pad(Xl, (0, max(0, Kc - Xl.shape[1]), 0, max(0, M - Xl.shape[0])))[:M, :Kc]
+    Yl = torch.nn.functional.pad(Yl, (0, max(0, Kc - Yl.shape[1]), 0, max(0, N - Yl.shape[0])))[:N, :Kc]
+    acc = Xl @ Yl.t()
+    if bias is not None:
+        acc = acc + bias[:N]
+    if epi == nv.EPI_BF16_RELU:
+        acc = torch.relu(acc)
+    elif epi == nv.EPI_BF16_MASK:
+        acc = acc * (aux[:M, :N].float() > 0)
+    elif epi == nv.EPI_BF16_ADD:
+        acc = acc + aux[:M, :N].float()
+    if epi == nv.EPI_F32_ATOMIC:
+        out[:M, :N] += acc
+    else:
+        out[:M, :N] = acc.to(out.dtype)
+    return out
+
+
+def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None):
+    v = X.float() @ W.float().t() + bias
+    if relu:
+        v = torch.relu(v)
+    if res is not None:
+        v = v + res.float()
+    mu = v.mean(-1, keepdim=True)
+    var = ((v - mu) ** 2).mean(-1, keepdim=True)
+    rs = torch.rsqrt(var + eps)
+    h = (v - mu) * rs
+    y = h * gamma + beta
+    if pe is not None:
+        y = y + pe[pos.long()]
+    out.copy_(y.to(BF16))
+    if xhat is not None:
+        xhat.copy_(h.to(BF16))
+    if rstd is not None:
+        rstd.copy_(rs.squeeze(-1))
+    if pre is not None:
+        pre.copy_(v.to(BF16))
+    return out
+
+
+def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None):
+    d, xh = dy.float(), xhat.float()
+    g = d * gamma
+    v = rstd.unsqueeze(-1) * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    if mask is not None:
+        v = v * (mask.float() > 0)
+    dx.copy_(v.to(BF16))
+    if dgamma is not None:
+        dgamma += (d * xh).sum(0)
+    if dbeta is not None:
+        dbeta += d.sum(0)
+    if dbias is not None:
+        dbias += v.sum(0)
+    return dx
+
+
+def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h):
+    dk = Q.shape[1] // H
+    qo, ql, ko, kl = int(q_off[b]), int(q_len[b]), int(k_off[b]), int(k_len[b])
+    cs = slice(h * dk, (h + 1) * dk)
+    q = Q[qo:qo + ql, cs].float()
+    k = K[ko:ko + kl, cs].float()
+    v = V[ko:ko + kl, cs].float()
+    s = q @ k.t() * scale
+    if causal:
+        s = s.masked_fill(torch.ones(ql, kl, dtype=torch.bool).triu(1), float("-inf"))
+    return q, k, v, s, slice(qo, qo + ql), slice(ko, ko + kl), cs
+
+
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale):
+    rows = Q.shape[0]
+    for b in range(q_off.numel()):
+        for h in range(n_head):
+            q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h)
+            p = torch.softmax(s, -1)
+            O[qs, cs] = (p.to(BF16).float() @ v).to(BF16)
+            lse.view(n_head, rows)[h, qs] = torch.logsumexp(s, -1) / math.log(2.0)
+    return O
+
+
+def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale):
+    rows = Q.shape[0]
+    for b in range(q_off.numel()):
+        for h in range(n_head):
+            q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h)
+            p = torch.exp2(s / math.log(2.0) - lse.view(n_head, rows)[h, qs].unsqueeze(-1))
+            do, o = dO[qs, cs].float(), O[qs, cs].float()
+            dl = (do * o).sum(-1, keepdim=True)
+            delta.view(n_head, rows)[h, qs] = dl.squeeze(-1)
+            dp = do @ v.t()
+            ds = (p * (dp - dl)).to(BF16).float()
+            dQ[qs, cs] = (ds @ k * scale).to(BF16)
+            dK[ks, cs] = (ds.t() @ q * scale).to(BF16)
+            dV[ks, cs] = (p.to(BF16).float().t() @ do).to(BF16)
+
+
+def colsum(x, out):
+    out += x.float().sum(0)
+    return out
+
+
+def row_index(off, length, max_len, row_pos, row_seq=None):
+    for b in range(off.numel()):
+        n, o = int(length[b]), int(off[b])
+        row_pos[o:o + n] = torch.arange(n, dtype=row_pos.dtype)
+        if row_seq is not None:
+            row_seq[o:o + n] = b
+    return row_pos
+
+
+def pack_rows(x, off, length, out):
+    for b in range(off.numel()):
+        n, o = int(length[b]), int(off[b])
+        out[o:o + n] = x[b, :n].to(BF16)
+    return out
+
+
+def unpack_rows(x, off, length, out):
+    out.zero_()
+    for b in range(off.numel()):
+        n, o = int(length[b]), int(off[b])
+        out[b, :n] = x[o:o + n].float()
+    return out
+
+
+def pack_grad(g, off, length, out):
+    for b in range(off.numel()):
+        n, o = int(length[b]), int(off[b])
+        out[o:o + n] = g[b, :n].to(BF16)
+    return out
+
+
+def embed_pe_fwd(tok, emb, pe, off, length, out):
+    for b in range(off.numel()):
+        n, o = int(length[b]), int(off[b])
+        out[o:o + n] = (emb[tok[b, :n]] + pe[:n]).to(BF16)
+    return out
+
+
+def embed_bwd(tok, dy, off, length, pad_idx, demb):
+    for b in range(off.numel()):
+        n, o = int(length[b]), int(off[b])
+        ids = tok[b, :n]
+        keep = ids != pad_idx
+        demb.index_add_(0, ids[keep], dy[o:o + n][keep].float())
+    return demb
+
+
+def cast_bf16(src, dst):
+    dst.copy_(src.to(BF16))
+    return dst
+
+
+_NAMES = ["gemm", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16"]
+
+
+@contextlib.contextmanager
+def emulated_kernels():
+    """Swap st_amd.native's entry points for the emulations above (CPU tensors allowed)."""
+    saved = {n: getattr(nv, n) for n in _NAMES}
+    saved_req = st_arena.ParamArena._require_gpu
+    try:
+        for n in _NAMES:
+            setattr(nv, n, globals()[n])
+        st_arena.ParamArena._require_gpu = staticmethod(lambda dev: None)
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(nv, n, f)
+        st_arena.ParamArena._require_gpu = saved_req

@@ -1,0 +1,275 @@
+"""-m gpu: every C-ABI kernel, called through st_amd.native on a real MI355X,
+against a plain PyTorch fp32 reference of the same op (tests/_emul.py - the
+same functions the CPU composition test uses) on identical seeded inputs.
+
+Tolerances: operands are bf16 on both sides, accumulation is fp32 on both
+sides, so differences come from accumulation order and one bf16 rounding of the
+result: rel-L2 <= 1e-2 for bf16 outputs, <= 2e-3 for fp32 outputs / reductions.
+"""
+import math
+
+import pytest
+import torch
+
+from st_amd import native as nv
+from tests import _emul as em
+
+pytestmark = pytest.mark.gpu
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def check(got, ref, tol, what):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert torch.isfinite(got).all(), "%s: non-finite output" % what
+    r = rel(got, ref)
+    if r > tol:
+        err = (got - ref).abs()
+        idx = torch.nonzero(err == err.max())[0].tolist()
+        raise AssertionError("%s: rel-L2 %.3e > %.1e; max |err| %.4g at %s (got %.5g, ref %.5g)"
+                             % (what, r, tol, err.max().item(), idx, got[tuple(idx)].item(), ref[tuple(idx)].item()))
+
+
+def g(*shape, seed=0, scale=1.0, dtype=BF16):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=gen) * scale).to(dtype)
+
+
+def cu(t):
+    return None if t is None else t.cuda()
+
+
+# ---- hardware layout probes -----------------------------------------------------------------
+def test_probe_tr16_layout():
+    """ds_read_b64_tr_b16 fragment: lane l gets c = hi*8..hi*8+7 of row (l & 31) from a [c][row] tile.
+    Bit patterns (c*64 + row) travel through the read untouched, so the check is exact."""
+    tile = (torch.arange(16).view(16, 1) * 64 + torch.arange(64).view(1, 64)).to(torch.int16)
+    out = torch.zeros(64, 8, dtype=BF16, device="cuda")
+    nv.probe_tr16(tile.cuda().contiguous().view(BF16), out)
+    torch.cuda.synchronize()
+    exp = torch.zeros(64, 8, dtype=torch.int16)
+    for l in range(64):
+        for j in range(8):
+            exp[l, j] = ((l >> 5) * 8 + j) * 64 + (l & 31)
+    got = out.view(torch.int16).cpu()
+    assert torch.equal(got, exp), "tr16 fragment layout differs: got (c,row) per lane\n%s" % [
+        [(int(v) // 64, int(v) % 64) for v in got[l]] for l in (0, 1, 4, 16, 17, 32, 48)]
+
+
+def test_probe_mfma_layout():
+    A = g(32, 16, seed=1)
+    Bt = g(32, 16, seed=2)
+    D = torch.zeros(32, 32, dtype=F32, device="cuda")
+    nv.probe_mfma(A.cuda(), Bt.cuda(), D)
+    torch.cuda.synchronize()
+    check(D, A.float() @ Bt.float().t(), 1e-5, "mfma 32x32x16 layout (asymmetric operands)")
+
+
+# ---- GEMM family ---------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 256, 80), (1000, 768, 256), (257, 1024, 256), (77, 256, 1024)])
+@pytest.mark.parametrize("epi", [nv.EPI_BF16, nv.EPI_BF16_RELU, nv.EPI_F32])
+def test_gemm_forward(M, N, K, epi):
+    X, W, b = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5), g(N, seed=3, dtype=F32)
+    odt = F32 if epi == nv.EPI_F32 else BF16
+    ref = em.gemm(X, W, torch.zeros(M, N, dtype=odt), bias=b, epi=epi)
+    out = nv.gemm(cu(X), cu(W), torch.full((M, N), float("nan"), dtype=odt, device="cuda"), bias=cu(b), epi=epi)
+    check(out, ref, 2e-3 if epi == nv.EPI_F32 else 1e-2, "gemm fwd %s epi %d" % ((M, N, K), epi))
+
+
+def test_gemm_strided_operands():
+    """Operands / outputs that are column slices of wider matrices (the fused qkv buffer)."""
+    M, d = 500, 256
+    big = g(M, 3 * d, seed=4)
+    W = g(d, d, seed=5, scale=d ** -0.5)
+    outbig = torch.zeros(M, 2 * d, dtype=BF16)
+    ref = em.gemm(big[:, d:2 * d], W, outbig.clone()[:, d:], bias=None)
+    ob = cu(outbig)
+    nv.gemm(cu(big)[:, d:2 * d], cu(W), ob[:, d:])
+    check(ob[:, d:], ref, 1e-2, "gemm strided")
+    assert ob[:, :d].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 256, 1024), (333, 768, 256), (64, 4344, 256)])
+@pytest.mark.parametrize("epi", [nv.EPI_BF16, nv.EPI_BF16_MASK, nv.EPI_BF16_ADD])
+def test_gemm_dgrad(M, N, K, epi):
+    """dx[M,K] = dy[M,N] W[N,K] (W read contraction-major through the transposing LDS read)."""
+    dy, W = g(M, N, seed=1), g(N, K, seed=2, scale=N ** -0.5)
+    aux = g(M, K, seed=3) if epi != nv.EPI_BF16 else None
+    ref = em.gemm(dy, W, torch.zeros(M, K, dtype=BF16), aux=aux, epi=epi, y_cmajor=True)
+    out = nv.gemm(cu(dy), cu(W), torch.full((M, K), float("nan"), dtype=BF16, device="cuda"), aux=cu(aux), epi=epi,
+                  y_cmajor=True)
+    check(out, ref, 1e-2, "gemm dgrad %s epi %d" % ((M, N, K), epi))
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(256, 128, 128, 1), (1000, 256, 256, 4), (5000, 768, 256, 16),
+                                          (999, 1024, 256, 3), (2000, 256, 1024, 8), (1206, 4344, 256, 5),
+                                          (777, 256, 80, 2)])
+def test_gemm_wgrad(M, N, K, splits):
+    """dW[N,K] += dy[M,N]^T x[M,K]: both operands contraction-major, split-K with fp32 atomics."""
+    dy, x = g(M, N, seed=1), g(M, K, seed=2)
+    init = g(N, K, seed=3, dtype=F32)
+    ref = em.gemm(dy, x, init.clone(), epi=nv.EPI_F32_ATOMIC, x_cmajor=True, y_cmajor=True, m=N)
+    out = nv.gemm(cu(dy), cu(x), cu(init.clone()), epi=nv.EPI_F32_ATOMIC, x_cmajor=True, y_cmajor=True, splits=splits,
+                  m=N)
+    check(out, ref, 2e-3, "gemm wgrad %s" % ((M, N, K, splits),))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1000, 256, 256), (130, 256, 1024), (70, 512, 512), (500, 256, 80)])
+@pytest.mark.parametrize("variant", ["res", "relu_pe"])
+def test_gemm_ln(M, N, K, variant):
+    X, W = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5)
+    b, gamma, beta = g(N, seed=3, dtype=F32), 1 + 0.2 * g(N, seed=4, dtype=F32), 0.2 * g(N, seed=5, dtype=F32)
+    res = g(M, N, seed=6) if variant == "res" else None
+    pe = g(64, N, seed=7, dtype=F32) if variant == "relu_pe" else None
+    pos = (torch.arange(M) % 64).to(I32) if variant == "relu_pe" else None
+    relu = variant == "relu_pe"
+
+    def run(fn, dev):
+        mv = (lambda t: None if t is None else t.to(dev))
+        out, xhat, pre = (torch.zeros(M, N, dtype=BF16, device=dev) for _ in range(3))
+        rstd = torch.zeros(M, dtype=F32, device=dev)
+        fn(mv(X), mv(W), mv(b), mv(res), mv(gamma), mv(beta), out, xhat, rstd, eps=1e-6, relu=relu, pe=mv(pe),
+           pos=mv(pos), pre=pre)
+        return out, xhat, rstd, pre
+
+    r = run(em.gemm_ln, "cpu")
+    o = run(nv.gemm_ln, "cuda")
+    for got, ref, nm, tol in zip(o, r, ("out", "xhat", "rstd", "pre"), (1e-2, 1e-2, 2e-3, 1e-2)):
+        check(got, ref, tol, "gemm_ln %s %s %s" % ((M, N, K), variant, nm))
+
+
+@pytest.mark.parametrize("M,N", [(100, 128), (1000, 256), (333, 512), (5000, 256)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_ln_bwd(M, N, masked):
+    dy, xhat = g(M, N, seed=1), g(M, N, seed=2)
+    rstd, gamma = g(M, seed=3, dtype=F32).abs() + 0.5, 1 + 0.2 * g(N, seed=4, dtype=F32)
+    mask = g(M, N, seed=5) if masked else None
+
+    def run(fn, dev):
+        mv = (lambda t: None if t is None else t.to(dev))
+        dx = torch.zeros(M, N, dtype=BF16, device=dev)
+        acc = [torch.ones(N, dtype=F32, device=dev) for _ in range(3)]   # accumulate semantics
+        fn(mv(dy), mv(xhat), mv(rstd), mv(gamma), dx, acc[0], acc[1], acc[2], mask=mv(mask))
+        return [dx] + acc
+
+    r, o = run(em.ln_bwd, "cpu"), run(nv.ln_bwd, "cuda")
+    for got, ref, nm, tol in zip(o, r, ("dx", "dgamma", "dbeta", "dbias"), (1e-2, 3e-3, 3e-3, 5e-3)):
+        check(got, ref, tol, "ln_bwd %s masked=%s %s" % ((M, N), masked, nm))
+
+
+# ---- attention ---------------------------------------------------------------------------
+def _attn_case(B, H, dk, q_lens, k_lens, causal, packed, seed):
+    d = H * dk
+    self_attn = q_lens is None
+    ql = k_lens if self_attn else q_lens
+    if packed:
+        q_off = [sum(ql[:i]) for i in range(B)]
+        k_off = [sum(k_lens[:i]) for i in range(B)]
+        Mq, Mk = sum(ql), sum(k_lens)
+    else:
+        Tq, Tk = max(ql), max(k_lens)
+        q_off, k_off = [i * Tq for i in range(B)], [i * Tk for i in range(B)]
+        Mq, Mk = B * Tq, B * Tk
+    ti = lambda v: torch.tensor(v, dtype=I32)
+    if self_attn:
+        qkv = g(Mq, 3 * d, seed=seed)
+        Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    else:
+        Q = g(Mq, d, seed=seed)
+        kv = g(Mk, 2 * d, seed=seed + 1)
+        K, V = kv[:, :d], kv[:, d:]
+    dO = g(Mq, d, seed=seed + 2)
+    return dict(Q=Q, K=K, V=V, dO=dO, q_off=ti(q_off), q_len=ti(ql), k_off=ti(k_off), k_len=ti(k_lens), H=H,
+                max_q=max(ql), max_k=max(k_lens), causal=causal, scale=1 / math.sqrt(dk), Mq=Mq, Mk=Mk, d=d)
+
+
+ATTN_CASES = [
+    # B, H, dk, q_lens (None = self), k_lens, causal, packed
+    (2, 2, 32, None, [7, 4], False, True),
+    (2, 2, 32, None, [7, 4], True, True),
+    (3, 4, 64, None, [200, 131, 64], False, True),
+    (3, 4, 64, None, [200, 131, 64], False, False),
+    (2, 4, 64, None, [300, 257], True, True),
+    (2, 4, 32, None, [129, 1], True, True),
+    (2, 4, 64, [50, 33], [1000, 517], False, True),
+    (3, 4, 32, [10, 5, 8], [60, 31, 45], False, True),
+    (2, 4, 64, None, [1000, 640], False, True),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(case):
+    c = _attn_case(*case, seed=11)
+
+    def run(fwd, bwd, dev):
+        mv = lambda t: t.to(dev)
+        Q, K, V, dO = mv(c["Q"]), mv(c["K"]), mv(c["V"]), mv(c["dO"])
+        meta = [mv(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
+        O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
+        lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device=dev)
+        fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], c["causal"], c["scale"])
+        delta = torch.zeros_like(lse)
+        dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
+        dK, dV = (torch.zeros(c["Mk"], c["d"], dtype=BF16, device=dev) for _ in range(2))
+        bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, *meta, c["H"], c["max_q"], c["max_k"], c["causal"], c["scale"])
+        return O, lse, dQ, dK, dV
+
+    r = run(em.attn_fwd, em.attn_bwd, "cpu")
+    o = run(nv.attn_fwd, nv.attn_bwd, "cuda")
+    # rows outside every utterance (padded layout) are untouched zeros on both sides
+    for got, ref, nm, tol in zip(o, r, ("O", "lse", "dQ", "dK", "dV"), (1.5e-2, 2e-3, 2.5e-2, 2.5e-2, 2e-2)):
+        check(got, ref, tol, "attention %s %s" % (case, nm))
+
+
+def test_attention_softmax_rescale_branch():
+    """One key spiked against one query so the running max jumps in a late tile."""
+    c = _attn_case(1, 1, 64, None, [300], False, True, seed=5)
+    Q, K = c["Q"].clone(), c["K"].clone()
+    K[250] = Q[17] * 4.0
+    O = torch.zeros(300, 64, dtype=BF16)
+    lse = torch.zeros(300, dtype=F32)
+    meta = [c[k] for k in ("q_off", "q_len", "k_off", "k_len")]
+    em.attn_fwd(Q, K, c["V"], O, lse, *meta, 1, 300, False, c["scale"])
+    Og, lg = torch.zeros(300, 64, dtype=BF16, device="cuda"), torch.zeros(300, dtype=F32, device="cuda")
+    nv.attn_fwd(cu(Q), cu(K), cu(c["V"]), Og, lg, *[cu(m) for m in meta], 1, 300, False, c["scale"])
+    check(Og, O, 1.5e-2, "attention rescale O")
+    check(lg, lse, 2e-3, "attention rescale lse")
+
+
+# ---- streaming kernels ----------------------------------------------------------------------
+def test_misc_kernels():
+    B, T, Fd, D, L, V = 3, 50, 80, 128, 12, 30
+    lens, tl = torch.tensor([50, 20, 33]), torch.tensor([12, 5, 9])
+    off = torch.tensor([0, 50, 70], dtype=I32)
+    toff = torch.tensor([0, 12, 17], dtype=I32)
+    x = g(B, T, Fd, seed=1, dtype=F32)
+    rows = int(lens.sum())
+    for dev, mod in (("cpu", em), ("cuda", nv)):
+        mv = lambda t: t.to(dev)
+        out = torch.zeros(rows, Fd, dtype=BF16, device=dev)
+        mod.pack_rows(mv(x), mv(off), mv(lens.to(I32)), out)
+        back = torch.full((B, T, Fd), 7.0, dtype=F32, device=dev)
+        mod.unpack_rows(out, mv(off), mv(lens.to(I32)), back)
+        pg = torch.zeros(rows, Fd, dtype=BF16, device=dev)
+        mod.pack_grad(mv(x), mv(off), mv(lens.to(I32)), pg)
+        pos = torch.zeros(rows, dtype=I32, device=dev)
+        mod.row_index(mv(off), mv(lens.to(I32)), 50, pos)
+        tok = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(3))
+        emb, pe = g(V, D, seed=4, dtype=F32), g(L, D, seed=5, dtype=F32)
+        eo = torch.zeros(int(tl.sum()), D, dtype=BF16, device=dev)
+        mod.embed_pe_fwd(mv(tok), mv(emb), mv(pe), mv(toff), mv(tl.to(I32)), eo)
+        demb = torch.ones(V, D, dtype=F32, device=dev)
+        mod.embed_bwd(mv(tok), eo, mv(toff), mv(tl.to(I32)), 0, demb)
+        cs = torch.ones(Fd, dtype=F32, device=dev)
+        mod.colsum(out, cs)
+        sh = torch.zeros(V * D, dtype=BF16, device=dev)
+        mod.cast_bf16(mv(emb).view(-1), sh)
+        res = dict(pack=out, unpack=back, pack_grad=pg, pos=pos, embed=eo, demb=demb, colsum=cs, cast=sh)
+        if dev == "cpu":
+            ref = res
+    for k in ref:
+        check(res[k], ref[k], 3e-3 if k in ("demb", "colsum") else 1e-6, "misc %s" % k)
