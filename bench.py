@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py - frames/sec/step of the speech-transformer training step on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: 6 enc + 6 dec layers, d_model 256, 4 heads,
+d_ff 1024, vocab 4337, 80-d fbank, B = 32 utterances PER GPU, T <= 1000 frames,
+L <= 50 tokens (seeded synthetic batch of BASELINE.md section 3, resident in HBM).
+One step = zero_grad + forward + CE(ignore_index=0) + backward + [RCCL gradient
+average] + global-norm clip + Noam-Adam, i.e. train.py:37-46 / train_multi.py:58-68.
+bf16 activations / fp32 accumulate, fp32 master weights.  Dropout is OFF (eval-mode
+modules under autograd = the parity mode the CPU baseline is quoted in as well);
+training-mode dropout is not implemented in the HIP path yet and nothing is skipped
+to compensate: every FLOP of the dropout-free step is executed.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+``roofline`` (dominant kernel, live HIP-event timing) and ``cpu_baseline`` (the CPU
+oracle restatement timed on this box's host cores; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "speech-tranformer-pytorch_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+C2 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_layer=6, num_dec_layer=6, n_heads=4,
+          d_k=64, d_v=64, d_model=256, d_inner_hid=1024, dropout=0.0, vocab_size=4337)
+BATCH, T_MAX, L_MAX, T_MIN, L_MIN = 32, 1000, 50, 500, 25
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def step_flops(in_len, tgt_len, c):
+    """Algorithmic FLOPs of one step at the valid lengths."""
+    d, dff, F, V = c["d_model"], c["d_inner_hid"], c["feature_dim"], c["vocab_size"]
+    fwd = 0.0
+    for t, l in zip(in_len.tolist(), tgt_len.tolist()):
+        fwd += 2 * t * F * d + c["num_enc_layer"] * (8 * t * d * d + 4 * t * t * d + 4 * t * d * dff)
+        fwd += c["num_dec_layer"] * (8 * l * d * d + 4 * l * l * d + 4 * l * d * d + 4 * t * d * d + 4 * l * t * d
+                                     + 4 * l * d * dff) + 2 * l * d * V
+    return 3.0 * fwd
+
+
+def kernel_report(records):
+    """Aggregate per-launch HIP-event timings into kernel classes with algorithmic work."""
+    agg = {}
+    for name, tag, ms in records:
+        flops, kind = 0.0, name
+        if tag is not None:
+            if tag[0] == "gemm":
+                _, xt, yt, M, N, K, epi = tag
+                kind = {(0, 0): "gemm_fwd", (0, 1): "gemm_dgrad", (1, 1): "gemm_wgrad"}[(xt, yt)]
+                flops = 2.0 * M * N * K
+            elif tag[0] == "gemm_ln":
+                kind, flops = "gemm_ln", 2.0 * tag[1] * tag[2] * tag[3]
+            elif tag[0] in ("attn_fwd", "attn_bwd"):
+                H, dk, causal, ql, kl = tag[1:6]
+                pairs = float((ql.double() * kl.double()).sum().item())
+                if causal:
+                    pairs *= 0.5
+                flops = 4.0 * pairs * dk * H          # two contractions of the non-recomputed work per kernel
+                kind = "attn_fwd" if tag[0] == "attn_fwd" else {1: "attn_bwd_dq", 2: "attn_bwd_dkv", 3: "attn_bwd"}[tag[6]]
+            elif tag[0] == "ln_bwd":
+                kind = "ln_bwd"
+        a = agg.setdefault(kind, {"ms": 0.0, "launches": 0, "flops": 0.0})
+        a["ms"] += ms
+        a["launches"] += 1
+        a["flops"] += flops
+    return agg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
+    args = ap.parse_args()
+
+    import transformer.Models as M
+    import transformer.Utils as U
+    from transformer.Optim import ScheduledOptim
+    from st_amd import dp, native, synthetic
+    from st_amd.arena import arena_of
+    from st_amd.trainer import TrainStep
+
+    rank, local, world = dp.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    native.load(build_if_missing=False)
+
+    torch.manual_seed(0)
+    model = M.Transformer(U.AttrDict(C2))
+    U.init_parameters(model)                      # train.py:116
+    model = model.eval().cuda()                   # eval(): every Dropout is identity; autograd still runs
+    arena = arena_of(model)
+    dp.broadcast_parameters(arena)                # train_multi.py:176
+    reducer = dp.GradReducer(arena, wire_dtype=torch.bfloat16 if args.wire_bf16 else None) if world > 1 else None
+    optim = ScheduledOptim(model, C2["d_model"], U.AttrDict(n_warmup_steps=12000))
+    step = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer)
+
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"],
+                                                          seed=rank, t_min=T_MIN, l_min=L_MIN)
+    xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()          # inputs resident in HBM before timing
+
+    def run(n):
+        last = None
+        for _ in range(n):
+            last = step(xg, in_len, tg, tgt_len, gg)
+        return last
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    loss, gnorm = run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    frames = torch.tensor([float(in_len.sum())], device="cuda")
+    el = torch.tensor([elapsed], device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(frames, op=dist.ReduceOp.SUM)
+    elapsed, frames = el.item(), frames.item()
+    ms_step = elapsed / args.steps * 1e3
+
+    # ---- roofline pass: per-launch HIP events on the launch stream (outside the timed region) ----
+    native.timing_start()
+    run(2)
+    agg = kernel_report(native.timing_stop())
+    total_ms = sum(a["ms"] for a in agg.values())
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    d = agg[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // 2,
+                "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
+    kernels = {k: {"ms_per_step": round(v["ms"] / 2, 3), "launches": v["launches"] // 2,
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] else None}
+               for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+
+    out = None
+    if rank == 0:
+        flops = step_flops(in_len, tgt_len, C2)
+        out = {
+            "metric": "frames/sec/step (80-d fbank, 6+6L d256) at 1/2/4/8 MI355X vs CPU ref",
+            "value": round(frames * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 6+6L d256 h4 dff1024 V4337, 80-d fbank, B=32 per GPU, "
+                                   "T<=1000 (%d valid frames on rank 0), L<=50; fwd+CE+bwd+clip+Adam, dropout off"
+                                   % int(in_len.sum()),
+                       "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                       "wire": "bf16" if args.wire_bf16 else "fp32"},
+            "loss": round(loss.item(), 4), "grad_norm": round(gnorm.item(), 4),
+            "step_tflops_valid": round(flops / (ms_step * 1e-3) / 1e12, 2),
+            "step_frac_of_bf16_peak": round(flops / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "kernel_ms_per_step": round(total_ms / 2, 3),
+            "roofline": roofline, "kernels": kernels,
+        }
+
+    # ---- CPU baseline: the oracle restatement on this box's host cores (rank 0, N = 1 only) -------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle as orc
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        p = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        b = {"x": x, "in_len": in_len, "tokens": tokens, "tgt_len": tgt_len, "gt": gt}
+        times = []
+        for i in range(args.cpu_steps + 1):       # first step is the warm-up
+            t = time.perf_counter()
+            res = orc.train_step(p, b, C2["n_heads"], C2["d_model"], 12000, 1, 5.0)
+            times.append(time.perf_counter() - t)
+        med = sorted(times[1:])[len(times[1:]) // 2]
+        out["cpu_baseline"] = {"value": round(float(in_len.sum()) / med, 1), "unit": "frames/s", "cores": cores,
+                               "kind": "port", "sec_per_step": round(med, 3),
+                               "sample": "%d full config-2 steps (B=32, %d frames) of the oracle restatement, fp32, "
+                                         "dropout off, after 1 warm-up; loss %.4f" % (args.cpu_steps, int(in_len.sum()),
+                                                                                      res["loss"].item())}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,12 +79,13 @@ int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
                 int H, int d_k, int max_q, int q_rows_total, int causal, float scale);
 
 /* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
- * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch. */
+ * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:
+ * parts & 1 = dQ (also writes delta), parts & 2 = dK/dV (reads delta); 3 = both. */
 int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                 const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                 void* dK, int lddk, void* dV, int lddv, const int* q_off, const int* q_len, const int* k_off,
                 const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
-                float scale);
+                float scale, int parts);
 
 /* out[N] (f32) += column sums of x (bf16 [M, N]) - bias gradients. */
 int st_colsum(st_stream_t stream, const void* x, int ld, int M, int N, float* out);

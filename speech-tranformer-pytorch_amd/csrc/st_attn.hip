@@ -408,11 +408,11 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   dim3 block(256);
   dim3 gq((max_q + WG_ROWS - 1) / WG_ROWS, H, B), gk((max_k + WG_ROWS - 1) / WG_ROWS, H, B);
   if (d_k == 64) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, a);
+    if (parts & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, a);
+    if (parts & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, a);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), gq, block, 0, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<32>), gk, block, 0, stream, a);
+    if (parts & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), gq, block, 0, stream, a);
+    if (parts & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<32>), gk, block, 0, stream, a);
   }
   ST_CHECK_LAUNCH();
   return 0;

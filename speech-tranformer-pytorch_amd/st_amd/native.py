@@ -39,7 +39,7 @@ SIGNATURES = {
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float],
+                    _c_float, _c_int],
     "st_colsum": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
@@ -55,6 +55,52 @@ SIGNATURES = {
 }
 
 _LIB = None
+_TIMING = None   # list of (kernel name, tag, start event, end event) while bench.py profiles a step
+_TAG = None
+
+
+class _Timed:
+    """Per-launch HIP-event bracket on torch's current stream (the stream the kernels are
+    launched on); off unless ``timing_start()`` was called - bench.py's roofline pass."""
+
+    def __init__(self, name, fn):
+        self.name, self.fn = name, fn
+
+    def __call__(self, *args):
+        global _TAG
+        if _TIMING is None:
+            return self.fn(*args)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = self.fn(*args)
+        e.record()
+        _TIMING.append((self.name, _TAG, s, e))
+        _TAG = None
+        return rc
+
+
+class _Lib:
+    pass
+
+
+def timing_start() -> None:
+    global _TIMING
+    _TIMING = []
+
+
+def timing_stop():
+    """-> list of (name, tag, milliseconds); synchronises the device."""
+    global _TIMING
+    torch.cuda.synchronize()
+    out = [(n, t, s.elapsed_time(e)) for n, t, s, e in (_TIMING or [])]
+    _TIMING = None
+    return out
+
+
+def _tag(*info) -> None:
+    global _TAG
+    if _TIMING is not None:
+        _TAG = info
 
 
 def lib_path() -> str:
@@ -71,11 +117,14 @@ def load(build_if_missing: bool = True):
         if not build_if_missing:
             raise RuntimeError("libst_hip.so not built: run `python __graft_entry__.py` (build())")
         _build.build_lib()
-    lib = ctypes.CDLL(path)
+    cdll = ctypes.CDLL(path)
+    lib = _Lib()
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn = getattr(cdll, name)  # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _c_int
+        setattr(lib, name, _Timed(name, fn))
+    lib._cdll = cdll
     _LIB = lib
     return lib
 
@@ -132,6 +181,7 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
     if epi in (EPI_BF16_MASK, EPI_BF16_ADD):
         _mat(aux, BF16, "aux")
         ldaux = aux.stride(0)
+    _tag("gemm", int(x_cmajor), int(y_cmajor), M, N, Kc, epi)
     rc = load().st_gemm(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0),
                         out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux, epi, splits)
     _check(rc, "st_gemm")
@@ -158,6 +208,7 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
         _mat(pe, F32, "pe")
         assert pe.stride(0) == N
         _vec(pos, I32, M, "pos")
+    _tag("gemm_ln", M, N, K)
     rc = load().st_gemm_ln(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), M, N, K, bias.data_ptr(), _p(res),
                            0 if res is None else res.stride(0), gamma.data_ptr(), beta.data_ptr(), float(eps),
                            int(relu), _p(pe), _p(pos), out.data_ptr(), out.stride(0), _p(xhat), _p(rstd), _p(pre))
@@ -174,6 +225,7 @@ def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=
         assert mask.stride(0) == N
     _vec(rstd, F32, M, "rstd"), _vec(gamma, F32, N, "gamma")
     _vec(dgamma, F32, N, "dgamma"), _vec(dbeta, F32, N, "dbeta"), _vec(dbias, F32, N, "dbias")
+    _tag("ln_bwd", M, N)
     rc = load().st_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                           _p(mask), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias), M, N)
     _check(rc, "st_ln_bwd")
@@ -189,6 +241,7 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
         _vec(t, I32, B, nm)
     rows = Q.shape[0]
     _vec(lse, F32, n_head * rows, "lse")
+    _tag("attn_fwd", n_head, d_k, int(causal), q_len, k_len)
     rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
                             k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), rows, int(causal),
@@ -197,18 +250,26 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     return O
 
 
-def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale):
+def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
+             parts=3):
+    """parts: 1 = dQ (+delta) kernel, 2 = dK/dV kernel (needs delta from part 1), 3 = both."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
         _mat(t, BF16, nm)
     B = q_off.numel()
     d_k = Q.shape[1] // n_head
     rows = Q.shape[0]
     _vec(lse, F32, n_head * rows, "lse"), _vec(delta, F32, n_head * rows, "delta")
+    if _TIMING is not None and parts == 3:   # profile the two kernels of the call separately
+        for part in (1, 2):
+            attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal,
+                     scale, parts=part)
+        return
+    _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts)
     rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(), delta.data_ptr(),
                             dQ.data_ptr(), dQ.stride(0), dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0),
                             q_off.data_ptr(), q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k,
-                            int(max_q), int(max_k), rows, int(causal), float(scale))
+                            int(max_q), int(max_k), rows, int(causal), float(scale), int(parts))
     _check(rc, "st_attn_bwd")
 
 
