@@ -40,7 +40,8 @@ enum {
   ST_EPI_F32 = 2,        /* D(f32)  = acc (+ bias)          Models.py:151 (logits)   */
   ST_EPI_BF16_MASK = 3,  /* D(bf16) = acc * (aux > 0)       ReLU backward            */
   ST_EPI_BF16_ADD = 4,   /* D(bf16) = acc + aux             residual-gradient add    */
-  ST_EPI_F32_ATOMIC = 5  /* D(f32) += acc (atomic, split-K) weight gradients         */
+  ST_EPI_F32_ATOMIC = 5, /* D(f32) += acc (atomic, split-K)                          */
+  ST_EPI_F32_ATOMIC_T = 6 /* D^T(f32)[j][i] += acc: weight gradients, coalesced atomics */
 };
 
 /* D[i][j] = sum_c X(i,c) * Y(j,c), bf16 operands, fp32 accumulate (MFMA).
@@ -49,7 +50,8 @@ enum {
  * (Attention.py:74-76,92; SubLayers.py:25-26; Models.py:145,151 and their
  * autograd backward): forward (0,0), dgrad (0,1), wgrad (1,1).
  * M rows of X, N rows of Y, Kc contraction length; `splits` > 1 only with
- * ST_EPI_F32_ATOMIC. */
+ * ST_EPI_F32_ATOMIC / ST_EPI_F32_ATOMIC_T (the latter stores the transposed
+ * result: D is [N, ldd >= M]). */
 int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy, void* D,
             int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi, int splits);
 

@@ -394,7 +394,7 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
                            const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta,
                            void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int* q_off,
                            const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q,
-                           int max_k, int q_rows_total, int causal, float scale) {
+                           int max_k, int q_rows_total, int causal, float scale, int parts) {
   if (B <= 0 || H <= 0 || max_q <= 0 || max_k <= 0) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;

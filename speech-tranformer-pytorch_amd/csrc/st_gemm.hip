@@ -26,7 +26,8 @@ constexpr int NAT_STRIDE = BK + 8;  // 80 B rows: conflict-free ds_read_b128 for
 
 __host__ __device__ constexpr int cm_stride(int rows) { return rows >= 64 ? rows + 32 : rows; }
 
-enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_BF16_ADD = 4, EPI_F32_ATOMIC = 5 };
+enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_BF16_ADD = 4, EPI_F32_ATOMIC = 5,
+           EPI_F32_ATOMIC_T = 6 };
 
 // ---- global -> register staging of one operand tile -----------------------------------------
 // natural: tile [ROWS][BK]; contraction-major: tile [BK][ROWS].
@@ -143,6 +144,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
       sy.store(ys(cur ^ 1));
     }
     __syncthreads();
+  }
+
+  // ---- weight-gradient epilogue: D^T[j][i] += acc.  The lane index i is the CONTIGUOUS axis of
+  // the output, so every atomic instruction covers 2 x 128 contiguous bytes (coalesced L2 atomics).
+  if (a.epi == EPI_F32_ATOMIC_T) {
+    float* D = reinterpret_cast<float*>(a.D);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int i = i0 + (wm * 2 + x) * 32 + (l & 31);
+      if (i >= a.M) continue;
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + (wn * 2 + y) * 32 + acc_row(r, hi);
+          if (j < a.N) atomicAdd(D + (size_t)j * a.ldd + i, acc[x][y][r]);
+        }
+    }
+    return;
   }
 
   // ---- epilogue: lane owns row i, registers run over j ------------------------------------
@@ -340,14 +360,14 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
                        void* D, int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi,
                        int splits) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
-  if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 5) return -1;
+  if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 6) return -1;
   if (x_cmajor && !y_cmajor) return -2;  // not needed by any caller
   // contraction-major operands are read in 8-row chunks: the caller guarantees the buffer is
   // padded (ld >= round_up(rows, 8)); rows beyond M / N only feed outputs that are never stored.
   if ((x_cmajor && ldx < ((M + 7) & ~7)) || (y_cmajor && ldy < ((N + 7) & ~7))) return -3;
-  if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && (ldd & 3)) return -4;
+  if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && (ldd & 3)) return -4;
   if (splits < 1) splits = 1;
-  if (epi != EPI_F32_ATOMIC) splits = 1;
+  if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T) splits = 1;
   GemmArgs a;
   a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
   a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux; a.epi = epi;

@@ -2,7 +2,10 @@
 
 hipcc cross-compiles without a GPU, so this runs in the CPU-only build
 container; the resulting .so travels to the GPU box with the source tree.
+Staleness is decided by a content hash of csrc/ stored next to the library
+(file mtimes do not survive the copy to the GPU box).
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -11,21 +14,30 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB = os.path.join(LIBDIR, "libst_hip.so")
+STAMP = LIB + ".srchash"
 SOURCES = ["st_gemm.hip", "st_attn.hip", "st_misc.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-shared",
          "-Wno-unused-result"]
 
 
+def source_hash() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for name in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    """Compile the library if it is missing or older than its sources."""
+    """Compile the library if it is missing or was built from different sources."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -37,6 +49,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(source_hash())
     return LIB
 
 

@@ -76,10 +76,11 @@ def _splits(M: int, N: int, K: int) -> int:
 
 
 def wgrad(dY, X, gW, rows=None):
-    """gW[n][k] += sum_m dY[m][n] X[m][k]   (both operands contraction-major)."""
+    """gW[n][k] += sum_m dY[m][n] X[m][k]   (both operands contraction-major).  The kernel's
+    lane axis is k (the contiguous axis of gW) so the split-K atomics are coalesced."""
     N = dY.shape[1] if rows is None else rows
-    nv.gemm(dY, X, gW, epi=nv.EPI_F32_ATOMIC, x_cmajor=True, y_cmajor=True, splits=_splits(dY.shape[0], N, X.shape[1]),
-            m=N)
+    nv.gemm(X, dY, gW, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True,
+            splits=_splits(dY.shape[0], N, X.shape[1]), n=N)
 
 
 def dgrad(dY, W, out, epi=nv.EPI_BF16, aux=None, kc=None):

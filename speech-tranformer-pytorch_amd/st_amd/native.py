@@ -19,7 +19,7 @@ import torch
 
 from . import build as _build
 
-EPI_BF16, EPI_BF16_RELU, EPI_F32, EPI_BF16_MASK, EPI_BF16_ADD, EPI_F32_ATOMIC = range(6)
+EPI_BF16, EPI_BF16_RELU, EPI_F32, EPI_BF16_MASK, EPI_BF16_ADD, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T = range(7)
 
 _c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 
@@ -170,12 +170,13 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
          m=None, n=None, kc=None):
     """out[i][j] (+)= sum_c X(i,c) Y(j,c).  ``*_cmajor``: that tensor is stored [c, rows]."""
     _mat(X, BF16, "X"), _mat(Y, BF16, "Y")
-    _mat(out, F32 if epi in (EPI_F32, EPI_F32_ATOMIC) else BF16, "out")
+    _mat(out, F32 if epi in (EPI_F32, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T) else BF16, "out")
     M = m if m is not None else (X.shape[1] if x_cmajor else X.shape[0])
     N = n if n is not None else (Y.shape[1] if y_cmajor else Y.shape[0])
     Kc = kc if kc is not None else (X.shape[0] if x_cmajor else X.shape[1])
-    if out.shape[0] < M or out.shape[1] < N:
-        raise ValueError("gemm: out %s too small for %dx%d" % (tuple(out.shape), M, N))
+    need = (N, M) if epi == EPI_F32_ATOMIC_T else (M, N)
+    if out.shape[0] < need[0] or out.shape[1] < need[1]:
+        raise ValueError("gemm: out %s too small for %dx%d" % (tuple(out.shape), need[0], need[1]))
     _vec(bias, F32, N, "bias")
     ldaux = 0
     if epi in (EPI_BF16_MASK, EPI_BF16_ADD):

@@ -38,6 +38,8 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
         acc = acc + aux[:M, :N].float()
     if epi == nv.EPI_F32_ATOMIC:
         out[:M, :N] += acc
+    elif epi == nv.EPI_F32_ATOMIC_T:
+        out[:N, :M] += acc.t()
     else:
         out[:M, :N] = acc.to(out.dtype)
     return out

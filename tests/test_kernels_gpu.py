@@ -116,6 +116,10 @@ def test_gemm_wgrad(M, N, K, splits):
     out = nv.gemm(cu(dy), cu(x), cu(init.clone()), epi=nv.EPI_F32_ATOMIC, x_cmajor=True, y_cmajor=True, splits=splits,
                   m=N)
     check(out, ref, 2e-3, "gemm wgrad %s" % ((M, N, K, splits),))
+    # the production form: lane axis = k, transposed (coalesced) atomic store
+    out_t = nv.gemm(cu(x), cu(dy), cu(init.clone()), epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True,
+                    splits=splits, n=N)
+    check(out_t, ref, 2e-3, "gemm wgrad (transposed store) %s" % ((M, N, K, splits),))
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1000, 256, 256), (130, 256, 1024), (70, 512, 512), (500, 256, 80)])
