@@ -27,10 +27,18 @@ BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 LN_EPS = 1e-6  # Attention.py:62, SubLayers.py:18, Models.py:32
 
 
-class Rows:
-    """How utterances map onto the rows of an activation matrix."""
+_ROWS_CACHE = {}
 
-    __slots__ = ("B", "off", "len", "max_len", "total", "_pos", "lens_host", "dense")
+
+class Rows:
+    """How utterances map onto the rows of an activation matrix.
+
+    Building one costs two small host->device copies; pageable H2D copies block the host
+    until the stream drains, so layouts are cached by their length vector (a training
+    loader revisits the same bucket shapes, bench.py the same batch) and the model builds
+    every layout it needs BEFORE launching the first kernel of a step."""
+
+    __slots__ = ("B", "off", "len", "max_len", "total", "_pos", "lens_host", "dense", "_scatter")
 
     def __init__(self, off, length, max_len, total, lens_host=None, dense=True):
         self.dense = dense  # every row of the matrix belongs to some utterance (no padding rows)
@@ -38,20 +46,41 @@ class Rows:
         self.off, self.len = off, length
         self.max_len, self.total = int(max_len), int(total)
         self._pos = None
+        self._scatter = None
         self.lens_host = lens_host
 
     @staticmethod
     def packed(lengths: torch.Tensor, device) -> "Rows":
         """Ragged layout: utterance b owns rows cumsum(len)[b-1] ... (no padding rows)."""
         host = lengths.detach().to("cpu", torch.int64)  # one D2H copy if the lengths live on the GPU
+        key = ("packed", str(device), host.numpy().tobytes())
+        hit = _ROWS_CACHE.get(key)
+        if hit is not None:
+            return hit
         off = torch.zeros_like(host)
         off[1:] = torch.cumsum(host, 0)[:-1]
-        return Rows(off.to(device=device, dtype=I32), host.to(device=device, dtype=I32), int(host.max()),
-                    int(host.sum()), host)
+        r = Rows(off.to(device=device, dtype=I32), host.to(device=device, dtype=I32), int(host.max()),
+                 int(host.sum()), host)
+        if len(_ROWS_CACHE) > 256:
+            _ROWS_CACHE.clear()
+        _ROWS_CACHE[key] = r
+        return r
 
     @staticmethod
     def padded(B: int, T: int, device, lengths: Optional[torch.Tensor] = None) -> "Rows":
         """Padded layout: utterance b owns rows b*T ... b*T+len[b]-1 (len = T when not given)."""
+        key = ("padded", str(device), B, T, None if lengths is None else lengths.detach().cpu().numpy().tobytes())
+        hit = _ROWS_CACHE.get(key)
+        if hit is not None:
+            return hit
+        r = Rows._padded(B, T, device, lengths)
+        if len(_ROWS_CACHE) > 256:
+            _ROWS_CACHE.clear()
+        _ROWS_CACHE[key] = r
+        return r
+
+    @staticmethod
+    def _padded(B, T, device, lengths):
         off = torch.arange(B, dtype=I32, device=device) * T
         if lengths is None:
             ln = torch.full((B,), T, dtype=I32, device=device)
@@ -60,6 +89,18 @@ class Rows:
             host = lengths.detach().to("cpu", torch.int64)
             ln = host.to(device=device, dtype=I32)
         return Rows(off, ln, T, B * T, host, dense=lengths is None)
+
+    def scatter_index(self, L: int) -> torch.Tensor:
+        """Row b*L + t of a padded [B, L, *] tensor for every packed row (int64, on device)."""
+        key = ("scatter", L)
+        cache = getattr(self, "_scatter", None)
+        if cache is None or cache[0] != key:
+            lens = self.lens_host
+            seq = torch.repeat_interleave(torch.arange(self.B), lens)
+            idx = seq * L + torch.cat([torch.arange(int(n)) for n in lens])
+            cache = (key, idx.to(self.off.device))
+            self._scatter = cache
+        return cache[1]
 
     @property
     def pos(self) -> torch.Tensor:

@@ -51,7 +51,7 @@ class Encoder(nn.Module):
                       beta_in=a.master(ln.bias), g_w_in=a.grad_view(lin.weight), g_b_in=a.grad_view(lin.bias),
                       g_gamma_in=a.grad_view(ln.weight), g_beta_in=a.grad_view(ln.bias))
 
-    def forward_rows(self, inputs, inputs_length):
+    def forward_rows(self, inputs, inputs_length, rows=None):
         """inputs [B, T, F] fp32 (zero past each length) -> (packed bf16 [sum(len), d], Rows)."""
         if self.training:
             raise NotImplementedError("HIP path: the front-end Dropout(p=0.5) of training mode (Models.py:31) is not "
@@ -59,7 +59,9 @@ class Encoder(nn.Module):
         _check_lengths(inputs_length, min(self.n_max_seq, inputs.shape[1]), "Encoder")
         arena = arena_of(self)
         with arena.scope():
-            rows = F_.Rows.packed(inputs_length, inputs.device)
+            if rows is None:
+                rows = F_.Rows.packed(inputs_length, inputs.device)
+            rows.pos                                      # position table built before the first launch
             xp = F_.PackFn.apply(inputs.float(), rows)
             e = F_.FrontendFn.apply(xp, self.input_proj[0].weight, self, rows)
             for layer in self.layer_stack:
@@ -91,11 +93,12 @@ class Decoder(nn.Module):
         return bundle(d_model=self.d_model, pad_idx=Constants.PAD, emb_params=[emb], emb_lo=lo, emb_hi=hi,
                       emb=a.master(emb), g_emb=a.grad_view(emb), pe=self.position_enc.pe[0])
 
-    def forward_rows(self, tokens, tgt_len, enc_rows_mat, in_rows):
+    def forward_rows(self, tokens, tgt_len, enc_rows_mat, in_rows, t_rows=None):
         _check_lengths(tgt_len, min(self.n_max_seq, tokens.shape[1]), "Decoder")
         arena = arena_of(self)
         with arena.scope():
-            t_rows = F_.Rows.packed(tgt_len, tokens.device)
+            if t_rows is None:
+                t_rows = F_.Rows.packed(tgt_len, tokens.device)
             y = F_.EmbedFn.apply(self.tgt_word_emb.weight, self, tokens.contiguous(), t_rows)
             for layer in self.layer_stack:
                 y = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows)
@@ -163,13 +166,15 @@ class Transformer(nn.Module):
         if self.return_attns:
             raise NotImplementedError("HIP path: attention maps are not materialised (config.return_attns must be falsy)")
         arena = arena_of(self)
-        with arena.scope():
-            enc, in_rows = self.encoder.forward_rows(inputs, inputs_pos)
-            dec, t_rows = self.decoder.forward_rows(targets, targets_pos, enc, in_rows)
-            logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self)       # [sum(tgt_len), v_pad]
         B, L = targets.shape
+        # every ragged layout (and its host->device copies) is set up before the first kernel launch
+        in_rows = F_.Rows.packed(inputs_pos, inputs.device)
+        t_rows = F_.Rows.packed(targets_pos, inputs.device)
+        flat_idx = t_rows.scatter_index(L)
+        with arena.scope():
+            enc, _ = self.encoder.forward_rows(inputs, inputs_pos, in_rows)
+            dec, _ = self.decoder.forward_rows(targets, targets_pos, enc, in_rows, t_rows)
+            logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self)       # [sum(tgt_len), v_pad]
         # scatter the ragged rows back to the padded [B, L, V] layout train.py:40 expects
-        seq = torch.repeat_interleave(torch.arange(B), t_rows.lens_host)
-        flat_idx = (seq * L + torch.cat([torch.arange(int(n)) for n in t_rows.lens_host])).to(logits.device)
         padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, flat_idx, logits)
         return padded.view(B, L, -1)[:, :, :self.vocab_size], ([], [], [])

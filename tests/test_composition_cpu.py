@@ -15,6 +15,12 @@ import oracle as orc
 from tests._emul import emulated_kernels
 
 
+# bf16 activations / fp32 accumulate against fp64 truth.  The reference itself under bf16 autocast
+# shows a per-tensor median of 3.5e-2; small decoder q/k projections, whose
+# gradient is a difference of nearly equal bf16-rounded terms (dP - delta), reach ~1e-1.
+GRAD_TOL_TENSOR, GRAD_TOL_MEDIAN, GRAD_TOL_GLOBAL = 1.5e-1, 4e-2, 3e-2
+
+
 def rel(a, b):
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
@@ -52,7 +58,7 @@ def run_c1_step(golden_dir, device):
         valid = (torch.arange(10).view(1, -1) < batch["tgt_len"].view(-1, 1))
         assert rel(logits[valid], truth["logits"][valid]) < 2e-2
         assert abs(loss.item() - truth["loss"].item()) < 2e-2 * truth["loss"].item()
-        bad = []
+        bad, rels, flat_g, flat_t = [], [], [], []
         for n, p in m.named_parameters():
             assert p.grad is not None, n
             g, t = p.grad.detach().cpu(), truth["grads"][n]
@@ -61,9 +67,14 @@ def run_c1_step(golden_dir, device):
                 # analytically zero; bf16 rounding of dK leaves noise well below the q-bias gradient scale
                 assert g.abs().max().item() < 2.5e-1 * truth["grads"][n.replace("linear_k", "linear_q")].abs().max().item() + 1e-6
                 continue
-            if rel(g, t) > 8e-2:
-                bad.append((n, rel(g, t)))
+            rels.append(rel(g, t))
+            flat_g.append(g.double().reshape(-1))
+            flat_t.append(t.double().reshape(-1))
+            if rels[-1] > GRAD_TOL_TENSOR:
+                bad.append((n, rels[-1]))
         assert not bad, bad
+        assert sorted(rels)[len(rels) // 2] < GRAD_TOL_MEDIAN, sorted(rels)[len(rels) // 2]
+        assert rel(torch.cat(flat_g), torch.cat(flat_t)) < GRAD_TOL_GLOBAL
         # the vocabulary slot is padded to a multiple of 8 rows in the arena; padding stays zero
         a = m._st_arena
         assert a.grad_view(m.tgt_word_proj.weight, 32)[30:].abs().max().item() == 0
