@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
+    ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
     args = ap.parse_args()
 
     import transformer.Models as M
@@ -143,7 +144,18 @@ def main():
     # ---- roofline pass: per-launch HIP events on the launch stream (outside the timed region) ----
     native.timing_start()
     run(2)
-    agg = kernel_report(native.timing_stop())
+    records = native.timing_stop()
+    agg = kernel_report(records)
+    if args.dump_kernels and rank == 0:
+        shapes = {}
+        for name, tag, ms in records:
+            key = name + ":" + ",".join(str(t) for t in (tag or ()) if not torch.is_tensor(t))
+            e = shapes.setdefault(key, [0, 0.0])
+            e[0] += 1
+            e[1] += ms
+        with open(args.dump_kernels, "w") as f:
+            json.dump({k: {"n": v[0] // 2, "avg_us": round(v[1] / v[0] * 1e3, 2), "ms_per_step": round(v[1] / 2, 4)}
+                       for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}, f, indent=1)
     total_ms = sum(a["ms"] for a in agg.values())
     dom = max(agg, key=lambda k: agg[k]["ms"])
     d = agg[dom]

@@ -14,7 +14,8 @@ namespace {
 // (dbias is the bias gradient of the Linear that feeds the LN: same column sum, free here.)
 // `mask` (optional, bf16 [M,N]): dx is zeroed where mask <= 0 - the ReLU that sits between the
 // Linear and the LN in the encoder front-end (Models.py:28-33).
-// One wave per row; each lane owns VPL = N/64 consecutive columns.
+// Each lane owns 8 consecutive columns (16-byte loads); a row takes N/8 lanes, so a wave streams
+// 64 / (N/8) rows at a time and two such row groups are in flight per iteration.
 // ---------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, int lddy,
@@ -22,60 +23,75 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      const float* __restrict__ gamma, const bf16* __restrict__ mask,
                                                      bf16* __restrict__ dx, int lddx, float* dgamma, float* dbeta,
                                                      float* dbias, int M) {
-  constexpr int VPL = N / 64;
-  typedef bf16 vec_t __attribute__((ext_vector_type(VPL)));
-  __shared__ float red[3][4][N];
+  constexpr int LPR = N / 8;        // lanes per row
+  constexpr int RPW = 64 / LPR;     // rows per wave per pass
+  constexpr int UNR = 2;
+  __shared__ float red[3][4 * RPW][N];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int c0 = l * VPL;
-  float gm[VPL], ag[VPL], ab[VPL], ax[VPL];
+  const int slot = l / LPR, c0 = (l % LPR) * 8;
+  float gm[8], ag[8], ab[8], ax[8];
 #pragma unroll
-  for (int e = 0; e < VPL; ++e) { gm[e] = gamma[c0 + e]; ag[e] = ab[e] = ax[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { gm[e] = gamma[c0 + e]; ag[e] = ab[e] = ax[e] = 0.f; }
 
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const vec_t vdy = *reinterpret_cast<const vec_t*>(dy + (size_t)row * lddy + c0);
-    const vec_t vxh = *reinterpret_cast<const vec_t*>(xhat + (size_t)row * N + c0);
-    float g[VPL], xh[VPL], s1 = 0.f, s2 = 0.f;
+  const int stride = gridDim.x * 4 * RPW * UNR;
+  for (int base = (blockIdx.x * 4 + wave) * RPW * UNR; base < M; base += stride) {
+    bf16x8 vdy[UNR], vxh[UNR], vmk[UNR];
+    float rs[UNR];
+    bool ok[UNR];
 #pragma unroll
-    for (int e = 0; e < VPL; ++e) {
-      const float d = (float)vdy[e];
-      xh[e] = (float)vxh[e];
-      g[e] = d * gm[e];
-      s1 += g[e];
-      s2 += g[e] * xh[e];
-      ag[e] += d * xh[e];
-      ab[e] += d;
+    for (int u = 0; u < UNR; ++u) {
+      const int row = base + u * RPW + slot;
+      ok[u] = row < M;
+      vdy[u] = gload8(dy + (size_t)row * lddy + c0, ok[u]);
+      vxh[u] = gload8(xhat + (size_t)row * N + c0, ok[u]);
+      if (mask) vmk[u] = gload8(mask + (size_t)row * N + c0, ok[u]);
+      rs[u] = ok[u] ? rstd[row] : 0.f;
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      s1 += __shfl_xor(s1, o, 64);
-      s2 += __shfl_xor(s2, o, 64);
-    }
-    const float rs = rstd[row], m1 = s1 * (1.f / N), m2 = s2 * (1.f / N);
-    vec_t out, mk;
-    if (mask) mk = *reinterpret_cast<const vec_t*>(mask + (size_t)row * N + c0);
+    for (int u = 0; u < UNR; ++u) {
+      const int row = base + u * RPW + slot;
+      float g[8], xh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < VPL; ++e) {
-      float v = rs * (g[e] - m1 - xh[e] * m2);
-      if (mask && !((float)mk[e] > 0.f)) v = 0.f;   // ReLU in front of the LN (encoder front-end)
-      out[e] = (bf16)v;
-      ax[e] += v;
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)vdy[u][e];
+        xh[e] = (float)vxh[u][e];
+        g[e] = d * gm[e];
+        s1 += g[e];
+        s2 += g[e] * xh[e];
+        ag[e] += d * xh[e];
+        ab[e] += d;
+      }
+#pragma unroll
+      for (int o = LPR / 2; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      const float m1 = s1 * (1.f / N), m2 = s2 * (1.f / N);
+      bf16x8 out;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = rs[u] * (g[e] - m1 - xh[e] * m2);
+        if (mask && !((float)vmk[u][e] > 0.f)) v = 0.f;   // ReLU in front of the LN (encoder front-end)
+        out[e] = (bf16)v;
+        ax[e] += v;
+      }
+      if (ok[u]) *reinterpret_cast<bf16x8*>(dx + (size_t)row * lddx + c0) = out;
     }
-    *reinterpret_cast<vec_t*>(dx + (size_t)row * lddx + c0) = out;
   }
 #pragma unroll
-  for (int e = 0; e < VPL; ++e) {
-    red[0][wave][c0 + e] = ag[e];
-    red[1][wave][c0 + e] = ab[e];
-    red[2][wave][c0 + e] = ax[e];
+  for (int e = 0; e < 8; ++e) {
+    red[0][wave * RPW + slot][c0 + e] = ag[e];
+    red[1][wave * RPW + slot][c0 + e] = ab[e];
+    red[2][wave * RPW + slot][c0 + e] = ax[e];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < N; c += 256) {
-    const float g4 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    const float b4 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    const float x4 = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
-    if (dgamma) atomicAdd(dgamma + c, g4);
-    if (dbeta) atomicAdd(dbeta + c, b4);
-    if (dbias) atomicAdd(dbias + c, x4);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4 * RPW; ++k) { t0 += red[0][k][c]; t1 += red[1][k][c]; t2 += red[2][k][c]; }
+    if (dgamma) atomicAdd(dgamma + c, t0);
+    if (dbeta) atomicAdd(dbeta + c, t1);
+    if (dbias) atomicAdd(dbias + c, t2);
   }
 }
 
@@ -229,7 +245,8 @@ extern "C" int st_ln_bwd(hipStream_t stream, const void* dy, int lddy, const voi
                          float* dbias, int M, int N) {
   if (M <= 0) return 0;
   if ((lddy & 7) || (lddx & 7)) return -1;
-  int blocks = (M + 3) / 4;
+  const int rows_per_block = 4 * (64 / (N / 8)) * 2;
+  int blocks = (M + rows_per_block - 1) / rows_per_block;
   if (blocks > 1024) blocks = 1024;
 #define ST_LN_BWD(NN)                                                                                         \
   hipLaunchKernelGGL((ln_bwd_kernel<NN>), dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, lddy,          \

@@ -148,6 +148,22 @@ class ParamArena:
         for p in fresh:
             p.grad = self.grad_view(p)
 
+    def zero_grads(self) -> None:
+        """One memset over the whole gradient buffer, with every ``p.grad`` (re)attached -
+        the arena's ``optimizer.zero_grad()`` (train.py:37)."""
+        self.grad.zero_()
+        base = self.grad.data_ptr()
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * self.offset[id(p)]:
+                p.grad = self.grad_view(p)
+
+    def flat_parameter(self) -> nn.Parameter:
+        """The whole arena as ONE parameter (grad = the flat gradient buffer): lets the
+        optimiser update every weight with a single fused kernel."""
+        fp = nn.Parameter(self.flat, requires_grad=False)
+        fp.grad = self.grad
+        return fp
+
     def set_grad_ready_callback(self, cb) -> None:
         self._grad_ready_cb = cb
 
