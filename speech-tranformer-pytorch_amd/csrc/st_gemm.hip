@@ -21,62 +21,66 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int NAT_STRIDE = BK + 8;  // 80 B rows: conflict-free ds_read_b128 for 16 consecutive rows
+constexpr int BK = 64;  // contraction elements per LDS tile = one 128-byte row of a natural tile
 
-__host__ __device__ constexpr int cm_stride(int rows) { return rows >= 64 ? rows + 32 : rows; }
+#define ST_AS1 __attribute__((address_space(1)))
+
+__device__ __attribute__((aligned(16))) bf16 g_zero_chunk[8];  // zero-initialised source for padding lanes
 
 enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_BF16_ADD = 4, EPI_F32_ATOMIC = 5,
            EPI_F32_ATOMIC_T = 6 };
 
-// ---- global -> register staging of one operand tile -----------------------------------------
-// natural: tile [ROWS][BK]; contraction-major: tile [BK][ROWS].
-template <int ROWS, bool CM>
-struct Stage {
-  static constexpr int CHUNKS = ROWS * BK / 8;
-  static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
-  bf16x8 v[PER_THREAD];
-
-  __device__ __forceinline__ void load(const bf16* __restrict__ base, int ld, int row0, int nrows, int c0, int c_end) {
-#pragma unroll
-    for (int p = 0; p < PER_THREAD; ++p) {
-      const int id = threadIdx.x + p * 256;
-      if (CHUNKS % 256 != 0 && id >= CHUNKS) { v[p] = zero_bf8(); continue; }
-      if (!CM) {
-        const int r = id / (BK / 8), ch = id % (BK / 8);
-        const int row = row0 + r, c = c0 + ch * 8;
-        v[p] = gload8(base + (size_t)row * ld + c, row < nrows && c < c_end);
-      } else {
-        const int cr = id / (ROWS / 8), ch = id % (ROWS / 8);
-        const int c = c0 + cr, row = row0 + ch * 8;
-        v[p] = gload8(base + (size_t)c * ld + row, c < c_end && row < nrows);
-      }
-    }
-  }
-  __device__ __forceinline__ void store(bf16* tile) const {
-#pragma unroll
-    for (int p = 0; p < PER_THREAD; ++p) {
-      const int id = threadIdx.x + p * 256;
-      if (CHUNKS % 256 != 0 && id >= CHUNKS) continue;
-      if (!CM) {
-        const int r = id / (BK / 8), ch = id % (BK / 8);
-        *reinterpret_cast<bf16x8*>(tile + r * NAT_STRIDE + ch * 8) = v[p];
-      } else {
-        const int cr = id / (ROWS / 8), ch = id % (ROWS / 8);
-        *reinterpret_cast<bf16x8*>(tile + cr * cm_stride(ROWS) + ch * 8) = v[p];
-      }
-    }
-  }
-};
+// ---- operand tiles: HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), no VGPR staging --------------
+// One wave-instruction moves 64 x 16 bytes to wave_base + 16 * lane, so the LDS image is lane-linear
+// and the bank-conflict swizzle lives on the per-lane SOURCE address; fragment reads undo it with the
+// same XOR (an involution):
+//   natural  [ROWS][64] : 16-byte chunk p of row r   holds logical chunk p ^ ((r >> 1) & 7)
+//                         -> any 16 consecutive rows read conflict-free with ds_read_b128
+//   c-major  [64][ROWS] : chunk p of contraction row c holds logical chunk p ^ ((c & 3) << 2)
+//                         -> the 4 c-rows of a ds_read_b64_tr_b16 land in 4 different 64-byte bank groups
+// Lanes outside the matrix (row >= nrows or c >= c_end) read a 16-byte zero chunk instead.
+template <int ROWS>
+__host__ __device__ constexpr int tile_elems() { return ROWS * BK; }
 
 template <int ROWS, bool CM>
-__host__ __device__ constexpr int tile_elems() { return CM ? BK * cm_stride(ROWS) : ROWS * NAT_STRIDE; }
+__device__ __forceinline__ void issue_tile(bf16* tile, const bf16* __restrict__ base, int ld, int row0, int nrows,
+                                           int c0, int c_end) {
+  static_assert(ROWS % 32 == 0 && (!CM || ROWS == 128), "tile shape");
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;
+#pragma unroll
+  for (int t = 0; t < ROWS / 32; ++t) {
+    const int I = t * 4 + w;  // wave-instruction index: 1 KiB of the tile each
+    const bf16* src;
+    if (!CM) {
+      const int r = I * 8 + (i >> 3), p = i & 7;
+      const int row = row0 + r, c = c0 + 8 * (p ^ ((r >> 1) & 7));
+      src = (row < nrows && c < c_end) ? base + (size_t)row * ld + c : g_zero_chunk;
+    } else {
+      const int cr = I * 4 + (i >> 4), p = i & 15;
+      const int c = c0 + cr, row = row0 + 8 * (p ^ ((cr & 3) << 2));
+      src = (c < c_end && row < nrows) ? base + (size_t)c * ld + row : g_zero_chunk;
+    }
+    __builtin_amdgcn_global_load_lds((const ST_AS1 void*)src, (ST_LDS void*)(tile + I * 512), 16, 0, 0);
+  }
+}
 
+// Fragment (8 contraction elements kk*16 + hi*8 .. +7 of operand row blk_row0 + (lane & 31)).
 template <int ROWS, bool CM>
 __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int kk) {
   const int l = threadIdx.x & 63, hi = l >> 5;
-  if (!CM) return frag_nat(tile, NAT_STRIDE, blk_row0 + (l & 31), kk * 16 + hi * 8);
-  return frag_tr(tile, cm_stride(ROWS), blk_row0, kk * 16 + hi * 8, kk * 16 + hi * 8 + 4);
+  if (!CM) {
+    const int r = blk_row0 + (l & 31), q = kk * 2 + hi;
+    return *reinterpret_cast<const bf16x8*>(tile + r * BK + ((q ^ ((r >> 1) & 7)) << 3));
+  }
+  const int t = l & 15, col = blk_row0 + ((l >> 4) & 1) * 16 + 4 * (t & 3);
+  const int ca = kk * 16 + hi * 8 + (t >> 2);            // ca & 3 == t >> 2
+  const bf16* pa = tile + ca * ROWS + (((col >> 3) ^ ((t >> 2) << 2)) << 3) + (col & 7);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pa));
+  const bf16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pa + 4 * ROWS));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = up[0]; f[5] = up[1]; f[6] = up[2]; f[7] = up[3];
+  return f;
 }
 
 struct GemmArgs {
@@ -93,8 +97,8 @@ struct GemmArgs {
 template <bool XT, bool YT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   constexpr int BM = 128, BN = 128;
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (tile_elems<BM, XT>() + tile_elems<BN, YT>())];
-  constexpr int XE = tile_elems<BM, XT>(), YE = tile_elems<BN, YT>();
+  constexpr int XE = tile_elems<BM>(), YE = tile_elems<BN>();
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (XE + YE)];
   auto xs = [&](int buf) { return smem + buf * (XE + YE); };
   auto ys = [&](int buf) { return smem + buf * (XE + YE) + XE; };
 
@@ -110,21 +114,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
 
-  Stage<BM, XT> sx;
-  Stage<BN, YT> sy;
   const int nk = (c_end - c_begin + BK - 1) / BK;
   if (nk > 0) {
-    sx.load(a.X, a.ldx, i0, a.M, c_begin, c_end);
-    sy.load(a.Y, a.ldy, j0, a.N, c_begin, c_end);
-    sx.store(xs(0));
-    sy.store(ys(0));
+    issue_tile<BM, XT>(xs(0), a.X, a.ldx, i0, a.M, c_begin, c_end);
+    issue_tile<BN, YT>(ys(0), a.Y, a.ldy, j0, a.N, c_begin, c_end);
   }
-  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+    // The compiler drains this wave's LDS-DMA (vmcnt(0)) in front of the barrier: past it tile kt is
+    // visible to every wave and buffer cur^1 (read during iteration kt-1) is free again.
+    __syncthreads();
     if (kt + 1 < nk) {
-      sx.load(a.X, a.ldx, i0, a.M, c_begin + (kt + 1) * BK, c_end);
-      sy.load(a.Y, a.ldy, j0, a.N, c_begin + (kt + 1) * BK, c_end);
+      issue_tile<BM, XT>(xs(cur ^ 1), a.X, a.ldx, i0, a.M, c_begin + (kt + 1) * BK, c_end);
+      issue_tile<BN, YT>(ys(cur ^ 1), a.Y, a.ldy, j0, a.N, c_begin + (kt + 1) * BK, c_end);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -139,11 +141,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
     }
-    if (kt + 1 < nk) {
-      sx.store(xs(cur ^ 1));
-      sy.store(ys(cur ^ 1));
-    }
-    __syncthreads();
   }
 
   // ---- weight-gradient epilogue: D^T[j][i] += acc.  The lane index i is the CONTIGUOUS axis of
@@ -234,9 +231,11 @@ template <int N>
 __global__ __launch_bounds__(256) void gemm_ln_kernel(GemmLnArgs a) {
   constexpr int WN = N / 128, WM = 4 / WN, BM = 32 * WM;
   static_assert(N == 128 || N == 256 || N == 512, "d_model must be 128, 256 or 512");
-  constexpr int XE = tile_elems<BM, false>(), YE = tile_elems<N, false>();
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (XE + YE)];
-  __shared__ float red[2][WM][WN][32];
+  constexpr int XE = tile_elems<BM>(), YE = tile_elems<N>();
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (XE + YE)];
+  // cross-wave row statistics alias the tile buffers (used only after the k-loop; keeps N = 256 at
+  // 80 KiB of LDS = two workgroups per CU)
+  float (*red)[WM][WN][32] = reinterpret_cast<float (*)[WM][WN][32]>(smem);
   auto xs = [&](int buf) { return smem + buf * (XE + YE); };
   auto ys = [&](int buf) { return smem + buf * (XE + YE) + XE; };
 
@@ -248,19 +247,15 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(GemmLnArgs a) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) acc[b] = zero16();
 
-  Stage<BM, false> sx;
-  Stage<N, false> sy;
   const int nk = (a.K + BK - 1) / BK;
-  sx.load(a.X, a.ldx, i0, a.M, 0, a.K);
-  sy.load(a.W, a.K, 0, N, 0, a.K);
-  sx.store(xs(0));
-  sy.store(ys(0));
-  __syncthreads();
+  issue_tile<BM, false>(xs(0), a.X, a.ldx, i0, a.M, 0, a.K);
+  issue_tile<N, false>(ys(0), a.W, a.K, 0, N, 0, a.K);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+    __syncthreads();   // LDS-DMA of tile kt drained + visible; buffer cur^1 free (see gemm_kernel)
     if (kt + 1 < nk) {
-      sx.load(a.X, a.ldx, i0, a.M, (kt + 1) * BK, a.K);
-      sy.load(a.W, a.K, 0, N, (kt + 1) * BK, a.K);
+      issue_tile<BM, false>(xs(cur ^ 1), a.X, a.ldx, i0, a.M, (kt + 1) * BK, a.K);
+      issue_tile<N, false>(ys(cur ^ 1), a.W, a.K, 0, N, (kt + 1) * BK, a.K);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -271,13 +266,9 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(GemmLnArgs a) {
         acc[b] = mfma32(yf, xf, acc[b]);
       }
     }
-    if (kt + 1 < nk) {
-      sx.store(xs(cur ^ 1));
-      sy.store(ys(cur ^ 1));
-    }
-    __syncthreads();
   }
 
+  if (WN > 1) __syncthreads();   // every wave is done reading the tiles before `red` overwrites them
   const int i = i0 + wm * 32 + (l & 31);
   const bool row_ok = i < a.M;
   // v = act(acc + bias) + residual ; column of (b, r): wn*128 + b*32 + acc_row(r, hi)
