@@ -91,7 +91,8 @@ struct GemmArgs {
   const float* bias;      // [N] or null
   const bf16* aux; int ldaux;  // mask source (EPI_BF16_MASK) or addend (EPI_BF16_ADD)
   int epi;
-  int c_per_split;        // contraction elements per blockIdx.z
+  int c_per_split;        // contraction elements per split
+  int tiles_i, tiles_j, splits;
 };
 
 template <bool XT, bool YT>
@@ -102,8 +103,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   auto xs = [&](int buf) { return smem + buf * (XE + YE); };
   auto ys = [&](int buf) { return smem + buf * (XE + YE) + XE; };
 
-  const int j0 = blockIdx.x * BN, i0 = blockIdx.y * BM;
-  const int c_begin = blockIdx.z * a.c_per_split;
+  // 1-D grid; workgroup b runs on XCD b % 8 (each XCD has its own L2).  Forward / dgrad: the i-tile
+  // is the fastest index, so one XCD sees a fixed subset of X row-tiles for every j (X streams from
+  // HBM once and is re-read from that XCD's L2; the small weight operand is shared by all XCDs).
+  // Weight gradients: the split index is fastest, so the (i, j) tiles of one contraction range meet
+  // in the same L2.
+  int bid = blockIdx.x, ti, tj, ts;
+  if (a.splits > 1) { ts = bid % a.splits; bid /= a.splits; ti = bid % a.tiles_i; tj = bid / a.tiles_i; }
+  else { ts = 0; ti = bid % a.tiles_i; tj = bid / a.tiles_i; }
+  const int j0 = tj * BN, i0 = ti * BM;
+  const int c_begin = ts * a.c_per_split;
   const int c_end = min(a.Kc, c_begin + a.c_per_split);
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -366,7 +375,8 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   per = (per + BK - 1) / BK * BK;
   splits = (Kc + per - 1) / per;
   a.c_per_split = per;
-  dim3 grid((N + 127) / 128, (M + 127) / 128, splits), block(256);
+  a.tiles_i = (M + 127) / 128; a.tiles_j = (N + 127) / 128; a.splits = splits;
+  dim3 grid(a.tiles_i * a.tiles_j * splits), block(256);
   if (!x_cmajor && !y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, a);
   else if (!x_cmajor && y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, a);
