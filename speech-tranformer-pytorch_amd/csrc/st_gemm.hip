@@ -171,50 +171,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     return;
   }
 
-  // ---- epilogue: lane owns row i, registers run over j ------------------------------------
+  // ---- fp32 epilogues (logits, plain split-K): lane owns row i, registers run over j --------------
+  if (a.epi == EPI_F32 || a.epi == EPI_F32_ATOMIC) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int i = i0 + (wm * 2 + x) * 32 + (l & 31);
+      if (i >= a.M) continue;
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j = j0 + (wn * 2 + y) * 32 + 8 * g + 4 * hi;
+          if (j >= a.N) continue;
+          f32x4 v = {acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]};
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + j);
+          float* d = reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j;
+          if (a.epi == EPI_F32) *reinterpret_cast<f32x4*>(d) = v;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(d + e, v[e]);
+          }
+        }
+    }
+    return;
+  }
+
+  // ---- bf16 epilogues: the tile goes through LDS so that HBM sees whole 256-byte row segments ----
+  // (a row-per-lane accumulator stored directly is 64 scattered 8-byte writes per instruction and
+  // store-issue bound).  Row stride 136 elements: the 8-byte accumulator writes are <= 2-way
+  // conflicted, the 16-byte read-back is conflict-free.
+  constexpr int CS = BN + 8;
+  bf16* ct = smem;
+  __syncthreads();   // every wave is done with the operand tiles
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
-    const int i = i0 + (wm * 2 + x) * 32 + (l & 31);
-    if (i >= a.M) continue;
+    const int il = (wm * 2 + x) * 32 + (l & 31);
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
+    for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int j = j0 + (wn * 2 + y) * 32 + 8 * g + 4 * hi;
-        if (j >= a.N) continue;   // N is a multiple of 4 for every caller (8 for bf16 outputs)
+        const int jl = (wn * 2 + y) * 32 + 8 * g + 4 * hi;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[x][y][4 * g + e];
-        if (a.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + j);
+        if (a.bias && j0 + jl < a.N) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + j0 + jl);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
+          for (int e = 0; e < 4; ++e) v[e] += bb[e];
         }
-        if (a.epi == EPI_F32) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j) = o;
-        } else if (a.epi == EPI_F32_ATOMIC) {
-          float* d = reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j;
+        if (a.epi == EPI_BF16_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(d + e, v[e]);
-        } else {
-          if (a.epi == EPI_BF16_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (a.epi == EPI_BF16_MASK) {
-            const bf16x4 m = *reinterpret_cast<const bf16x4*>(a.aux + (size_t)i * a.ldaux + j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((float)m[e] > 0.f) ? v[e] : 0.f;
-          } else if (a.epi == EPI_BF16_ADD) {
-            const bf16x4 m = *reinterpret_cast<const bf16x4*>(a.aux + (size_t)i * a.ldaux + j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)m[e];
-          }
-          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = o;
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(ct + il * CS + jl) = o;
       }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < BM * BN / 8 / 256; ++p) {
+    const int id = p * 256 + threadIdx.x;
+    const int il = id / (BN / 8), jl = (id % (BN / 8)) * 8;
+    const int i = i0 + il, j = j0 + jl;
+    if (i >= a.M || j >= a.N) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + il * CS + jl);
+    if (a.epi == EPI_BF16_MASK) {
+      const bf16x8 m = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)i * a.ldaux + j);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((float)m[e] > 0.f) ? v[e] : (bf16)0.f;
+    } else if (a.epi == EPI_BF16_ADD) {
+      const bf16x8 m = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)i * a.ldaux + j);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)m[e]);
     }
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
   }
 }
 
@@ -365,7 +395,8 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   // contraction-major operands are read in 8-row chunks: the caller guarantees the buffer is
   // padded (ld >= round_up(rows, 8)); rows beyond M / N only feed outputs that are never stored.
   if ((x_cmajor && ldx < ((M + 7) & ~7)) || (y_cmajor && ldy < ((N + 7) & ~7))) return -3;
-  if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && (ldd & 3)) return -4;
+  if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && ((ldd & 7) || (N & 7))) return -4;
+  if ((epi == EPI_BF16_MASK || epi == EPI_BF16_ADD) && (ldaux & 7)) return -5;
   if (splits < 1) splits = 1;
   if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T) splits = 1;
   GemmArgs a;
