@@ -101,6 +101,30 @@ __device__ __forceinline__ bf16x8 pack_acc8(const f32x16& a, int r0) {
   return f;
 }
 
+// ---- LDS-DMA (global_load_lds) issued from inline asm -----------------------------------------
+// Lane i of the wave copies 16 (or 4) bytes from its own global address to LDS byte address
+// lds_dst + 16*i (4*i); lds_dst must be wave-uniform.  Issued through asm on purpose: hipcc knows
+// nothing about these loads, so it neither drains them (vmcnt(0)) in front of LDS reads / barriers nor
+// counts them - the kernels place counted s_waitcnt vmcnt(N) themselves (cdna_hip_programming 5.7).
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(__UINTPTR_TYPE__)(ST_LDS const char*)p;
+}
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// Make the compiler retire its own wait for an ordinary load HERE (a register use), so that it does
+// not place an s_waitcnt vmcnt(0) for it inside a loop that has asm LDS-DMA in flight.
+template <typename T> __device__ __forceinline__ void touch(T& v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
