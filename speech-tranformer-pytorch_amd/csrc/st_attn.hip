@@ -209,29 +209,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) s[kb] = mfma32(rd_nat<DK, SWZ_NAT>(ks, kb * 32 + (l & 31), t), qf[t], s[kb]);
     }
-    // mask + running max (log2 domain)
+    // The softmax arithmetic is the VALU critical path (the MFMAs of a tile take ~512 cycles, a
+    // naive per-element mask/scale/exp chain ~3000): masks only on tiles that cross a sequence end or
+    // the diagonal (wave-uniform test), scale folded into one fma feeding the raw v_exp_f32.
+    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + wave * 32);
+    if (!full) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt + kb * 32 + acc_row(r, hi);
+          if (key >= lk || (a.causal && key > q)) s[kb][r] = -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt + kb * 32 + acc_row(r, hi);
-        const bool dead = key >= lk || (a.causal && key > q);
-        const float v = dead ? -INFINITY : s[kb][r] * c2;
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, wave_xor32(mx));
-    const float m_new = fmaxf(m, mx);
+    const float m_new = fmaxf(m, mx * c2);           // log2 domain
     // m_new is finite from the first tile on (key 0 is visible to every query); guard anyway
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m - m_use);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[kb][r] - m_use);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c2, -m_use));
         s[kb][r] = p;
         psum += p;
       }
@@ -327,6 +333,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const bf16* ks = smem + (it % RING) * 2 * TE;
     const bf16* vs = ks + TE;
     const int kt = it * TILE;
+    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + wave * 32);   // no masks needed
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s = zero16(), dp = zero16();
@@ -335,12 +342,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         s = mfma32(rd_nat<DK, SWZ_NAT>(ks, kb * 32 + (l & 31), t), qf[t], s);
         dp = mfma32(rd_nat<DK, SWZ_NAT>(vs, kb * 32 + (l & 31), t), dof[t], dp);
       }
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt + kb * 32 + acc_row(r, hi);
-        const bool dead = key >= lk || (a.causal && key > q);
-        const float p = dead ? 0.f : exp2f(s[r] * c2 - lse_r);
-        s[r] = p * (dp[r] - dl);
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r)) * (dp[r] - dl);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt + kb * 32 + acc_row(r, hi);
+          const bool dead = key >= lk || (a.causal && key > q);
+          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r));
+          s[r] = p * (dp[r] - dl);
+        }
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
@@ -427,6 +439,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bf16* dos = qs + TE;
     const float* stat = reinterpret_cast<const float*>(qs + 2 * TE + wave * 256);   // [0..63] lse, [64..127] delta
     const int qt = q_begin + it * TILE;
+    // wave-uniform: every (query, key) pair of this tile x this wave's 32 keys is unmasked
+    const bool full = (qt + TILE <= lq) && (k0 + wave * 32 + 32 <= lk) && (!a.causal || k0 + wave * 32 + 31 <= qt);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s = zero16(), dp = zero16();
@@ -441,14 +455,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         const int ql = qb * 32 + 8 * g + 4 * hi;
         const f32x4 ls = *reinterpret_cast<const f32x4*>(stat + ql);
         const f32x4 dl = *reinterpret_cast<const f32x4*>(stat + 64 + ql);
+        if (full) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const int qq = qt + ql + e;
-          const bool dead = !k_ok || qq >= lq || (a.causal && key > qq);
-          const float pv = dead ? 0.f : exp2f(s[r] * c2 - ls[e]);
-          p[r] = pv;
-          s[r] = pv * (dp[r] - dl[e]);
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
+            p[r] = pv;
+            s[r] = pv * (dp[r] - dl[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const int qq = qt + ql + e;
+            const bool dead = !k_ok || qq >= lq || (a.causal && key > qq);
+            const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
+            p[r] = pv;
+            s[r] = pv * (dp[r] - dl[e]);
+          }
         }
       }
 #pragma unroll
