@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the individual C-ABI kernels at the config-2 shapes (development aid).
+
+Each kernel is launched N times back-to-back on one stream and timed with one event pair, so
+launch gaps are amortised; reports us/launch, algorithmic TFLOP/s and GB/s."""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "speech-tranformer-pytorch_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+from st_amd import native as nv  # noqa: E402
+from st_amd import synthetic  # noqa: E402
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+dev = "cuda"
+N_IT = int(os.environ.get("N_IT", "30"))
+
+
+def timeit(fn, n=N_IT):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+def rnd(*shape, dtype=BF16):
+    return (torch.randn(*shape, device=dev) * 0.5).to(dtype)
+
+
+def report(name, us, flops=0.0, nbytes=0.0):
+    print("%-44s %9.2f us  %8.1f TFLOP/s  %8.1f GB/s" % (name, us, flops / us / 1e6, nbytes / us / 1e3))
+
+
+_, _, in_len, tgt_len, _ = synthetic.make_batch(32, 1000, 50, 80, 4337, seed=0, t_min=500, l_min=25)
+M, Md = int(in_len.sum()), int(tgt_len.sum())
+d, dff, H = 256, 1024, 4
+which = sys.argv[1:] or ["gemm", "attn", "misc"]
+
+if "gemm" in which:
+    for (m, n, k, tag) in [(M, 768, 256, "qkv"), (M, 1024, 256, "ffn1"), (M, 512, 256, "kv"), (Md, 768, 256, "dec qkv"),
+                           (Md, 1024, 256, "dec ffn1")]:
+        X, W, b, out = rnd(m, k), rnd(n, k), rnd(n, dtype=F32), torch.empty(m, n, dtype=BF16, device=dev)
+        us = timeit(lambda: nv.gemm(X, W, out, bias=b, epi=nv.EPI_BF16_RELU))
+        report("fwd   %-8s [%d,%d]x[%d,%d]^T" % (tag, m, k, n, k), us, 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
+    for (m, n, k, tag) in [(M, 1024, 256, "dh=ds*W2"), (M, 256, 1024, "dx=dh*W1"), (M, 768, 256, "dx=dqkv*Wqkv"),
+                           (M, 256, 256, "dctx=ds*Wo"), (Md, 256, 1024, "dec dx=dh*W1")]:
+        # out[m, n] = dY[m, k] W[k, n]
+        dY, W, out, aux = rnd(m, k), rnd(k, n), torch.empty(m, n, dtype=BF16, device=dev), rnd(m, n)
+        us = timeit(lambda: nv.gemm(dY, W, out, aux=aux, epi=nv.EPI_BF16_ADD, y_cmajor=True))
+        report("dgrad %-14s [%d,%d]x[%d,%d]" % (tag, m, k, k, n), us, 2.0 * m * n * k, 2.0 * (m * k + n * k + 2 * m * n))
+    from st_amd.functional import _splits
+    for (m, n, k, tag) in [(M, 768, 256, "qkv"), (M, 1024, 256, "w1"), (M, 256, 1024, "w2"), (M, 256, 256, "wo"),
+                           (Md, 1024, 256, "dec w1")]:
+        dY, X, g = rnd(m, n), rnd(m, k), torch.zeros(n, k, dtype=F32, device=dev)
+        sp = _splits(m, n, k)
+        us = timeit(lambda: nv.gemm(X, dY, g, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=sp, n=n))
+        report("wgrad %-8s dW[%d,%d] m=%d s=%d" % (tag, n, k, m, sp), us, 2.0 * m * n * k, 2.0 * (m * n + m * k))
+    for (m, k, tag) in [(M, 256, "wo"), (M, 1024, "ffn2"), (Md, 256, "dec wo"), (Md, 1024, "dec ffn2")]:
+        X, W = rnd(m, k), rnd(d, k)
+        b, gm, bt = rnd(d, dtype=F32), rnd(d, dtype=F32), rnd(d, dtype=F32)
+        res, out, xh = rnd(m, d), torch.empty(m, d, dtype=BF16, device=dev), torch.empty(m, d, dtype=BF16, device=dev)
+        rstd = torch.empty(m, dtype=F32, device=dev)
+        us = timeit(lambda: nv.gemm_ln(X, W, b, res, gm, bt, out, xh, rstd))
+        report("gemm_ln %-8s [%d,%d]" % (tag, m, k), us, 2.0 * m * d * k, 2.0 * (m * k + 3 * m * d))
+
+if "attn" in which:
+    def offs(lens):
+        o = torch.zeros_like(lens)
+        o[1:] = torch.cumsum(lens, 0)[:-1]
+        return o.to(dev, I32), lens.to(dev, I32)
+
+    qo, ql = offs(in_len)
+    to, tl = offs(tgt_len)
+    scale = 1 / math.sqrt(64)
+    cases = [("enc self", M, M, qo, ql, qo, ql, int(in_len.max()), int(in_len.max()), False, True),
+             ("dec self causal", Md, Md, to, tl, to, tl, 50, 50, True, True),
+             ("cross", Md, M, to, tl, qo, ql, 50, int(in_len.max()), False, False)]
+    for name, mq, mk, q_off, q_len, k_off, k_len, maxq, maxk, causal, self_attn in cases:
+        if self_attn:
+            qkv = rnd(mq, 3 * d)
+            Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        else:
+            Q, kv = rnd(mq, d), rnd(mk, 2 * d)
+            K, V = kv[:, :d], kv[:, d:]
+        O, dO = torch.empty(mq, d, dtype=BF16, device=dev), rnd(mq, d)
+        lse, delta = torch.empty(H * mq, dtype=F32, device=dev), torch.empty(H * mq, dtype=F32, device=dev)
+        dQ = torch.empty(mq, d, dtype=BF16, device=dev)
+        dK, dV = torch.empty(mk, d, dtype=BF16, device=dev), torch.empty(mk, d, dtype=BF16, device=dev)
+        pairs = float((q_len.double() * k_len.double()).sum()) * (0.5 if causal else 1.0)
+        fl = 4.0 * pairs * d
+        us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale))
+        report("attn fwd  " + name, us, fl)
+        for part, nm in ((1, "dq "), (2, "dkv")):
+            us = timeit(lambda: nv.attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, H, maxq,
+                                            maxk, causal, scale, parts=part))
+            report("attn bwd %s " % nm + name, us, fl)
+
+if "misc" in which:
+    for m in (M, Md):
+        dy, xh, rs, gm = rnd(m, d), rnd(m, d), rnd(m, dtype=F32).abs() + 0.5, rnd(d, dtype=F32)
+        dx = torch.empty(m, d, dtype=BF16, device=dev)
+        a, b, c = (torch.zeros(d, dtype=F32, device=dev) for _ in range(3))
+        us = timeit(lambda: nv.ln_bwd(dy, xh, rs, gm, dx, a, b, c))
+        report("ln_bwd [%d,%d]" % (m, d), us, 0, 2.0 * 3 * m * d)
+    for (m, n) in ((M, 768), (M, 1024), (Md, 768)):
+        x, o = rnd(m, n), torch.zeros(n, dtype=F32, device=dev)
+        us = timeit(lambda: nv.colsum(x, o))
+        report("colsum [%d,%d]" % (m, n), us, 0, 2.0 * m * n)
