@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
+                                                            "the captured HIP graph of the step")
     args = ap.parse_args()
 
     import transformer.Models as M
@@ -110,7 +112,7 @@ def main():
     dp.broadcast_parameters(arena)                # train_multi.py:176
     reducer = dp.GradReducer(arena, wire_dtype=torch.bfloat16 if args.wire_bf16 else None) if world > 1 else None
     optim = ScheduledOptim(model, C2["d_model"], U.AttrDict(n_warmup_steps=12000))
-    step = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer)
+    step = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
 
     x, tokens, in_len, tgt_len, gt = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"],
                                                           seed=rank, t_min=T_MIN, l_min=L_MIN)
@@ -127,7 +129,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
+    run(max(args.warmup, 3 if not args.no_graph else 0))     # graph mode: 2 eager steps, then capture + first replay
     barrier()
     t0 = time.perf_counter()
     loss, gnorm = run(args.steps)
@@ -142,6 +144,7 @@ def main():
     ms_step = elapsed / args.steps * 1e3
 
     # ---- roofline pass: per-launch HIP events on the launch stream (outside the timed region) ----
+    step.use_graph = False                      # per-launch events need real launches, not a graph replay
     native.timing_start()
     run(2)
     records = native.timing_stop()
@@ -180,6 +183,7 @@ def main():
                                    "T<=1000 (%d valid frames on rank 0), L<=50; fwd+CE+bwd+clip+Adam, dropout off"
                                    % int(in_len.sum()),
                        "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                       "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
                        "wire": "bf16" if args.wire_bf16 else "fp32"},
             "loss": round(loss.item(), 4), "grad_norm": round(gnorm.item(), 4),
             "step_tflops_valid": round(flops / (ms_step * 1e-3) / 1e12, 2),

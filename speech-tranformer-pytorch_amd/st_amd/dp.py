@@ -178,6 +178,18 @@ class GradReducer:
             w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((w, g, None))
 
+    def detach(self) -> None:
+        """Stop firing from backward (HIP-graph mode: backward is a graph replay, the
+        all-reduces are issued explicitly with :meth:`reduce_all`)."""
+        self.arena.set_grad_ready_callback(None)
+
+    def reduce_all(self) -> None:
+        """All-reduce every bucket now (in production order) and finish the average."""
+        if self.world == 1:
+            return
+        self._fired = [False] * len(self.buckets)
+        self.synchronize()
+
     def synchronize(self) -> None:
         """Flush buckets that never filled, wait for every all-reduce and finish the
         average; afterwards ``arena.grad`` holds the rank-mean gradient."""

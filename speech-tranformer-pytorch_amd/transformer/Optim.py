@@ -1,4 +1,5 @@
 """Noam-scheduled Adam (drop-in for reference transformer/Optim.py:6-45)."""
+import torch
 import torch.optim as optim
 
 from transformer.Utils import learn_rate
@@ -19,8 +20,11 @@ class ScheduledOptim(object):
             # zero gradients and therefore never move.
             from st_amd.arena import arena_of
             self.arena = arena_of(model)
-            self.optimizer = optim.Adam([self.arena.flat_parameter()], lr=self.lr, betas=(0.9, 0.98), eps=1e-9,
-                                        fused=True)
+            # the rate lives in a device scalar and the step counter on the device (capturable), so the
+            # whole update can be replayed from a HIP graph while the Noam rate still changes per step
+            self.lr_tensor = torch.zeros((), dtype=torch.float32, device=self.arena.device)
+            self.optimizer = optim.Adam([self.arena.flat_parameter()], lr=self.lr_tensor, betas=(0.9, 0.98), eps=1e-9,
+                                        fused=True, capturable=True)
         else:
             self.optimizer = optim.Adam(params, lr=self.lr, betas=(0.9, 0.98), eps=1e-9)
         self.d_model = d_model
@@ -28,6 +32,10 @@ class ScheduledOptim(object):
 
     def step(self, global_step):
         self.update_learning_rate(global_step)
+        self.optimizer.step()
+
+    def step_captured(self):
+        """The update alone (rate already set with update_learning_rate) - what a HIP graph captures."""
         self.optimizer.step()
 
     def zero_grad(self):
@@ -44,5 +52,8 @@ class ScheduledOptim(object):
 
     def update_learning_rate(self, global_step):
         self.lr = learn_rate(self.d_model, self.n_warmup_steps, global_step)
+        if self.arena is not None:
+            self.lr_tensor.fill_(self.lr)
+            return
         for group in self.optimizer.param_groups:
             group['lr'] = self.lr
