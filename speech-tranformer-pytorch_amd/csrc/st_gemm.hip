@@ -9,28 +9,46 @@
 // transformer/Models.py:28-33,145):
 //   forward  y  = x W^T      : X = x  [M,K] natural,      Y = W  [N,K] natural
 //   dgrad    dx = dy W       : X = dy [M,N] natural,      Y = W  [N,K] contraction-major (c = n)
-//   wgrad    dW = dy^T x     : X = dy [M,N] contr.-major, Y = x  [M,K] contraction-major (c = m)
+//   wgrad    dW = dy^T x     : X = x  [M,K] contr.-major, Y = dy [M,N] contraction-major (c = m)
 // so no transposed copy of a weight or an activation is ever written to HBM.
 //
-// Tile: 128 x 128 x 32, 256 threads = 2 x 2 waves, each wave 64 x 64 = 2 x 2
-// v_mfma_f32_32x32x16_bf16 tiles.  The accumulator is kept TRANSPOSED (the
-// X-row index i is the lane, the Y-row index j runs over registers) so the
-// epilogue owns whole output rows per lane: 8-byte packed bf16 row stores and
-// lane-local LayerNorm statistics (st_gemm_ln).
+// Structure (why): every GEMM of this model has a short contraction (256..1024, or a split of
+// the token axis), so a 128x128 output tile needs only ~1 us of MFMA time while an HBM/L2 tile
+// fetch takes ~2 us under load - a tile-per-workgroup kernel with one tile of prefetch measured
+// 3x slower than its own MFMA + HBM bounds.  The kernels are therefore PERSISTENT (one
+// 512-thread workgroup per CU walking a list of output tiles) with the waves SPECIALISED:
+//   waves 4-7  loaders  : LDS-DMA (global_load_lds_dwordx4) of 128x64 operand tiles into a 4-slot
+//                         LDS ring, 3 (tile, k-step) items ahead - across output-tile boundaries;
+//                         they issue nothing else, so a counted s_waitcnt vmcnt(N) is exact;
+//   waves 0-3  consumers: 2x2 waves x (2x2 v_mfma_f32_32x32x16_bf16), epilogue from registers
+//                         through a wave-private LDS patch to coalesced 128-byte row segments.
+// One s_barrier per item orders ring slots between the two roles.  The accumulator is kept
+// TRANSPOSED (X row i on the lane, Y row j over registers): per-row LayerNorm statistics and
+// row-contiguous stores need no cross-lane traffic beyond one exchange with lane ^ 32.
 #include "st_common.cuh"
 
 namespace {
 
-constexpr int BK = 64;  // contraction elements per LDS tile = one 128-byte row of a natural tile
-
-#define ST_AS1 __attribute__((address_space(1)))
+constexpr int BK = 64;    // contraction elements per LDS tile = one 128-byte row of a natural tile
+constexpr int RING = 4;   // ring slots of st_gemm (3 items in flight)
 
 __device__ __attribute__((aligned(16))) bf16 g_zero_chunk[8];  // zero-initialised source for padding lanes
+__device__ __attribute__((aligned(16))) float g_zero_f32[4];   // stands in for an absent bias vector
 
 enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_BF16_ADD = 4, EPI_F32_ATOMIC = 5,
            EPI_F32_ATOMIC_T = 6 };
 
-// ---- operand tiles: HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), no VGPR staging --------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Loader wave: wait until at most `younger` items (IPW wave-instructions each) are still in flight.
+template <int IPW>
+__device__ __forceinline__ void wait_items(int younger) {
+  if (younger >= 2) wait_vmcnt<2 * IPW>();
+  else if (younger == 1) wait_vmcnt<IPW>();
+  else wait_vmcnt<0>();
+}
+
+// ---- operand tiles: HBM -> LDS by LDS-DMA, no VGPR staging ------------------------------------
 // One wave-instruction moves 64 x 16 bytes to wave_base + 16 * lane, so the LDS image is lane-linear
 // and the bank-conflict swizzle lives on the per-lane SOURCE address; fragment reads undo it with the
 // same XOR (an involution):
@@ -39,17 +57,18 @@ enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_
 //   c-major  [64][ROWS] : chunk p of contraction row c holds logical chunk p ^ ((c & 3) << 2)
 //                         -> the 4 c-rows of a ds_read_b64_tr_b16 land in 4 different 64-byte bank groups
 // Lanes outside the matrix (row >= nrows or c >= c_end) read a 16-byte zero chunk instead.
+// `lw` = index of the issuing wave among the 4 waves that share the tile (wave-uniform).
 template <int ROWS>
 __host__ __device__ constexpr int tile_elems() { return ROWS * BK; }
 
 template <int ROWS, bool CM>
 __device__ __forceinline__ void issue_tile(bf16* tile, const bf16* __restrict__ base, int ld, int row0, int nrows,
-                                           int c0, int c_end) {
+                                           int c0, int c_end, int lw) {
   static_assert(ROWS % 32 == 0 && (!CM || ROWS == 128), "tile shape");
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;
+  const int i = threadIdx.x & 63;
 #pragma unroll
   for (int t = 0; t < ROWS / 32; ++t) {
-    const int I = t * 4 + w;  // wave-instruction index: 1 KiB of the tile each
+    const int I = t * 4 + lw;  // wave-instruction index: 1 KiB of the tile each
     const bf16* src;
     if (!CM) {
       const int r = I * 8 + (i >> 3), p = i & 7;
@@ -60,7 +79,7 @@ __device__ __forceinline__ void issue_tile(bf16* tile, const bf16* __restrict__ 
       const int c = c0 + cr, row = row0 + 8 * (p ^ ((cr & 3) << 2));
       src = (c < c_end && row < nrows) ? base + (size_t)c * ld + row : g_zero_chunk;
     }
-    __builtin_amdgcn_global_load_lds((const ST_AS1 void*)src, (ST_LDS void*)(tile + I * 512), 16, 0, 0);
+    lds_dma16(src, lds_addr(tile + I * 512));
   }
 }
 
@@ -95,96 +114,99 @@ struct GemmArgs {
   int tiles_i, tiles_j, splits;
 };
 
+// ---- the (output tile, k-step) item stream of one persistent workgroup --------------------------
+// Tile order: forward / dgrad - the i-tile is the fastest index (neighbouring workgroups, which sit on
+// different XCDs, stream different X row-tiles against the same small weight tile); weight gradients -
+// the split index is fastest (the (i, j) tiles of one contraction range meet in time).
+struct Work {
+  int tile, kt, nk, i0, j0, c_begin, c_end;
+  bool valid;
+};
+
+__device__ __forceinline__ void work_load(Work& w, const GemmArgs& a, int total) {
+  w.valid = w.tile < total;
+  if (!w.valid) return;
+  int bid = w.tile, ts = 0;
+  if (a.splits > 1) { ts = bid % a.splits; bid /= a.splits; }
+  w.i0 = (bid % a.tiles_i) * 128;
+  w.j0 = (bid / a.tiles_i) * 128;
+  w.c_begin = ts * a.c_per_split;
+  w.c_end = min(a.Kc, w.c_begin + a.c_per_split);
+  w.nk = (w.c_end - w.c_begin + BK - 1) / BK;
+  w.kt = 0;
+}
+
+__device__ __forceinline__ void work_next(Work& w, const GemmArgs& a, int total) {
+  if (++w.kt >= w.nk) {
+    w.tile += gridDim.x;
+    work_load(w, a, total);
+  }
+}
+
 template <bool XT, bool YT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
-  constexpr int BM = 128, BN = 128;
-  constexpr int XE = tile_elems<BM>(), YE = tile_elems<BN>();
-  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (XE + YE)];
-  auto xs = [&](int buf) { return smem + buf * (XE + YE); };
-  auto ys = [&](int buf) { return smem + buf * (XE + YE) + XE; };
-
-  // 1-D grid; workgroup b runs on XCD b % 8 (each XCD has its own L2).  Forward / dgrad: the i-tile
-  // is the fastest index, so one XCD sees a fixed subset of X row-tiles for every j (X streams from
-  // HBM once and is re-read from that XCD's L2; the small weight operand is shared by all XCDs).
-  // Weight gradients: the split index is fastest, so the (i, j) tiles of one contraction range meet
-  // in the same L2.
-  int bid = blockIdx.x, ti, tj, ts;
-  if (a.splits > 1) { ts = bid % a.splits; bid /= a.splits; ti = bid % a.tiles_i; tj = bid / a.tiles_i; }
-  else { ts = 0; ti = bid % a.tiles_i; tj = bid / a.tiles_i; }
-  const int j0 = tj * BN, i0 = ti * BM;
-  const int c_begin = ts * a.c_per_split;
-  const int c_end = min(a.Kc, c_begin + a.c_per_split);
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  f32x16 acc[2][2];
+__device__ __forceinline__ void gemm_loader(const GemmArgs& a, bf16* ring, int lw, int total) {
+  constexpr int XE = tile_elems<128>(), SLOT = 2 * XE;
+  Work cur, ahead;
+  cur.tile = blockIdx.x;
+  work_load(cur, a, total);
+  ahead = cur;
+  int issued = 0, done = 0;
+  auto issue = [&]() {
+    bf16* slot = ring + (issued % RING) * SLOT;
+    const int c0 = ahead.c_begin + ahead.kt * BK;
+    issue_tile<128, XT>(slot, a.X, a.ldx, ahead.i0, a.M, c0, ahead.c_end, lw);
+    issue_tile<128, YT>(slot + XE, a.Y, a.ldy, ahead.j0, a.N, c0, ahead.c_end, lw);
+    ++issued;
+    work_next(ahead, a, total);
+  };
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
-
-  const int nk = (c_end - c_begin + BK - 1) / BK;
-  if (nk > 0) {
-    issue_tile<BM, XT>(xs(0), a.X, a.ldx, i0, a.M, c_begin, c_end);
-    issue_tile<BN, YT>(ys(0), a.Y, a.ldy, j0, a.N, c_begin, c_end);
+  for (int p = 0; p < RING - 1; ++p)
+    if (ahead.valid) issue();
+  while (cur.valid) {
+    wait_items<8>(issued - done - 1);   // item `done` has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();       // ... for every loader; consumers are done with item done-1
+    if (ahead.valid) issue();           // refill the slot item done-1 occupied
+    ++done;
+    work_next(cur, a, total);
   }
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    // The compiler drains this wave's LDS-DMA (vmcnt(0)) in front of the barrier: past it tile kt is
-    // visible to every wave and buffer cur^1 (read during iteration kt-1) is free again.
-    __syncthreads();
-    if (kt + 1 < nk) {
-      issue_tile<BM, XT>(xs(cur ^ 1), a.X, a.ldx, i0, a.M, c_begin + (kt + 1) * BK, c_end);
-      issue_tile<BN, YT>(ys(cur ^ 1), a.Y, a.ldy, j0, a.N, c_begin + (kt + 1) * BK, c_end);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 xf[2], yf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        xf[t] = read_frag<BM, XT>(xs(cur), (wm * 2 + t) * 32, kk);
-        yf[t] = read_frag<BN, YT>(ys(cur), (wn * 2 + t) * 32, kk);
-      }
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
-    }
-  }
+}
 
-  // ---- weight-gradient epilogue: D^T[j][i] += acc.  The lane index i is the CONTIGUOUS axis of
-  // the output, so every atomic instruction covers 2 x 128 contiguous bytes (coalesced L2 atomics).
+// Epilogue of one consumer wave: its 64 x 64 sub-tile at (i0 + wm*64, j0 + wn*64).
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const bf16x8 (&auxv)[8], int i0,
+                                              int j0, bf16* patch, int wm, int wn) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+  const int ib = i0 + wm * 64, jb = j0 + wn * 64;
   if (a.epi == EPI_F32_ATOMIC_T) {
+    // D^T[j][i] += acc: the lane index i is the CONTIGUOUS axis of the output, so every atomic
+    // instruction covers 2 x 128 contiguous bytes (coalesced L2 atomics).
     float* D = reinterpret_cast<float*>(a.D);
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-      const int i = i0 + (wm * 2 + x) * 32 + (l & 31);
+      const int i = ib + x * 32 + r;
       if (i >= a.M) continue;
 #pragma unroll
       for (int y = 0; y < 2; ++y)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = j0 + (wn * 2 + y) * 32 + acc_row(r, hi);
-          if (j < a.N) atomicAdd(D + (size_t)j * a.ldd + i, acc[x][y][r]);
+        for (int q = 0; q < 16; ++q) {
+          const int j = jb + y * 32 + acc_row(q, hi);
+          if (j < a.N) atomicAdd(D + (size_t)j * a.ldd + i, acc[x][y][q]);
         }
     }
     return;
   }
-
-  // ---- fp32 epilogues (logits, plain split-K): lane owns row i, registers run over j --------------
-  if (a.epi == EPI_F32 || a.epi == EPI_F32_ATOMIC) {
+  if (a.epi == EPI_F32 || a.epi == EPI_F32_ATOMIC) {   // logits / plain split-K: row-per-lane fp32
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-      const int i = i0 + (wm * 2 + x) * 32 + (l & 31);
+      const int i = ib + x * 32 + r;
       if (i >= a.M) continue;
 #pragma unroll
       for (int y = 0; y < 2; ++y)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int j = j0 + (wn * 2 + y) * 32 + 8 * g + 4 * hi;
+          const int j = jb + y * 32 + 8 * g + 4 * hi;
           if (j >= a.N) continue;
           f32x4 v = {acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]};
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + j);
+          v += *reinterpret_cast<const f32x4*>(a.bias ? a.bias + j : g_zero_f32);
           float* d = reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j;
           if (a.epi == EPI_F32) *reinterpret_cast<f32x4*>(d) = v;
           else {
@@ -195,57 +217,124 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
     return;
   }
-
-  // ---- bf16 epilogues: the tile goes through LDS so that HBM sees whole 256-byte row segments ----
-  // (a row-per-lane accumulator stored directly is 64 scattered 8-byte writes per instruction and
-  // store-issue bound).  Row stride 136 elements: the 8-byte accumulator writes are <= 2-way
-  // conflicted, the 16-byte read-back is conflict-free.
-  constexpr int CS = BN + 8;
-  bf16* ct = smem;
-  __syncthreads();   // every wave is done with the operand tiles
+  // bf16 outputs: registers -> wave-private [64][64] LDS patch (16-byte chunks XOR-swizzled by row)
+  // -> 128-byte row segments.  A row-per-lane accumulator stored directly is 64 scattered 8-byte
+  // writes per instruction and store-issue bound.
+  // Bias vectors first, branch-free and all in flight together (a load inside a per-vector `if` is
+  // followed by its own s_waitcnt vmcnt(0): 16 serialised L2 round trips per tile).
+  f32x4 bv[2][4];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j = jb + y * 32 + 8 * g + 4 * hi;
+      const float* src = (a.bias != nullptr && j < a.N) ? a.bias + j : g_zero_f32;
+      bv[y][g] = *reinterpret_cast<const f32x4*>(src);
+    }
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
-    const int il = (wm * 2 + x) * 32 + (l & 31);
+    const int il = x * 32 + r;
 #pragma unroll
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int jl = (wn * 2 + y) * 32 + 8 * g + 4 * hi;
+        const int jl = y * 32 + 8 * g + 4 * hi;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[x][y][4 * g + e];
-        if (a.bias && j0 + jl < a.N) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + j0 + jl);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bb[e];
-        }
+        for (int e = 0; e < 4; ++e) v[e] += bv[y][g][e];
         if (a.epi == EPI_BF16_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *reinterpret_cast<bf16x4*>(ct + il * CS + jl) = o;
+        *reinterpret_cast<bf16x4*>(patch + il * 64 + (((jl >> 3) ^ (il & 7)) << 3) + (jl & 7)) = o;
       }
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int p = 0; p < BM * BN / 8 / 256; ++p) {
-    const int id = p * 256 + threadIdx.x;
-    const int il = id / (BN / 8), jl = (id % (BN / 8)) * 8;
-    const int i = i0 + il, j = j0 + jl;
-    if (i >= a.M || j >= a.N) continue;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + il * CS + jl);
+  for (int p = 0; p < 8; ++p) {
+    const int id = p * 64 + l, rr = id >> 3, c = id & 7;
+    const int i = ib + rr, j = jb + c * 8;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rr * 64 + ((c ^ (rr & 7)) << 3));
     if (a.epi == EPI_BF16_MASK) {
-      const bf16x8 m = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)i * a.ldaux + j);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ((float)m[e] > 0.f) ? v[e] : (bf16)0.f;
+      for (int e = 0; e < 8; ++e) v[e] = ((float)auxv[p][e] > 0.f) ? v[e] : (bf16)0.f;
     } else if (a.epi == EPI_BF16_ADD) {
-      const bf16x8 m = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)i * a.ldaux + j);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)m[e]);
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)auxv[p][e]);
     }
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
+    if (i < a.M && j < a.N) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads retired before the next tile rewrites it
+}
+
+template <bool XT, bool YT>
+__device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* ring, bf16* patch, int wave, int total) {
+  constexpr int XE = tile_elems<128>(), SLOT = 2 * XE;
+  const int wm = wave >> 1, wn = wave & 1;
+  Work cur;
+  cur.tile = blockIdx.x;
+  work_load(cur, a, total);
+  f32x16 acc[2][2];
+  bf16x8 auxv[8];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) auxv[p] = zero_bf8();
+  const bool use_aux = a.epi == EPI_BF16_MASK || a.epi == EPI_BF16_ADD;
+  int f = 0;
+  while (cur.valid) {
+    if (use_aux && cur.kt == 0) {
+      // the mask / addend block of this wave's sub-tile: 8 coalesced 16-byte chunks per lane, requested
+      // at the first k-step so that their latency hides under the tile's MFMAs
+      const int l = threadIdx.x & 63;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int id = p * 64 + l, i = cur.i0 + wm * 64 + (id >> 3), j = cur.j0 + wn * 64 + (id & 7) * 8;
+        auxv[p] = gload8(a.aux + (size_t)i * a.ldaux + j, i < a.M && j < a.N);
+      }
+    }
+    __builtin_amdgcn_s_barrier();   // item f is in its slot
+    const bf16* xs = ring + (f % RING) * SLOT;
+    const bf16* ys = xs + XE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 xf[2], yf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        xf[t] = read_frag<128, XT>(xs, (wm * 2 + t) * 32, kk);
+        yf[t] = read_frag<128, YT>(ys, (wn * 2 + t) * 32, kk);
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
+    }
+    if (cur.kt == cur.nk - 1) {
+      gemm_epilogue(a, acc, auxv, cur.i0, cur.j0, patch, wm, wn);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+    }
+    ++f;
+    work_next(cur, a, total);
+  }
+}
+
+template <bool XT, bool YT>
+__global__ __launch_bounds__(512) void gemm_kernel(GemmArgs a) {
+  constexpr int SLOT = 2 * tile_elems<128>();
+  __shared__ __attribute__((aligned(1024))) bf16 smem[RING * SLOT + 4 * 4096];   // 128 KiB ring + 4 x 8 KiB patches
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int total = a.tiles_i * a.tiles_j * a.splits;
+  if (wave >= 4) gemm_loader<XT, YT>(a, smem, wave - 4, total);
+  else gemm_consumer<XT, YT>(a, smem, smem + RING * SLOT + wave * 4096, wave, total);
 }
 
 // ---- GEMM + bias (+ReLU) (+residual) + LayerNorm (+positional-encoding add) -------------------
@@ -264,62 +353,64 @@ struct GemmLnArgs {
   bf16* xhat;                 // normalised value (saved for backward), ld = N
   float* rstd;                // [M]
   bf16* pre;                  // optional: pre-LN value (front-end ReLU mask), ld = N
+  int tiles;                  // row tiles
 };
 
-template <int N>
-__global__ __launch_bounds__(256) void gemm_ln_kernel(GemmLnArgs a) {
-  constexpr int WN = N / 128, WM = 4 / WN, BM = 32 * WM;
-  static_assert(N == 128 || N == 256 || N == 512, "d_model must be 128, 256 or 512");
-  constexpr int XE = tile_elems<BM>(), YE = tile_elems<N>();
-  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (XE + YE)];
-  // cross-wave row statistics alias the tile buffers (used only after the k-loop; keeps N = 256 at
-  // 80 KiB of LDS = two workgroups per CU)
-  float (*red)[WM][WN][32] = reinterpret_cast<float (*)[WM][WN][32]>(smem);
-  auto xs = [&](int buf) { return smem + buf * (XE + YE); };
-  auto ys = [&](int buf) { return smem + buf * (XE + YE) + XE; };
+// Geometry: consumers are WM x WN waves, each 32 rows x 128 columns (4 MFMA tiles); BM = 32 * WM rows
+// per workgroup tile, all N columns.  N = 128: 4 x 1, N = 256: 2 x 2, N = 512: 1 x 4.
+template <int N> struct LnGeo {
+  static constexpr int WN = N / 128, WM = 4 / WN, BM = 32 * WM;
+  static constexpr int XE = BM * BK, YE = N * BK, SLOT = XE + YE;
+  static constexpr int IPW = BM / 32 + N / 32;   // LDS-DMA instructions per loader wave per item
+};
 
-  const int i0 = blockIdx.x * BM;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-
-  f32x16 acc[4];
+// Store a wave's [32 rows][128 cols] block of values (row-per-lane registers, column of (b, g, e) =
+// b*32 + 8g + 4hi + e) through its private LDS patch as 256-byte row segments.
+template <typename F>
+__device__ __forceinline__ void ln_store_block(bf16* patch, bf16* gbase, int ld, int nvalid_rows, F value) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] = zero16();
-
-  const int nk = (a.K + BK - 1) / BK;
-  issue_tile<BM, false>(xs(0), a.X, a.ldx, i0, a.M, 0, a.K);
-  issue_tile<N, false>(ys(0), a.W, a.K, 0, N, 0, a.K);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    __syncthreads();   // LDS-DMA of tile kt drained + visible; buffer cur^1 free (see gemm_kernel)
-    if (kt + 1 < nk) {
-      issue_tile<BM, false>(xs(cur ^ 1), a.X, a.ldx, i0, a.M, (kt + 1) * BK, a.K);
-      issue_tile<N, false>(ys(cur ^ 1), a.W, a.K, 0, N, (kt + 1) * BK, a.K);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const bf16x8 xf = read_frag<BM, false>(xs(cur), wm * 32, kk);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const bf16x8 yf = read_frag<N, false>(ys(cur), wn * 128 + b * 32, kk);
-        acc[b] = mfma32(yf, xf, acc[b]);
-      }
-    }
-  }
-
-  if (WN > 1) __syncthreads();   // every wave is done reading the tiles before `red` overwrites them
-  const int i = i0 + wm * 32 + (l & 31);
-  const bool row_ok = i < a.M;
-  // v = act(acc + bias) + residual ; column of (b, r): wn*128 + b*32 + acc_row(r, hi)
-  float sum = 0.f;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < 4; ++b)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int j = wn * 128 + b * 32 + 8 * g + 4 * hi;
+      const int jl = b * 32 + 8 * g + 4 * hi;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)value(b, 4 * g + e);
+      *reinterpret_cast<bf16x4*>(patch + r * 128 + (((jl >> 3) ^ (r & 15)) << 3) + (jl & 7)) = o;
+      if (g == 3) __builtin_amdgcn_sched_barrier(0);   // keep the per-column vector loads of one 32-column block together
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int id = p * 64 + l, rr = id >> 4, c = id & 15;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rr * 128 + ((c ^ (rr & 15)) << 3));
+    if (rr < nvalid_rows) *reinterpret_cast<bf16x8*>(gbase + (size_t)rr * ld + c * 8) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// The row-wise epilogue shared by the persistent and the simple kernel.  `acc` holds x W^T for rows
+// i_base + (lane & 31), columns wn*128 + ...; `resv` the 8 residual chunks this lane prefetched
+// (chunk id = p*64 + lane -> row id >> 4, 16-byte column chunk id & 15 of the wave's block).
+template <int N, typename SyncFn>
+__device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4], bool have_res, int i_base, int wm,
+                                            int wn, bf16* patch, float* red, SyncFn sync) {
+  constexpr int WN = LnGeo<N>::WN, WM = LnGeo<N>::WM;
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+  const int i = i_base + r;
+  const bool row_ok = i < a.M;
+  const int nvalid = min(32, a.M - i_base);
+  float sum = 0.f;   // (the residual block already sits in the patch: ln_stage_res)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int jl = b * 32 + 8 * g + 4 * hi, j = wn * 128 + jl;
       const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + j);
       bf16x4 rr = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-      if (a.res && row_ok) rr = *reinterpret_cast<const bf16x4*>(a.res + (size_t)i * a.ldres + j);
+      if (have_res) rr = *reinterpret_cast<const bf16x4*>(patch + r * 128 + (((jl >> 3) ^ (r & 15)) << 3) + (jl & 7));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = acc[b][4 * g + e] + bb[e];
@@ -329,59 +420,187 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(GemmLnArgs a) {
         sum += v;
       }
     }
-  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   sum += wave_xor32(sum);
   if (WN > 1) {
-    if (hi == 0) red[0][wm][wn][l & 31] = sum;
-    __syncthreads();
+    if (hi == 0) red[(wm * WN + wn) * 32 + r] = sum;
+    sync();
     sum = 0.f;
 #pragma unroll
-    for (int w = 0; w < WN; ++w) sum += red[0][wm][w][l & 31];
+    for (int w = 0; w < WN; ++w) sum += red[(wm * WN + w) * 32 + r];
   }
   const float mean = sum * (1.f / N);
   float sq = 0.f;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = acc[b][r] - mean;
+    for (int q = 0; q < 16; ++q) {
+      const float d = acc[b][q] - mean;
       sq += d * d;
     }
   sq += wave_xor32(sq);
   if (WN > 1) {
-    if (hi == 0) red[1][wm][wn][l & 31] = sq;
-    __syncthreads();
+    if (hi == 0) red[WM * WN * 32 + (wm * WN + wn) * 32 + r] = sq;
+    sync();
     sq = 0.f;
 #pragma unroll
-    for (int w = 0; w < WN; ++w) sq += red[1][wm][w][l & 31];
+    for (int w = 0; w < WN; ++w) sq += red[WM * WN * 32 + (wm * WN + w) * 32 + r];
   }
   const float rstd = rsqrtf(sq * (1.f / N) + a.eps);
-  if (!row_ok) return;
-  if (a.rstd && wn == 0 && hi == 0) a.rstd[i] = rstd;
-  const float* perow = (a.pe != nullptr) ? a.pe + (size_t)a.pos[i] * N : nullptr;
+  if (a.rstd && row_ok && wn == 0 && hi == 0) a.rstd[i] = rstd;
+  const float* perow = (a.pe != nullptr && row_ok) ? a.pe + (size_t)a.pos[i] * N + wn * 128 : nullptr;
+  const float* gm = a.gamma + wn * 128;
+  const float* bt = a.beta + wn * 128;
+  if (a.pre)
+    ln_store_block(patch, a.pre + (size_t)i_base * N + wn * 128, N, nvalid, [&](int b, int q) { return acc[b][q]; });
+  if (a.xhat)
+    ln_store_block(patch, a.xhat + (size_t)i_base * N + wn * 128, N, nvalid,
+                   [&](int b, int q) { return (acc[b][q] - mean) * rstd; });
+  ln_store_block(patch, a.out + (size_t)i_base * a.ldo + wn * 128, a.ldo, nvalid, [&](int b, int q) {
+    const int j4 = b * 32 + 8 * (q >> 2) + 4 * hi;   // the four e = q & 3 of one (b, g) share these vector loads
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gm + j4);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt + j4);
+    f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
+    if (perow) p4 = *reinterpret_cast<const f32x4*>(perow + j4);
+    return (acc[b][q] - mean) * rstd * g4[q & 3] + b4[q & 3] + p4[q & 3];
+  });
+}
+
+// Park the prefetched residual chunks in the wave's patch (row-per-lane reads in ln_epilogue).
+__device__ __forceinline__ void ln_stage_res(bf16* patch, const bf16x8 (&resv)[8]) {
+  const int l = threadIdx.x & 63;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int p = 0; p < 8; ++p) {
+    const int id = p * 64 + l, rr = id >> 4, c = id & 15;
+    *reinterpret_cast<bf16x8*>(patch + rr * 128 + ((c ^ (rr & 15)) << 3)) = resv[p];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Prefetch this lane's 8 residual chunks of the wave's [32][128] block (issued at the first k-step
+// of a tile so their latency hides under the tile's MFMAs).
+template <int N>
+__device__ __forceinline__ void ln_prefetch_res(const GemmLnArgs& a, bf16x8 (&resv)[8], int i_base, int wn) {
+  const int l = threadIdx.x & 63;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int j = wn * 128 + b * 32 + 8 * g + 4 * hi;
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + j);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(a.beta + j);
-      f32x4 pe = {0.f, 0.f, 0.f, 0.f};
-      if (perow) pe = *reinterpret_cast<const f32x4*>(perow + j);
-      bf16x4 xh, yo, pr;
+  for (int p = 0; p < 8; ++p) {
+    const int id = p * 64 + l, rr = id >> 4, c = id & 15;
+    resv[p] = gload8(a.res + (size_t)(i_base + rr) * a.ldres + wn * 128 + c * 8, i_base + rr < a.M);
+  }
+}
+
+// Persistent, wave-specialised version (N = 128, 256): 3-slot ring.
+template <int N>
+__global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs a) {
+  using G = LnGeo<N>;
+  constexpr int RL = 3;
+  __shared__ __attribute__((aligned(1024))) bf16 smem[RL * G::SLOT + 4 * 4096 + 1024];
+  bf16* patches = smem + RL * G::SLOT;
+  float* red = reinterpret_cast<float*>(patches + 4 * 4096);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nk = (a.K + BK - 1) / BK;
+  const int my_tiles = (a.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int items = my_tiles * nk;
+
+  if (wave >= 4) {   // ---- loader ----
+    const int lw = wave - 4;
+    int issued = 0;
+    auto issue = [&]() {
+      const int tile = blockIdx.x + (issued / nk) * gridDim.x, kt = issued % nk;
+      bf16* slot = smem + (issued % RL) * G::SLOT;
+      issue_tile<G::BM, false>(slot, a.X, a.ldx, tile * G::BM, a.M, kt * BK, a.K, lw);
+      issue_tile<N, false>(slot + G::XE, a.W, a.K, 0, N, kt * BK, a.K, lw);
+      ++issued;
+    };
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = acc[b][4 * g + e];
-        const float h = (v - mean) * rstd;
-        xh[e] = (bf16)h;
-        yo[e] = (bf16)(h * gm[e] + bt[e] + pe[e]);
-        pr[e] = (bf16)v;
+    for (int p = 0; p < RL - 1; ++p)
+      if (issued < items) issue();
+    for (int done = 0; done < items; ++done) {
+      wait_items<G::IPW>(min(issued - done - 1, 1));
+      __builtin_amdgcn_s_barrier();
+      if (issued < items) issue();
+      if (G::WN > 1 && (done % nk) == nk - 1) {   // mirror the consumers' two statistics barriers
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
       }
-      *reinterpret_cast<bf16x4*>(a.out + (size_t)i * a.ldo + j) = yo;
-      if (a.xhat) *reinterpret_cast<bf16x4*>(a.xhat + (size_t)i * N + j) = xh;
-      if (a.pre) *reinterpret_cast<bf16x4*>(a.pre + (size_t)i * N + j) = pr;
+    }
+    return;
+  }
+  // ---- consumer ----
+  const int wm = wave / G::WN, wn = wave % G::WN;
+  bf16* patch = patches + wave * 4096;
+  f32x16 acc[4];
+  bf16x8 resv[8];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = zero16();
+  for (int f = 0; f < items; ++f) {
+    const int tile = blockIdx.x + (f / nk) * gridDim.x, kt = f % nk;
+    const int i_base = tile * G::BM + wm * 32;
+    if (kt == 0 && a.res) ln_prefetch_res<N>(a, resv, i_base, wn);
+    if (kt == nk - 1 && a.res) ln_stage_res(patch, resv);   // registers free again before the epilogue
+    __builtin_amdgcn_s_barrier();
+    const bf16* xs = smem + (f % RL) * G::SLOT;
+    const bf16* ys = xs + G::XE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const bf16x8 xf = read_frag<G::BM, false>(xs, wm * 32, kk);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = mfma32(read_frag<N, false>(ys, wn * 128 + b * 32, kk), xf, acc[b]);
+    }
+    if (kt == nk - 1) {
+      ln_epilogue<N>(a, acc, a.res != nullptr, i_base, wm, wn, patch, red, [] { __builtin_amdgcn_s_barrier(); });
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = zero16();
     }
   }
+}
+
+// Simple version (N = 512: the ring of the persistent kernel does not fit next to a 64 KiB weight tile):
+// one 32-row tile per 256-thread workgroup, double-buffered LDS-DMA.
+template <int N>
+__global__ __launch_bounds__(256) void gemm_ln_simple_kernel(GemmLnArgs a) {
+  using G = LnGeo<N>;
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * G::SLOT + 1024];
+  bf16* patches = smem;   // the output patches alias the ring (used after the k-loop only)
+  float* red = reinterpret_cast<float*>(smem + 2 * G::SLOT);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / G::WN, wn = wave % G::WN;
+  const int i0 = blockIdx.x * G::BM, i_base = i0 + wm * 32;
+  f32x16 acc[4];
+  bf16x8 resv[8];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = zero16();
+  if (a.res) {
+    ln_prefetch_res<N>(a, resv, i_base, wn);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < 8; ++p) touch(resv[p]);
+  }
+  const int nk = (a.K + BK - 1) / BK;
+  issue_tile<G::BM, false>(smem, a.X, a.ldx, i0, a.M, 0, a.K, wave);
+  issue_tile<N, false>(smem + G::XE, a.W, a.K, 0, N, 0, a.K, wave);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (kt + 1 < nk) {
+      bf16* nxt = smem + (cur ^ 1) * G::SLOT;
+      issue_tile<G::BM, false>(nxt, a.X, a.ldx, i0, a.M, (kt + 1) * BK, a.K, wave);
+      issue_tile<N, false>(nxt + G::XE, a.W, a.K, 0, N, (kt + 1) * BK, a.K, wave);
+    }
+    const bf16* xs = smem + cur * G::SLOT;
+    const bf16* ys = xs + G::XE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const bf16x8 xf = read_frag<G::BM, false>(xs, wm * 32, kk);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = mfma32(read_frag<N, false>(ys, wn * 128 + b * 32, kk), xf, acc[b]);
+    }
+  }
+  __syncthreads();   // every wave is done with the ring before the patches overwrite it
+  if (a.res) ln_stage_res(patches + wave * 4096, resv);
+  ln_epilogue<N>(a, acc, a.res != nullptr, i_base, wm, wn, patches + wave * 4096, red, [] { __syncthreads(); });
 }
 
 }  // namespace
@@ -407,7 +626,8 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   splits = (Kc + per - 1) / per;
   a.c_per_split = per;
   a.tiles_i = (M + 127) / 128; a.tiles_j = (N + 127) / 128; a.splits = splits;
-  dim3 grid(a.tiles_i * a.tiles_j * splits), block(256);
+  const int total = a.tiles_i * a.tiles_j * splits;
+  dim3 grid(total < 256 ? total : 256), block(512);   // one persistent workgroup per CU
   if (!x_cmajor && !y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, a);
   else if (!x_cmajor && y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, a);
@@ -420,17 +640,24 @@ extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void
                           float eps, int relu, const float* pe, const int* pos, void* out, int ldo, void* xhat,
                           float* rstd, void* pre) {
   if (M <= 0) return 0;
-  if ((ldx & 7) || (K & 7) || !bias || !gamma || !beta || !out) return -1;
+  if ((ldx & 7) || (K & 7) || (ldo & 7) || (res && (ldres & 7)) || !bias || !gamma || !beta || !out) return -1;
   if (pe && !pos) return -2;
   GemmLnArgs a;
   a.X = (const bf16*)X; a.ldx = ldx; a.W = (const bf16*)W; a.M = M; a.K = K; a.bias = bias;
   a.res = (const bf16*)res; a.ldres = ldres; a.gamma = gamma; a.beta = beta; a.eps = eps; a.relu = relu;
   a.pe = pe; a.pos = pos; a.out = (bf16*)out; a.ldo = ldo; a.xhat = (bf16*)xhat; a.rstd = rstd; a.pre = (bf16*)pre;
-  dim3 block(256);
-  if (N == 128) hipLaunchKernelGGL((gemm_ln_kernel<128>), dim3((M + 127) / 128), block, 0, stream, a);
-  else if (N == 256) hipLaunchKernelGGL((gemm_ln_kernel<256>), dim3((M + 63) / 64), block, 0, stream, a);
-  else if (N == 512) hipLaunchKernelGGL((gemm_ln_kernel<512>), dim3((M + 31) / 32), block, 0, stream, a);
-  else return -3;
+  if (N == 128) {
+    a.tiles = (M + 127) / 128;
+    hipLaunchKernelGGL((gemm_ln_kernel<128>), dim3(a.tiles < 256 ? a.tiles : 256), dim3(512), 0, stream, a);
+  } else if (N == 256) {
+    a.tiles = (M + 63) / 64;
+    hipLaunchKernelGGL((gemm_ln_kernel<256>), dim3(a.tiles < 256 ? a.tiles : 256), dim3(512), 0, stream, a);
+  } else if (N == 512) {
+    a.tiles = (M + 31) / 32;
+    hipLaunchKernelGGL((gemm_ln_simple_kernel<512>), dim3(a.tiles), dim3(256), 0, stream, a);
+  } else {
+    return -3;
+  }
   ST_CHECK_LAUNCH();
   return 0;
 }
