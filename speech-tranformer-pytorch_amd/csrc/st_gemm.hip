@@ -115,31 +115,46 @@ struct GemmArgs {
 };
 
 // ---- the (output tile, k-step) item stream of one persistent workgroup --------------------------
-// Tile order: forward / dgrad - the i-tile is the fastest index (neighbouring workgroups, which sit on
-// different XCDs, stream different X row-tiles against the same small weight tile); weight gradients -
-// the split index is fastest (the (i, j) tiles of one contraction range meet in time).
+// XCD-aware tile order.  Workgroup w runs on XCD w % 8 (its own 4 MiB L2; L2s are not shared), so
+// tiles that read the same operand panel should meet on ONE XCD at about the same time:
+//   forward / dgrad : XCD x owns the X row-tiles i = x, x+8, ...; its workgroups walk (i, j) with j
+//                     fastest, so the tiles_j tiles that share X row-tile i run side by side on that XCD -
+//                     the panel crosses the fabric once and is re-read from L2 (the weights are small
+//                     and end up resident in every L2);
+//   weight gradients: XCD x owns the splits s = x, x+8, ... and walks the (i, j) tiles of one split.
+// (i-fastest order across all workgroups - every re-read of an X panel from a different XCD - measured
+// no faster than a tile-per-workgroup launch: the fabric, not HBM or MFMA, was the limit.)
 struct Work {
-  int tile, kt, nk, i0, j0, c_begin, c_end;
+  int q, kt, nk, i0, j0, c_begin, c_end;   // q = index into this XCD's tile list
   bool valid;
 };
 
-__device__ __forceinline__ void work_load(Work& w, const GemmArgs& a, int total) {
-  w.valid = w.tile < total;
+__device__ __forceinline__ void work_load(Work& w, const GemmArgs& a, int xcd) {
+  const int minor = a.splits > 1 ? a.tiles_i * a.tiles_j : a.tiles_j;
+  const int major_n = a.splits > 1 ? a.splits : a.tiles_i;
+  const int major = xcd + 8 * (w.q / minor), mi = w.q % minor;
+  w.valid = major < major_n;
   if (!w.valid) return;
-  int bid = w.tile, ts = 0;
-  if (a.splits > 1) { ts = bid % a.splits; bid /= a.splits; }
-  w.i0 = (bid % a.tiles_i) * 128;
-  w.j0 = (bid / a.tiles_i) * 128;
+  int ts = 0, ti, tj;
+  if (a.splits > 1) { ts = major; ti = mi % a.tiles_i; tj = mi / a.tiles_i; }
+  else { ti = major; tj = mi; }
+  w.i0 = ti * 128;
+  w.j0 = tj * 128;
   w.c_begin = ts * a.c_per_split;
   w.c_end = min(a.Kc, w.c_begin + a.c_per_split);
   w.nk = (w.c_end - w.c_begin + BK - 1) / BK;
   w.kt = 0;
 }
 
-__device__ __forceinline__ void work_next(Work& w, const GemmArgs& a, int total) {
+__device__ __forceinline__ void work_init(Work& w, const GemmArgs& a) {
+  w.q = blockIdx.x >> 3;                 // slot of this workgroup on its XCD
+  work_load(w, a, blockIdx.x & 7);
+}
+
+__device__ __forceinline__ void work_next(Work& w, const GemmArgs& a) {
   if (++w.kt >= w.nk) {
-    w.tile += gridDim.x;
-    work_load(w, a, total);
+    w.q += gridDim.x >> 3;               // gridDim.x is a multiple of 8
+    work_load(w, a, blockIdx.x & 7);
   }
 }
 
@@ -147,8 +162,7 @@ template <bool XT, bool YT>
 __device__ __forceinline__ void gemm_loader(const GemmArgs& a, bf16* ring, int lw, int total) {
   constexpr int XE = tile_elems<128>(), SLOT = 2 * XE;
   Work cur, ahead;
-  cur.tile = blockIdx.x;
-  work_load(cur, a, total);
+  work_init(cur, a);
   ahead = cur;
   int issued = 0, done = 0;
   auto issue = [&]() {
@@ -157,7 +171,7 @@ __device__ __forceinline__ void gemm_loader(const GemmArgs& a, bf16* ring, int l
     issue_tile<128, XT>(slot, a.X, a.ldx, ahead.i0, a.M, c0, ahead.c_end, lw);
     issue_tile<128, YT>(slot + XE, a.Y, a.ldy, ahead.j0, a.N, c0, ahead.c_end, lw);
     ++issued;
-    work_next(ahead, a, total);
+    work_next(ahead, a);
   };
 #pragma unroll
   for (int p = 0; p < RING - 1; ++p)
@@ -167,7 +181,7 @@ __device__ __forceinline__ void gemm_loader(const GemmArgs& a, bf16* ring, int l
     __builtin_amdgcn_s_barrier();       // ... for every loader; consumers are done with item done-1
     if (ahead.valid) issue();           // refill the slot item done-1 occupied
     ++done;
-    work_next(cur, a, total);
+    work_next(cur, a);
   }
 }
 
@@ -276,8 +290,7 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
   constexpr int XE = tile_elems<128>(), SLOT = 2 * XE;
   const int wm = wave >> 1, wn = wave & 1;
   Work cur;
-  cur.tile = blockIdx.x;
-  work_load(cur, a, total);
+  work_init(cur, a);
   f32x16 acc[2][2];
   bf16x8 auxv[8];
 #pragma unroll
@@ -323,7 +336,7 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
         for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
     }
     ++f;
-    work_next(cur, a, total);
+    work_next(cur, a);
   }
 }
 
@@ -627,7 +640,7 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   a.c_per_split = per;
   a.tiles_i = (M + 127) / 128; a.tiles_j = (N + 127) / 128; a.splits = splits;
   const int total = a.tiles_i * a.tiles_j * splits;
-  dim3 grid(total < 256 ? total : 256), block(512);   // one persistent workgroup per CU
+  dim3 grid(total < 256 ? ((total + 7) & ~7) : 256), block(512);   // one persistent workgroup per CU, 8 | grid
   if (!x_cmajor && !y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, stream, a);
   else if (!x_cmajor && y_cmajor) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, stream, a);
