@@ -315,19 +315,25 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
     __builtin_amdgcn_s_barrier();   // item f is in its slot
     const bf16* xs = ring + (f % RING) * SLOT;
     const bf16* ys = xs + XE;
+    // All 16 fragment reads of the item are issued up front into their own registers; the MFMAs then
+    // start as the first fragments arrive.  (With one consumer wave per SIMD nothing else hides an
+    // LDS round trip: the compiler's read -> lgkmcnt(0) -> 2 MFMAs -> read ... schedule on 3 recycled
+    // fragment registers ran the matrix pipe at ~30 %.)
+    bf16x8 xf[BK / 16][2], yf[BK / 16][2];
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 xf[2], yf[2];
+    for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        xf[t] = read_frag<128, XT>(xs, (wm * 2 + t) * 32, kk);
-        yf[t] = read_frag<128, YT>(ys, (wn * 2 + t) * 32, kk);
+        xf[kk][t] = read_frag<128, XT>(xs, (wm * 2 + t) * 32, kk);
+        yf[kk][t] = read_frag<128, YT>(ys, (wn * 2 + t) * 32, kk);
       }
+    __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler would sink them back)
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
-    }
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[kk][y], xf[kk][x], acc[x][y]);
     if (cur.kt == cur.nk - 1) {
       gemm_epilogue(a, acc, auxv, cur.i0, cur.j0, patch, wm, wn);
 #pragma unroll
@@ -556,10 +562,19 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(GemmLnArgs a) {
     const bf16* xs = smem + (f % RL) * G::SLOT;
     const bf16* ys = xs + G::XE;
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const bf16x8 xf = read_frag<G::BM, false>(xs, wm * 32, kk);
+    for (int h2 = 0; h2 < 2; ++h2) {   // two half-items: 10 fragment reads in flight, then 8 MFMAs
+      bf16x8 xf[2], yf[2][4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = mfma32(read_frag<N, false>(ys, wn * 128 + b * 32, kk), xf, acc[b]);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        xf[k2] = read_frag<G::BM, false>(xs, wm * 32, h2 * 2 + k2);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) yf[k2][b] = read_frag<N, false>(ys, wn * 128 + b * 32, h2 * 2 + k2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = mfma32(yf[k2][b], xf[k2], acc[b]);
     }
     if (kt == nk - 1) {
       ln_epilogue<N>(a, acc, a.res != nullptr, i_base, wm, wn, patch, red, [] { __builtin_amdgcn_s_barrier(); });
@@ -605,10 +620,19 @@ __global__ __launch_bounds__(256) void gemm_ln_simple_kernel(GemmLnArgs a) {
     const bf16* xs = smem + cur * G::SLOT;
     const bf16* ys = xs + G::XE;
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const bf16x8 xf = read_frag<G::BM, false>(xs, wm * 32, kk);
+    for (int h2 = 0; h2 < 2; ++h2) {   // two half-items: 10 fragment reads in flight, then 8 MFMAs
+      bf16x8 xf[2], yf[2][4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = mfma32(read_frag<N, false>(ys, wn * 128 + b * 32, kk), xf, acc[b]);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        xf[k2] = read_frag<G::BM, false>(xs, wm * 32, h2 * 2 + k2);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) yf[k2][b] = read_frag<N, false>(ys, wn * 128 + b * 32, h2 * 2 + k2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = mfma32(yf[k2][b], xf[k2], acc[b]);
     }
   }
   __syncthreads();   // every wave is done with the ring before the patches overwrite it
