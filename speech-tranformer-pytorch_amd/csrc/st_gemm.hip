@@ -17,9 +17,14 @@
 // fetch takes ~2 us under load - a tile-per-workgroup kernel with one tile of prefetch measured
 // 3x slower than its own MFMA + HBM bounds.  The kernels are therefore PERSISTENT (one
 // 512-thread workgroup per CU walking a list of output tiles) with the waves SPECIALISED:
-//   waves 4-7  loaders  : LDS-DMA (global_load_lds_dwordx4) of 128x64 operand tiles into a 4-slot
-//                         LDS ring, 3 (tile, k-step) items ahead - across output-tile boundaries;
-//                         they issue nothing else, so a counted s_waitcnt vmcnt(N) is exact;
+//   waves 4-7  loaders  : keep the next 4 (tile, k-step) items of 128x64 operand tiles in flight in
+//                         their REGISTERS (global_load_dwordx4, across output-tile boundaries) and
+//                         copy one item per step into a 2-slot LDS double buffer (ds_write_b128).
+//                         Registers, not LDS-DMA: measured in-kernel, global_load_lds tops out at
+//                         ~10 B/clk/CU whatever the source (even with every operand row aliased to
+//                         one cache line), a quarter of what the MFMA side of these GEMMs needs,
+//                         while L2 -> VGPR streams at up to 64 B/clk/CU and the VGPR file of the four
+//                         loader waves holds 128 KiB in flight (LDS could hold 96);
 //   waves 0-3  consumers: 2x2 waves x (2x2 v_mfma_f32_32x32x16_bf16), epilogue from registers
 //                         through a wave-private LDS patch to coalesced 128-byte row segments.
 // One s_barrier per item orders ring slots between the two roles.  The accumulator is kept
@@ -83,6 +88,37 @@ __device__ __forceinline__ void issue_tile(bf16* tile, const bf16* __restrict__ 
   }
 }
 
+// Register-staged variant of issue_tile: the same LDS image, filled in two steps - load() puts this
+// wave's share of a tile (ROWS/32 x 16 bytes per lane) in flight into VGPRs, store() writes it to LDS
+// later.  Ordinary loads: the compiler's counted s_waitcnt vmcnt keeps younger items in flight.
+template <int ROWS, bool CM>
+struct TileRegs {
+  static_assert(ROWS % 32 == 0 && (!CM || ROWS == 128), "tile shape");
+  bf16x8 v[ROWS / 32];
+  __device__ __forceinline__ void load(const bf16* __restrict__ base, int ld, int row0, int nrows, int c0, int c_end,
+                                       int lw) {
+    const int i = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < ROWS / 32; ++t) {
+      const int I = t * 4 + lw;
+      if (!CM) {
+        const int r = I * 8 + (i >> 3), p = i & 7;
+        const int row = row0 + r, c = c0 + 8 * (p ^ ((r >> 1) & 7));
+        v[t] = gload8(base + (size_t)row * ld + c, row < nrows && c < c_end);
+      } else {
+        const int cr = I * 4 + (i >> 4), p = i & 15;
+        const int c = c0 + cr, row = row0 + 8 * (p ^ ((cr & 3) << 2));
+        v[t] = gload8(base + (size_t)c * ld + row, c < c_end && row < nrows);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(bf16* tile, int lw) const {
+    const int i = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < ROWS / 32; ++t) *reinterpret_cast<bf16x8*>(tile + (t * 4 + lw) * 512 + i * 8) = v[t];
+  }
+};
+
 // Fragment (8 contraction elements kk*16 + hi*8 .. +7 of operand row blk_row0 + (lane & 31)).
 template <int ROWS, bool CM>
 __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int kk) {
@@ -101,6 +137,11 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int 
   f[4] = up[0]; f[5] = up[1]; f[6] = up[2]; f[7] = up[3];
   return f;
 }
+
+#ifdef ST_PROF
+__device__ unsigned long long g_prof[256 * 8];   // per workgroup: barrier-wait, mfma, epilogue, total cycles, tiles
+#define PROF_NOW() __builtin_readcyclecounter()
+#endif
 
 struct GemmArgs {
   const bf16* X; int ldx;
@@ -159,35 +200,43 @@ __device__ __forceinline__ void work_next(Work& w, const GemmArgs& a) {
 }
 
 template <bool XT, bool YT>
-__device__ __forceinline__ void gemm_loader(const GemmArgs& a, bf16* ring, int lw, int total) {
-  constexpr int XE = tile_elems<128>(), SLOT = 2 * XE;
+__device__ __forceinline__ void gemm_loader(const GemmArgs& a, bf16* ring, int lw) {
+  constexpr int XE = tile_elems<128>(), SLOT = 2 * XE, D = 4;   // D items in flight in registers
+  TileRegs<128, XT> rx[D];
+  TileRegs<128, YT> ry[D];
   Work cur, ahead;
   work_init(cur, a);
   ahead = cur;
-  int issued = 0, done = 0;
-  auto issue = [&]() {
-    bf16* slot = ring + (issued % RING) * SLOT;
+  auto fetch = [&](TileRegs<128, XT>& x, TileRegs<128, YT>& y) {
     const int c0 = ahead.c_begin + ahead.kt * BK;
-    issue_tile<128, XT>(slot, a.X, a.ldx, ahead.i0, a.M, c0, ahead.c_end, lw);
-    issue_tile<128, YT>(slot + XE, a.Y, a.ldy, ahead.j0, a.N, c0, ahead.c_end, lw);
-    ++issued;
+    x.load(a.X, a.ldx, ahead.i0, a.M, c0, ahead.c_end, lw);
+    y.load(a.Y, a.ldy, ahead.j0, a.N, c0, ahead.c_end, lw);
     work_next(ahead, a);
   };
 #pragma unroll
-  for (int p = 0; p < RING - 1; ++p)
-    if (ahead.valid) issue();
-  while (cur.valid) {
-    wait_items<8>(issued - done - 1);   // item `done` has landed (this wave's share)
-    __builtin_amdgcn_s_barrier();       // ... for every loader; consumers are done with item done-1
-    if (ahead.valid) issue();           // refill the slot item done-1 occupied
-    ++done;
-    work_next(cur, a);
+  for (int d = 0; d < D; ++d)
+    if (ahead.valid) fetch(rx[d], ry[d]);
+  int k = 0;
+  for (;;) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (!cur.valid) return;
+      // item k -> slot k & 1: the consumers left that slot (item k-2) before they reached barrier k-1
+      bf16* slot = ring + (k & 1) * SLOT;
+      rx[d].store(slot, lw);
+      ry[d].store(slot + XE, lw);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();        // barrier k: item k is readable
+      if (ahead.valid) fetch(rx[d], ry[d]);
+      ++k;
+      work_next(cur, a);
+    }
   }
 }
 
 // Epilogue of one consumer wave: its 64 x 64 sub-tile at (i0 + wm*64, j0 + wn*64).
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const bf16x8 (&auxv)[8], int i0,
-                                              int j0, bf16* patch, int wm, int wn) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const bf16x8 (&auxv)[8],
+                                              const f32x4 (&bv)[2][4], int i0, int j0, bf16* patch, int wm, int wn) {
   const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
   const int ib = i0 + wm * 64, jb = j0 + wn * 64;
   if (a.epi == EPI_F32_ATOMIC_T) {
@@ -220,7 +269,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           const int j = jb + y * 32 + 8 * g + 4 * hi;
           if (j >= a.N) continue;
           f32x4 v = {acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]};
-          v += *reinterpret_cast<const f32x4*>(a.bias ? a.bias + j : g_zero_f32);
+          v += bv[y][g];
           float* d = reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j;
           if (a.epi == EPI_F32) *reinterpret_cast<f32x4*>(d) = v;
           else {
@@ -234,17 +283,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
   // bf16 outputs: registers -> wave-private [64][64] LDS patch (16-byte chunks XOR-swizzled by row)
   // -> 128-byte row segments.  A row-per-lane accumulator stored directly is 64 scattered 8-byte
   // writes per instruction and store-issue bound.
-  // Bias vectors first, branch-free and all in flight together (a load inside a per-vector `if` is
-  // followed by its own s_waitcnt vmcnt(0): 16 serialised L2 round trips per tile).
-  f32x4 bv[2][4];
-#pragma unroll
-  for (int y = 0; y < 2; ++y)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int j = jb + y * 32 + 8 * g + 4 * hi;
-      const float* src = (a.bias != nullptr && j < a.N) ? a.bias + j : g_zero_f32;
-      bv[y][g] = *reinterpret_cast<const f32x4*>(src);
-    }
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
     const int il = x * 32 + r;
@@ -286,13 +324,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
 }
 
 template <bool XT, bool YT>
-__device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* ring, bf16* patch, int wave, int total) {
+__device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* ring, bf16* patch, int wave) {
   constexpr int XE = tile_elems<128>(), SLOT = 2 * XE;
   const int wm = wave >> 1, wn = wave & 1;
   Work cur;
   work_init(cur, a);
   f32x16 acc[2][2];
   bf16x8 auxv[8];
+  f32x4 bv[2][4];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -301,7 +340,25 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
   for (int p = 0; p < 8; ++p) auxv[p] = zero_bf8();
   const bool use_aux = a.epi == EPI_BF16_MASK || a.epi == EPI_BF16_ADD;
   int f = 0;
+#ifdef ST_PROF
+  unsigned long long p_wait = 0, p_mma = 0, p_epi = 0, p_tiles = 0, p_start = PROF_NOW();
+#endif
   while (cur.valid) {
+#ifdef ST_PROF
+    const unsigned long long t0 = PROF_NOW();
+#endif
+    if (cur.kt == 0) {
+      // bias vectors of this wave's 64 columns: requested at the first k-step, branch-free and all in
+      // flight together (in the epilogue they cost a full loaded-memory round trip, ~4k cycles per tile)
+      const int hi = (threadIdx.x & 63) >> 5;
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j = cur.j0 + wn * 64 + y * 32 + 8 * g + 4 * hi;
+          bv[y][g] = *reinterpret_cast<const f32x4*>((a.bias != nullptr && j < a.N) ? a.bias + j : g_zero_f32);
+        }
+    }
     if (use_aux && cur.kt == 0) {
       // the mask / addend block of this wave's sub-tile: 8 coalesced 16-byte chunks per lane, requested
       // at the first k-step so that their latency hides under the tile's MFMAs
@@ -313,7 +370,10 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
       }
     }
     __builtin_amdgcn_s_barrier();   // item f is in its slot
-    const bf16* xs = ring + (f % RING) * SLOT;
+#ifdef ST_PROF
+    const unsigned long long t1 = PROF_NOW();
+#endif
+    const bf16* xs = ring + (f & 1) * SLOT;
     const bf16* ys = xs + XE;
     // All 16 fragment reads of the item are issued up front into their own registers; the MFMAs then
     // start as the first fragments arrive.  (With one consumer wave per SIMD nothing else hides an
@@ -334,26 +394,39 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[kk][y], xf[kk][x], acc[x][y]);
+#ifdef ST_PROF
+    asm volatile("s_nop 0" : "+v"(acc[1][1]));
+    const unsigned long long t2 = PROF_NOW();
+    p_wait += t1 - t0; p_mma += t2 - t1;
+#endif
     if (cur.kt == cur.nk - 1) {
-      gemm_epilogue(a, acc, auxv, cur.i0, cur.j0, patch, wm, wn);
+      gemm_epilogue(a, acc, auxv, bv, cur.i0, cur.j0, patch, wm, wn);
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+#ifdef ST_PROF
+      p_epi += PROF_NOW() - t2; ++p_tiles;
+#endif
     }
     ++f;
     work_next(cur, a);
   }
+#ifdef ST_PROF
+  if (wave == 0 && (threadIdx.x & 63) == 0) {
+    unsigned long long* o = g_prof + blockIdx.x * 8;
+    o[0] = p_wait; o[1] = p_mma; o[2] = p_epi; o[3] = PROF_NOW() - p_start; o[4] = p_tiles; o[5] = f;
+  }
+#endif
 }
 
 template <bool XT, bool YT>
 __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs a) {
   constexpr int SLOT = 2 * tile_elems<128>();
-  __shared__ __attribute__((aligned(1024))) bf16 smem[RING * SLOT + 4 * 4096];   // 128 KiB ring + 4 x 8 KiB patches
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * SLOT + 4 * 4096];   // 2 x 32 KiB tiles + 4 x 8 KiB patches
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int total = a.tiles_i * a.tiles_j * a.splits;
-  if (wave >= 4) gemm_loader<XT, YT>(a, smem, wave - 4, total);
-  else gemm_consumer<XT, YT>(a, smem, smem + RING * SLOT + wave * 4096, wave, total);
+  if (wave >= 4) gemm_loader<XT, YT>(a, smem, wave - 4);
+  else gemm_consumer<XT, YT>(a, smem, smem + 2 * SLOT + wave * 4096, wave);
 }
 
 // ---- GEMM + bias (+ReLU) (+residual) + LayerNorm (+positional-encoding add) -------------------
@@ -641,6 +714,12 @@ __global__ __launch_bounds__(256) void gemm_ln_simple_kernel(GemmLnArgs a) {
 }
 
 }  // namespace
+
+#ifdef ST_PROF
+extern "C" int st_prof_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 256 * 8);
+}
+#endif
 
 extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
                        void* D, int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi,
