@@ -141,6 +141,10 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int 
 #ifdef ST_PROF
 __device__ unsigned long long g_prof[256 * 8];   // per workgroup: barrier-wait, mfma, epilogue, total cycles, tiles
 #define PROF_NOW() __builtin_readcyclecounter()
+__device__ int g_dbg;   // bit 0: skip output stores, bit 1: skip operand loads, bit 2: skip LDS tile writes
+#define DBG(bit) (g_dbg & (bit))
+#else
+#define DBG(bit) 0
 #endif
 
 struct GemmArgs {
@@ -223,11 +227,16 @@ __device__ __forceinline__ void gemm_loader(const GemmArgs& a, bf16* ring, int l
       if (!cur.valid) return;
       // item k -> slot k & 1: the consumers left that slot (item k-2) before they reached barrier k-1
       bf16* slot = ring + (k & 1) * SLOT;
-      rx[d].store(slot, lw);
-      ry[d].store(slot + XE, lw);
+      if (!DBG(4)) {
+        rx[d].store(slot, lw);
+        ry[d].store(slot + XE, lw);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();        // barrier k: item k is readable
-      if (ahead.valid) fetch(rx[d], ry[d]);
+      if (ahead.valid) {
+        if (!DBG(2)) fetch(rx[d], ry[d]);
+        else work_next(ahead, a);
+      }
       ++k;
       work_next(cur, a);
     }
@@ -318,7 +327,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)auxv[p][e]);
     }
-    if (i < a.M && j < a.N) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
+    if (i < a.M && j < a.N && !DBG(1)) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads retired before the next tile rewrites it
 }
@@ -341,7 +350,7 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
   const bool use_aux = a.epi == EPI_BF16_MASK || a.epi == EPI_BF16_ADD;
   int f = 0;
 #ifdef ST_PROF
-  unsigned long long p_wait = 0, p_mma = 0, p_epi = 0, p_tiles = 0, p_start = PROF_NOW();
+  unsigned long long p_wait = 0, p_mma = 0, p_epi = 0, p_tiles = 0, p_pre = 0, p_start = PROF_NOW();
 #endif
   while (cur.valid) {
 #ifdef ST_PROF
@@ -369,9 +378,13 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
         auxv[p] = gload8(a.aux + (size_t)i * a.ldaux + j, i < a.M && j < a.N);
       }
     }
+#ifdef ST_PROF
+    const unsigned long long t0b = PROF_NOW();
+#endif
     __builtin_amdgcn_s_barrier();   // item f is in its slot
 #ifdef ST_PROF
     const unsigned long long t1 = PROF_NOW();
+    p_pre += t0b - t0;
 #endif
     const bf16* xs = ring + (f & 1) * SLOT;
     const bf16* ys = xs + XE;
@@ -397,7 +410,7 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
 #ifdef ST_PROF
     asm volatile("s_nop 0" : "+v"(acc[1][1]));
     const unsigned long long t2 = PROF_NOW();
-    p_wait += t1 - t0; p_mma += t2 - t1;
+    p_wait += t1 - t0b; p_mma += t2 - t1;
 #endif
     if (cur.kt == cur.nk - 1) {
       gemm_epilogue(a, acc, auxv, bv, cur.i0, cur.j0, patch, wm, wn);
@@ -415,7 +428,7 @@ __device__ __forceinline__ void gemm_consumer(const GemmArgs& a, const bf16* rin
 #ifdef ST_PROF
   if (wave == 0 && (threadIdx.x & 63) == 0) {
     unsigned long long* o = g_prof + blockIdx.x * 8;
-    o[0] = p_wait; o[1] = p_mma; o[2] = p_epi; o[3] = PROF_NOW() - p_start; o[4] = p_tiles; o[5] = f;
+    o[0] = p_wait; o[1] = p_mma; o[2] = p_epi; o[3] = PROF_NOW() - p_start; o[4] = p_tiles; o[5] = f; o[6] = p_pre;
   }
 #endif
 }
@@ -716,6 +729,7 @@ __global__ __launch_bounds__(256) void gemm_ln_simple_kernel(GemmLnArgs a) {
 }  // namespace
 
 #ifdef ST_PROF
+extern "C" int st_prof_dbg(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int)); }
 extern "C" int st_prof_read(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 256 * 8);
 }

@@ -56,10 +56,13 @@ def run(ldx, ldy, tag):
     torch.cuda.synchronize()
     lib.st_prof_read(buf)
     a = np.array(buf[:], dtype=np.float64).reshape(256, 8)
-    print("%-28s %7.2f us | per tile: wait %.0f mfma %.0f epi %.0f total %.0f" % ((tag, s.elapsed_time(e) * 100) + tuple(
-        a[:, i].sum() / a[:, 4].sum() for i in range(4))))
+    print("%-28s %7.2f us | per tile: wait %.0f mfma %.0f epi %.0f total %.0f prefetch-block %.0f" % ((tag, s.elapsed_time(e) * 100) + tuple(
+        a[:, i].sum() / a[:, 4].sum() for i in (0, 1, 2, 3, 6))))
 
 run(K, K, "normal")
-run(0, K, "X rows aliased (ldx=0)")
-run(K, 0, "W rows aliased (ldy=0)")
 run(0, 0, "both aliased")
+for flag, tag in ((1, "no output stores"), (2, "no operand loads"), (4, "no LDS tile writes"), (6, "no loads, no LDS writes"),
+                  (7, "no loads/LDS writes/stores")):
+    lib.st_prof_dbg(flag)
+    run(K, K, tag)
+lib.st_prof_dbg(0)
