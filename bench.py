@@ -79,18 +79,67 @@ def kernel_report(records):
     return agg
 
 
+def cpu_worker(args):
+    """Child process: time the CPU oracle (fp32, dropout off) on the first --cpu-utts utterances of the
+    benchmark batch, same seeded weights as the GPU model; prints the cpu_baseline JSON object."""
+    import oracle as orc
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import synthetic
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 64))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = M.Transformer(U.AttrDict(C2))
+    U.init_parameters(model)
+    p = {k: v.detach().float().clone() for k, v in model.state_dict().items()}
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"],
+                                                          seed=0, t_min=T_MIN, l_min=L_MIN)
+    n = args.cpu_utts
+    b = {"x": x[:n], "in_len": in_len[:n], "tokens": tokens[:n], "tgt_len": tgt_len[:n], "gt": gt[:n]}
+    # the oracle's forward / loss (autograd backward) + the stock CPU optimiser path of train.py:44-46
+    leaves = {k: (v.requires_grad_(True) if not k.endswith(".pe") else v) for k, v in p.items()}
+    params = [v for k, v in leaves.items() if not k.endswith(".pe")]
+    opt = torch.optim.Adam(params, lr=orc.noam_lr(C2["d_model"], 12000, 1), betas=(0.9, 0.98), eps=1e-9)
+    times, loss = [], None
+    for _ in range(args.cpu_steps + 1):       # first step is the warm-up
+        t = time.perf_counter()
+        opt.zero_grad()
+        logits, _ = orc.transformer(leaves, b["x"], b["in_len"], b["tokens"], b["tgt_len"], C2["n_heads"])
+        loss = orc.cross_entropy(logits, b["gt"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        times.append(time.perf_counter() - t)
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    frames = int(in_len[:n].sum())
+    print(json.dumps({"value": round(frames / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+                      "sec_per_step": round(med, 3),
+                      "sample": "%d steps (after 1 warm-up) of the oracle restatement (fwd + CE + autograd bwd + clip + "
+                                "torch Adam) on the first %d of the 32 utterances (%d valid frames), fp32, dropout "
+                                "off, torch %d threads; loss %.4f" % (args.cpu_steps, n, frames, cores, loss.item())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-utts", type=int, default=8, help="utterances of the batch the CPU baseline is timed on")
+    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
                                                             "the captured HIP graph of the step")
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args)
 
     import transformer.Models as M
     import transformer.Utils as U
@@ -193,23 +242,18 @@ def main():
         }
 
     # ---- CPU baseline: the oracle restatement on this box's host cores (rank 0, N = 1 only) -------
+    # Runs in a child process with a hard timeout so that a slow / oversubscribed host can never
+    # stall the benchmark: a bounded sample (the first CPU_UTTS utterances of the same batch).
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle as orc
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        p = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-        b = {"x": x, "in_len": in_len, "tokens": tokens, "tgt_len": tgt_len, "gt": gt}
-        times = []
-        for i in range(args.cpu_steps + 1):       # first step is the warm-up
-            t = time.perf_counter()
-            res = orc.train_step(p, b, C2["n_heads"], C2["d_model"], 12000, 1, 5.0)
-            times.append(time.perf_counter() - t)
-        med = sorted(times[1:])[len(times[1:]) // 2]
-        out["cpu_baseline"] = {"value": round(float(in_len.sum()) / med, 1), "unit": "frames/s", "cores": cores,
-                               "kind": "port", "sec_per_step": round(med, 3),
-                               "sample": "%d full config-2 steps (B=32, %d frames) of the oracle restatement, fp32, "
-                                         "dropout off, after 1 warm-up; loss %.4f" % (args.cpu_steps, int(in_len.sum()),
-                                                                                      res["loss"].item())}
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-steps",
+                                str(args.cpu_steps), "--cpu-utts", str(args.cpu_utts)], capture_output=True, text=True,
+                               timeout=args.cpu_timeout)
+            out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001 - the GPU number must still be reported
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
+                                   "sample": "CPU baseline did not finish within %ds (%s)" % (args.cpu_timeout, type(e).__name__)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -93,9 +93,7 @@ def feature_info_mask(lengths: torch.Tensor) -> torch.Tensor:
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """``nn.LayerNorm(d, eps=1e-6)`` (Attention.py:62, SubLayers.py:18,
     Models.py:32): biased variance over the last dim."""
-    mu = x.mean(-1, keepdim=True)
-    var = ((x - mu) ** 2).mean(-1, keepdim=True)
-    return (x - mu) / torch.sqrt(var + eps) * w + b
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)   # same definition, one fused pass on the CPU
 
 
 def multi_head_attention(p: Params, pre: str, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
@@ -120,9 +118,9 @@ def multi_head_attention(p: Params, pre: str, q: torch.Tensor, k: torch.Tensor, 
     qh = split(F.linear(q, p[pre + "linear_q.weight"], p[pre + "linear_q.bias"]))
     kh = split(F.linear(k, p[pre + "linear_k.weight"], p[pre + "linear_k.bias"]))
     vh = split(F.linear(v, p[pre + "linear_v.weight"], p[pre + "linear_v.bias"]))
-    scores = torch.matmul(qh, kh.transpose(2, 3)) / math.sqrt(dk)
+    scores = torch.matmul(qh, kh.transpose(2, 3)).div_(math.sqrt(dk))      # in place, as Attention.py:82-87
     if mask is not None:
-        scores = scores.masked_fill(mask.unsqueeze(1), float("-inf"))
+        scores.masked_fill_(mask.unsqueeze(1), float("-inf"))
     attn = torch.softmax(scores, dim=-1)
     ctx = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(bsz, lq, d)
     out = F.linear(ctx, p[pre + "output_linear.weight"], p[pre + "output_linear.bias"])
