@@ -735,7 +735,9 @@ extern "C" int st_prof_read(unsigned long long* host) {
 }
 #endif
 
-extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
+// Development reference only (see st_gemm_sym.hip for the production st_gemm): the persistent,
+// wave-specialised variant, kept for A/B measurements with tools/prof_gemm.py.
+extern "C" int st_gemm_ws(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
                        void* D, int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi,
                        int splits) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;

@@ -1,0 +1,305 @@
+// st_gemm: symmetric (every wave loads, multiplies and stores) bf16 MFMA GEMM for gfx950.
+//
+//   D[i][j] = sum_c X(i,c) * Y(j,c)            fp32 accumulate
+//   forward  y  = x W^T      : X = x  [M,K] natural,      Y = W  [N,K] natural
+//   dgrad    dx = dy W       : X = dy [M,N] natural,      Y = W  [N,K] contraction-major (c = n)
+//   wgrad    dW = dy^T x     : X = x  [M,K] contr.-major, Y = dy [M,N] contraction-major (c = m)
+// (contraction-major operands are read from LDS with ds_read_b64_tr_b16 - no transposed copy of a
+// weight or an activation ever goes to HBM).  Reference lines replaced: transformer/Attention.py:74-76,92,
+// transformer/SubLayers.py:25-26, transformer/Models.py:145,151 and their autograd.
+//
+// Why this shape (measured on MI355X with in-kernel cycle probes, tools/prof_gemm.py):
+//  * a persistent, wave-specialised variant (st_gemm.hip: 4 loader + 4 consumer waves, one workgroup per
+//    CU) spent ~12k cycles per 128x128x256 tile against 2k cycles of MFMA work - with ONE compute wave per
+//    SIMD every dependent VALU instruction of the epilogue / address code pays full pipeline latency and
+//    nothing overlaps an LDS round trip; LDS-DMA (global_load_lds) additionally tops out at ~10 B/clk/CU;
+//  * so: 256-thread workgroups, 40 KiB of LDS and <= 128 VGPRs -> 3-4 workgroups (waves per SIMD) per CU,
+//    each running the plain loop  [global -> registers two k-tiles ahead] -> [LDS double buffer] -> MFMA.
+//    Other resident workgroups cover a workgroup's prologue, LDS latencies and epilogue.
+// Tile 128 x 128 x 32; wave tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16; accumulator TRANSPOSED (X row on
+// the lane, Y rows over registers).  bf16 outputs leave through an LDS patch as 256-byte row segments.
+#include "st_common.cuh"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NS = BK + 8;    // natural tile row stride (80 B): conflict-free ds_read_b128 over 16 rows
+constexpr int CS_CM = 160;    // contraction-major tile row stride (128 + 32): the 4 c-rows of a tr read hit 4 bank groups
+constexpr int TILE_E = 5120;  // elements of either tile image (128 x 40 = 32 x 160)
+
+__device__ __attribute__((aligned(16))) float g_zero_f32[4];
+
+enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_BF16_ADD = 4, EPI_F32_ATOMIC = 5,
+           EPI_F32_ATOMIC_T = 6 };
+
+struct GemmArgs {
+  const bf16* X; int ldx;
+  const bf16* Y; int ldy;
+  void* D; int ldd;
+  int M, N, Kc;
+  const float* bias;
+  const bf16* aux; int ldaux;
+  int c_per_split, tiles_i, tiles_j, splits;
+};
+
+// This thread's share (2 x 16 bytes) of a 128 x 32 operand tile, global -> registers -> LDS.
+template <bool CM>
+struct Stage {
+  bf16x8 v[2];
+  __device__ __forceinline__ void load(const bf16* __restrict__ base, int ld, int row0, int nrows, int c0, int c_end) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int id = threadIdx.x + p * 256;
+      if (!CM) {
+        const int r = id >> 2, ch = id & 3;                   // [128 rows][4 chunks]
+        const int row = row0 + r, c = c0 + ch * 8;
+        v[p] = gload8(base + (size_t)row * ld + c, row < nrows && c < c_end);
+      } else {
+        const int cr = id >> 4, ch = id & 15;                 // [32 c-rows][16 chunks]
+        const int c = c0 + cr, row = row0 + ch * 8;
+        v[p] = gload8(base + (size_t)c * ld + row, c < c_end && row < nrows);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(bf16* tile) const {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int id = threadIdx.x + p * 256;
+      if (!CM) *reinterpret_cast<bf16x8*>(tile + (id >> 2) * NS + (id & 3) * 8) = v[p];
+      else *reinterpret_cast<bf16x8*>(tile + (id >> 4) * CS_CM + (id & 15) * 8) = v[p];
+    }
+  }
+};
+
+template <bool CM>
+__device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int kk) {
+  const int l = threadIdx.x & 63, hi = l >> 5;
+  if (!CM) return frag_nat(tile, NS, blk_row0 + (l & 31), kk * 16 + hi * 8);
+  return frag_tr(tile, CS_CM, blk_row0, kk * 16 + hi * 8, kk * 16 + hi * 8 + 4);
+}
+
+template <bool XT, bool YT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[4 * TILE_E];   // 2 buffers x (X tile + Y tile) = 40 KiB
+  // XCD-local tile walk: workgroup b runs on XCD b % 8 (own L2).  forward / dgrad: an XCD owns X row-tiles
+  // i = x, x+8, ... and its consecutive workgroups take the tiles_j tiles that share one row-tile (the panel
+  // crosses the fabric once); weight gradients: an XCD owns splits s = x, x+8, ... and walks their (i, j) tiles.
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int minor = a.splits > 1 ? a.tiles_i * a.tiles_j : a.tiles_j;
+  const int major = xcd + 8 * (q / minor), mi = q % minor;
+  if (major >= (a.splits > 1 ? a.splits : a.tiles_i)) return;
+  int ts = 0, ti, tj;
+  if (a.splits > 1) { ts = major; ti = mi % a.tiles_i; tj = mi / a.tiles_i; }
+  else { ti = major; tj = mi; }
+  const int i0 = ti * 128, j0 = tj * 128;
+  const int c_begin = ts * a.c_per_split, c_end = min(a.Kc, c_begin + a.c_per_split);
+  const int nk = (c_end - c_begin + BK - 1) / BK;
+
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  auto xs = [&](int buf) { return smem + buf * 2 * TILE_E; };
+  auto ys = [&](int buf) { return smem + buf * 2 * TILE_E + TILE_E; };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+
+  // two k-tiles in flight in registers (A: even tiles, B: odd tiles) + one in LDS being consumed
+  Stage<XT> ax, bx;
+  Stage<YT> ay, by;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 xf[2], yf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        xf[t] = read_frag<XT>(xs(buf), (wm * 2 + t) * 32, kk);
+        yf[t] = read_frag<YT>(ys(buf), (wn * 2 + t) * 32, kk);
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
+    }
+  };
+  ax.load(a.X, a.ldx, i0, a.M, c_begin, c_end);
+  ay.load(a.Y, a.ldy, j0, a.N, c_begin, c_end);
+  if (nk > 1) {
+    bx.load(a.X, a.ldx, i0, a.M, c_begin + BK, c_end);
+    by.load(a.Y, a.ldy, j0, a.N, c_begin + BK, c_end);
+  }
+  ax.store(xs(0));
+  ay.store(ys(0));
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) {
+      ax.load(a.X, a.ldx, i0, a.M, c_begin + (kt + 2) * BK, c_end);
+      ay.load(a.Y, a.ldy, j0, a.N, c_begin + (kt + 2) * BK, c_end);
+    }
+    compute(0);
+    if (kt + 1 < nk) {
+      bx.store(xs(1));
+      by.store(ys(1));
+    }
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) {
+      bx.load(a.X, a.ldx, i0, a.M, c_begin + (kt + 3) * BK, c_end);
+      by.load(a.Y, a.ldy, j0, a.N, c_begin + (kt + 3) * BK, c_end);
+    }
+    compute(1);
+    if (kt + 2 < nk) {
+      ax.store(xs(0));
+      ay.store(ys(0));
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogues ------------------------------------------------------------------------------
+  const int ib = i0 + wm * 64, jb = j0 + wn * 64;
+  if (EPI == EPI_F32_ATOMIC_T) {
+    // D^T[j][i] += acc: the lane index i is the contiguous axis of dW -> coalesced fp32 atomics
+    float* D = reinterpret_cast<float*>(a.D);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int i = ib + x * 32 + r;
+      if (i >= a.M) continue;
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int j = jb + y * 32 + acc_row(t, hi);
+          if (j < a.N) atomicAdd(D + (size_t)j * a.ldd + i, acc[x][y][t]);
+        }
+    }
+    return;
+  }
+  // bias vectors of this wave's 64 columns: branch-free, all in flight together
+  f32x4 bv[2][4];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j = jb + y * 32 + 8 * g + 4 * hi;
+      bv[y][g] = *reinterpret_cast<const f32x4*>((a.bias != nullptr && j < a.N) ? a.bias + j : g_zero_f32);
+    }
+  if (EPI == EPI_F32 || EPI == EPI_F32_ATOMIC) {   // logits (row-per-lane fp32 vectors)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int i = ib + x * 32 + r;
+      if (i >= a.M) continue;
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j = jb + y * 32 + 8 * g + 4 * hi;
+          if (j >= a.N) continue;
+          f32x4 v = {acc[x][y][4 * g], acc[x][y][4 * g + 1], acc[x][y][4 * g + 2], acc[x][y][4 * g + 3]};
+          v += bv[y][g];
+          float* d = reinterpret_cast<float*>(a.D) + (size_t)i * a.ldd + j;
+          if (EPI == EPI_F32) *reinterpret_cast<f32x4*>(d) = v;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(d + e, v[e]);
+          }
+        }
+    }
+    return;
+  }
+  // bf16 outputs: the whole 128 x 128 tile goes through LDS (row stride 136) and leaves as 256-byte row
+  // segments (a row-per-lane accumulator stored directly = 64 scattered 8-byte writes per instruction).
+  constexpr int PS = 136;
+  bf16* ct = smem;   // the operand buffers are free: the loop ended on a barrier
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int il = (wm * 2 + x) * 32 + r;
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int jl = (wn * 2 + y) * 32 + 8 * g + 4 * hi;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[x][y][4 * g + e] + bv[y][g][e];
+          if (EPI == EPI_BF16_RELU) v = fmaxf(v, 0.f);
+          o[e] = (bf16)v;
+        }
+        *reinterpret_cast<bf16x4*>(ct + il * PS + jl) = o;
+      }
+  }
+  // the mask / addend chunks this thread will need: requested before the barrier, all in flight together
+  bf16x8 auxv[8];
+  if (EPI == EPI_BF16_MASK || EPI == EPI_BF16_ADD) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int id = p * 256 + threadIdx.x, i = i0 + (id >> 4), j = j0 + (id & 15) * 8;
+      auxv[p] = gload8(a.aux + (size_t)i * a.ldaux + j, i < a.M && j < a.N);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int id = p * 256 + threadIdx.x, il = id >> 4, jl = (id & 15) * 8;
+    const int i = i0 + il, j = j0 + jl;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(ct + il * PS + jl);
+    if (EPI == EPI_BF16_MASK) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((float)auxv[p][e] > 0.f) ? v[e] : (bf16)0.f;
+    } else if (EPI == EPI_BF16_ADD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)auxv[p][e]);
+    }
+    if (i < a.M && j < a.N) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
+  }
+}
+
+template <bool XT, bool YT>
+int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
+  dim3 block(256);
+#define ST_CASE(E) case E: hipLaunchKernelGGL((gemm_sym_kernel<XT, YT, E>), grid, block, 0, stream, a); break;
+  switch (epi) {
+    ST_CASE(EPI_BF16) ST_CASE(EPI_BF16_RELU) ST_CASE(EPI_F32) ST_CASE(EPI_BF16_MASK) ST_CASE(EPI_BF16_ADD)
+    ST_CASE(EPI_F32_ATOMIC) ST_CASE(EPI_F32_ATOMIC_T)
+    default: return -1;
+  }
+#undef ST_CASE
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
+                       void* D, int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi,
+                       int splits) {
+  if (M <= 0 || N <= 0 || Kc <= 0) return 0;
+  if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 6) return -1;
+  if (x_cmajor && !y_cmajor) return -2;  // not needed by any caller
+  // contraction-major operands are read in 8-row chunks: the caller guarantees the buffer is
+  // padded (ld >= round_up(rows, 8)); rows beyond M / N only feed outputs that are never stored.
+  if ((x_cmajor && ldx < ((M + 7) & ~7)) || (y_cmajor && ldy < ((N + 7) & ~7))) return -3;
+  if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && ((ldd & 7) || (N & 7))) return -4;
+  if ((epi == EPI_BF16_MASK || epi == EPI_BF16_ADD) && (ldaux & 7)) return -5;
+  if (splits < 1) splits = 1;
+  if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T) splits = 1;
+  GemmArgs a;
+  a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
+  a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux;
+  int per = (Kc + splits - 1) / splits;
+  per = (per + BK - 1) / BK * BK;
+  splits = (Kc + per - 1) / per;
+  a.c_per_split = per;
+  a.tiles_i = (M + 127) / 128; a.tiles_j = (N + 127) / 128; a.splits = splits;
+  const int minor = splits > 1 ? a.tiles_i * a.tiles_j : a.tiles_j;
+  const int major_n = splits > 1 ? splits : a.tiles_i;
+  dim3 grid(8 * ((major_n + 7) / 8) * minor);
+  int rc;
+  if (!x_cmajor && !y_cmajor) rc = launch<false, false>(stream, a, epi, grid);
+  else if (!x_cmajor && y_cmajor) rc = launch<false, true>(stream, a, epi, grid);
+  else rc = launch<true, true>(stream, a, epi, grid);
+  if (rc) return rc;
+  ST_CHECK_LAUNCH();
+  return 0;
+}

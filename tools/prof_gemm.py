@@ -16,7 +16,7 @@ if not os.path.exists(so):
                     "-shared", src, "-o", so], check=True)
 lib = ctypes.CDLL(so)
 V = ctypes.c_void_p
-lib.st_gemm.argtypes = [V, ctypes.c_int, ctypes.c_int, V, ctypes.c_int, V, ctypes.c_int, V, ctypes.c_int, ctypes.c_int,
+lib.st_gemm_ws.argtypes = [V, ctypes.c_int, ctypes.c_int, V, ctypes.c_int, V, ctypes.c_int, V, ctypes.c_int, ctypes.c_int,
                         ctypes.c_int, ctypes.c_int, V, V, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 M, N, K = 24060, 1024, 256
 X = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
@@ -25,12 +25,12 @@ b = torch.randn(N, device="cuda")
 out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for it in range(3):
-    rc = lib.st_gemm(st, 0, 0, X.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
+    rc = lib.st_gemm_ws(st, 0, 0, X.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
     assert rc == 0
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
-lib.st_gemm(st, 0, 0, X.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
+lib.st_gemm_ws(st, 0, 0, X.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
 e.record()
 torch.cuda.synchronize()
 print("kernel us", s.elapsed_time(e) * 1e3)
@@ -47,11 +47,11 @@ print("per tile: wait %.0f mfma %.0f epi %.0f total %.0f" % tuple(a[:, i].sum() 
 # ---- where do the bytes come from?  alias operand rows (ld = 0) so a panel is a single cache line ----
 def run(ldx, ldy, tag):
     for _ in range(3):
-        lib.st_gemm(st, 0, 0, X.data_ptr(), ldx, W.data_ptr(), ldy, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
+        lib.st_gemm_ws(st, 0, 0, X.data_ptr(), ldx, W.data_ptr(), ldy, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
     torch.cuda.synchronize()
     s.record()
     for _ in range(10):
-        lib.st_gemm(st, 0, 0, X.data_ptr(), ldx, W.data_ptr(), ldy, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
+        lib.st_gemm_ws(st, 0, 0, X.data_ptr(), ldx, W.data_ptr(), ldy, out.data_ptr(), N, M, N, K, b.data_ptr(), None, 0, 1, 1)
     e.record()
     torch.cuda.synchronize()
     lib.st_prof_read(buf)
