@@ -22,10 +22,10 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int NS = BK + 8;    // natural tile row stride (80 B): conflict-free ds_read_b128 over 16 rows
-constexpr int CS_CM = 160;    // contraction-major tile row stride (128 + 32): the 4 c-rows of a tr read hit 4 bank groups
-constexpr int TILE_E = 5120;  // elements of either tile image (128 x 40 = 32 x 160)
+constexpr int BK = 64;
+constexpr int NS = BK + 8;    // natural tile row stride (144 B): conflict-free ds_read_b128 over 16 rows
+constexpr int CS_CM = 144;    // contraction-major tile row stride (128 + 16): the 4 c-rows of a tr read hit 4 bank groups
+constexpr int TILE_E = 9216;  // elements of either tile image (128 x 72 = 64 x 144)
 
 __device__ __attribute__((aligned(16))) float g_zero_f32[4];
 
@@ -42,30 +42,52 @@ struct GemmArgs {
   int c_per_split, tiles_i, tiles_j, splits;
 };
 
-// This thread's share (2 x 16 bytes) of a 128 x 32 operand tile, global -> registers -> LDS.
+// This thread's share (4 x 16 bytes) of a 128 x 64 operand tile.  The byte offsets from the k-tile's
+// (wave-uniform) base are fixed for the whole kernel, so the inner loop carries no address arithmetic and no
+// guards: rows past the edge are clamped onto a valid row (they only feed outputs that are never stored);
+// only a k-tile that crosses c_end takes the guarded path (out-of-range chunks come from a zero buffer).
+template <bool CM>
+struct Addr {
+  uint32_t off[4];
+  __device__ __forceinline__ void init(int ld, int row0, int nrows) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int id = threadIdx.x + p * 256;
+      if (!CM) {                                                // [128 rows][8 chunks]
+        const int row = min(row0 + (id >> 3), nrows - 1);
+        off[p] = ((uint32_t)row * (uint32_t)ld + (id & 7) * 8) * 2u;
+      } else {                                                  // [64 c-rows][16 chunks]
+        int row = row0 + (id & 15) * 8;
+        if (row >= nrows) row = row0;
+        off[p] = ((uint32_t)(id >> 4) * (uint32_t)ld + row) * 2u;
+      }
+    }
+  }
+};
+
 template <bool CM>
 struct Stage {
-  bf16x8 v[2];
-  __device__ __forceinline__ void load(const bf16* __restrict__ base, int ld, int row0, int nrows, int c0, int c_end) {
+  bf16x8 v[4];
+  __device__ __forceinline__ void load(const Addr<CM>& ad, const bf16* __restrict__ base, int ld, int c0, int c_end) {
+    const char* kb = reinterpret_cast<const char*>(base) + (CM ? (size_t)c0 * ld * 2 : (size_t)c0 * 2);
+    if (c0 + BK <= c_end) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int id = threadIdx.x + p * 256;
-      if (!CM) {
-        const int r = id >> 2, ch = id & 3;                   // [128 rows][4 chunks]
-        const int row = row0 + r, c = c0 + ch * 8;
-        v[p] = gload8(base + (size_t)row * ld + c, row < nrows && c < c_end);
-      } else {
-        const int cr = id >> 4, ch = id & 15;                 // [32 c-rows][16 chunks]
-        const int c = c0 + cr, row = row0 + ch * 8;
-        v[p] = gload8(base + (size_t)c * ld + row, c < c_end && row < nrows);
+      for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const bf16x8*>(kb + ad.off[p]);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int id = threadIdx.x + p * 256;
+        const bool ok = CM ? (c0 + (id >> 4) < c_end) : (c0 + (id & 7) * 8 < c_end);
+        const char* ptr = ok ? kb + ad.off[p] : reinterpret_cast<const char*>(g_zero_f32);
+        v[p] = *reinterpret_cast<const bf16x8*>(ptr);
       }
     }
   }
   __device__ __forceinline__ void store(bf16* tile) const {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 4; ++p) {
       const int id = threadIdx.x + p * 256;
-      if (!CM) *reinterpret_cast<bf16x8*>(tile + (id >> 2) * NS + (id & 3) * 8) = v[p];
+      if (!CM) *reinterpret_cast<bf16x8*>(tile + (id >> 3) * NS + (id & 7) * 8) = v[p];
       else *reinterpret_cast<bf16x8*>(tile + (id >> 4) * CS_CM + (id & 15) * 8) = v[p];
     }
   }
@@ -80,7 +102,7 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int 
 
 template <bool XT, bool YT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16 smem[4 * TILE_E];   // 2 buffers x (X tile + Y tile) = 40 KiB
+  __shared__ __attribute__((aligned(16))) bf16 smem[4 * TILE_E];   // 2 buffers x (X tile + Y tile) = 72 KiB
   // XCD-local tile walk: workgroup b runs on XCD b % 8 (own L2).  forward / dgrad: an XCD owns X row-tiles
   // i = x, x+8, ... and its consecutive workgroups take the tiles_j tiles that share one row-tile (the panel
   // crosses the fabric once); weight gradients: an XCD owns splits s = x, x+8, ... and walks their (i, j) tiles.
@@ -106,9 +128,23 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
 
+  Addr<XT> adx;
+  Addr<YT> ady;
+  adx.init(a.ldx, i0, a.M);
+  ady.init(a.ldy, j0, a.N);
   // two k-tiles in flight in registers (A: even tiles, B: odd tiles) + one in LDS being consumed
   Stage<XT> ax, bx;
   Stage<YT> ay, by;
+  auto loadA = [&](int kt) {
+    ax.load(adx, a.X, a.ldx, c_begin + kt * BK, c_end);
+    ay.load(ady, a.Y, a.ldy, c_begin + kt * BK, c_end);
+  };
+  auto loadB = [&](int kt) {
+    bx.load(adx, a.X, a.ldx, c_begin + kt * BK, c_end);
+    by.load(ady, a.Y, a.ldy, c_begin + kt * BK, c_end);
+  };
+  auto storeA = [&]() { ax.store(xs(0)); ay.store(ys(0)); };
+  auto storeB = [&]() { bx.store(xs(1)); by.store(ys(1)); };
   auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -124,38 +160,37 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
         for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
     }
   };
-  ax.load(a.X, a.ldx, i0, a.M, c_begin, c_end);
-  ay.load(a.Y, a.ldy, j0, a.N, c_begin, c_end);
-  if (nk > 1) {
-    bx.load(a.X, a.ldx, i0, a.M, c_begin + BK, c_end);
-    by.load(a.Y, a.ldy, j0, a.N, c_begin + BK, c_end);
-  }
-  ax.store(xs(0));
-  ay.store(ys(0));
+  loadA(0);
+  if (nk > 1) loadB(1);
+  storeA();
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) {
-      ax.load(a.X, a.ldx, i0, a.M, c_begin + (kt + 2) * BK, c_end);
-      ay.load(a.Y, a.ldy, j0, a.N, c_begin + (kt + 2) * BK, c_end);
-    }
+  int kt = 0;
+  // steady state: no conditionals, so the compiler's s_waitcnt vmcnt() stays counted (the loads of tile
+  // kt+2 remain in flight across the LDS store of tile kt+1)
+  for (; kt + 3 < nk; kt += 2) {
+    loadA(kt + 2);
     compute(0);
-    if (kt + 1 < nk) {
-      bx.store(xs(1));
-      by.store(ys(1));
-    }
+    storeB();
     __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) {
-      bx.load(a.X, a.ldx, i0, a.M, c_begin + (kt + 3) * BK, c_end);
-      by.load(a.Y, a.ldy, j0, a.N, c_begin + (kt + 3) * BK, c_end);
-    }
+    loadB(kt + 3);
+    compute(1);
+    storeA();
+    __syncthreads();
+  }
+  // tail: 1..3 tiles left; tile kt is in LDS buffer 0, tile kt+1 (if any) in the B registers
+  if (kt + 2 < nk) loadA(kt + 2);
+  compute(0);
+  if (kt + 1 < nk) {
+    storeB();
+    __syncthreads();
     compute(1);
     if (kt + 2 < nk) {
-      ax.store(xs(0));
-      ay.store(ys(0));
+      storeA();
+      __syncthreads();
+      compute(0);
     }
-    __syncthreads();
   }
+  __syncthreads();   // the epilogue reuses the operand buffers
 
   // ---- epilogues ------------------------------------------------------------------------------
   const int ib = i0 + wm * 64, jb = j0 + wn * 64;
@@ -211,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
   // bf16 outputs: the whole 128 x 128 tile goes through LDS (row stride 136) and leaves as 256-byte row
   // segments (a row-per-lane accumulator stored directly = 64 scattered 8-byte writes per instruction).
   constexpr int PS = 136;
-  bf16* ct = smem;   // the operand buffers are free: the loop ended on a barrier
+  bf16* ct = smem;   // the operand buffers are free (barrier above)
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
     const int il = (wm * 2 + x) * 32 + r;
