@@ -51,9 +51,13 @@ enum {
  * autograd backward): forward (0,0), dgrad (0,1), wgrad (1,1).
  * M rows of X, N rows of Y, Kc contraction length; `splits` > 1 only with
  * ST_EPI_F32_ATOMIC / ST_EPI_F32_ATOMIC_T (the latter stores the transposed
- * result: D is [N, ldd >= M]). */
+ * result: D is [N, ldd >= M]).
+ * bias: fp32 [N], read and added to the accumulator - EXCEPT with
+ * ST_EPI_F32_ATOMIC_T, where a non-NULL bias is the fp32 [N] bias-GRADIENT
+ * accumulator: bias[j] += sum_c Y(j,c) (the column sums of dy, i.e. the
+ * nn.Linear bias gradient, produced by the weight-gradient launch itself). */
 int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy, void* D,
-            int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi, int splits);
+            int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits);
 
 /* out = LayerNorm(act(X W^T + bias) + res) * gamma + beta (+ pe[pos[row]]),
  * N = d_model in {128, 256, 512}.  Replaces output_linear + residual +

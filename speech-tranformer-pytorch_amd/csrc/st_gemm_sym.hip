@@ -128,6 +128,15 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
 
+  // weight-gradient launches can also produce the bias gradient: sum_c Y(j,c) = one more MFMA per Y
+  // fragment against a fragment of ones, on the (otherwise idle) matrix pipe of the ti == 0 workgroups
+  constexpr bool CSUM = (EPI == EPI_F32_ATOMIC_T);
+  const bool do_cs = CSUM && a.bias != nullptr && ti == 0 && wm == 0;
+  f32x16 cs[2] = {zero16(), zero16()};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
   Addr<XT> adx;
   Addr<YT> ady;
   adx.init(a.ldx, i0, a.M);
@@ -158,6 +167,12 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) acc[x][y] = mfma32(yf[y], xf[x], acc[x][y]);
+      if (CSUM) {
+        if (do_cs) {
+#pragma unroll
+          for (int y = 0; y < 2; ++y) cs[y] = mfma32(yf[y], ones, cs[y]);
+        }
+      }
     }
   };
   loadA(0);
@@ -207,6 +222,16 @@ __global__ __launch_bounds__(256, 2) void gemm_sym_kernel(GemmArgs a) {
         for (int t = 0; t < 16; ++t) {
           const int j = jb + y * 32 + acc_row(t, hi);
           if (j < a.N) atomicAdd(D + (size_t)j * a.ldd + i, acc[x][y][t]);
+        }
+    }
+    if (do_cs && r == 0) {   // every column of cs holds the same sums: lanes 0 and 32 carry all 32 rows
+      float* db = const_cast<float*>(a.bias);
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int j = jb + y * 32 + acc_row(t, hi);
+          if (j < a.N) atomicAdd(db + j, cs[y][t]);
         }
     }
     return;
@@ -307,7 +332,7 @@ int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
 }  // namespace
 
 extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
-                       void* D, int ldd, int M, int N, int Kc, const float* bias, const void* aux, int ldaux, int epi,
+                       void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi,
                        int splits) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
   if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 6) return -1;

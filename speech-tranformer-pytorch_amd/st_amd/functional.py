@@ -122,11 +122,12 @@ def _splits(M: int, N: int, K: int) -> int:
     return s
 
 
-def wgrad(dY, X, gW, rows=None):
+def wgrad(dY, X, gW, rows=None, gB=None):
     """gW[n][k] += sum_m dY[m][n] X[m][k]   (both operands contraction-major).  The kernel's
-    lane axis is k (the contiguous axis of gW) so the split-K atomics are coalesced."""
+    lane axis is k (the contiguous axis of gW) so the split-K atomics are coalesced.
+    ``gB``: the same launch also accumulates the bias gradient gB[n] += sum_m dY[m][n]."""
     N = dY.shape[1] if rows is None else rows
-    nv.gemm(X, dY, gW, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True,
+    nv.gemm(X, dY, gW, bias=gB, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True,
             splits=_splits(dY.shape[0], N, X.shape[1]), n=N)
 
 
@@ -203,15 +204,12 @@ class MhaFn(torch.autograd.Function):
         dx_q = _empty(Mq, d, x_q)
         dx_kv = None
         if x_kv is None:
-            wgrad(dqkv, x_q, s.g_w_qkv)
-            nv.colsum(dqkv, s.g_b_qkv)
+            wgrad(dqkv, x_q, s.g_w_qkv, gB=s.g_b_qkv)
             dgrad(dqkv, s.w_qkv, dx_q, epi=nv.EPI_BF16_ADD, aux=ds)
         else:
-            wgrad(dqkv, x_q, s.g_w_q)
-            nv.colsum(dqkv, s.g_b_q)
+            wgrad(dqkv, x_q, s.g_w_q, gB=s.g_b_q)
             dgrad(dqkv, s.w_q, dx_q, epi=nv.EPI_BF16_ADD, aux=ds)
-            wgrad(dkv, x_kv, s.g_w_kv)
-            nv.colsum(dkv, s.g_b_kv)
+            wgrad(dkv, x_kv, s.g_w_kv, gB=s.g_b_kv)
             dx_kv = _empty(x_kv.shape[0], d, x_q)
             dgrad(dkv, s.w_kv, dx_kv)
         arena.grads_ready(s.lo, s.hi)
@@ -247,8 +245,7 @@ class FfnFn(torch.autograd.Function):
         wgrad(ds, h, s.g_w2)
         dh = _empty(M, s.d_ff, x)
         dgrad(ds, s.w2, dh, epi=nv.EPI_BF16_MASK, aux=h)
-        wgrad(dh, x, s.g_w1)
-        nv.colsum(dh, s.g_b1)
+        wgrad(dh, x, s.g_w1, gB=s.g_b1)
         dx = _empty(M, d, x)
         dgrad(dh, s.w1, dx, epi=nv.EPI_BF16_ADD, aux=ds)
         arena.grads_ready(s.lo, s.hi)

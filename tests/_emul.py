@@ -28,7 +28,10 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
     Xl = torch.nn.functional.pad(Xl, (0, max(0, Kc - Xl.shape[1]), 0, max(0, M - Xl.shape[0])))[:M, :Kc]
     Yl = torch.nn.functional.pad(Yl, (0, max(0, Kc - Yl.shape[1]), 0, max(0, N - Yl.shape[0])))[:N, :Kc]
     acc = Xl @ Yl.t()
-    if bias is not None:
+    if epi == nv.EPI_F32_ATOMIC_T:
+        if bias is not None:
+            bias[:N] += Yl.sum(1)      # fused bias gradient
+    elif bias is not None:
         acc = acc + bias[:N]
     if epi == nv.EPI_BF16_RELU:
         acc = torch.relu(acc)

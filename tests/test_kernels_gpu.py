@@ -120,6 +120,13 @@ def test_gemm_wgrad(M, N, K, splits):
     out_t = nv.gemm(cu(x), cu(dy), cu(init.clone()), epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True,
                     splits=splits, n=N)
     check(out_t, ref, 2e-3, "gemm wgrad (transposed store) %s" % ((M, N, K, splits),))
+    # ... which can also accumulate the bias gradient (column sums of dy)
+    b0 = g(1, N, seed=4, dtype=F32).view(-1)
+    db = cu(b0.clone())
+    out_b = nv.gemm(cu(x), cu(dy), cu(init.clone()), bias=db, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True,
+                    splits=splits, n=N)
+    check(out_b, ref, 2e-3, "gemm wgrad + bias grad %s" % ((M, N, K, splits),))
+    check(db, b0 + dy.float().sum(0), 2e-3, "fused bias grad %s" % ((M, N, K, splits),))
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1000, 256, 256), (130, 256, 1024), (70, 512, 512), (500, 256, 80)])
