@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev tool: build st_gemm.hip with -DST_PROF and print per-workgroup phase cycles of one GEMM."""
+"""Dev tool: build tools/dev/st_gemm_ws.hip (the persistent wave-specialised A/B reference) with -DST_PROF and print per-workgroup phase cycles of one GEMM."""
 import ctypes
 import os
 import subprocess
@@ -8,11 +8,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
 
-src = os.path.join(ROOT, "speech-tranformer-pytorch_amd", "csrc", "st_gemm.hip")
+src = os.path.join(ROOT, "tools", "dev", "st_gemm_ws.hip")
+inc = os.path.join(ROOT, "speech-tranformer-pytorch_amd", "csrc")
 so = os.path.join(ROOT, "gpurun_out", "libst_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 if not os.path.exists(so):
-    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-DST_PROF", "-fPIC",
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-DST_PROF", "-I", inc, "-fPIC",
                     "-shared", src, "-o", so], check=True)
 lib = ctypes.CDLL(so)
 V = ctypes.c_void_p
