@@ -113,9 +113,10 @@ class Rows:
 
 def _splits(M: int, N: int, K: int) -> int:
     """Split count of the token (contraction) axis of a weight-gradient GEMM: a power of two so that the
-    persistent kernel's XCD-local tile walk keeps one split per XCD slot; ~2 tiles of work per CU."""
+    kernel's XCD-local tile walk keeps whole splits on one XCD; one 8-wave workgroup per CU (its two wave
+    groups split the range once more internally - fewer splits = fewer fp32 atomics, the bound here)."""
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    want = max(1, min((M + 255) // 256, (512 + tiles - 1) // tiles))
+    want = max(1, min((M + 255) // 256, (256 + tiles - 1) // tiles))
     s = 1
     while s * 2 <= want:
         s *= 2

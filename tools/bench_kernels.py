@@ -62,7 +62,7 @@ if "gemm" in which:
     for (m, n, k, tag) in [(M, 768, 256, "qkv"), (M, 1024, 256, "w1"), (M, 256, 1024, "w2"), (M, 256, 256, "wo"),
                            (Md, 1024, 256, "dec w1")]:
         dY, X, g = rnd(m, n), rnd(m, k), torch.zeros(n, k, dtype=F32, device=dev)
-        sp = _splits(m, n, k)
+        sp = int(os.environ.get("ST_SPLITS", _splits(m, n, k)))
         us = timeit(lambda: nv.gemm(X, dY, g, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=sp, n=n))
         report("wgrad %-8s dW[%d,%d] m=%d s=%d" % (tag, n, k, m, sp), us, 2.0 * m * n * k, 2.0 * (m * n + m * k))
     for (m, k, tag) in [(M, 256, "wo"), (M, 1024, "ffn2"), (Md, 256, "dec wo"), (Md, 1024, "dec ffn2")]:
