@@ -79,19 +79,25 @@ int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, co
 /* Fused masked attention forward: softmax(Q K^T * scale, keys >= k_len[b]
  * and (causal) keys > query masked) V, per head; replaces Attention.py:82-90
  * and the dense masks of Utils.py:41-70.  lse (f32 [H, q_rows_total], log2
- * domain) is saved for the backward.  d_k in {32, 64}. */
+ * domain) is saved for the backward.  d_k in {32, 64}.
+ * work (optional, device int32 [n_work]): the (utterance, 128-query tile)
+ * pairs to run, packed (b << 16) | tile and sorted by decreasing cost, so the
+ * ragged batch is list-scheduled longest-first; NULL = enumerate every tile
+ * of every utterance up to max_q. */
 int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
                 int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
-                int H, int d_k, int max_q, int q_rows_total, int causal, float scale);
+                int H, int d_k, int max_q, int q_rows_total, int causal, float scale, const int* work, int n_work);
 
 /* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
  * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:
- * parts & 1 = dQ (also writes delta), parts & 2 = dK/dV (reads delta); 3 = both. */
+ * parts & 1 = dQ (also writes delta), parts & 2 = dK/dV (reads delta); 3 = both.
+ * work_q / work_k: optional work lists (see st_attn_fwd) over 128-query tiles
+ * (dQ kernel) and 128-key tiles (dK/dV kernel). */
 int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                 const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                 void* dK, int lddk, void* dV, int lddv, const int* q_off, const int* q_len, const int* k_off,
                 const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
-                float scale, int parts);
+                float scale, int parts, const int* work_q, int n_work_q, const int* work_k, int n_work_k);
 
 /* out[N] (f32) += column sums of x (bf16 [M, N]) - bias gradients. */
 int st_colsum(st_stream_t stream, const void* x, int ld, int M, int N, float* out);

@@ -18,22 +18,22 @@
 // lane-local and the second MFMA of every pair consumes the first one's accumulator
 // registers directly (pack_acc8) - no P / dS round trip through LDS.
 //
-// Memory pipeline: the streamed operand tiles (K/V, or Q/dO + their lse/delta) arrive by
-// LDS-DMA (global_load_lds) into a 4-slot LDS ring, three tiles ahead of the MFMAs, with a
-// counted s_waitcnt vmcnt(N) + one raw s_barrier per tile (the loop issues no other vector
-// memory operation, so the in-order counter is exact).  Measured tile latency under load is
-// ~2 us against ~0.3 us of MFMA work per tile: without the ring the kernels are latency-bound.
+// Work decomposition: one workgroup (4 waves x 32 rows) per (utterance, head, 128-row tile).  The host
+// passes a WORK LIST of (utterance, tile) pairs sorted by decreasing cost (number of streamed tiles), so the
+// hardware dispatcher - which hands out workgroups in blockIdx order as CUs free up - does longest-first
+// list scheduling over the ragged batch; without a list the kernels enumerate utterance-major.
+//
+// Memory pipeline (same scheme as st_gemm_sym.hip; measured: the kernels are instruction-issue bound, and
+// LDS-DMA tops out at ~10 B/clk/CU): every thread carries 16-byte chunks of the streamed 64-row tiles
+// global -> registers (two tiles in flight) -> padded LDS double buffer, with byte offsets fixed for the whole
+// kernel - the steady-state loop has no address arithmetic, no guards and one barrier per tile.  Rows past
+// the end of a sequence are CLAMPED onto its last row (finite data); the mask path zeroes their weight.
 #include "st_common.cuh"
 
 namespace {
 
-#define ST_AS1 __attribute__((address_space(1)))
-
 constexpr int TILE = 64;      // rows (keys or queries) per streamed tile
-constexpr int RING = 4;       // LDS ring slots; RING-1 tiles in flight
 constexpr int WG_ROWS = 128;  // rows owned by a workgroup (4 waves x 32)
-
-__device__ __attribute__((aligned(16))) bf16 g_zero_row[8];  // zero source for rows past the end
 
 struct AttnArgs {
   const bf16* Q; int ldq;
@@ -48,73 +48,121 @@ struct AttnArgs {
   float* delta;                   // [H][q_rows_total]
   const int* q_off; const int* q_len;
   const int* k_off; const int* k_len;
+  const int* work;                // (b << 16) | tile, sorted by decreasing cost; or null
+  int tiles_max;                  // without a work list: tiles per utterance enumerated
+  int H;
   int q_rows_total;
   int causal;
   float scale;                    // 1/sqrt(d_k)
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Wait until at most `younger` tiles (of IPI wave-instructions each) are still in flight.
-template <int IPI>
-__device__ __forceinline__ void wait_tiles(int younger) {
-  if (younger >= 2) wait_vmcnt<2 * IPI>();
-  else if (younger == 1) wait_vmcnt<IPI>();
-  else wait_vmcnt<0>();
-}
-
-// ---- [64 x DK] bf16 tile images in LDS -----------------------------------------------------------
-// Lane-linear (LDS-DMA) image: 16-byte chunk p of row r holds logical chunk p ^ swz(r).
-//   SWZ_NAT: swz(r) = (r >> SH) & (CPR - 1)  -> ds_read_b128 row fragments of 16 consecutive rows are
-//            conflict-free (transposing reads of the same tile are 2-way conflicted);
-//   SWZ_TR : swz(r) = ((r >> 1) & 1) << 2 (DK = 64) -> the 4 rows of a ds_read_b64_tr_b16 fall into
-//            4 different 64-byte bank groups (tile only read through the transposing read).
-enum { SWZ_NAT = 0, SWZ_TR = 1 };
-
-template <int DK, int MODE>
-__device__ __forceinline__ int swz(int r) {
-  constexpr int CPR = DK / 8;
-  if (MODE == SWZ_NAT) return (r >> (DK == 64 ? 1 : 2)) & (CPR - 1);
-  return DK == 64 ? ((r >> 1) & 1) << 2 : 0;
-}
-
-// Issue the LDS-DMA of rows r0 .. r0+63 (zero rows past nvalid) of a [*, ld] matrix, column slice
-// starting at `base`, into `tile`.  DK/32 wave-instructions per wave.
-template <int DK, int MODE>
-__device__ __forceinline__ void issue_rows(bf16* tile, const bf16* __restrict__ base, int ld, int r0, int nvalid) {
-  constexpr int CPR = DK / 8, RPI = 64 / CPR;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = threadIdx.x & 63;
-#pragma unroll
-  for (int t = 0; t < DK / 32; ++t) {
-    const int I = t * 4 + w;
-    const int r = I * RPI + i / CPR, p = i % CPR;
-    const bf16* src = (r0 + r < nvalid) ? base + (size_t)(r0 + r) * ld + ((p ^ swz<DK, MODE>(r)) << 3) : g_zero_row;
-    lds_dma16(src, lds_addr(tile + I * 512));
+// blockIdx.x -> (utterance, head, tile)
+__device__ __forceinline__ void decode_item(const AttnArgs& a, int& b, int& h, int& tile) {
+  const int idx = blockIdx.x / a.H;
+  h = blockIdx.x % a.H;
+  if (a.work) {
+    const int w = a.work[idx];
+    b = w >> 16;
+    tile = w & 0xffff;
+  } else {
+    b = idx / a.tiles_max;
+    tile = idx % a.tiles_max;
   }
 }
 
+// ---- streamed [64 x DK] tiles ----------------------------------------------------------------------
+// LDS image: natural rows, stride DK + 8 elements (144 B / 80 B): ds_read_b128 row fragments over 16 rows
+// and the 4-row groups of ds_read_b64_tr_b16 are both bank-conflict free (DK = 64).
+template <int DK> struct TileGeo {
+  static constexpr int STR = DK + 8, E = TILE * STR, CPR = DK / 8, CH = DK / 32;   // CH chunks per thread
+};
+
+template <int DK>
+struct Stage {
+  using G = TileGeo<DK>;
+  bf16x8 v[G::CH];
+  // chunk id = tid + p*256 -> tile row id / CPR, 16-byte chunk id % CPR
+  static __device__ __forceinline__ void offsets(uint32_t (&off)[G::CH], int ld) {
+#pragma unroll
+    for (int p = 0; p < G::CH; ++p) {
+      const int id = threadIdx.x + p * 256;
+      off[p] = ((uint32_t)(id / G::CPR) * (uint32_t)ld + (id % G::CPR) * 8) * 2u;
+    }
+  }
+  // rows r0 .. r0+63 of the utterance's column slice `base`; rows >= nvalid read row nvalid-1
+  __device__ __forceinline__ void load(const uint32_t (&off)[G::CH], const bf16* __restrict__ base, int ld, int r0,
+                                       int nvalid) {
+    if (r0 + TILE <= nvalid) {
+      const char* tb = reinterpret_cast<const char*>(base + (size_t)r0 * ld);
+#pragma unroll
+      for (int p = 0; p < G::CH; ++p) v[p] = *reinterpret_cast<const bf16x8*>(tb + off[p]);
+    } else {
+#pragma unroll
+      for (int p = 0; p < G::CH; ++p) {
+        const int id = threadIdx.x + p * 256;
+        const int row = min(r0 + id / G::CPR, nvalid - 1);
+        v[p] = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + (id % G::CPR) * 8);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(bf16* tile) const {
+#pragma unroll
+    for (int p = 0; p < G::CH; ++p) {
+      const int id = threadIdx.x + p * 256;
+      *reinterpret_cast<bf16x8*>(tile + (id / G::CPR) * G::STR + (id % G::CPR) * 8) = v[p];
+    }
+  }
+};
+
 // Row fragment: elements t16*16 + hi*8 .. +7 of tile row R (A or B operand, contraction along DK).
-template <int DK, int MODE>
+template <int DK>
 __device__ __forceinline__ bf16x8 rd_nat(const bf16* tile, int R, int t16) {
   const int hi = (threadIdx.x & 63) >> 5;
-  return *reinterpret_cast<const bf16x8*>(tile + R * DK + (((t16 * 2 + hi) ^ swz<DK, MODE>(R)) << 3));
+  return frag_nat(tile, TileGeo<DK>::STR, R, t16 * 16 + hi * 8);
 }
-
 // Transposing fragment: for column d0 + (lane & 31), the 8 tile rows base+0..3 and base+8..11
 // (base already includes 4*hi) - the contraction runs over the tile's ROWS.
-template <int DK, int MODE>
+template <int DK>
 __device__ __forceinline__ bf16x8 rd_tr(const bf16* tile, int d0, int base) {
-  const int l = threadIdx.x & 63, t = l & 15;
-  const int col = d0 + ((l >> 4) & 1) * 16 + 4 * (t & 3);
-  const int ra = base + (t >> 2), rb = ra + 8;
-  const bf16* pa = tile + ra * DK + (((col >> 3) ^ swz<DK, MODE>(ra)) << 3) + (col & 7);
-  const bf16* pb = tile + rb * DK + (((col >> 3) ^ swz<DK, MODE>(rb)) << 3) + (col & 7);
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pa));
-  const bf16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pb));
-  bf16x8 f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-  f[4] = up[0]; f[5] = up[1]; f[6] = up[2]; f[7] = up[3];
-  return f;
+  return frag_tr(tile, TileGeo<DK>::STR, d0, base, base + 8);
+}
+
+// The software pipeline shared by the three kernels.  load(set, tile) fills register set `set`,
+// store(set) writes it to LDS buffer `set`, compute(buf, tile) consumes LDS buffer `buf`.
+// Steady state has no conditionals, so the compiler's s_waitcnt vmcnt() stays counted: the loads of
+// tile it+2 remain in flight across the LDS store of tile it+1.
+template <typename L, typename S, typename C>
+__device__ __forceinline__ void stream_tiles(int ntiles, L load, S store, C compute) {
+  if (ntiles <= 0) return;   // (workgroup-uniform) nothing visible: the accumulators stay zero
+  load(0, 0);
+  if (ntiles > 1) load(1, 1);
+  store(0);
+  __syncthreads();
+  int it = 0;
+  for (; it + 3 < ntiles; it += 2) {
+    load(0, it + 2);
+    compute(0, it);
+    store(1);
+    __syncthreads();
+    load(1, it + 3);
+    compute(1, it + 1);
+    store(0);
+    __syncthreads();
+  }
+  // tail: 1..3 tiles left; tile `it` is in LDS buffer 0, tile it+1 (if any) in register set 1
+  if (it + 2 < ntiles) load(0, it + 2);
+  compute(0, it);
+  if (it + 1 < ntiles) {
+    store(1);
+    __syncthreads();
+    compute(1, it + 1);
+    if (it + 2 < ntiles) {
+      store(0);
+      __syncthreads();
+      compute(0, it + 2);
+    }
+  }
+  __syncthreads();   // the epilogue reuses the tile buffers
 }
 
 // Store a transposed accumulator tile (lane = row, registers = DK columns) as coalesced rows:
@@ -146,24 +194,24 @@ __device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward.  grid = (ceil(max_q / 128), H, B).  Each wave owns 32 query rows (lane & 31).
+// Forward.  Each wave owns 32 query rows (lane & 31); key / value tiles are streamed.
 // ---------------------------------------------------------------------------------------------
 template <int DK>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  using G = TileGeo<DK>;
   constexpr int NT = DK / 16;   // k-steps of the QK^T contraction
   constexpr int ND = DK / 32;   // 32-wide output column tiles
-  constexpr int TE = TILE * DK; // elements per tile
-  constexpr int IPI = 2 * (DK / 32);
-  __shared__ __attribute__((aligned(1024))) bf16 smem[RING * 2 * TE];
+  __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];   // 2 buffers x (K tile, V tile)
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  int b, h, tile;
+  decode_item(a, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
-  const int q0 = blockIdx.x * WG_ROWS;
+  const int q0 = tile * WG_ROWS;
   if (q0 >= lq) return;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
   const int q = q0 + wave * 32 + (l & 31);
   const bool q_ok = q < lq;
-  const size_t qrow = (size_t)a.q_off[b] + q;
+  const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
   const float c2 = a.scale * 1.4426950408889634f;  // scores -> log2 domain
 
   const int k_hi = a.causal ? min(lk, q0 + WG_ROWS) : lk;   // keys this workgroup can see
@@ -173,45 +221,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
   bf16x8 qf[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) qf[t] = gload8(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8, q_ok);
-  // the Q fragments are in registers before the counted waits below start counting ring tiles
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int t = 0; t < NT; ++t) touch(qf[t]);
-#pragma unroll
-  for (int t = 0; t < RING - 1; ++t)
-    if (t < ntiles) {
-      issue_rows<DK, SWZ_NAT>(smem + t * 2 * TE, kbase, a.ldk, t * TILE, lk);
-      issue_rows<DK, SWZ_TR>(smem + t * 2 * TE + TE, vbase, a.ldv, t * TILE, lk);
-    }
+  for (int t = 0; t < NT; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8);
+
+  uint32_t offk[G::CH], offv[G::CH];
+  Stage<DK>::offsets(offk, a.ldk);
+  Stage<DK>::offsets(offv, a.ldv);
+  Stage<DK> sk[2], sv[2];
 
   f32x16 o[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) o[d] = zero16();
   float m = -INFINITY, lsum = 0.f;
 
-  for (int it = 0; it < ntiles; ++it) {
-    wait_tiles<IPI>(min(RING - 2, ntiles - 1 - it));
-    __builtin_amdgcn_s_barrier();   // tile `it` landed for every wave; slot of tile it-1 is free
-    if (it + RING - 1 < ntiles) {
-      const int nt = it + RING - 1, slot = nt % RING;
-      issue_rows<DK, SWZ_NAT>(smem + slot * 2 * TE, kbase, a.ldk, nt * TILE, lk);
-      issue_rows<DK, SWZ_TR>(smem + slot * 2 * TE + TE, vbase, a.ldv, nt * TILE, lk);
-    }
-    const bf16* ks = smem + (it % RING) * 2 * TE;
-    const bf16* vs = ks + TE;
+  auto load = [&](int set, int it) {
+    sk[set].load(offk, kbase, a.ldk, it * TILE, lk);
+    sv[set].load(offv, vbase, a.ldv, it * TILE, lk);
+  };
+  auto store = [&](int set) {
+    sk[set].store(smem + set * 2 * G::E);
+    sv[set].store(smem + set * 2 * G::E + G::E);
+  };
+  auto compute = [&](int buf, int it) {
+    const bf16* ks = smem + buf * 2 * G::E;
+    const bf16* vs = ks + G::E;
     const int kt = it * TILE;
-
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       s[kb] = zero16();
 #pragma unroll
-      for (int t = 0; t < NT; ++t) s[kb] = mfma32(rd_nat<DK, SWZ_NAT>(ks, kb * 32 + (l & 31), t), qf[t], s[kb]);
+      for (int t = 0; t < NT; ++t) s[kb] = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s[kb]);
     }
-    // The softmax arithmetic is the VALU critical path (the MFMAs of a tile take ~512 cycles, a
-    // naive per-element mask/scale/exp chain ~3000): masks only on tiles that cross a sequence end or
-    // the diagonal (wave-uniform test), scale folded into one fma feeding the raw v_exp_f32.
+    // masks only on tiles that cross a sequence end or the diagonal (wave-uniform test)
     const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + wave * 32);
     if (!full) {
 #pragma unroll
@@ -228,10 +269,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
     mx = fmaxf(mx, wave_xor32(mx));
-    const float m_new = fmaxf(m, mx * c2);           // log2 domain
-    // m_new is finite from the first tile on (key 0 is visible to every query); guard anyway
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+    // log2 domain; m_new is finite from the first tile on (key 0 is visible to every query)
+    const float m_new = fmaxf(m, mx * c2);
+    if (__any(m_new != m)) {   // the running maximum settles after a few tiles: skip the rescale then
+      const float m_fin = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m - m_fin);
+      lsum *= alpha;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      m = m_new;
+    }
+    const float m_use = (m == -INFINITY) ? 0.f : m;
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -241,12 +291,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         s[kb][r] = p;
         psum += p;
       }
-    lsum = lsum * alpha + psum;
-    m = m_new;
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    lsum += psum;
     // O^T += V^T P^T : A operand = V^T (transposing LDS read), B operand = P^T (own registers)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -255,14 +300,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         const bf16x8 pf = pack_acc8(s[kb], 8 * hf);
         const int base = kb * 32 + 16 * hf + 4 * hi;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) o[d] = mfma32(rd_tr<DK, SWZ_TR>(vs, d * 32, base), pf, o[d]);
+        for (int d = 0; d < ND; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
       }
-  }
+  };
+  stream_tiles(ntiles, load, store, compute);
 
   const float ltot = lsum + wave_xor32(lsum);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
   if (q_ok && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
-  __builtin_amdgcn_s_barrier();   // every wave is done with the ring: reuse it for the output patches
   store_rows<DK>(smem + wave * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + wave * 32,
                  min(32, lq - (q0 + wave * 32)));
 }
@@ -272,18 +317,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 //   P^T = exp2(S^T c2 - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta),  dQ^T += K^T dS^T
 // ---------------------------------------------------------------------------------------------
 template <int DK>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
-  constexpr int NT = DK / 16, ND = DK / 32, TE = TILE * DK, IPI = 2 * (DK / 32);
-  __shared__ __attribute__((aligned(1024))) bf16 smem[RING * 2 * TE];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  using G = TileGeo<DK>;
+  constexpr int NT = DK / 16, ND = DK / 32;
+  __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  int b, h, tile;
+  decode_item(a, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
-  const int q0 = blockIdx.x * WG_ROWS;
+  const int q0 = tile * WG_ROWS;
   if (q0 >= lq) return;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
   const int q = q0 + wave * 32 + (l & 31);
   const bool q_ok = q < lq;
-  const size_t qrow = (size_t)a.q_off[b] + q;
+  const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
   const float c2 = a.scale * 1.4426950408889634f;
 
   const int k_hi = a.causal ? min(lk, q0 + WG_ROWS) : lk;
@@ -296,42 +343,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = h * DK + t * 16 + hi * 8;
-    qf[t] = gload8(a.Q + qrow * a.ldq + col, q_ok);
-    dof[t] = gload8(a.dO + qrow * a.lddo + col, q_ok);
-    const bf16x8 of = gload8(a.O + qrow * a.ldo + col, q_ok);
+    qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + col);
+    dof[t] = *reinterpret_cast<const bf16x8*>(a.dO + qrow * a.lddo + col);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + qrow * a.ldo + col);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dl += (float)dof[t][e] * (float)of[e];
   }
   dl += wave_xor32(dl);
-  const float lse = q_ok ? a.lse[(size_t)h * a.q_rows_total + qrow] : INFINITY;
+  const float lse = a.lse[(size_t)h * a.q_rows_total + qrow];
   if (q_ok && hi == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue loads / stores retired before counting tiles
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { touch(qf[t]); touch(dof[t]); }
-  float lse_r = lse;
-  touch(lse_r);
-  touch(dl);
-#pragma unroll
-  for (int t = 0; t < RING - 1; ++t)
-    if (t < ntiles) {
-      issue_rows<DK, SWZ_NAT>(smem + t * 2 * TE, kbase, a.ldk, t * TILE, lk);
-      issue_rows<DK, SWZ_NAT>(smem + t * 2 * TE + TE, vbase, a.ldv, t * TILE, lk);
-    }
+
+  uint32_t offk[G::CH], offv[G::CH];
+  Stage<DK>::offsets(offk, a.ldk);
+  Stage<DK>::offsets(offv, a.ldv);
+  Stage<DK> sk[2], sv[2];
 
   f32x16 dq[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) dq[d] = zero16();
 
-  for (int it = 0; it < ntiles; ++it) {
-    wait_tiles<IPI>(min(RING - 2, ntiles - 1 - it));
-    __builtin_amdgcn_s_barrier();
-    if (it + RING - 1 < ntiles) {
-      const int nt = it + RING - 1, slot = nt % RING;
-      issue_rows<DK, SWZ_NAT>(smem + slot * 2 * TE, kbase, a.ldk, nt * TILE, lk);
-      issue_rows<DK, SWZ_NAT>(smem + slot * 2 * TE + TE, vbase, a.ldv, nt * TILE, lk);
-    }
-    const bf16* ks = smem + (it % RING) * 2 * TE;
-    const bf16* vs = ks + TE;
+  auto load = [&](int set, int it) {
+    sk[set].load(offk, kbase, a.ldk, it * TILE, lk);
+    sv[set].load(offv, vbase, a.ldv, it * TILE, lk);
+  };
+  auto store = [&](int set) {
+    sk[set].store(smem + set * 2 * G::E);
+    sv[set].store(smem + set * 2 * G::E + G::E);
+  };
+  auto compute = [&](int buf, int it) {
+    const bf16* ks = smem + buf * 2 * G::E;
+    const bf16* vs = ks + G::E;
     const int kt = it * TILE;
     const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + wave * 32);   // no masks needed
 #pragma unroll
@@ -339,18 +380,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        s = mfma32(rd_nat<DK, SWZ_NAT>(ks, kb * 32 + (l & 31), t), qf[t], s);
-        dp = mfma32(rd_nat<DK, SWZ_NAT>(vs, kb * 32 + (l & 31), t), dof[t], dp);
+        s = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s);
+        dp = mfma32(rd_nat<DK>(vs, kb * 32 + (l & 31), t), dof[t], dp);
       }
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r)) * (dp[r] - dl);
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse)) * (dp[r] - dl);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt + kb * 32 + acc_row(r, hi);
           const bool dead = key >= lk || (a.causal && key > q);
-          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_r));
+          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse));
           s[r] = p * (dp[r] - dl);
         }
       }
@@ -359,43 +400,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         const bf16x8 dsf = pack_acc8(s, 8 * hf);
         const int base = kb * 32 + 16 * hf + 4 * hi;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) dq[d] = mfma32(rd_tr<DK, SWZ_NAT>(ks, d * 32, base), dsf, dq[d]);
+        for (int d = 0; d < ND; ++d) dq[d] = mfma32(rd_tr<DK>(ks, d * 32, base), dsf, dq[d]);
       }
     }
-  }
-  __builtin_amdgcn_s_barrier();
+  };
+  stream_tiles(ntiles, load, store, compute);
   store_rows<DK>(smem + wave * 32 * DK, dq, a.scale, a.dQ + (size_t)a.q_off[b] * a.lddq + h * DK, a.lddq,
                  q0 + wave * 32, min(32, lq - (q0 + wave * 32)));
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward, part 2: dK, dV.  grid = (ceil(max_k / 128), H, B); each wave owns 32 keys (lane & 31)
-// and loops over 64-query tiles streamed through the LDS ring (Q rows, dO rows, and a per-wave
-// copy of the tile's 64 lse + 64 delta values).
+// Backward, part 2: dK, dV.  Each wave owns 32 keys (lane & 31) and loops over 64-query tiles
+// (Q rows, dO rows and the tile's 64 lse + 64 delta values).
 //   S = Q K^T (lane = key, registers = queries),  P = exp2(S c2 - lse[q])
 //   dV^T += dO^T P,   dP = dO V^T,   dS = P (dP - delta[q]),   dK^T += Q^T dS
 // ---------------------------------------------------------------------------------------------
 template <int DK>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
-  constexpr int NT = DK / 16, ND = DK / 32, TE = TILE * DK, IPI = 2 * (DK / 32) + 2;
-  constexpr int SLOT = 2 * TE + 4 * 256;   // Q tile, dO tile, 4 x 512 B per-wave statistics (bf16 elements)
-  __shared__ __attribute__((aligned(1024))) bf16 smem[RING * SLOT];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+  using G = TileGeo<DK>;
+  constexpr int NT = DK / 16, ND = DK / 32;
+  constexpr int BUF = 2 * G::E + 256;   // Q tile, dO tile, lse[64] + delta[64] (fp32, counted in bf16 elements)
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * BUF];
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  int b, h, tile;
+  decode_item(a, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
-  const int k0 = blockIdx.x * WG_ROWS;
+  const int k0 = tile * WG_ROWS;
   if (k0 >= lk) return;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5;
-  const int wu = __builtin_amdgcn_readfirstlane(wave);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
   const int key = k0 + wave * 32 + (l & 31);
   const bool k_ok = key < lk;
-  const size_t krow = (size_t)a.k_off[b] + key;
+  const size_t krow = (size_t)a.k_off[b] + min(key, lk - 1);
   const float c2 = a.scale * 1.4426950408889634f;
 
   const bf16* qbase = a.Q + (size_t)a.q_off[b] * a.ldq + h * DK;
   const bf16* dobase = a.dO + (size_t)a.q_off[b] * a.lddo + h * DK;
-  const float* lse = a.lse + (size_t)h * a.q_rows_total + a.q_off[b];
-  const float* delta = a.delta + (size_t)h * a.q_rows_total + a.q_off[b];
+  // threads 0..63 carry the tile's lse values, 64..127 its delta values (128.. duplicate them)
+  const float* statsrc = ((threadIdx.x & 64) ? a.delta : a.lse) + (size_t)h * a.q_rows_total + a.q_off[b];
   const int q_begin = a.causal ? (k0 / TILE) * TILE : 0;  // queries before the first key see none of them
   const int ntiles = (lq - q_begin + TILE - 1) / TILE;
 
@@ -403,41 +444,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = h * DK + t * 16 + hi * 8;
-    kf[t] = gload8(a.K + krow * a.ldk + col, k_ok);
-    vf[t] = gload8(a.V + krow * a.ldv + col, k_ok);
+    kf[t] = *reinterpret_cast<const bf16x8*>(a.K + krow * a.ldk + col);
+    vf[t] = *reinterpret_cast<const bf16x8*>(a.V + krow * a.ldv + col);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { touch(kf[t]); touch(vf[t]); }
 
-  // one ring item = 64 Q rows, 64 dO rows and (per wave) lse[64], delta[64]: lane i fetches one
-  // float of each (4-byte LDS-DMA; queries past lq read a zero and are masked by index below)
-  auto issue_tile = [&](int slot, int qt) {
-    bf16* base = smem + slot * SLOT;
-    issue_rows<DK, SWZ_NAT>(base, qbase, a.ldq, qt, lq);
-    issue_rows<DK, SWZ_NAT>(base + TE, dobase, a.lddo, qt, lq);
-    const bool in = qt + l < lq;
-    const void* sl = in ? (const void*)(lse + qt + l) : (const void*)g_zero_row;
-    const void* sd = in ? (const void*)(delta + qt + l) : (const void*)g_zero_row;
-    bf16* st = base + 2 * TE + wu * 256;
-    lds_dma4(sl, lds_addr(st));
-    lds_dma4(sd, lds_addr(st + 128));
-  };
-#pragma unroll
-  for (int t = 0; t < RING - 1; ++t)
-    if (t < ntiles) issue_tile(t, q_begin + t * TILE);
+  uint32_t offq[G::CH], offo[G::CH];
+  Stage<DK>::offsets(offq, a.ldq);
+  Stage<DK>::offsets(offo, a.lddo);
+  Stage<DK> sq[2], so[2];
+  float sst[2];
 
   f32x16 dk[ND], dv[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) { dk[d] = zero16(); dv[d] = zero16(); }
 
-  for (int it = 0; it < ntiles; ++it) {
-    wait_tiles<IPI>(min(RING - 2, ntiles - 1 - it));
-    __builtin_amdgcn_s_barrier();
-    if (it + RING - 1 < ntiles) issue_tile((it + RING - 1) % RING, q_begin + (it + RING - 1) * TILE);
-    const bf16* qs = smem + (it % RING) * SLOT;
-    const bf16* dos = qs + TE;
-    const float* stat = reinterpret_cast<const float*>(qs + 2 * TE + wave * 256);   // [0..63] lse, [64..127] delta
+  auto load = [&](int set, int it) {
+    const int qt = q_begin + it * TILE;
+    sq[set].load(offq, qbase, a.ldq, qt, lq);
+    so[set].load(offo, dobase, a.lddo, qt, lq);
+    sst[set] = statsrc[min(qt + (int)(threadIdx.x & 63), lq - 1)];
+  };
+  auto store = [&](int set) {
+    bf16* base = smem + set * BUF;
+    sq[set].store(base);
+    so[set].store(base + G::E);
+    reinterpret_cast<float*>(base + 2 * G::E)[threadIdx.x & 127] = sst[set];
+  };
+  auto compute = [&](int buf, int it) {
+    const bf16* qs = smem + buf * BUF;
+    const bf16* dos = qs + G::E;
+    const float* stat = reinterpret_cast<const float*>(qs + 2 * G::E);   // [0..63] lse, [64..127] delta
     const int qt = q_begin + it * TILE;
     // wave-uniform: every (query, key) pair of this tile x this wave's 32 keys is unmasked
     const bool full = (qt + TILE <= lq) && (k0 + wave * 32 + 32 <= lk) && (!a.causal || k0 + wave * 32 + 31 <= qt);
@@ -446,8 +482,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        s = mfma32(rd_nat<DK, SWZ_NAT>(qs, qb * 32 + (l & 31), t), kf[t], s);
-        dp = mfma32(rd_nat<DK, SWZ_NAT>(dos, qb * 32 + (l & 31), t), vf[t], dp);
+        s = mfma32(rd_nat<DK>(qs, qb * 32 + (l & 31), t), kf[t], s);
+        dp = mfma32(rd_nat<DK>(dos, qb * 32 + (l & 31), t), vf[t], dp);
       }
       f32x16 p;
 #pragma unroll
@@ -482,13 +518,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         const int base = qb * 32 + 16 * hf + 4 * hi;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-          dv[d] = mfma32(rd_tr<DK, SWZ_NAT>(dos, d * 32, base), pf, dv[d]);
-          dk[d] = mfma32(rd_tr<DK, SWZ_NAT>(qs, d * 32, base), dsf, dk[d]);
+          dv[d] = mfma32(rd_tr<DK>(dos, d * 32, base), pf, dv[d]);
+          dk[d] = mfma32(rd_tr<DK>(qs, d * 32, base), dsf, dk[d]);
         }
       }
     }
-  }
-  __builtin_amdgcn_s_barrier();
+  };
+  stream_tiles(ntiles, load, store, compute);
   const int nrows = min(32, lk - (k0 + wave * 32));
   store_rows<DK>(smem + wave * 64 * DK, dk, a.scale, a.dK + (size_t)a.k_off[b] * a.lddk + h * DK, a.lddk,
                  k0 + wave * 32, nrows);
@@ -502,21 +538,30 @@ int check_common(int d_k, int ldq, int ldk, int ldv) {
   return 0;
 }
 
+// grid size and enumeration mode for one family of workgroups
+int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
+  a.work = work;
+  a.H = H;
+  a.tiles_max = (max_rows + WG_ROWS - 1) / WG_ROWS;
+  return (work ? n_work : B * a.tiles_max) * H;
+}
+
 }  // namespace
 
 extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                            void* O, int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off,
                            const int* k_len, int B, int H, int d_k, int max_q, int q_rows_total, int causal,
-                           float scale) {
-  if (B <= 0 || H <= 0 || max_q <= 0) return 0;
+                           float scale, const int* work, int n_work) {
+  if (B <= 0 || H <= 0 || max_q <= 0 || (work && n_work <= 0)) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
   if (ldo & 7) return -3;
+  if (B > 32767) return -4;
   AttnArgs a = {};
   a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
   a.O = (bf16*)O; a.ldo = ldo; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
-  dim3 grid((max_q + WG_ROWS - 1) / WG_ROWS, H, B), block(256);
+  dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
   if (d_k == 64) hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, stream, a);
   ST_CHECK_LAUNCH();
@@ -527,11 +572,13 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
                            const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta,
                            void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int* q_off,
                            const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q,
-                           int max_k, int q_rows_total, int causal, float scale, int parts) {
+                           int max_k, int q_rows_total, int causal, float scale, int parts, const int* work_q,
+                           int n_work_q, const int* work_k, int n_work_k) {
   if (B <= 0 || H <= 0 || max_q <= 0 || max_k <= 0) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
   if ((ldo & 7) || (lddo & 7) || (lddq & 7) || (lddk & 7) || (lddv & 7)) return -3;
+  if (B > 32767) return -4;
   AttnArgs a = {};
   a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
   a.O = (bf16*)O; a.ldo = ldo; a.dO = (const bf16*)dO; a.lddo = lddo; a.lse = (float*)lse; a.delta = delta;
@@ -539,13 +586,15 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
   dim3 block(256);
-  dim3 gq((max_q + WG_ROWS - 1) / WG_ROWS, H, B), gk((max_k + WG_ROWS - 1) / WG_ROWS, H, B);
-  if (d_k == 64) {
-    if (parts & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, a);
-    if (parts & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, a);
-  } else {
-    if (parts & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), gq, block, 0, stream, a);
-    if (parts & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<32>), gk, block, 0, stream, a);
+  if ((parts & 1) && !(work_q && n_work_q <= 0)) {
+    dim3 gq(plan(a, work_q, n_work_q, B, H, max_q));
+    if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), gq, block, 0, stream, a);
+  }
+  if ((parts & 2) && !(work_k && n_work_k <= 0)) {
+    dim3 gk(plan(a, work_k, n_work_k, B, H, max_k));
+    if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<32>), gk, block, 0, stream, a);
   }
   ST_CHECK_LAUNCH();
   return 0;

@@ -38,7 +38,7 @@ class Rows:
     loader revisits the same bucket shapes, bench.py the same batch) and the model builds
     every layout it needs BEFORE launching the first kernel of a step."""
 
-    __slots__ = ("B", "off", "len", "max_len", "total", "_pos", "lens_host", "dense", "_scatter")
+    __slots__ = ("B", "off", "len", "max_len", "total", "_pos", "lens_host", "dense", "_scatter", "_work")
 
     def __init__(self, off, length, max_len, total, lens_host=None, dense=True):
         self.dense = dense  # every row of the matrix belongs to some utterance (no padding rows)
@@ -47,6 +47,7 @@ class Rows:
         self.max_len, self.total = int(max_len), int(total)
         self._pos = None
         self._scatter = None
+        self._work = {}
         self.lens_host = lens_host
 
     @staticmethod
@@ -111,6 +112,35 @@ class Rows:
         return self._pos
 
 
+def attn_work(q_rows: Rows, k_rows: Rows, causal: bool):
+    """Work lists of the attention kernels for one (query layout, key layout, causal) combination:
+    int32 device vectors of (b << 16) | tile over 128-query tiles (forward, dQ) and 128-key tiles (dK/dV),
+    sorted by decreasing number of streamed 64-row tiles - the dispatcher hands workgroups out in this
+    order, i.e. longest-first list scheduling of the ragged batch.  Cached on the query layout; the model
+    calls this while it builds the layouts, before the first kernel of a step (no H2D copy mid-step)."""
+    key = (id(k_rows), bool(causal))
+    hit = q_rows._work.get(key)
+    if hit is not None and hit[0] is k_rows:
+        return hit[1], hit[2]
+    lq = q_rows.lens_host.tolist() if q_rows.lens_host is not None else [q_rows.max_len] * q_rows.B
+    lk = k_rows.lens_host.tolist() if k_rows.lens_host is not None else [k_rows.max_len] * k_rows.B
+    wq, wk = [], []
+    for b in range(q_rows.B):
+        for t in range((lq[b] + 127) // 128):
+            seen = min(lk[b], (t + 1) * 128) if causal else lk[b]
+            wq.append(((seen + 63) // 64, (b << 16) | t))
+        for t in range((lk[b] + 127) // 128):
+            q_begin = (t * 128 // 64) * 64 if causal else 0
+            wk.append(((lq[b] - q_begin + 63) // 64, (b << 16) | t))
+    dev = q_rows.off.device
+    out = []
+    for w in (wq, wk):
+        w.sort(key=lambda c: -c[0])
+        out.append(torch.tensor([c[1] for c in w], dtype=I32).to(dev))
+    q_rows._work[key] = (k_rows, out[0], out[1])
+    return out[0], out[1]
+
+
 def _splits(M: int, N: int, K: int) -> int:
     """Split count of the token (contraction) axis of a weight-gradient GEMM: a power of two so that the
     kernel's XCD-local tile walk keeps whole splits on one XCD; one 8-wave workgroup per CU (its two wave
@@ -166,7 +196,7 @@ class MhaFn(torch.autograd.Function):
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         scale = 1.0 / math.sqrt(d // H)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
-                    scale)
+                    scale, work=attn_work(q_rows, k_rows, causal)[0])
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
@@ -200,8 +230,9 @@ class MhaFn(torch.autograd.Function):
             dkv = _empty(x_kv.shape[0], 2 * d, x_q) if k_rows.dense else \
                 torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
+        work_q, work_k = attn_work(q_rows, k_rows, ctx.causal)
         nv.attn_bwd(Q, K, V, attn_ctx, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
-                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale)
+                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k)
         dx_q = _empty(Mq, d, x_q)
         dx_kv = None
         if x_kv is None:

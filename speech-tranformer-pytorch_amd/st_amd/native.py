@@ -35,11 +35,11 @@ SIGNATURES = {
                   _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int],
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float],
+                    _c_float, _c_void_p, _c_int],
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float, _c_int],
+                    _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int],
     "st_colsum": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
@@ -233,7 +233,15 @@ def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=
     return dx
 
 
-def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale):
+def _work(w):
+    if w is None:
+        return None, 0
+    _vec(w, I32, w.numel(), "work")
+    return w.data_ptr(), w.numel()
+
+
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None):
+    """work: optional int32 device list of (b << 16) | q_tile, heaviest first (functional.attn_work)."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
         _mat(t, BF16, nm)
     B = q_off.numel()
@@ -246,13 +254,13 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
                             k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), rows, int(causal),
-                            float(scale))
+                            float(scale), *_work(work))
     _check(rc, "st_attn_fwd")
     return O
 
 
 def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
-             parts=3):
+             parts=3, work_q=None, work_k=None):
     """parts: 1 = dQ (+delta) kernel, 2 = dK/dV kernel (needs delta from part 1), 3 = both."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
         _mat(t, BF16, nm)
@@ -263,14 +271,15 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
     if _TIMING is not None and parts == 3:   # profile the two kernels of the call separately
         for part in (1, 2):
             attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal,
-                     scale, parts=part)
+                     scale, parts=part, work_q=work_q, work_k=work_k)
         return
     _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts)
     rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(), delta.data_ptr(),
                             dQ.data_ptr(), dQ.stride(0), dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0),
                             q_off.data_ptr(), q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k,
-                            int(max_q), int(max_k), rows, int(causal), float(scale), int(parts))
+                            int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),
+                            *_work(work_k))
     _check(rc, "st_attn_bwd")
 
 

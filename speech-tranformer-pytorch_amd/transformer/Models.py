@@ -171,6 +171,10 @@ class Transformer(nn.Module):
         in_rows = F_.Rows.packed(inputs_pos, inputs.device)
         t_rows = F_.Rows.packed(targets_pos, inputs.device)
         flat_idx = t_rows.scatter_index(L)
+        in_rows.pos, t_rows.pos
+        F_.attn_work(in_rows, in_rows, False)     # encoder self-attention
+        F_.attn_work(t_rows, t_rows, True)        # decoder self-attention (causal)
+        F_.attn_work(t_rows, in_rows, False)      # decoder-encoder attention
         with arena.scope():
             enc, _ = self.encoder.forward_rows(inputs, inputs_pos, in_rows)
             dec, _ = self.decoder.forward_rows(targets, targets_pos, enc, in_rows, t_rows)

@@ -100,7 +100,7 @@ def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h):
     return q, k, v, s, slice(qo, qo + ql), slice(ko, ko + kl), cs
 
 
-def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale):
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):
@@ -111,7 +111,8 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     return O
 
 
-def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale):
+def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
+             parts=3, work_q=None, work_k=None):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):

@@ -82,10 +82,14 @@ if "attn" in which:
     qo, ql = offs(in_len)
     to, tl = offs(tgt_len)
     scale = 1 / math.sqrt(64)
-    cases = [("enc self", M, M, qo, ql, qo, ql, int(in_len.max()), int(in_len.max()), False, True),
-             ("dec self causal", Md, Md, to, tl, to, tl, 50, 50, True, True),
-             ("cross", Md, M, to, tl, qo, ql, 50, int(in_len.max()), False, False)]
-    for name, mq, mk, q_off, q_len, k_off, k_len, maxq, maxk, causal, self_attn in cases:
+    from st_amd.functional import Rows, attn_work
+    in_rows, t_rows = Rows.packed(in_len, dev), Rows.packed(tgt_len, dev)
+    use_work = not os.environ.get("ST_NO_WORK")
+    cases = [("enc self", M, M, qo, ql, qo, ql, int(in_len.max()), int(in_len.max()), False, True, in_rows, in_rows),
+             ("dec self causal", Md, Md, to, tl, to, tl, 50, 50, True, True, t_rows, t_rows),
+             ("cross", Md, M, to, tl, qo, ql, 50, int(in_len.max()), False, False, t_rows, in_rows)]
+    for name, mq, mk, q_off, q_len, k_off, k_len, maxq, maxk, causal, self_attn, qr, kr in cases:
+        wq, wk = attn_work(qr, kr, causal) if use_work else (None, None)
         if self_attn:
             qkv = rnd(mq, 3 * d)
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
@@ -98,11 +102,11 @@ if "attn" in which:
         dK, dV = torch.empty(mk, d, dtype=BF16, device=dev), torch.empty(mk, d, dtype=BF16, device=dev)
         pairs = float((q_len.double() * k_len.double()).sum()) * (0.5 if causal else 1.0)
         fl = 4.0 * pairs * d
-        us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale))
+        us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale, work=wq))
         report("attn fwd  " + name, us, fl)
         for part, nm in ((1, "dq "), (2, "dkv")):
             us = timeit(lambda: nv.attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, H, maxq,
-                                            maxk, causal, scale, parts=part))
+                                            maxk, causal, scale, parts=part, work_q=wq, work_k=wk))
             report("attn bwd %s " % nm + name, us, fl)
 
 if "misc" in which:
