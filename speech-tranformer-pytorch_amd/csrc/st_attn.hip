@@ -383,18 +383,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         s = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s);
         dp = mfma32(rd_nat<DK>(vs, kb * 32 + (l & 31), t), dof[t], dp);
       }
-      if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse)) * (dp[r] - dl);
-      } else {
+      for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, -lse);
+      if (!full) {   // masked pairs: exp2(-inf) = 0 (one wave-uniform branch; the exp chain stays straight-line)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt + kb * 32 + acc_row(r, hi);
-          const bool dead = key >= lk || (a.causal && key > q);
-          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse));
-          s[r] = p * (dp[r] - dl);
+          if (key >= lk || (a.causal && key > q)) s[r] = -INFINITY;
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * (dp[r] - dl);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const bf16x8 dsf = pack_acc8(s, 8 * hf);
@@ -485,31 +484,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         s = mfma32(rd_nat<DK>(qs, qb * 32 + (l & 31), t), kf[t], s);
         dp = mfma32(rd_nat<DK>(dos, qb * 32 + (l & 31), t), vf[t], dp);
       }
-      f32x16 p;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ql = qb * 32 + 8 * g + 4 * hi;
         const f32x4 ls = *reinterpret_cast<const f32x4*>(stat + ql);
         const f32x4 dl = *reinterpret_cast<const f32x4*>(stat + 64 + ql);
-        if (full) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
-            p[r] = pv;
-            s[r] = pv * (dp[r] - dl[e]);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            const int qq = qt + ql + e;
-            const bool dead = !k_ok || qq >= lq || (a.causal && key > qq);
-            const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
-            p[r] = pv;
-            s[r] = pv * (dp[r] - dl[e]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          s[4 * g + e] = fmaf(s[4 * g + e], c2, -ls[e]);
+          dp[4 * g + e] -= dl[e];
         }
+      }
+      if (!full) {   // masked pairs: exp2(-inf) = 0 (one wave-uniform branch; the exp chain stays straight-line)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = qt + qb * 32 + acc_row(r, hi);
+          if (!k_ok || qq >= lq || (a.causal && key > qq)) s[r] = -INFINITY;
+        }
+      }
+      f32x16 p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(s[r]);
+        s[r] = p[r] * dp[r];
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
