@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from .arena import arena_of
 from .dp import GradReducer
+from .functional import side_wgrads
 
 
 def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
@@ -48,11 +49,14 @@ class TrainStep:
         self._loss = self._gnorm = None
 
     # ---- the two halves of a step -------------------------------------------------------------
-    def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth):
+    def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, side=False):
         self.optimizer.zero_grad()
         logits, _ = self.model(inputs, input_lengths, targets, target_lengths)
         loss = self.crit(logits.contiguous().view(-1, self.vocab_size), ground_truth.contiguous().view(-1))
-        loss.backward()
+        # captured graph: the decoder's weight gradients fork onto a side stream (the eager path keeps one
+        # stream: its gradient-ready hooks assume a weight gradient is enqueued when the layer's backward returns)
+        with side_wgrads(side):
+            loss.backward()
         return loss.detach()
 
     def _clip_and_update(self):
@@ -98,7 +102,7 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.detach()                       # bucket all-reduces are issued explicitly between the graphs
         with torch.cuda.graph(self._g_fb, pool=pool):
-            self._loss = self._forward_backward(*batch)
+            self._loss = self._forward_backward(*batch, side=True)
         with torch.cuda.graph(self._g_opt, pool=pool):
             self._gnorm = self._clip_and_update()
         # capture only records; the step that triggered it is executed by the replay that follows

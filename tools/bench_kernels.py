@@ -20,10 +20,25 @@ dev = "cuda"
 N_IT = int(os.environ.get("N_IT", "30"))
 
 
+COLD = bool(os.environ.get("ST_COLD"))
+_flush = torch.empty(256 << 20, dtype=torch.uint8, device=dev) if COLD else None
+
+
 def timeit(fn, n=N_IT):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if COLD:   # every launch starts with cold caches: 256 MiB memset in between, only the kernel is timed
+        tot = 0.0
+        for _ in range(n):
+            _flush.fill_(1)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            tot += s.elapsed_time(e)
+        return tot / n * 1e3
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n):
