@@ -236,6 +236,33 @@ def test_attention_fwd_bwd(case):
         check(got, ref, tol, "attention %s %s" % (case, nm))
 
 
+def test_attention_work_lists_match_plain_enumeration():
+    """The longest-first work lists only reorder workgroups: results are bit-identical to the plain grid."""
+    from st_amd.functional import Rows, attn_work
+    lens_q, lens_k = torch.tensor([50, 33, 1, 47]), torch.tensor([1000, 517, 130, 64])
+    for q_lens, k_lens, causal in ((lens_k, lens_k, False), (lens_q, lens_q, True), (lens_q, lens_k, False)):
+        self_attn = q_lens is k_lens
+        c = _attn_case(4, 4, 64, None if self_attn else q_lens.tolist(), k_lens.tolist(), causal, True, seed=3)
+        q_rows = Rows.packed(q_lens, "cuda")
+        k_rows = q_rows if self_attn else Rows.packed(k_lens, "cuda")
+        wq, wk = attn_work(q_rows, k_rows, causal)
+        outs = []
+        for use in (False, True):
+            Q, K, V, dO = cu(c["Q"]), cu(c["K"]), cu(c["V"]), cu(c["dO"])
+            meta = [cu(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
+            O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
+            lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device="cuda")
+            nv.attn_fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], causal, c["scale"], work=wq if use else None)
+            delta = torch.zeros_like(lse)
+            dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
+            dK, dV = (torch.zeros(c["Mk"], c["d"], dtype=BF16, device="cuda") for _ in range(2))
+            nv.attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, *meta, c["H"], c["max_q"], c["max_k"], causal,
+                        c["scale"], work_q=wq if use else None, work_k=wk if use else None)
+            outs.append((O, lse, dQ, dK, dV))
+        for a, b, nm in zip(outs[0], outs[1], ("O", "lse", "dQ", "dK", "dV")):
+            assert torch.equal(a, b), "work list changed %s (causal=%s)" % (nm, causal)
+
+
 def test_attention_softmax_rescale_branch():
     """One key spiked against one query so the running max jumps in a late tile."""
     c = _attn_case(1, 1, 64, None, [300], False, True, seed=5)
