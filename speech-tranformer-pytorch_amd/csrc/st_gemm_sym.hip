@@ -22,10 +22,18 @@
 
 namespace {
 
-constexpr int BK = 64;
+#ifndef ST_GEMM_BK
+#define ST_GEMM_BK 64
+#endif
+#ifndef ST_GEMM_OCC
+#define ST_GEMM_OCC 2
+#endif
+constexpr int BK = ST_GEMM_BK;
 constexpr int NS = BK + 8;    // natural tile row stride (144 B): conflict-free ds_read_b128 over 16 rows
 constexpr int CS_CM = 144;    // contraction-major tile row stride (128 + 16): the 4 c-rows of a tr read hit 4 bank groups
-constexpr int TILE_E = 9216;  // elements of either tile image (128 x 72 = 64 x 144)
+constexpr int TILE_E = (128 * NS > BK * CS_CM) ? 128 * NS : BK * CS_CM;   // elements of either tile image
+constexpr int CH = BK / 16;   // 16-byte chunks per thread per operand tile
+constexpr int CPR = BK / 8;   // chunks per natural row
 
 __device__ __attribute__((aligned(16))) float g_zero_f32[4];
 
@@ -48,14 +56,14 @@ struct GemmArgs {
 // only a k-tile that crosses c_end takes the guarded path (out-of-range chunks come from a zero buffer).
 template <bool CM>
 struct Addr {
-  uint32_t off[4];
+  uint32_t off[CH];
   __device__ __forceinline__ void init(int tid, int ld, int row0, int nrows) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < CH; ++p) {
       const int id = tid + p * 256;
-      if (!CM) {                                                // [128 rows][8 chunks]
-        const int row = min(row0 + (id >> 3), nrows - 1);
-        off[p] = ((uint32_t)row * (uint32_t)ld + (id & 7) * 8) * 2u;
+      if (!CM) {                                                // [128 rows][CPR chunks]
+        const int row = min(row0 + id / CPR, nrows - 1);
+        off[p] = ((uint32_t)row * (uint32_t)ld + (id % CPR) * 8) * 2u;
       } else {                                                  // [64 c-rows][16 chunks]
         int row = row0 + (id & 15) * 8;
         if (row >= nrows) row = row0;
@@ -67,18 +75,18 @@ struct Addr {
 
 template <bool CM>
 struct Stage {
-  bf16x8 v[4];
+  bf16x8 v[CH];
   __device__ __forceinline__ void load(int tid, const Addr<CM>& ad, const bf16* __restrict__ base, int ld, int c0,
                                        int c_end) {
     const char* kb = reinterpret_cast<const char*>(base) + (CM ? (size_t)c0 * ld * 2 : (size_t)c0 * 2);
     if (c0 + BK <= c_end) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const bf16x8*>(kb + ad.off[p]);
+      for (int p = 0; p < CH; ++p) v[p] = *reinterpret_cast<const bf16x8*>(kb + ad.off[p]);
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < CH; ++p) {
         const int id = tid + p * 256;
-        const bool ok = CM ? (c0 + (id >> 4) < c_end) : (c0 + (id & 7) * 8 < c_end);
+        const bool ok = CM ? (c0 + (id >> 4) < c_end) : (c0 + (id % CPR) * 8 < c_end);
         const char* ptr = ok ? kb + ad.off[p] : reinterpret_cast<const char*>(g_zero_f32);
         v[p] = *reinterpret_cast<const bf16x8*>(ptr);
       }
@@ -86,9 +94,9 @@ struct Stage {
   }
   __device__ __forceinline__ void store(int tid, bf16* tile) const {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < CH; ++p) {
       const int id = tid + p * 256;
-      if (!CM) *reinterpret_cast<bf16x8*>(tile + (id >> 3) * NS + (id & 7) * 8) = v[p];
+      if (!CM) *reinterpret_cast<bf16x8*>(tile + (id / CPR) * NS + (id % CPR) * 8) = v[p];
       else *reinterpret_cast<bf16x8*>(tile + (id >> 4) * CS_CM + (id & 15) * 8) = v[p];
     }
   }
@@ -106,8 +114,10 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int 
 // CU still runs 8 waves but issues HALF the fp32 atomics of two independent split-K workgroups (the atomic
 // epilogue is what bounds split-K here: 64 splits take 62 us where 16 take 34 us on dW[1024,256], m = 24060).
 template <bool XT, bool YT, int EPI, int KG>
-__global__ __launch_bounds__(256 * KG, 2 / KG) void gemm_sym_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16 smem_all[KG * 4 * TILE_E];   // per group: 2 buffers x (X + Y tile) = 72 KiB
+__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_kernel(GemmArgs a) {
+  // per group: 2 buffers x (X + Y tile) = 72 KiB; KG = 2 also needs 4 x 96 x 64 floats for the accumulator hand-over
+  constexpr int XCH_E = KG > 1 ? 4 * 96 * 64 * 2 : 0;
+  __shared__ __attribute__((aligned(16))) bf16 smem_all[KG * 4 * TILE_E > XCH_E ? KG * 4 * TILE_E : XCH_E];
   const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0, tid = threadIdx.x & 255;
   bf16* smem = smem_all + grp * 4 * TILE_E;
   // XCD-local tile walk: workgroup b runs on XCD b % 8 (own L2).  forward / dgrad: an XCD owns X row-tiles
