@@ -10,10 +10,11 @@ d_ff 1024, vocab 4337, 80-d fbank, B = 32 utterances PER GPU, T <= 1000 frames,
 L <= 50 tokens (seeded synthetic batch of BASELINE.md section 3, resident in HBM).
 One step = zero_grad + forward + CE(ignore_index=0) + backward + [RCCL gradient
 average] + global-norm clip + Noam-Adam, i.e. train.py:37-46 / train_multi.py:58-68.
-bf16 activations / fp32 accumulate, fp32 master weights.  Dropout is OFF (eval-mode
-modules under autograd = the parity mode the CPU baseline is quoted in as well);
-training-mode dropout is not implemented in the HIP path yet and nothing is skipped
-to compensate: every FLOP of the dropout-free step is executed.
+bf16 activations / fp32 accumulate, fp32 master weights.  The headline number is the
+dropout-free step (eval-mode modules under autograd = the parity mode the oracle, the
+goldens and the CPU baseline are quoted in); the same step in training mode
+(model.train(): in-kernel dropout, p = 0.1 / front-end 0.5) is timed in a second pass
+and reported as ``train_mode`` on the same line.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
 ``roofline`` (dominant kernel, live HIP-event timing) and ``cpu_baseline`` (the CPU
@@ -34,7 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 C2 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_layer=6, num_dec_layer=6, n_heads=4,
-          d_k=64, d_v=64, d_model=256, d_inner_hid=1024, dropout=0.0, vocab_size=4337)
+          d_k=64, d_v=64, d_model=256, d_inner_hid=1024, dropout=0.1, vocab_size=4337)
 BATCH, T_MAX, L_MAX, T_MIN, L_MIN = 32, 1000, 50, 500, 25
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -135,6 +136,7 @@ def main():
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
+    ap.add_argument("--no-train-mode", action="store_true", help="skip the extra (untimed-region) training-mode pass")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
                                                             "the captured HIP graph of the step")
     args = ap.parse_args()
@@ -220,6 +222,27 @@ def main():
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] else None}
                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
 
+    # ---- training mode (model.train(): dropout 0.1 in every layer, 0.5 in the front-end, as train.py:21 runs
+    # the reference) - a second, separately timed pass; the headline above stays the dropout-free parity step
+    # that the CPU baseline and the oracle comparison use.  N = 1 only.
+    train_mode = None
+    if world == 1 and not args.no_train_mode:
+        model.train()
+        step_t = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, use_graph=not args.no_graph)
+        for _ in range(4):
+            step_t(xg, in_len, tg, tgt_len, gg)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_t, _ = step_t(xg, in_len, tg, tgt_len, gg)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        train_mode = {"ms_per_step": round(dt / args.steps * 1e3, 3), "value": round(frames * args.steps / dt, 1),
+                      "unit": "frames/s", "loss": round(loss_t.item(), 4),
+                      "note": "model.train(): in-kernel counter-based dropout, p = 0.1 (attention probabilities, FFN "
+                              "x2 per layer) and 0.5 (front-end); same step otherwise"}
+        model.eval()
+
     out = None
     if rank == 0:
         flops = step_flops(in_len, tgt_len, C2)
@@ -240,6 +263,8 @@ def main():
             "kernel_ms_per_step": round(total_ms / 2, 3),
             "roofline": roofline, "kernels": kernels,
         }
+        if train_mode is not None:
+            out["train_mode"] = train_mode
 
     # ---- CPU baseline: the oracle restatement on this box's host cores (rank 0, N = 1 only) -------
     # Runs in a child process with a hard timeout so that a slow / oversubscribed host can never

@@ -44,6 +44,15 @@ enum {
   ST_EPI_F32_ATOMIC_T = 6 /* D^T(f32)[j][i] += acc: weight gradients, coalesced atomics */
 };
 
+/* Training-mode dropout (nn.Dropout in Attention.py:89, SubLayers.py:25,27,
+ * Models.py:31).  Every entry point that can drop takes the same four
+ * arguments: drop_seed (DEVICE pointer to a 32-bit seed; NULL = no dropout),
+ * drop_salt (per-call-site constant), drop_thresh (round(256 p); an element
+ * is kept iff its 8-bit draw >= thresh) and drop_scale (256 / (256 - thresh)).
+ * Masks are a pure function of (*drop_seed, salt, element index): backward
+ * entry points regenerate them from the same arguments, and a captured HIP
+ * graph draws new masks on every replay once *drop_seed is advanced. */
+
 /* D[i][j] = sum_c X(i,c) * Y(j,c), bf16 operands, fp32 accumulate (MFMA).
  * x_cmajor / y_cmajor: operand stored [c][rows] instead of [rows][c].
  * Replaces the three GEMMs of every nn.Linear on the path
@@ -55,26 +64,36 @@ enum {
  * bias: fp32 [N], read and added to the accumulator - EXCEPT with
  * ST_EPI_F32_ATOMIC_T, where a non-NULL bias is the fp32 [N] bias-GRADIENT
  * accumulator: bias[j] += sum_c Y(j,c) (the column sums of dy, i.e. the
- * nn.Linear bias gradient, produced by the weight-gradient launch itself). */
+ * nn.Linear bias gradient, produced by the weight-gradient launch itself).
+ * Dropout: ST_EPI_BF16_RELU drops after the ReLU (SubLayers.py:25);
+ * ST_EPI_BF16_MASK multiplies the surviving (aux > 0) elements by drop_scale
+ * (backward of the former; aux is the dropped activation). */
 int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy, void* D,
-            int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits);
+            int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits,
+            const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
 /* out = LayerNorm(act(X W^T + bias) + res) * gamma + beta (+ pe[pos[row]]),
  * N = d_model in {128, 256, 512}.  Replaces output_linear + residual +
  * layernorm (Attention.py:92-94), fc2 + residual + layernorm
  * (SubLayers.py:26-27) and, with relu=1 and the PE add, the encoder front-end
  * (Models.py:28-33,42-44).  Saves xhat (bf16 [M,N]) and rstd (f32 [M]) for the
- * backward; `pre` (optional) receives the pre-LN value (front-end ReLU mask). */
+ * backward; `pre` (optional) receives the pre-LN value (front-end ReLU mask).
+ * drop_where: 1 = dropout on act(X W^T + bias) before the LayerNorm
+ * (Models.py:31), 2 = dropout on the LayerNorm output (SubLayers.py:27). */
 int st_gemm_ln(st_stream_t stream, const void* X, int ldx, const void* W, int M, int N, int K, const float* bias,
                const void* res, int ldres, const float* gamma, const float* beta, float eps, int relu,
-               const float* pe, const int* pos, void* out, int ldo, void* xhat, float* rstd, void* pre);
+               const float* pe, const int* pos, void* out, int ldo, void* xhat, float* rstd, void* pre,
+               const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int drop_where);
 
 /* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
  * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).
  * mask (optional bf16 [M,N]): dx is zeroed where mask <= 0 (front-end ReLU,
- * Models.py:28-33). */
+ * Models.py:28-33) and scaled by mask_scale elsewhere (1/(1-p) of the dropout
+ * between that ReLU and the LN).  drop_*: the forward dropped the LayerNorm
+ * OUTPUT (st_gemm_ln drop_where = 2): dy is masked / rescaled first. */
 int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, const float* rstd, const float* gamma,
-              const void* mask, void* dx, int lddx, float* dgamma, float* dbeta, float* dbias, int M, int N);
+              const void* mask, void* dx, int lddx, float* dgamma, float* dbeta, float* dbias, int M, int N,
+              const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, float mask_scale);
 
 /* Fused masked attention forward: softmax(Q K^T * scale, keys >= k_len[b]
  * and (causal) keys > query masked) V, per head; replaces Attention.py:82-90
@@ -83,10 +102,12 @@ int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, co
  * work (optional, device int32 [n_work]): the (utterance, 128-query tile)
  * pairs to run, packed (b << 16) | tile and sorted by decreasing cost, so the
  * ragged batch is list-scheduled longest-first; NULL = enumerate every tile
- * of every utterance up to max_q. */
+ * of every utterance up to max_q.  drop_*: dropout on the attention
+ * probabilities (Attention.py:89); pass the same values to st_attn_bwd. */
 int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
                 int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
-                int H, int d_k, int max_q, int q_rows_total, int causal, float scale, const int* work, int n_work);
+                int H, int d_k, int max_q, int q_rows_total, int causal, float scale, const int* work, int n_work,
+                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
 /* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
  * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:
@@ -97,7 +118,8 @@ int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
                 const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                 void* dK, int lddk, void* dV, int lddv, const int* q_off, const int* q_len, const int* k_off,
                 const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
-                float scale, int parts, const int* work_q, int n_work_q, const int* work_k, int n_work_k);
+                float scale, int parts, const int* work_q, int n_work_q, const int* work_k, int n_work_k,
+                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
 /* out[N] (f32) += column sums of x (bf16 [M, N]) - bias gradients. */
 int st_colsum(st_stream_t stream, const void* x, int ld, int M, int N, float* out);

@@ -38,7 +38,7 @@ __all__ = [
     "decoder_layer", "encoder", "decoder", "transformer", "cross_entropy",
     "label_smoothing_loss", "noam_lr", "xavier_init_", "make_params",
     "param_names", "train_step", "dp_average_grads", "synthetic_batch",
-    "count_step_flops",
+    "count_step_flops", "dropout_masks",
 ]
 
 
@@ -90,6 +90,39 @@ def feature_info_mask(lengths: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------
 # Sub-layers
 # --------------------------------------------------------------------------
+# Training-mode ``nn.Dropout`` (Attention.py:89, SubLayers.py:25,27, Models.py:31) restated with the Bernoulli
+# draw SUPPLIED by the caller: ``out = x * keep / (1 - p)``.  Parity tests hand the oracle exactly the masks the
+# HIP kernels draw (their counter-based generator cannot match torch's stream); without a provider dropout is
+# the identity, i.e. the reference in eval() mode - the default parity mode.
+_DROPOUT_PROVIDER = None
+
+
+class dropout_masks:
+    """``with dropout_masks(fn):`` - ``fn(site, shape)`` returns ``keep / (1 - p)`` (a tensor broadcastable to
+    ``shape``) or None; sites are visited in forward order: "front", then per layer "attn" (per attention),
+    "ffn1", "ffn2"."""
+
+    def __init__(self, provider):
+        self.provider = provider
+
+    def __enter__(self):
+        global _DROPOUT_PROVIDER
+        self.saved, _DROPOUT_PROVIDER = _DROPOUT_PROVIDER, self.provider
+        return self
+
+    def __exit__(self, *exc):
+        global _DROPOUT_PROVIDER
+        _DROPOUT_PROVIDER = self.saved
+        return False
+
+
+def _dropout(x: torch.Tensor, site: str) -> torch.Tensor:
+    if _DROPOUT_PROVIDER is None:
+        return x
+    m = _DROPOUT_PROVIDER(site, x.shape)
+    return x if m is None else x * m.to(x.dtype)
+
+
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """``nn.LayerNorm(d, eps=1e-6)`` (Attention.py:62, SubLayers.py:18,
     Models.py:32): biased variance over the last dim."""
@@ -99,7 +132,8 @@ def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1
 def multi_head_attention(p: Params, pre: str, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                          mask: Optional[torch.Tensor], n_head: int,
                          return_attn: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """``MultiHeadAttention.forward`` (Attention.py:64-96), dropout = identity.
+    """``MultiHeadAttention.forward`` (Attention.py:64-96), dropout = identity unless
+    a ``dropout_masks`` provider is active.
 
     Q/K/V projections with bias (:74-76), split heads (:68-69,78-80),
     ``scores = QK^T / sqrt(d_k)`` (:82), ``masked_fill(-inf)`` (:84-87), softmax
@@ -121,7 +155,7 @@ def multi_head_attention(p: Params, pre: str, q: torch.Tensor, k: torch.Tensor, 
     scores = torch.matmul(qh, kh.transpose(2, 3)).div_(math.sqrt(dk))      # in place, as Attention.py:82-87
     if mask is not None:
         scores.masked_fill_(mask.unsqueeze(1), float("-inf"))
-    attn = torch.softmax(scores, dim=-1)
+    attn = _dropout(torch.softmax(scores, dim=-1), "attn")                  # Attention.py:89
     ctx = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(bsz, lq, d)
     out = F.linear(ctx, p[pre + "output_linear.weight"], p[pre + "output_linear.bias"])
     out = layer_norm(out + q, p[pre + "layernorm.weight"], p[pre + "layernorm.bias"])
@@ -131,9 +165,9 @@ def multi_head_attention(p: Params, pre: str, q: torch.Tensor, k: torch.Tensor, 
 def positionwise_ffn(p: Params, pre: str, x: torch.Tensor) -> torch.Tensor:
     """``PositionwiseFeedForward.forward`` (SubLayers.py:24-28), dropout =
     identity: ``LN(x + fc2(relu(fc1(x))))``."""
-    h = torch.relu(F.linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"]))
+    h = _dropout(torch.relu(F.linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"])), "ffn1")   # SubLayers.py:25
     y = F.linear(h, p[pre + "fc2.weight"], p[pre + "fc2.bias"])
-    return layer_norm(x + y, p[pre + "layernorm.weight"], p[pre + "layernorm.bias"])
+    return _dropout(layer_norm(x + y, p[pre + "layernorm.weight"], p[pre + "layernorm.bias"]), "ffn2")   # :27
 
 
 def encoder_layer(p: Params, pre: str, x: torch.Tensor, mask, n_head: int, return_attn: bool = False):
@@ -167,7 +201,7 @@ def encoder(p: Params, x: torch.Tensor, in_len: torch.Tensor, n_head: int,
 
     ``e = LN(relu(x W_in^T + b_in))`` (:28-33; the Dropout() at :31 is identity
     in eval), ``e += PE(lengths)`` (:43-44), key-padding mask (:46), N layers."""
-    e = torch.relu(F.linear(x, p[pre + "input_proj.0.weight"], p[pre + "input_proj.0.bias"]))
+    e = _dropout(torch.relu(F.linear(x, p[pre + "input_proj.0.weight"], p[pre + "input_proj.0.bias"])), "front")
     e = layer_norm(e, p[pre + "input_proj.3.weight"], p[pre + "input_proj.3.bias"])
     e = e + positional_encoding(p[pre + "position_enc.pe"].to(e.dtype), in_len)
     mask = padding_info_mask(in_len, in_len)

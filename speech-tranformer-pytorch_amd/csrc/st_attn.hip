@@ -54,6 +54,7 @@ struct AttnArgs {
   int q_rows_total;
   int causal;
   float scale;                    // 1/sqrt(d_k)
+  DropArgs drop;                  // attention-probability dropout (Attention.py:89), training mode only
 };
 
 // blockIdx.x -> (utterance, head, tile)
@@ -196,7 +197,29 @@ __device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float
 // ---------------------------------------------------------------------------------------------
 // Forward.  Each wave owns 32 query rows (lane & 31); key / value tiles are streamed.
 // ---------------------------------------------------------------------------------------------
-template <int DK>
+// 16-bit keep mask of one lane's 16 accumulator registers: register r <-> pair (fixed, var0 + acc_row(r, hi)).
+// FIXED_IS_Q: the lane's own index is the query (forward / dQ: registers run over keys), else it is the key.
+template <bool FIXED_IS_Q>
+__device__ __forceinline__ uint32_t keep_mask16(const Drop& dr, int bh, int fixed, int var0, int hi) {
+  uint32_t km = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int v = var0 + 8 * g + 4 * hi;   // 4 consecutive indices v .. v+3 (v % 4 == 0): two 2 x 2 blocks
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const uint32_t bits = FIXED_IS_Q ? dr.bits(drop_counter_qk(bh, fixed, v + 2 * hb))
+                                       : dr.bits(drop_counter_qk(bh, v + 2 * hb, fixed));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int byte = FIXED_IS_Q ? 2 * (fixed & 1) + e : 2 * e + (fixed & 1);
+        if (dr.keep(bits, byte)) km |= 1u << (4 * g + 2 * hb + e);
+      }
+    }
+  }
+  return km;
+}
+
+template <int DK, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   using G = TileGeo<DK>;
   constexpr int NT = DK / 16;   // k-steps of the QK^T contraction
@@ -213,6 +236,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const bool q_ok = q < lq;
   const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
   const float c2 = a.scale * 1.4426950408889634f;  // scores -> log2 domain
+  const Drop dr = make_drop(a.drop);
+  const int bh = b * a.H + h;
 
   const int k_hi = a.causal ? min(lk, q0 + WG_ROWS) : lk;   // keys this workgroup can see
   const int ntiles = (k_hi + TILE - 1) / TILE;
@@ -292,6 +317,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         psum += p;
       }
     lsum += psum;
+    if (DROP) {   // dropped probabilities leave the normaliser untouched; the 1/(1-p) scale is folded into `inv`
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const uint32_t km = keep_mask16<true>(dr, bh, q, kt + kb * 32, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!((km >> r) & 1u)) s[kb][r] = 0.f;
+      }
+    }
     // O^T += V^T P^T : A operand = V^T (transposing LDS read), B operand = P^T (own registers)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -306,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   stream_tiles(ntiles, load, store, compute);
 
   const float ltot = lsum + wave_xor32(lsum);
-  const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+  const float inv = ltot > 0.f ? (DROP ? dr.scale : 1.f) / ltot : 0.f;
   if (q_ok && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
   store_rows<DK>(smem + wave * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + wave * 32,
                  min(32, lq - (q0 + wave * 32)));
@@ -316,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // Backward, part 1: dQ (and delta = rowsum(dO * O)).  Same decomposition as the forward.
 //   P^T = exp2(S^T c2 - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta),  dQ^T += K^T dS^T
 // ---------------------------------------------------------------------------------------------
-template <int DK>
+template <int DK, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   using G = TileGeo<DK>;
   constexpr int NT = DK / 16, ND = DK / 32;
@@ -332,6 +366,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const bool q_ok = q < lq;
   const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
   const float c2 = a.scale * 1.4426950408889634f;
+  const Drop dr = make_drop(a.drop);
+  const int bh = b * a.H + h;
 
   const int k_hi = a.causal ? min(lk, q0 + WG_ROWS) : lk;
   const int ntiles = (k_hi + TILE - 1) / TILE;
@@ -392,6 +428,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           if (key >= lk || (a.causal && key > q)) s[r] = -INFINITY;
         }
       }
+      if (DROP) {   // dS = P (M dP / (1-p) - delta)
+        const uint32_t km = keep_mask16<true>(dr, bh, q, kt + kb * 32, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = ((km >> r) & 1u) ? dp[r] * dr.scale : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * (dp[r] - dl);
 #pragma unroll
@@ -414,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 //   S = Q K^T (lane = key, registers = queries),  P = exp2(S c2 - lse[q])
 //   dV^T += dO^T P,   dP = dO V^T,   dS = P (dP - delta[q]),   dK^T += Q^T dS
 // ---------------------------------------------------------------------------------------------
-template <int DK>
+template <int DK, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   using G = TileGeo<DK>;
   constexpr int NT = DK / 16, ND = DK / 32;
@@ -431,6 +472,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const bool k_ok = key < lk;
   const size_t krow = (size_t)a.k_off[b] + min(key, lk - 1);
   const float c2 = a.scale * 1.4426950408889634f;
+  const Drop dr = make_drop(a.drop);
+  const int bh = b * a.H + h;
 
   const bf16* qbase = a.Q + (size_t)a.q_off[b] * a.ldq + h * DK;
   const bf16* dobase = a.dO + (size_t)a.q_off[b] * a.lddo + h * DK;
@@ -484,6 +527,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         s = mfma32(rd_nat<DK>(qs, qb * 32 + (l & 31), t), kf[t], s);
         dp = mfma32(rd_nat<DK>(dos, qb * 32 + (l & 31), t), vf[t], dp);
       }
+      uint32_t km = 0xffffu;
+      if (DROP) {   // dS = P (M dP / (1-p) - delta), and dV takes the dropped, rescaled P
+        km = keep_mask16<false>(dr, bh, key, qt + qb * 32, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = ((km >> r) & 1u) ? dp[r] * dr.scale : 0.f;
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ql = qb * 32 + 8 * g + 4 * hi;
@@ -507,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) {
         p[r] = __builtin_amdgcn_exp2f(s[r]);
         s[r] = p[r] * dp[r];
+        if (DROP) p[r] = ((km >> r) & 1u) ? p[r] * dr.scale : 0.f;
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
@@ -535,6 +585,15 @@ int check_common(int d_k, int ldq, int ldk, int ldv) {
   return 0;
 }
 
+bool set_drop(AttnArgs& a, const unsigned* seed, unsigned salt, int thresh, float scale) {
+  const bool on = seed != nullptr && thresh > 0;
+  a.drop.seed = on ? seed : nullptr;
+  a.drop.salt = salt;
+  a.drop.thresh = on ? thresh : 0;
+  a.drop.scale = on ? scale : 1.f;
+  return on;
+}
+
 // grid size and enumeration mode for one family of workgroups
 int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
   a.work = work;
@@ -548,7 +607,8 @@ int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
 extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                            void* O, int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off,
                            const int* k_len, int B, int H, int d_k, int max_q, int q_rows_total, int causal,
-                           float scale, const int* work, int n_work) {
+                           float scale, const int* work, int n_work, const unsigned* drop_seed, unsigned drop_salt,
+                           int drop_thresh, float drop_scale) {
   if (B <= 0 || H <= 0 || max_q <= 0 || (work && n_work <= 0)) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
@@ -558,9 +618,12 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
   a.O = (bf16*)O; a.ldo = ldo; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
+  const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
-  if (d_k == 64) hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, stream, a);
+  if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 0, stream, a);
+  else if (d_k == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, stream, a);
+  else if (!drop) hipLaunchKernelGGL((attn_fwd_kernel<32, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, stream, a);
   ST_CHECK_LAUNCH();
   return 0;
 }
@@ -570,7 +633,8 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
                            void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int* q_off,
                            const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q,
                            int max_k, int q_rows_total, int causal, float scale, int parts, const int* work_q,
-                           int n_work_q, const int* work_k, int n_work_k) {
+                           int n_work_q, const int* work_k, int n_work_k, const unsigned* drop_seed,
+                           unsigned drop_salt, int drop_thresh, float drop_scale) {
   if (B <= 0 || H <= 0 || max_q <= 0 || max_k <= 0) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
@@ -582,16 +646,21 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   a.dQ = (bf16*)dQ; a.lddq = lddq; a.dK = (bf16*)dK; a.lddk = lddk; a.dV = (bf16*)dV; a.lddv = lddv;
   a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
+  const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   dim3 block(256);
   if ((parts & 1) && !(work_q && n_work_q <= 0)) {
     dim3 gq(plan(a, work_q, n_work_q, B, H, max_q));
-    if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), gq, block, 0, stream, a);
+    if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, block, 0, stream, a);
+    else if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 0, stream, a);
+    else if (!drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<32, false>), gq, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<32, true>), gq, block, 0, stream, a);
   }
   if ((parts & 2) && !(work_k && n_work_k <= 0)) {
     dim3 gk(plan(a, work_k, n_work_k, B, H, max_k));
-    if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<32>), gk, block, 0, stream, a);
+    if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, block, 0, stream, a);
+    else if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, block, 0, stream, a);
+    else if (!drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, false>), gk, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, true>), gk, block, 0, stream, a);
   }
   ST_CHECK_LAUNCH();
   return 0;

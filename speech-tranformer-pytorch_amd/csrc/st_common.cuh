@@ -127,4 +127,48 @@ template <typename T> __device__ __forceinline__ void touch(T& v) { asm volatile
 
 __device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+// ---- dropout (training mode of nn.Dropout: Attention.py:89, SubLayers.py:25,27, Models.py:31) --------------
+// Counter-based: one 32-bit hash per counter yields FOUR 8-bit keep decisions, so a mask is a pure function of
+// (device seed, call-site salt, element index) - the backward kernels regenerate it instead of reading a saved
+// mask, and a HIP-graph replay draws fresh masks because the seed lives in device memory (advanced per step).
+// keep iff byte >= thresh, thresh = round(256 p); survivors are scaled by 256 / (256 - thresh) (exactly unbiased
+// for the realised keep probability; 8-bit thresholds as in FlashAttention's dropout).
+__device__ __forceinline__ uint32_t st_hash32(uint32_t x) {   // "lowbias32" integer finaliser
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+struct Drop {
+  uint32_t key;     // st_hash32(seed + salt * 0x9e3779b9)
+  int thresh;       // 0 = dropout off
+  float scale;
+  __device__ __forceinline__ bool on() const { return thresh > 0; }
+  __device__ __forceinline__ uint32_t bits(uint32_t counter) const { return st_hash32(counter ^ key); }
+  __device__ __forceinline__ bool keep(uint32_t bits, int byte) const {
+    return (int)((bits >> (8 * byte)) & 0xffu) >= thresh;
+  }
+};
+// host-side argument block shared by the entry points that take dropout
+struct DropArgs {
+  const unsigned* seed;   // device pointer (null = off)
+  unsigned salt;
+  int thresh;
+  float scale;
+};
+__device__ __forceinline__ Drop make_drop(const DropArgs& d) {
+  Drop r;
+  r.thresh = d.seed ? d.thresh : 0;
+  r.scale = d.scale;
+  r.key = d.seed ? st_hash32(*d.seed + d.salt * 0x9e3779b9u) : 0u;
+  return r;
+}
+// row-matrix elements: counter of the 4 consecutive columns col .. col+3 (col % 4 == 0) of `row`
+__device__ __forceinline__ uint32_t drop_counter_rc(int row, int col, int ncols) {
+  return (uint32_t)row * (uint32_t)(ncols >> 2) + (uint32_t)(col >> 2);
+}
+// attention probabilities: counter of the 2 x 2 block containing (query q, key k) of head slot bh;
+// byte index of (q, k) inside it = 2 * (q & 1) + (k & 1)
+__device__ __forceinline__ uint32_t drop_counter_qk(int bh, int q, int k) {
+  return (((uint32_t)(q >> 1) << 15) | (uint32_t)(k >> 1)) + (uint32_t)bh * 0x85ebca6bu;
+}
+
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }

@@ -35,6 +35,8 @@ struct GemmLnArgs {
   bf16* xhat;                 // normalised value (saved for backward), ld = N
   float* rstd;                // [M]
   bf16* pre;                  // optional: pre-LN value (front-end ReLU mask), ld = N
+  DropArgs drop;              // training-mode dropout (null seed = off)
+  int drop_where;             // 1: on act(xW^T+b) before the LayerNorm (Models.py:31); 2: on the LayerNorm output (SubLayers.py:27)
 };
 
 // Geometry: WM x WN waves, each 32 rows x 128 columns (4 MFMA tiles).  N = 128: 4 x 1 (BM = 128),
@@ -83,7 +85,7 @@ struct Stage {
 };
 
 // Store a wave's [32 rows][128 cols] block of values (row-per-lane registers, column of (b, g, e) =
-// b*32 + 8g + 4hi + e) through its private LDS patch as 256-byte row segments.
+// b*32 + 8g + 4hi + e; value(b, g) yields e = 0..3) through its private LDS patch as 256-byte row segments.
 template <typename F>
 __device__ __forceinline__ void ln_store_block(bf16* patch, bf16* gbase, int ld, int nvalid_rows, F value) {
   const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
@@ -92,9 +94,10 @@ __device__ __forceinline__ void ln_store_block(bf16* patch, bf16* gbase, int ld,
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int jl = b * 32 + 8 * g + 4 * hi;
+      const f32x4 v4 = value(b, g);   // columns jl .. jl+3 of this lane's row
       bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)value(b, 4 * g + e);
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)v4[e];
       *reinterpret_cast<bf16x4*>(patch + r * 128 + (((jl >> 3) ^ (r & 15)) << 3) + (jl & 7)) = o;
       if (g == 3) __builtin_amdgcn_sched_barrier(0);   // keep the per-column vector loads of one 32-column block together
     }
@@ -119,6 +122,8 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
   const int i = i_base + r;
   const bool row_ok = i < a.M;
   const int nvalid = min(32, a.M - i_base);
+  const Drop dr = make_drop(a.drop);
+  const bool drop_pre = dr.on() && a.drop_where == 1, drop_out = dr.on() && a.drop_where == 2;
   float sum = 0.f;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -128,10 +133,13 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
       const f32x4 bb = *reinterpret_cast<const f32x4*>(a.bias + j);
       bf16x4 rr = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
       if (have_res) rr = *reinterpret_cast<const bf16x4*>(patch + r * 128 + (((jl >> 3) ^ (r & 15)) << 3) + (jl & 7));
+      uint32_t bits = 0;
+      if (drop_pre) bits = dr.bits(drop_counter_rc(i, j, N));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = acc[b][4 * g + e] + bb[e];
         if (a.relu) v = fmaxf(v, 0.f);
+        if (drop_pre) v = dr.keep(bits, e) ? v * dr.scale : 0.f;
         v += (float)rr[e];
         acc[b][4 * g + e] = v;
         sum += v;
@@ -169,17 +177,31 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
   const float* gm = a.gamma + wn * 128;
   const float* bt = a.beta + wn * 128;
   if (a.pre)
-    ln_store_block(patch, a.pre + (size_t)i_base * N + wn * 128, N, nvalid, [&](int b, int q) { return acc[b][q]; });
+    ln_store_block(patch, a.pre + (size_t)i_base * N + wn * 128, N, nvalid, [&](int b, int g) {
+      return f32x4{acc[b][4 * g], acc[b][4 * g + 1], acc[b][4 * g + 2], acc[b][4 * g + 3]};
+    });
   if (a.xhat)
-    ln_store_block(patch, a.xhat + (size_t)i_base * N + wn * 128, N, nvalid,
-                   [&](int b, int q) { return (acc[b][q] - mean) * rstd; });
-  ln_store_block(patch, a.out + (size_t)i_base * a.ldo + wn * 128, a.ldo, nvalid, [&](int b, int q) {
-    const int j4 = b * 32 + 8 * (q >> 2) + 4 * hi;   // the four e = q & 3 of one (b, g) share these vector loads
+    ln_store_block(patch, a.xhat + (size_t)i_base * N + wn * 128, N, nvalid, [&](int b, int g) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (acc[b][4 * g + e] - mean) * rstd;
+      return v;
+    });
+  ln_store_block(patch, a.out + (size_t)i_base * a.ldo + wn * 128, a.ldo, nvalid, [&](int b, int g) {
+    const int j4 = b * 32 + 8 * g + 4 * hi;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(gm + j4);
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt + j4);
     f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
     if (perow) p4 = *reinterpret_cast<const f32x4*>(perow + j4);
-    return (acc[b][q] - mean) * rstd * g4[q & 3] + b4[q & 3] + p4[q & 3];
+    uint32_t bits = 0;
+    if (drop_out) bits = dr.bits(drop_counter_rc(i, wn * 128 + j4, N));
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (acc[b][4 * g + e] - mean) * rstd * g4[e] + b4[e] + p4[e];
+      if (drop_out) v[e] = dr.keep(bits, e) ? v[e] * dr.scale : 0.f;
+    }
+    return v;
   });
 }
 
@@ -277,7 +299,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
 extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void* W, int M, int N, int K,
                           const float* bias, const void* res, int ldres, const float* gamma, const float* beta,
                           float eps, int relu, const float* pe, const int* pos, void* out, int ldo, void* xhat,
-                          float* rstd, void* pre) {
+                          float* rstd, void* pre, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh,
+                          float drop_scale, int drop_where) {
   if (M <= 0) return 0;
   if ((ldx & 7) || (K & 7) || (ldo & 7) || (res && (ldres & 7)) || !bias || !gamma || !beta || !out) return -1;
   if (pe && !pos) return -2;
@@ -285,6 +308,9 @@ extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void
   a.X = (const bf16*)X; a.ldx = ldx; a.W = (const bf16*)W; a.M = M; a.K = K; a.bias = bias;
   a.res = (const bf16*)res; a.ldres = ldres; a.gamma = gamma; a.beta = beta; a.eps = eps; a.relu = relu;
   a.pe = pe; a.pos = pos; a.out = (bf16*)out; a.ldo = ldo; a.xhat = (bf16*)xhat; a.rstd = rstd; a.pre = (bf16*)pre;
+  const bool drop = drop_seed != nullptr && drop_thresh > 0 && (drop_where == 1 || drop_where == 2);
+  a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
+  a.drop.scale = drop ? drop_scale : 1.f; a.drop_where = drop ? drop_where : 0;
 #define ST_LN(NN) \
   hipLaunchKernelGGL((gemm_ln_kernel<NN>), dim3((M + Geo<NN>::BM - 1) / Geo<NN>::BM), dim3(256), 0, stream, a)
   if (N == 128) ST_LN(128);

@@ -48,6 +48,7 @@ struct GemmArgs {
   const float* bias;
   const bf16* aux; int ldaux;
   int c_per_split, tiles_i, tiles_j, splits;
+  DropArgs drop;   // EPI_BF16_RELU: dropout after the ReLU (SubLayers.py:25); EPI_BF16_MASK: .scale on the survivors
 };
 
 // This thread's share (4 x 16 bytes) of a 128 x 64 operand tile.  The byte offsets from the k-tile's
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_k
   // segments (a row-per-lane accumulator stored directly = 64 scattered 8-byte writes per instruction).
   constexpr int PS = 136;
   bf16* ct = smem;   // the operand buffers are free (barrier above)
+  const Drop dr = make_drop(a.drop);
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
     const int il = (wm * 2 + x) * 32 + r;
@@ -334,10 +336,18 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_k
       for (int g = 0; g < 4; ++g) {
         const int jl = (wn * 2 + y) * 32 + 8 * g + 4 * hi;
         bf16x4 o;
+        uint32_t bits = 0;
+        if (EPI == EPI_BF16_RELU) {
+          if (dr.on()) bits = dr.bits(drop_counter_rc(i0 + il, j0 + jl, a.N));   // wave-uniform branch, training only
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[x][y][4 * g + e] + bv[y][g][e];
-          if (EPI == EPI_BF16_RELU) v = fmaxf(v, 0.f);
+          if (EPI == EPI_BF16_RELU) {
+            v = fmaxf(v, 0.f);
+            if (dr.on()) v = dr.keep(bits, e) ? v * dr.scale : 0.f;
+          }
+          if (EPI == EPI_BF16_MASK) v *= a.drop.scale;   // 1 unless the forward dropped h (SubLayers.py:25)
           o[e] = (bf16)v;
         }
         *reinterpret_cast<bf16x4*>(ct + il * PS + jl) = o;
@@ -386,7 +396,7 @@ int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
 
 extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
                        void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi,
-                       int splits) {
+                       int splits, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
   if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 6) return -1;
   if (x_cmajor && !y_cmajor) return -2;  // not needed by any caller
@@ -400,6 +410,9 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   GemmArgs a;
   a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
   a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux;
+  const bool drop = epi == EPI_BF16_RELU && drop_seed != nullptr && drop_thresh > 0;
+  a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
+  a.drop.scale = (drop || epi == EPI_BF16_MASK) && drop_scale > 0.f ? drop_scale : 1.f;
   int per = (Kc + splits - 1) / splits;
   per = (per + BK - 1) / BK * BK;
   splits = (Kc + per - 1) / per;

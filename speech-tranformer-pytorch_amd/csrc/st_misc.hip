@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      const bf16* __restrict__ xhat, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const bf16* __restrict__ mask,
                                                      bf16* __restrict__ dx, int lddx, float* dgamma, float* dbeta,
-                                                     float* dbias, int M) {
+                                                     float* dbias, int M, DropArgs drop, float mask_scale) {
   constexpr int LPR = N / 8;        // lanes per row
   constexpr int RPW = 64 / LPR;     // rows per wave per pass
   constexpr int UNR = 2;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   float gm[8], ag[8], ab[8], ax[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { gm[e] = gamma[c0 + e]; ag[e] = ab[e] = ax[e] = 0.f; }
+  const Drop dr = make_drop(drop);   // dropout on the LayerNorm OUTPUT (SubLayers.py:27): dy <- dy * keep / (1-p)
 
   const int stride = gridDim.x * 4 * RPW * UNR;
   for (int base = (blockIdx.x * 4 + wave) * RPW * UNR; base < M; base += stride) {
@@ -51,9 +52,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     for (int u = 0; u < UNR; ++u) {
       const int row = base + u * RPW + slot;
       float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+      uint32_t bits[2] = {0, 0};
+      if (dr.on()) {
+        bits[0] = dr.bits(drop_counter_rc(row, c0, N));
+        bits[1] = dr.bits(drop_counter_rc(row, c0 + 4, N));
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float d = (float)vdy[u][e];
+        float d = (float)vdy[u][e];
+        if (dr.on()) d = dr.keep(bits[e >> 2], e & 3) ? d * dr.scale : 0.f;
         xh[e] = (float)vxh[u][e];
         g[e] = d * gm[e];
         s1 += g[e];
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = rs[u] * (g[e] - m1 - xh[e] * m2);
-        if (mask && !((float)vmk[u][e] > 0.f)) v = 0.f;   // ReLU in front of the LN (encoder front-end)
+        if (mask) v = ((float)vmk[u][e] > 0.f) ? v * mask_scale : 0.f;   // ReLU (+dropout) in front of the LN (front-end)
         out[e] = (bf16)v;
         ax[e] += v;
       }
@@ -242,7 +249,8 @@ __global__ void probe_mfma_kernel(const bf16* A, const bf16* Bt, float* D) {
 
 extern "C" int st_ln_bwd(hipStream_t stream, const void* dy, int lddy, const void* xhat, const float* rstd,
                          const float* gamma, const void* mask, void* dx, int lddx, float* dgamma, float* dbeta,
-                         float* dbias, int M, int N) {
+                         float* dbias, int M, int N, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh,
+                         float drop_scale, float mask_scale) {
   if (M <= 0) return 0;
   if ((lddy & 7) || (lddx & 7)) return -1;
   const int rows_per_block = 4 * (64 / (N / 8)) * 2;
@@ -250,9 +258,15 @@ extern "C" int st_ln_bwd(hipStream_t stream, const void* dy, int lddy, const voi
   // one workgroup per CU: every workgroup ends with 3 N same-address fp32 atomics (dgamma / dbeta / dbias),
   // and those serialise - 1024 workgroups took 30 us on [24060, 256], 256 take 16 us (measured)
   if (blocks > 256) blocks = 256;
+  DropArgs drop;
+  const bool on = drop_seed != nullptr && drop_thresh > 0;
+  drop.seed = on ? drop_seed : nullptr; drop.salt = drop_salt; drop.thresh = on ? drop_thresh : 0;
+  drop.scale = on ? drop_scale : 1.f;
+  if (!(mask_scale > 0.f)) mask_scale = 1.f;
 #define ST_LN_BWD(NN)                                                                                         \
   hipLaunchKernelGGL((ln_bwd_kernel<NN>), dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, lddy,          \
-                     (const bf16*)xhat, rstd, gamma, (const bf16*)mask, (bf16*)dx, lddx, dgamma, dbeta, dbias, M)
+                     (const bf16*)xhat, rstd, gamma, (const bf16*)mask, (bf16*)dx, lddx, dgamma, dbeta, dbias, M, \
+                     drop, mask_scale)
   if (N == 128) ST_LN_BWD(128);
   else if (N == 256) ST_LN_BWD(256);
   else if (N == 512) ST_LN_BWD(512);

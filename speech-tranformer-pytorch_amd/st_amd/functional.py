@@ -215,9 +215,9 @@ def wgrad(dY, X, gW, rows=None, gB=None):
     nv.gemm(X, dY, gW, bias=gB, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=splits, n=N)
 
 
-def dgrad(dY, W, out, epi=nv.EPI_BF16, aux=None, kc=None):
-    """out[m][k] = sum_n dY[m][n] W[n][k]  (+ aux | masked by aux > 0)."""
-    return nv.gemm(dY, W, out, epi=epi, aux=aux, y_cmajor=True, kc=kc)
+def dgrad(dY, W, out, epi=nv.EPI_BF16, aux=None, kc=None, drop=None):
+    """out[m][k] = sum_n dY[m][n] W[n][k]  (+ aux | masked by aux > 0, survivors scaled by drop.scale)."""
+    return nv.gemm(dY, W, out, epi=epi, aux=aux, y_cmajor=True, kc=kc, drop=drop)
 
 
 def _empty(rows, cols, like, dtype=BF16):
@@ -229,7 +229,7 @@ class MhaFn(torch.autograd.Function):
     """out = LN(attn(x_q W_q, x_kv W_k, x_kv W_v) W_o + b_o + x_q)   (Attention.py:64-96, R2)."""
 
     @staticmethod
-    def forward(ctx, x_q, x_kv, anchor, mod, q_rows: Rows, k_rows: Rows, causal: bool, want_attn: bool):
+    def forward(ctx, x_q, x_kv, anchor, mod, q_rows: Rows, k_rows: Rows, causal: bool, want_attn: bool, drop=None):
         s = mod._st
         d, H = s.d_model, s.n_head
         Mq = x_q.shape[0]
@@ -249,12 +249,13 @@ class MhaFn(torch.autograd.Function):
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         scale = 1.0 / math.sqrt(d // H)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
-                    scale, work=attn_work(q_rows, k_rows, causal)[0])
+                    scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop)
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
         ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
+        ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
         return out
 
     @staticmethod
@@ -285,7 +286,7 @@ class MhaFn(torch.autograd.Function):
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
         work_q, work_k = attn_work(q_rows, k_rows, ctx.causal)
         nv.attn_bwd(Q, K, V, attn_ctx, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
-                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k)
+                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop)
         dx_q = _empty(Mq, d, x_q)
         dx_kv = None
         if x_kv is None:
@@ -298,23 +299,25 @@ class MhaFn(torch.autograd.Function):
             dx_kv = _empty(x_kv.shape[0], d, x_q)
             dgrad(dkv, s.w_kv, dx_kv)
         arena.grads_ready(s.lo, s.hi)
-        return dx_q, dx_kv, None, None, None, None, None, None
+        return dx_q, dx_kv, None, None, None, None, None, None, None
 
 
 class FfnFn(torch.autograd.Function):
     """out = LN(x + fc2(relu(fc1(x))))   (SubLayers.py:24-28)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mod):
+    def forward(ctx, x, anchor, mod, drop1=None, drop2=None):
+        """drop1: dropout after the ReLU (SubLayers.py:25); drop2: on the LayerNorm output (SubLayers.py:27)."""
         s = mod._st
         M, d = x.shape
         h = _empty(M, s.d_ff, x)
-        nv.gemm(x, s.w1, h, bias=s.b1, epi=nv.EPI_BF16_RELU)
+        nv.gemm(x, s.w1, h, bias=s.b1, epi=nv.EPI_BF16_RELU, drop=drop1)
         out, xhat = _empty(M, d, x), _empty(M, d, x)
         rstd = torch.empty(M, dtype=F32, device=x.device)
-        nv.gemm_ln(h, s.w2, s.b2, x, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
+        nv.gemm_ln(h, s.w2, s.b2, x, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS, drop=drop2,
+                   drop_where=2 if drop2 is not None else 0)
         ctx.save_for_backward(x, h, xhat, rstd)
-        ctx.mod = mod
+        ctx.mod, ctx.drop1, ctx.drop2 = mod, drop1, drop2
         return out
 
     @staticmethod
@@ -326,31 +329,33 @@ class FfnFn(torch.autograd.Function):
         dout = dout.contiguous()
         arena.attach_grads(s.params, s.lo, s.hi)
         ds = _empty(M, d, x)
-        nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b2)
+        nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b2, drop=ctx.drop2)
         wgrad(ds, h, s.g_w2)
         dh = _empty(M, s.d_ff, x)
-        dgrad(ds, s.w2, dh, epi=nv.EPI_BF16_MASK, aux=h)
+        dgrad(ds, s.w2, dh, epi=nv.EPI_BF16_MASK, aux=h, drop=ctx.drop1)   # h is the dropped activation: 0 where dropped
         wgrad(dh, x, s.g_w1, gB=s.g_b1)
         dx = _empty(M, d, x)
         dgrad(dh, s.w1, dx, epi=nv.EPI_BF16_ADD, aux=ds)
         arena.grads_ready(s.lo, s.hi)
-        return dx, None, None
+        return dx, None, None, None, None
 
 
 class FrontendFn(torch.autograd.Function):
     """e = LN(relu(x W_in^T + b_in)) + PE[pos]   (Models.py:28-33 eval-mode, 42-44)."""
 
     @staticmethod
-    def forward(ctx, xp, anchor, mod, rows: Rows):
+    def forward(ctx, xp, anchor, mod, rows: Rows, drop=None):
+        """drop: the Dropout between the ReLU and the LayerNorm (Models.py:31, p = 0.5 in training mode)."""
         s = mod._st
         M = xp.shape[0]
         d = s.d_model
         out, xhat, pre = _empty(M, d, xp), _empty(M, d, xp), _empty(M, d, xp)
         rstd = torch.empty(M, dtype=F32, device=xp.device)
         nv.gemm_ln(xp, s.w_in, s.b_in, None, s.gamma_in, s.beta_in, out, xhat, rstd, eps=LN_EPS, relu=True, pe=s.pe,
-                   pos=rows.pos, pre=pre)
+                   pos=rows.pos, pre=pre, drop=drop, drop_where=1 if drop is not None else 0)
         ctx.save_for_backward(xp, xhat, rstd, pre)
         ctx.mod = mod
+        ctx.mask_scale = drop.scale if drop is not None else 1.0   # `pre` is 0 where the ReLU or the dropout zeroed
         ctx.need_dx = xp.requires_grad
         return out
 
@@ -363,14 +368,15 @@ class FrontendFn(torch.autograd.Function):
         dout = dout.contiguous()
         arena.attach_grads(s.front_params, s.front_lo, s.front_hi)
         dz = _empty(M, d, xp)
-        nv.ln_bwd(dout, xhat, rstd, s.gamma_in, dz, s.g_gamma_in, s.g_beta_in, s.g_b_in, mask=pre)
+        nv.ln_bwd(dout, xhat, rstd, s.gamma_in, dz, s.g_gamma_in, s.g_beta_in, s.g_b_in, mask=pre,
+                  mask_scale=ctx.mask_scale)
         wgrad(dz, xp, s.g_w_in)
         dxp = None
         if ctx.need_dx:
             dxp = _empty(M, xp.shape[1], xp)
             dgrad(dz, s.w_in, dxp)
         arena.grads_ready(s.front_lo, s.front_hi)
-        return dxp, None, None, None
+        return dxp, None, None, None, None
 
 
 class EmbedFn(torch.autograd.Function):

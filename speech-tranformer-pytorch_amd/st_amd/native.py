@@ -22,24 +22,25 @@ from . import build as _build
 EPI_BF16, EPI_BF16_RELU, EPI_F32, EPI_BF16_MASK, EPI_BF16_ADD, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T = range(7)
 
 _c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
+_c_uint = ctypes.c_uint
 
 # name -> argtypes (restype is int everywhere); must mirror include/st_hip.h exactly.
 SIGNATURES = {
     "st_version": [],
     "st_gemm": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
-                _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int],
+                _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                    _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
-                   _c_void_p, _c_void_p],
+                   _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
     "st_ln_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
-                  _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int],
+                  _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_float],
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float, _c_void_p, _c_int],
+                    _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int],
+                    _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_colsum": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
@@ -165,9 +166,36 @@ def _vec(t: Optional[torch.Tensor], dtype, n: int, name: str) -> None:
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 
 
+class Drop:
+    """One dropout call site (nn.Dropout in training mode): ``seed`` is a 1-element int32 DEVICE tensor (the
+    kernels read it, so a captured HIP graph draws new masks once it is advanced), ``salt`` a per-site
+    constant, ``p`` the drop probability - quantised to 8 bits: keep iff draw >= round(256 p), survivors scaled
+    by 256 / (256 - thresh).  The backward of an op takes the same Drop object as its forward."""
+    __slots__ = ("seed", "salt", "thresh", "scale")
+
+    def __init__(self, seed: torch.Tensor, salt: int, p: float):
+        if not (seed.is_cuda and seed.dtype == torch.int32 and seed.numel() == 1):
+            raise ValueError("Drop: seed must be a 1-element int32 tensor on the GPU")
+        if not 0.0 <= p < 1.0:
+            raise ValueError("Drop: p must be in [0, 1)")
+        self.seed, self.salt = seed, int(salt) & 0xFFFFFFFF
+        self.thresh = min(255, int(round(256.0 * p)))
+        self.scale = 256.0 / (256 - self.thresh)
+
+    @property
+    def p_effective(self) -> float:
+        return self.thresh / 256.0
+
+
+def _drop(d: Optional["Drop"]):
+    if d is None or d.thresh == 0:
+        return None, 0, 0, 1.0
+    return d.seed.data_ptr(), d.salt, d.thresh, d.scale
+
+
 # ------------------------------------------------------------------------------------------------
 def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1,
-         m=None, n=None, kc=None):
+         m=None, n=None, kc=None, drop=None):
     """out[i][j] (+)= sum_c X(i,c) Y(j,c).  ``*_cmajor``: that tensor is stored [c, rows]."""
     _mat(X, BF16, "X"), _mat(Y, BF16, "Y")
     _mat(out, F32 if epi in (EPI_F32, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T) else BF16, "out")
@@ -184,12 +212,15 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
         ldaux = aux.stride(0)
     _tag("gemm", int(x_cmajor), int(y_cmajor), M, N, Kc, epi)
     rc = load().st_gemm(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0),
-                        out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux, epi, splits)
+                        out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux, epi, splits,
+                        *(_drop(drop) if epi in (EPI_BF16_RELU, EPI_BF16_MASK) else _drop(None)))
     _check(rc, "st_gemm")
     return out
 
 
-def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None):
+def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None,
+            drop=None, drop_where=0):
+    """drop_where: 1 = dropout before the LayerNorm (after bias / ReLU), 2 = on the LayerNorm output."""
     _mat(X, BF16, "X"), _mat(W, BF16, "W"), _mat(out, BF16, "out")
     M, K = X.shape
     N = W.shape[0]
@@ -212,12 +243,14 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
     _tag("gemm_ln", M, N, K)
     rc = load().st_gemm_ln(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), M, N, K, bias.data_ptr(), _p(res),
                            0 if res is None else res.stride(0), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                           int(relu), _p(pe), _p(pos), out.data_ptr(), out.stride(0), _p(xhat), _p(rstd), _p(pre))
+                           int(relu), _p(pe), _p(pos), out.data_ptr(), out.stride(0), _p(xhat), _p(rstd), _p(pre),
+                           *_drop(drop if drop_where in (1, 2) else None), int(drop_where))
     _check(rc, "st_gemm_ln")
     return out
 
 
-def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None):
+def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None, drop=None, mask_scale=1.0):
+    """drop: the forward dropped the LayerNorm output; mask_scale: 1/(1-p) of a dropout between `mask`'s ReLU and the LN."""
     _mat(dy, BF16, "dy"), _mat(xhat, BF16, "xhat"), _mat(dx, BF16, "dx")
     M, N = dy.shape
     assert xhat.stride(0) == N
@@ -228,7 +261,8 @@ def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=
     _vec(dgamma, F32, N, "dgamma"), _vec(dbeta, F32, N, "dbeta"), _vec(dbias, F32, N, "dbias")
     _tag("ln_bwd", M, N)
     rc = load().st_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                          _p(mask), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias), M, N)
+                          _p(mask), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias), M, N, *_drop(drop),
+                          float(mask_scale))
     _check(rc, "st_ln_bwd")
     return dx
 
@@ -240,7 +274,7 @@ def _work(w):
     return w.data_ptr(), w.numel()
 
 
-def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None):
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None):
     """work: optional int32 device list of (b << 16) | q_tile, heaviest first (functional.attn_work)."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
         _mat(t, BF16, nm)
@@ -254,13 +288,13 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
                             k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), rows, int(causal),
-                            float(scale), *_work(work))
+                            float(scale), *_work(work), *_drop(drop))
     _check(rc, "st_attn_fwd")
     return O
 
 
 def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
-             parts=3, work_q=None, work_k=None):
+             parts=3, work_q=None, work_k=None, drop=None):
     """parts: 1 = dQ (+delta) kernel, 2 = dK/dV kernel (needs delta from part 1), 3 = both."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
         _mat(t, BF16, nm)
@@ -271,7 +305,7 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
     if _TIMING is not None and parts == 3:   # profile the two kernels of the call separately
         for part in (1, 2):
             attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal,
-                     scale, parts=part, work_q=work_q, work_k=work_k)
+                     scale, parts=part, work_q=work_q, work_k=work_k, drop=drop)
         return
     _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts)
     rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
@@ -279,7 +313,7 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
                             dQ.data_ptr(), dQ.stride(0), dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0),
                             q_off.data_ptr(), q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k,
                             int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),
-                            *_work(work_k))
+                            *_work(work_k), *_drop(drop))
     _check(rc, "st_attn_bwd")
 
 

@@ -1,0 +1,57 @@
+"""Dropout randomness of the HIP path (training mode of the reference's nn.Dropout sites: Attention.py:89,
+SubLayers.py:25,27, Models.py:31).
+
+The kernels draw counter-based masks: a mask is a pure function of (device seed, call-site salt, element
+index), see csrc/st_common.cuh.  This module owns the two host-visible pieces:
+
+* the SEED - one int32 element per device, in device memory.  Kernels read it at run time, so a captured HIP
+  graph draws fresh masks on every replay as long as ``advance()`` (itself capturable: an in-place add) runs
+  once per step; ``trainer.TrainStep`` does that.  Initialised from ``torch.initial_seed()``, so
+  ``torch.manual_seed`` makes runs reproducible; ``manual_seed`` here re-seeds explicitly.
+* the SALT - a host counter handed out per dropout call, so two sites (or two eager calls of one site) never
+  share a mask even between ``advance()`` calls.  A backward pass reuses the forward's (seed tensor, salt).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import native as nv
+
+_seeds: Dict[str, torch.Tensor] = {}
+_salt = 0
+
+
+def seed_tensor(device) -> torch.Tensor:
+    key = str(torch.device(device))
+    t = _seeds.get(key)
+    if t is None:
+        t = torch.tensor([torch.initial_seed() & 0x7FFFFFFF], dtype=torch.int32, device=device)
+        _seeds[key] = t
+    return t
+
+
+def manual_seed(seed: int) -> None:
+    """Re-seed every device's dropout stream (and restart the salt counter)."""
+    global _salt
+    _salt = 0
+    for t in _seeds.values():
+        t.fill_(int(seed) & 0x7FFFFFFF)
+
+
+def advance(device=None) -> None:
+    """Move to the next step's masks (in-place on the device: safe inside a HIP-graph capture)."""
+    for key, t in _seeds.items():
+        if device is None or key == str(torch.device(device)):
+            t.add_(1)
+
+
+def site(device, p: float) -> Optional["nv.Drop"]:
+    """A dropout call site for one forward call (None when p == 0): pass it to the forward kernel wrapper
+    and keep it for the backward."""
+    global _salt
+    if p <= 0.0:
+        return None
+    _salt = (_salt + 1) & 0xFFFFFFFF
+    return nv.Drop(seed_tensor(device), _salt, p)

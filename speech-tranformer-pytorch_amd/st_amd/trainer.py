@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from .arena import arena_of
 from .dp import GradReducer
+from . import rng
 from .functional import side_wgrads
 
 
@@ -51,6 +52,7 @@ class TrainStep:
     # ---- the two halves of a step -------------------------------------------------------------
     def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, side=False):
         self.optimizer.zero_grad()
+        rng.advance()                          # next step's dropout masks (an in-place device add: capturable)
         logits, _ = self.model(inputs, input_lengths, targets, target_lengths)
         loss = self.crit(logits.contiguous().view(-1, self.vocab_size), ground_truth.contiguous().view(-1))
         # captured graph: the decoder's weight gradients fork onto a side stream (the eager path keeps one

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from st_amd import functional as F_
+from st_amd import rng
 from st_amd.arena import arena_of, bundle
 from transformer.Utils import LengthMask, lengths_from_mask
 
@@ -25,7 +26,8 @@ class MultiHeadAttention(nn.Module):
         reference discards it, train.py:39);
       * ``mask`` may be a :class:`LengthMask`; a dense mask is analysed back
         into lengths (slow path);
-      * training-mode dropout (p > 0) is not implemented yet and raises.
+      * training-mode dropout draws counter-based masks inside the kernels (st_amd/rng.py): same distribution as
+        nn.Dropout with p quantised to 1/256, a different random stream.
     """
 
     def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1):
@@ -69,18 +71,17 @@ class MultiHeadAttention(nn.Module):
             g_w_o=a.grad_view(o.weight), g_b_o=a.grad_view(o.bias),
             g_gamma=a.grad_view(ln.weight), g_beta=a.grad_view(ln.bias))
 
-    def _check_dropout(self):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("HIP path: training-mode dropout is not implemented yet; "
-                                      "build the model with dropout=0 or call .eval()")
+    def _drop(self, device):
+        """Attention-probability dropout (Attention.py:89) of this call, or None in eval mode / p = 0."""
+        return rng.site(device, self.dropout.p) if self.training else None
 
     # ---- fast path: bf16 row matrices ----------------------------------------------------------
     def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal):
         """x_q [Mq, d] (and x_kv [Mk, d] for cross-attention, else None) bf16 row matrices."""
-        self._check_dropout()
         arena = arena_of(self)
         with arena.scope():
-            return F_.MhaFn.apply(x_q, x_kv, self.linear_q.weight, self, q_rows, k_rows, bool(causal), False)
+            return F_.MhaFn.apply(x_q, x_kv, self.linear_q.weight, self, q_rows, k_rows, bool(causal), False,
+                                  self._drop(x_q.device))
 
     # ---- reference API -------------------------------------------------------------------------
     def forward(self, q, k, v, mask=None):

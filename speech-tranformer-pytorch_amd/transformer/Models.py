@@ -15,6 +15,7 @@ import torch.nn as nn
 
 import transformer.Constants as Constants
 from st_amd import functional as F_
+from st_amd import rng
 from st_amd.arena import arena_of, bundle
 from transformer.Embedding import PositionalEncoding
 from transformer.Layers import EncoderLayer, DecoderLayer
@@ -53,9 +54,6 @@ class Encoder(nn.Module):
 
     def forward_rows(self, inputs, inputs_length, rows=None):
         """inputs [B, T, F] fp32 (zero past each length) -> (packed bf16 [sum(len), d], Rows)."""
-        if self.training:
-            raise NotImplementedError("HIP path: the front-end Dropout(p=0.5) of training mode (Models.py:31) is not "
-                                      "implemented yet; call .eval() (autograd still works - the parity mode)")
         _check_lengths(inputs_length, min(self.n_max_seq, inputs.shape[1]), "Encoder")
         arena = arena_of(self)
         with arena.scope():
@@ -63,7 +61,8 @@ class Encoder(nn.Module):
                 rows = F_.Rows.packed(inputs_length, inputs.device)
             rows.pos                                      # position table built before the first launch
             xp = F_.PackFn.apply(inputs.float(), rows)
-            e = F_.FrontendFn.apply(xp, self.input_proj[0].weight, self, rows)
+            drop = rng.site(inputs.device, self.input_proj[2].p) if self.training else None   # Models.py:31: p = 0.5
+            e = F_.FrontendFn.apply(xp, self.input_proj[0].weight, self, rows, drop)
             for layer in self.layer_stack:
                 e = layer.forward_rows(e, rows)
         return e, rows

@@ -4,6 +4,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from st_amd import functional as F_
+from st_amd import rng
 from st_amd.arena import arena_of, bundle
 
 
@@ -37,12 +38,11 @@ class PositionwiseFeedForward(nn.Module):
                       g_b2=a.grad_view(f2.bias), g_gamma=a.grad_view(ln.weight), g_beta=a.grad_view(ln.bias))
 
     def forward_rows(self, x):
-        if self.training and (self.dropout1.p > 0 or self.dropout2.p > 0):
-            raise NotImplementedError("HIP path: training-mode dropout is not implemented yet; "
-                                      "build the model with dropout=0 or call .eval()")
+        d1 = rng.site(x.device, self.dropout1.p) if self.training else None      # SubLayers.py:25
+        d2 = rng.site(x.device, self.dropout2.p) if self.training else None      # SubLayers.py:27 (after the LN)
         arena = arena_of(self)
         with arena.scope():
-            return F_.FfnFn.apply(x, self.fc1.weight, self)
+            return F_.FfnFn.apply(x, self.fc1.weight, self, d1, d2)
 
     def forward(self, inputs):
         shape = inputs.shape

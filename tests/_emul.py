@@ -17,9 +17,58 @@ from st_amd import native as nv
 
 BF16, F32 = torch.bfloat16, torch.float32
 
+# ---- dropout: the same counter-based masks as csrc/st_common.cuh (st_hash32, Drop, drop_counter_*) ----------
+_M32 = 0xFFFFFFFF
+
+
+def _hash32(x):
+    """lowbias32 on an int64 tensor holding uint32 values (int64 products wrap; the low 32 bits are exact)."""
+    x = x & _M32
+    x = x ^ (x >> 16)
+    x = (x * 0x7feb352d) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846ca68b) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+class Drop:
+    """CPU stand-in for st_amd.native.Drop (same fields, seed may live on the CPU)."""
+
+    def __init__(self, seed, salt, p):
+        self.seed, self.salt = seed, int(salt) & _M32
+        self.thresh = min(255, int(round(256.0 * p)))
+        self.scale = 256.0 / (256 - self.thresh)
+
+
+def _on(d):
+    return d is not None and d.thresh > 0
+
+
+def _key(d):
+    seed = int(d.seed.reshape(-1)[0].item()) & _M32
+    return int(_hash32(torch.tensor((seed + d.salt * 0x9e3779b9) & _M32, dtype=torch.int64)))
+
+
+def keep_rc(d, rows, cols, ncols):
+    """bool [len(rows), len(cols)]: element (row, col) of a row matrix with ``ncols`` columns survives."""
+    rows, cols = rows.to(torch.int64).view(-1, 1), cols.to(torch.int64).view(1, -1)
+    cnt = (rows * (ncols >> 2) + (cols >> 2)) & _M32
+    bits = _hash32(cnt ^ _key(d))
+    return ((bits >> (8 * (cols & 3))) & 0xFF) >= d.thresh
+
+
+def keep_qk(d, bh, nq, nk):
+    """bool [nq, nk]: attention probability (q, k) of head slot bh survives."""
+    q, k = torch.arange(nq, dtype=torch.int64).view(-1, 1), torch.arange(nk, dtype=torch.int64).view(1, -1)
+    cnt = ((((q >> 1) << 15) | (k >> 1)) + bh * 0x85ebca6b) & _M32
+    bits = _hash32(cnt ^ _key(d))
+    return ((bits >> (8 * (2 * (q & 1) + (k & 1)))) & 0xFF) >= d.thresh
+
+
 
 def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1, m=None, n=None,
-         kc=None):
+         kc=None, drop=None):
     Xl = (X.t() if x_cmajor else X).float()      # logical [M, Kc]
     Yl = (Y.t() if y_cmajor else Y).float()      # logical [N, Kc]
     M = m if m is not None else Xl.shape[0]
@@ -35,8 +84,10 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
         acc = acc + bias[:N]
     if epi == nv.EPI_BF16_RELU:
         acc = torch.relu(acc)
+        if _on(drop):
+            acc = acc * keep_rc(drop, torch.arange(M), torch.arange(N), N) * drop.scale
     elif epi == nv.EPI_BF16_MASK:
-        acc = acc * (aux[:M, :N].float() > 0)
+        acc = acc * (aux[:M, :N].float() > 0) * (drop.scale if _on(drop) else 1.0)
     elif epi == nv.EPI_BF16_ADD:
         acc = acc + aux[:M, :N].float()
     if epi == nv.EPI_F32_ATOMIC:
@@ -48,10 +99,14 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
     return out
 
 
-def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None):
+def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None,
+            drop=None, drop_where=0):
     v = X.float() @ W.float().t() + bias
+    M, N = v.shape
     if relu:
         v = torch.relu(v)
+    if _on(drop) and drop_where == 1:
+        v = v * keep_rc(drop, torch.arange(M), torch.arange(N), N) * drop.scale
     if res is not None:
         v = v + res.float()
     mu = v.mean(-1, keepdim=True)
@@ -61,6 +116,8 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
     y = h * gamma + beta
     if pe is not None:
         y = y + pe[pos.long()]
+    if _on(drop) and drop_where == 2:
+        y = y * keep_rc(drop, torch.arange(M), torch.arange(N), N) * drop.scale
     out.copy_(y.to(BF16))
     if xhat is not None:
         xhat.copy_(h.to(BF16))
@@ -71,12 +128,14 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
     return out
 
 
-def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None):
+def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None, drop=None, mask_scale=1.0):
     d, xh = dy.float(), xhat.float()
+    if _on(drop):
+        d = d * keep_rc(drop, torch.arange(d.shape[0]), torch.arange(d.shape[1]), d.shape[1]) * drop.scale
     g = d * gamma
     v = rstd.unsqueeze(-1) * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
     if mask is not None:
-        v = v * (mask.float() > 0)
+        v = v * (mask.float() > 0) * mask_scale
     dx.copy_(v.to(BF16))
     if dgamma is not None:
         dgamma += (d * xh).sum(0)
@@ -100,19 +159,24 @@ def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h):
     return q, k, v, s, slice(qo, qo + ql), slice(ko, ko + kl), cs
 
 
-def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None):
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):
             q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h)
             p = torch.softmax(s, -1)
+            if _on(drop):   # the kernel drops un-normalised weights and folds 1/(1-p) into the final 1/l
+                p = p * keep_qk(drop, b * n_head + h, *s.shape)
+                O[qs, cs] = (p.to(BF16).float() @ v * drop.scale).to(BF16)
+                lse.view(n_head, rows)[h, qs] = torch.logsumexp(s, -1) / math.log(2.0)
+                continue
             O[qs, cs] = (p.to(BF16).float() @ v).to(BF16)
             lse.view(n_head, rows)[h, qs] = torch.logsumexp(s, -1) / math.log(2.0)
     return O
 
 
 def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
-             parts=3, work_q=None, work_k=None):
+             parts=3, work_q=None, work_k=None, drop=None):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):
@@ -122,10 +186,14 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
             dl = (do * o).sum(-1, keepdim=True)
             delta.view(n_head, rows)[h, qs] = dl.squeeze(-1)
             dp = do @ v.t()
+            pv = p
+            if _on(drop):
+                keep = keep_qk(drop, b * n_head + h, *s.shape) * drop.scale
+                dp, pv = dp * keep, p * keep
             ds = (p * (dp - dl)).to(BF16).float()
             dQ[qs, cs] = (ds @ k * scale).to(BF16)
             dK[ks, cs] = (ds.t() @ q * scale).to(BF16)
-            dV[ks, cs] = (p.to(BF16).float().t() @ do).to(BF16)
+            dV[ks, cs] = (pv.to(BF16).float().t() @ do).to(BF16)
 
 
 def colsum(x, out):
@@ -194,7 +262,9 @@ def emulated_kernels():
     """Swap st_amd.native's entry points for the emulations above (CPU tensors allowed)."""
     saved = {n: getattr(nv, n) for n in _NAMES}
     saved_req = st_arena.ParamArena._require_gpu
+    saved_drop = nv.Drop
     try:
+        nv.Drop = Drop
         for n in _NAMES:
             setattr(nv, n, globals()[n])
         st_arena.ParamArena._require_gpu = staticmethod(lambda dev: None)
@@ -202,4 +272,5 @@ def emulated_kernels():
     finally:
         for n, f in saved.items():
             setattr(nv, n, f)
+        nv.Drop = saved_drop
         st_arena.ParamArena._require_gpu = saved_req

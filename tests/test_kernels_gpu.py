@@ -311,3 +311,110 @@ def test_misc_kernels():
             ref = res
     for k in ref:
         check(res[k], ref[k], 3e-3 if k in ("demb", "colsum") else 1e-6, "misc %s" % k)
+
+
+# ---- training-mode dropout: counter-based masks, bit-identical to the emulation's hash -----------------
+def _drops(salt, p, seed=1234567):
+    """The same dropout call site for the kernels (device seed) and the emulation (host seed)."""
+    return (nv.Drop(torch.tensor([seed], dtype=I32, device="cuda"), salt, p),
+            em.Drop(torch.tensor([seed], dtype=I32), salt, p))
+
+
+def _zero_pattern_equal(got, ref, what):
+    """Dropped elements are exact zeros on both sides: the MASKS must agree element for element."""
+    zg, zr = (got.detach().float().cpu() == 0), (ref.detach().float().cpu() == 0)
+    bad = (zg != zr).sum().item()
+    # an un-dropped value can round to an exact bf16 zero on one side only - vanishingly rare, never systematic
+    assert bad <= 1e-5 * zg.numel(), "%s: dropout masks differ in %d of %d elements" % (what, bad, zg.numel())
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_gemm_relu_dropout_and_mask_scale(p):
+    M, N, K = 777, 1024, 256
+    x, W, b = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5), g(N, seed=3, dtype=F32)
+    dn, de = _drops(11, p)
+    ref = em.gemm(x, W, torch.zeros(M, N, dtype=BF16), bias=b, epi=nv.EPI_BF16_RELU, drop=de)
+    out = nv.gemm(cu(x), cu(W), torch.zeros(M, N, dtype=BF16, device="cuda"), bias=cu(b), epi=nv.EPI_BF16_RELU, drop=dn)
+    check(out, ref, 1e-2, "gemm relu+dropout p=%g" % p)
+    _zero_pattern_equal(out, ref, "gemm relu+dropout p=%g" % p)
+    kept = (out.float() != 0).float().mean().item() / (ref.float().relu() >= 0).float().mean().item()
+    # backward of the same site: dgrad masked by the dropped activation, survivors scaled by 1/(1-p)
+    dy, W2 = g(M, 256, seed=4), g(256, N, seed=5, scale=N ** -0.5)
+    ref_d = em.gemm(dy, W2, torch.zeros(M, N, dtype=BF16), aux=ref, epi=nv.EPI_BF16_MASK, y_cmajor=True, drop=de)
+    out_d = nv.gemm(cu(dy), cu(W2), torch.zeros(M, N, dtype=BF16, device="cuda"), aux=out, epi=nv.EPI_BF16_MASK,
+                    y_cmajor=True, drop=dn)
+    check(out_d, ref_d, 1e-2, "gemm mask+scale p=%g" % p)
+    assert kept > 0
+
+
+@pytest.mark.parametrize("N", [128, 256])
+@pytest.mark.parametrize("where", [1, 2])
+def test_gemm_ln_dropout(N, where):
+    M, K, p = 500, 256 if where == 2 else 80, 0.2 if where == 2 else 0.5
+    X, W = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5)
+    b, gamma, beta = g(N, seed=3, dtype=F32), 1 + 0.2 * g(N, seed=4, dtype=F32), 0.2 * g(N, seed=5, dtype=F32)
+    res = g(M, N, seed=6) if where == 2 else None
+    dn, de = _drops(5 + where, p)
+
+    def run(fn, dev, d):
+        mv = (lambda t: None if t is None else t.to(dev))
+        out, xhat, pre = (torch.zeros(M, N, dtype=BF16, device=dev) for _ in range(3))
+        rstd = torch.zeros(M, dtype=F32, device=dev)
+        fn(mv(X), mv(W), mv(b), mv(res), mv(gamma), mv(beta), out, xhat, rstd, eps=1e-6, relu=where == 1, pre=pre,
+           drop=d, drop_where=where)
+        return out, xhat, rstd, pre
+
+    r, o = run(em.gemm_ln, "cpu", de), run(nv.gemm_ln, "cuda", dn)
+    for got, ref, nm, tol in zip(o, r, ("out", "xhat", "rstd", "pre"), (1e-2, 1e-2, 2e-3, 1e-2)):
+        check(got, ref, tol, "gemm_ln dropout where=%d N=%d %s" % (where, N, nm))
+    _zero_pattern_equal(o[0] if where == 2 else o[3], r[0] if where == 2 else r[3], "gemm_ln dropout where=%d" % where)
+
+
+def test_ln_bwd_dropout_and_mask_scale():
+    M, N = 1000, 256
+    dy, xhat = g(M, N, seed=1), g(M, N, seed=2)
+    rstd, gamma = g(M, seed=3, dtype=F32).abs() + 0.5, 1 + 0.2 * g(N, seed=4, dtype=F32)
+    mask = g(M, N, seed=5)
+    dn, de = _drops(9, 0.2)
+
+    def run(fn, dev, d, mk, ms):
+        mv = (lambda t: None if t is None else t.to(dev))
+        dx = torch.zeros(M, N, dtype=BF16, device=dev)
+        acc = [torch.ones(N, dtype=F32, device=dev) for _ in range(3)]
+        fn(mv(dy), mv(xhat), mv(rstd), mv(gamma), dx, acc[0], acc[1], acc[2], mask=mv(mk), drop=d, mask_scale=ms)
+        return [dx] + acc
+
+    for mk, ms, d_n, d_e, what in ((None, 1.0, dn, de, "dropout on dy"), (mask, 2.0, None, None, "mask scale")):
+        r, o = run(em.ln_bwd, "cpu", d_e, mk, ms), run(nv.ln_bwd, "cuda", d_n, mk, ms)
+        for got, ref, nm, tol in zip(o, r, ("dx", "dgamma", "dbeta", "dbias"), (1e-2, 3e-3, 3e-3, 5e-3)):
+            check(got, ref, tol, "ln_bwd %s %s" % (what, nm))
+
+
+@pytest.mark.parametrize("case", [(2, 2, 32, None, [7, 4], True, True), (3, 4, 64, None, [200, 131, 64], False, True),
+                                  (2, 4, 64, [50, 33], [300, 257], False, True),
+                                  (2, 4, 32, None, [129, 70], True, False)])
+def test_attention_dropout(case):
+    c = _attn_case(*case, seed=21)
+    dn, de = _drops(3, 0.2)
+
+    def run(fwd, bwd, dev, d):
+        mv = lambda t: t.to(dev)
+        Q, K, V, dO = mv(c["Q"]), mv(c["K"]), mv(c["V"]), mv(c["dO"])
+        meta = [mv(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
+        O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
+        lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device=dev)
+        fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], c["causal"], c["scale"], drop=d)
+        delta = torch.zeros_like(lse)
+        dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
+        dK, dV = (torch.zeros(c["Mk"], c["d"], dtype=BF16, device=dev) for _ in range(2))
+        bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, *meta, c["H"], c["max_q"], c["max_k"], c["causal"], c["scale"],
+            drop=d)
+        return O, lse, dQ, dK, dV
+
+    r = run(em.attn_fwd, em.attn_bwd, "cpu", de)
+    o = run(nv.attn_fwd, nv.attn_bwd, "cuda", dn)
+    for got, ref, nm, tol in zip(o, r, ("O", "lse", "dQ", "dK", "dV"), (2e-2, 2e-3, 3e-2, 3e-2, 2.5e-2)):
+        check(got, ref, tol, "attention dropout %s %s" % (case, nm))
+    # and the masks really are drawn: the dropout-free output differs
+    o0 = run(nv.attn_fwd, nv.attn_bwd, "cuda", None)
+    assert rel(o[0], o0[0]) > 5e-2

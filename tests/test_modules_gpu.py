@@ -17,6 +17,11 @@ def test_c1_full_step_gpu(golden_dir):
     comp.run_c1_step(golden_dir, "cuda")
 
 
+def test_c1_full_step_training_mode_dropout_gpu(golden_dir):
+    """model.train(): the kernels' own dropout masks handed to the fp64 oracle - same tolerances as eval mode."""
+    comp.run_c1_step_dropout(golden_dir, "cuda")
+
+
 def test_standalone_modules_gpu(golden_dir):
     comp.run_standalone_modules(golden_dir, "cuda")
 

@@ -37,3 +37,24 @@ def test_work_lists_cover_every_tile_once_and_sort_by_cost():
         assert min(cq) >= 1 and min(ck) >= 1
         # cached on the query layout
         assert attn_work(qr, kr, causal)[0] is wq
+
+
+def test_dropout_hash_statistics():
+    """The counter-based dropout masks (tests/_emul mirrors csrc/st_common.cuh bit for bit; the GPU tests pin
+    that): keep rate = 1 - round(256 p)/256, different salts / seeds give independent masks."""
+    from tests import _emul as em
+    seed = torch.tensor([42], dtype=torch.int32)
+    for p in (0.1, 0.2, 0.5):
+        d = em.Drop(seed, 7, p)
+        keep = em.keep_rc(d, torch.arange(2000), torch.arange(256), 256)
+        want = 1.0 - d.thresh / 256.0
+        assert abs(keep.float().mean().item() - want) < 4e-3
+        assert abs(d.scale * want - 1.0) < 1e-6                     # unbiased for the realised keep rate
+        assert (keep.float().mean(0) - want).abs().max() < 0.05      # no dead / always-on columns
+        assert (keep.float().mean(1) - want).abs().max() < 0.12      # ... or rows
+        other = em.keep_rc(em.Drop(seed, 8, p), torch.arange(2000), torch.arange(256), 256)
+        agree = (keep == other).float().mean().item()
+        assert abs(agree - (want * want + (1 - want) ** 2)) < 6e-3   # independent masks
+        kq = em.keep_qk(d, 3, 300, 500)
+        assert abs(kq.float().mean().item() - want) < 6e-3
+        assert abs((kq == em.keep_qk(d, 4, 300, 500)).float().mean().item() - (want * want + (1 - want) ** 2)) < 8e-3
