@@ -74,3 +74,25 @@ def test_native_library_is_loaded():
     assert lib.st_version() >= 1
     with open("/proc/self/maps") as f:
         assert "libst_hip.so" in f.read()
+
+
+def test_loss_heads_on_gpu(golden_dir):
+    """transformer/Loss.py runs on the GPU (the reference's version builds CPU temporaries) and matches the CPU value."""
+    import os
+    import numpy as np
+    import torch
+    from transformer.Loss import CTCAttentionLoss, LabelSmoothingLoss
+    fx = dict(np.load(os.path.join(golden_dir, "loss_optim.npz")))
+    logits, target = torch.from_numpy(fx["logits"]).cuda().requires_grad_(True), torch.from_numpy(fx["target"]).cuda()
+    for ign in (0, -1, 5):
+        crit = LabelSmoothingLoss(0.1, 30, weight=torch.ones(1, 30), ignore_index=ign).cuda()
+        loss = crit(logits, target)
+        assert abs(loss.item() - float(fx["loss_ign%d" % ign])) <= 5e-6 * abs(float(fx["loss_ign%d" % ign]))
+    loss.backward()
+    assert torch.isfinite(logits.grad).all()
+    head = CTCAttentionLoss(16, 12).cuda()
+    g = torch.Generator().manual_seed(5)
+    enc, dec = torch.randn(3, 40, 16, generator=g).cuda(), torch.randn(3, 6, 12, generator=g).cuda()
+    tgt = torch.randint(1, 12, (3, 6), generator=g).cuda()
+    total, att, ctc = head(enc, torch.tensor([40, 33, 21]), dec, tgt, torch.tensor([6, 4, 5]), tgt)
+    assert torch.isfinite(total)
