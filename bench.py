@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) carrying
 oracle restatement timed on this box's host cores; N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -214,8 +215,17 @@ def main():
     dom = max(agg, key=lambda k: agg[k]["ms"])
     d = agg[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    # HBM bytes per launch of that kernel class from the PMC passes (tools/pmc_traffic.sh: separate rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950 read correction applied); the summary
+    # travels with the repo under profiles/ because counters cannot be collected inside the timed run.
+    traffic = None
+    pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
+    if pmc:
+        with open(pmc[-1]) as f:
+            traffic = json.load(f).get(dom, {}).get("bytes")
     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "traffic": None if traffic is None else round(traffic),
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // 2,
                 "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
     kernels = {k: {"ms_per_step": round(v["ms"] / 2, 3), "launches": v["launches"] // 2,

@@ -53,8 +53,16 @@ class TrainStep:
     def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, side=False):
         self.optimizer.zero_grad()
         rng.advance()                          # next step's dropout masks (an in-place device add: capturable)
-        logits, _ = self.model(inputs, input_lengths, targets, target_lengths)
-        loss = self.crit(logits.contiguous().view(-1, self.vocab_size), ground_truth.contiguous().view(-1))
+        if hasattr(self.model, "forward_packed"):
+            # loss over the valid tokens only: the kernels' ragged logits rows against the matching ground-truth
+            # entries.  Identical to train.py:40 on the padded [B, L, V] tensor: its padded positions carry
+            # ground truth 0 = ignore_index, and the mean is over non-ignored tokens either way.
+            logits, t_rows = self.model.forward_packed(inputs, input_lengths, targets, target_lengths)
+            truth = ground_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ground_truth.shape[1]))
+            loss = self.crit(logits, truth)
+        else:
+            logits, _ = self.model(inputs, input_lengths, targets, target_lengths)
+            loss = self.crit(logits.contiguous().view(-1, self.vocab_size), ground_truth.contiguous().view(-1))
         # captured graph: the decoder's weight gradients fork onto a side stream (the eager path keeps one
         # stream: its gradient-ready hooks assume a weight gradient is enqueued when the layer's backward returns)
         with side_wgrads(side):

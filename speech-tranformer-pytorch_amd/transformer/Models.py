@@ -158,18 +158,18 @@ class Transformer(nn.Module):
         return bundle(v_pad=v_pad, vocab_params=[w], vocab_lo=lo, vocab_hi=hi,
                       w_vocab=a.bf16(w, v_pad), g_w_vocab=a.grad_view(w, v_pad))
 
-    def forward(self, inputs, inputs_pos, targets=None, targets_pos=None):
-        """inputs [B, T, F]; inputs_pos [B] input lengths; targets [B, L] tokens;
-        targets_pos [B] target lengths (the current train.py:39 calling convention)
-        -> (seq_logit [B, L, V] fp32, ([], [], []))."""
+    def forward_packed(self, inputs, inputs_pos, targets, targets_pos):
+        """The same computation with the logits left in the ragged layout the kernels produce:
+        -> (logits [sum(targets_pos), V] fp32 (a column slice of a [*, v_pad] buffer), Rows of the target side).
+        ``Rows.scatter_index(L)`` maps row r to its position b*L + t in the padded layout; trainer.TrainStep uses
+        this form so that the loss runs over valid tokens only and nothing is scattered back to [B, L, V]."""
         if self.return_attns:
             raise NotImplementedError("HIP path: attention maps are not materialised (config.return_attns must be falsy)")
         arena = arena_of(self)
-        B, L = targets.shape
         # every ragged layout (and its host->device copies) is set up before the first kernel launch
         in_rows = F_.Rows.packed(inputs_pos, inputs.device)
         t_rows = F_.Rows.packed(targets_pos, inputs.device)
-        flat_idx = t_rows.scatter_index(L)
+        t_rows.scatter_index(targets.shape[1])
         in_rows.pos, t_rows.pos
         F_.attn_work(in_rows, in_rows, False)     # encoder self-attention
         F_.attn_work(t_rows, t_rows, True)        # decoder self-attention (causal)
@@ -178,6 +178,14 @@ class Transformer(nn.Module):
             enc, _ = self.encoder.forward_rows(inputs, inputs_pos, in_rows)
             dec, _ = self.decoder.forward_rows(targets, targets_pos, enc, in_rows, t_rows)
             logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self)       # [sum(tgt_len), v_pad]
+        return logits[:, :self.vocab_size], t_rows
+
+    def forward(self, inputs, inputs_pos, targets=None, targets_pos=None):
+        """inputs [B, T, F]; inputs_pos [B] input lengths; targets [B, L] tokens;
+        targets_pos [B] target lengths (the current train.py:39 calling convention)
+        -> (seq_logit [B, L, V] fp32, ([], [], []))."""
+        B, L = targets.shape
+        logits, t_rows = self.forward_packed(inputs, inputs_pos, targets, targets_pos)
         # scatter the ragged rows back to the padded [B, L, V] layout train.py:40 expects
-        padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, flat_idx, logits)
-        return padded.view(B, L, -1)[:, :, :self.vocab_size], ([], [], [])
+        padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, t_rows.scatter_index(L), logits)
+        return padded.view(B, L, -1), ([], [], [])
