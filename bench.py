@@ -63,6 +63,8 @@ def kernel_report(records):
                 _, xt, yt, M, N, K, epi = tag
                 kind = {(0, 0): "gemm_fwd", (0, 1): "gemm_dgrad", (1, 1): "gemm_wgrad"}[(xt, yt)]
                 flops = 2.0 * M * N * K
+            elif tag[0] == "wgrad_group":      # several weight gradients in one launch; tag = (name, n, flops)
+                kind, flops = "gemm_wgrad", float(tag[2])
             elif tag[0] == "gemm_ln":
                 kind, flops = "gemm_ln", 2.0 * tag[1] * tag[2] * tag[3]
             elif tag[0] in ("attn_fwd", "attn_bwd"):

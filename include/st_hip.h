@@ -72,6 +72,16 @@ int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int l
             int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits,
             const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
+/* n weight-gradient problems in ONE launch (the decoder's are ~20 workgroups
+ * each: launched one by one they are pure latency).  Problem q:
+ *   dW[q][N_out, K_in] (f32, ld lddw) += dY[q]^T X[q],  db[q][N_out] += colsum(dY[q])   (db or db[q] may be NULL)
+ * with X[q] bf16 [tokens, K_in] (ld ldx), dY[q] bf16 [tokens, N_out] (ld lddy),
+ * i.e. st_gemm(1, 1, X, ldx, dY, lddy, dW, lddw, K_in, N_out, tokens, db, .., ST_EPI_F32_ATOMIC_T, splits[q]).
+ * All arrays are HOST arrays of length n (the descriptors travel in the kernel arguments). */
+int st_wgrad_group(st_stream_t stream, int n, const void* const* X, const int* ldx, const void* const* dY,
+                   const int* lddy, float* const* dW, const int* lddw, float* const* db, const int* tokens,
+                   const int* K_in, const int* N_out, const int* splits);
+
 /* out = LayerNorm(act(X W^T + bias) + res) * gamma + beta (+ pe[pos[row]]),
  * N = d_model in {128, 256, 512}.  Replaces output_linear + residual +
  * layernorm (Attention.py:92-94), fc2 + residual + layernorm

@@ -114,17 +114,22 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int 
 // contraction range with its own LDS buffers; group 1 hands its accumulators to group 0 through LDS, so a
 // CU still runs 8 waves but issues HALF the fp32 atomics of two independent split-K workgroups (the atomic
 // epilogue is what bounds split-K here: 64 splits take 62 us where 16 take 34 us on dW[1024,256], m = 24060).
+// LDS of one workgroup: per group 2 buffers x (X + Y tile) = 72 KiB; KG = 2 also needs 4 x 96 x 64 floats for the
+// accumulator hand-over.
+template <int KG> struct SmemSize {
+  static constexpr int XCH_E = KG > 1 ? 4 * 96 * 64 * 2 : 0;
+  static constexpr int E = KG * 4 * TILE_E > XCH_E ? KG * 4 * TILE_E : XCH_E;
+};
+
+// One output tile (of one split) of one problem; `bid` is the workgroup's index within that problem's grid.
 template <bool XT, bool YT, int EPI, int KG>
-__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_kernel(GemmArgs a) {
-  // per group: 2 buffers x (X + Y tile) = 72 KiB; KG = 2 also needs 4 x 96 x 64 floats for the accumulator hand-over
-  constexpr int XCH_E = KG > 1 ? 4 * 96 * 64 * 2 : 0;
-  __shared__ __attribute__((aligned(16))) bf16 smem_all[KG * 4 * TILE_E > XCH_E ? KG * 4 * TILE_E : XCH_E];
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem_all) {
   const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0, tid = threadIdx.x & 255;
   bf16* smem = smem_all + grp * 4 * TILE_E;
   // XCD-local tile walk: workgroup b runs on XCD b % 8 (own L2).  forward / dgrad: an XCD owns X row-tiles
   // i = x, x+8, ... and its consecutive workgroups take the tiles_j tiles that share one row-tile (the panel
   // crosses the fabric once); weight gradients: an XCD owns splits s = x, x+8, ... and walks their (i, j) tiles.
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int xcd = bid & 7, q = bid >> 3;
   const int minor = a.splits > 1 ? a.tiles_i * a.tiles_j : a.tiles_j;
   const int major = xcd + 8 * (q / minor), mi = q % minor;
   if (major >= (a.splits > 1 ? a.splits : a.tiles_i)) return;
@@ -379,6 +384,38 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_k
   }
 }
 
+template <bool XT, bool YT, int EPI, int KG>
+__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 smem_all[SmemSize<KG>::E];
+  gemm_body<XT, YT, EPI, KG>(a, blockIdx.x, smem_all);
+}
+
+// Several weight-gradient problems in ONE launch (the decoder's are ~20 workgroups each and pure latency when
+// launched one by one).  The descriptors travel in the kernel-argument segment - no device-side table.
+constexpr int GROUP_MAX = 40;
+struct GroupProblem {
+  const bf16* X; const bf16* Y; float* D; float* bias;
+  int ldx, ldy, ldd, M, N, Kc, c_per_split, tiles_i, tiles_j, splits;
+};
+struct GroupArgs {
+  int n;
+  int first[GROUP_MAX + 1];   // first workgroup of problem p; first[n] = grid size
+  GroupProblem p[GROUP_MAX];
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_wgrad_group_kernel(GroupArgs g) {
+  __shared__ __attribute__((aligned(16))) bf16 smem_all[SmemSize<2>::E];
+  int pi = 0;
+  while (pi + 1 < g.n && (int)blockIdx.x >= g.first[pi + 1]) ++pi;   // workgroup-uniform
+  const GroupProblem& p = g.p[pi];
+  GemmArgs a;
+  a.X = p.X; a.ldx = p.ldx; a.Y = p.Y; a.ldy = p.ldy; a.D = p.D; a.ldd = p.ldd;
+  a.M = p.M; a.N = p.N; a.Kc = p.Kc; a.bias = p.bias; a.aux = nullptr; a.ldaux = 0;
+  a.c_per_split = p.c_per_split; a.tiles_i = p.tiles_i; a.tiles_j = p.tiles_j; a.splits = p.splits;
+  a.drop.seed = nullptr; a.drop.salt = 0; a.drop.thresh = 0; a.drop.scale = 1.f;
+  gemm_body<true, true, EPI_F32_ATOMIC_T, 2>(a, (int)blockIdx.x - g.first[pi], smem_all);
+}
+
 template <bool XT, bool YT>
 int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
 #define ST_CASE(E, KG) \
@@ -393,6 +430,48 @@ int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
 }
 
 }  // namespace
+
+namespace {
+// split-K plan shared by st_gemm and st_wgrad_group: returns the grid size
+int plan_splits(GemmArgs& a, int splits) {
+  int per = (a.Kc + splits - 1) / splits;
+  per = (per + BK - 1) / BK * BK;
+  splits = (a.Kc + per - 1) / per;
+  a.c_per_split = per;
+  a.tiles_i = (a.M + 127) / 128; a.tiles_j = (a.N + 127) / 128; a.splits = splits;
+  const int minor = splits > 1 ? a.tiles_i * a.tiles_j : a.tiles_j;
+  const int major_n = splits > 1 ? splits : a.tiles_i;
+  return 8 * ((major_n + 7) / 8) * minor;
+}
+}  // namespace
+
+extern "C" int st_wgrad_group(hipStream_t stream, int n, const void* const* X, const int* ldx, const void* const* dY,
+                              const int* lddy, float* const* dW, const int* lddw, float* const* db, const int* tokens,
+                              const int* K_in, const int* N_out, const int* splits) {
+  for (int base = 0; base < n; base += GROUP_MAX) {
+    GroupArgs g;
+    g.n = 0;
+    g.first[0] = 0;
+    for (int q = base; q < n && q < base + GROUP_MAX; ++q) {
+      if (tokens[q] <= 0 || K_in[q] <= 0 || N_out[q] <= 0) continue;
+      if ((ldx[q] & 7) || (lddy[q] & 7) || (N_out[q] & 3)) return -1;
+      if (ldx[q] < ((K_in[q] + 7) & ~7) || lddy[q] < ((N_out[q] + 7) & ~7)) return -3;
+      GemmArgs a;
+      a.M = K_in[q]; a.N = N_out[q]; a.Kc = tokens[q];
+      const int grid = plan_splits(a, splits[q] < 1 ? 1 : splits[q]);
+      GroupProblem& p = g.p[g.n];
+      p.X = (const bf16*)X[q]; p.ldx = ldx[q]; p.Y = (const bf16*)dY[q]; p.ldy = lddy[q]; p.D = dW[q]; p.ldd = lddw[q];
+      p.bias = db ? db[q] : nullptr; p.M = a.M; p.N = a.N; p.Kc = a.Kc; p.c_per_split = a.c_per_split;
+      p.tiles_i = a.tiles_i; p.tiles_j = a.tiles_j; p.splits = a.splits;
+      g.first[g.n + 1] = g.first[g.n] + grid;
+      ++g.n;
+    }
+    if (g.n == 0) continue;
+    hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(g.first[g.n]), dim3(512), 0, stream, g);
+    ST_CHECK_LAUNCH();
+  }
+  return 0;
+}
 
 extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
                        void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi,
@@ -413,14 +492,7 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   const bool drop = epi == EPI_BF16_RELU && drop_seed != nullptr && drop_thresh > 0;
   a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
   a.drop.scale = (drop || epi == EPI_BF16_MASK) && drop_scale > 0.f ? drop_scale : 1.f;
-  int per = (Kc + splits - 1) / splits;
-  per = (per + BK - 1) / BK * BK;
-  splits = (Kc + per - 1) / per;
-  a.c_per_split = per;
-  a.tiles_i = (M + 127) / 128; a.tiles_j = (N + 127) / 128; a.splits = splits;
-  const int minor = splits > 1 ? a.tiles_i * a.tiles_j : a.tiles_j;
-  const int major_n = splits > 1 ? splits : a.tiles_i;
-  dim3 grid(8 * ((major_n + 7) / 8) * minor);
+  dim3 grid(plan_splits(a, splits));
   int rc;
   if (!x_cmajor && !y_cmajor) rc = launch<false, false>(stream, a, epi, grid);
   else if (!x_cmajor && y_cmajor) rc = launch<false, true>(stream, a, epi, grid);

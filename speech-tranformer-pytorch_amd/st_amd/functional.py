@@ -153,53 +153,40 @@ def _splits(M: int, N: int, K: int) -> int:
     return s
 
 
-class _Side:
+class _Deferred:
     """Weight-gradient launches produce nothing the rest of the backward pass reads (only parameter
-    gradients).  Inside ``side_wgrads()`` the decoder's (small, latency-bound: ~20 workgroups each) are
-    therefore DEFERRED and issued together on a second HIP stream once the decoder's backward is done
-    (``flush_side_wgrads`` from EmbedFn.backward): one fork / one join in the captured graph, and the ~40
-    launches overlap the encoder's backward instead of sitting on the critical path.  A fork per launch was
-    measured slower than no fork at all (cross-queue dependencies cost more than the launches).  The
-    operands are kept alive until the join."""
+    gradients).  Inside ``deferred_wgrads()`` the decoder-sized ones (~20 workgroups each: pure launch latency
+    one by one, 36 of them per step) are therefore collected and issued as ONE grouped launch
+    (``st_wgrad_group``) once the decoder's backward is done (``flush_deferred_wgrads`` from EmbedFn.backward).
+    Measured on config 2: 36 launches x ~11 us -> one launch of ~30 us.  Moving that launch (or the individual
+    ones) to a second stream inside the captured graph was tried and is slower: a cross-queue dependency costs
+    ~50 us in a HIP graph, and the 8-wave workgroups of the grouped launch evict the encoder's backward from
+    whole CUs.  The operand tensors stay referenced by the list until the launch is enqueued."""
     active = False
-    stream = None
     pending = []
-    keep = []
-    MAX_ROWS = 4096     # only launches that cannot fill the GPU are worth moving
+    MAX_ROWS = 4096     # only launches that cannot fill the GPU are worth deferring
 
 
-def flush_side_wgrads():
-    if not _Side.pending:
-        return
-    _Side.stream.wait_stream(torch.cuda.current_stream())      # every deferred operand is complete on the main stream
-    with torch.cuda.stream(_Side.stream):
-        for X, dY, gW, gB, splits, N in _Side.pending:
-            nv.gemm(X, dY, gW, bias=gB, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=splits, n=N)
-    _Side.keep.extend(_Side.pending)
-    _Side.pending.clear()
+def flush_deferred_wgrads():
+    if _Deferred.pending:
+        nv.wgrad_group(_Deferred.pending)
+        _Deferred.pending.clear()
 
 
-class side_wgrads:
-    """Context manager around loss.backward(): defer + side-stream the small weight-gradient GEMMs; joins on
-    exit (inside a HIP-graph capture this records a fork/join, which is how trainer.TrainStep uses it)."""
+class deferred_wgrads:
+    """Context manager around loss.backward(): batch the small weight-gradient GEMMs into one grouped launch
+    (flushed at the end of the decoder's backward, or on exit)."""
 
     def __init__(self, enable: bool = True):
         self.enable = enable
 
     def __enter__(self):
-        if self.enable:
-            if _Side.stream is None:
-                _Side.stream = torch.cuda.Stream()
-            _Side.active = True
+        _Deferred.active = self.enable
         return self
 
     def __exit__(self, *exc):
-        if self.enable:
-            _Side.active = False
-            flush_side_wgrads()
-            if _Side.keep:
-                torch.cuda.current_stream().wait_stream(_Side.stream)
-                _Side.keep.clear()
+        flush_deferred_wgrads()
+        _Deferred.active = False
         return False
 
 
@@ -209,8 +196,8 @@ def wgrad(dY, X, gW, rows=None, gB=None):
     ``gB``: the same launch also accumulates the bias gradient gB[n] += sum_m dY[m][n]."""
     N = dY.shape[1] if rows is None else rows
     splits = _splits(dY.shape[0], N, X.shape[1])
-    if _Side.active and dY.shape[0] <= _Side.MAX_ROWS:
-        _Side.pending.append((X, dY, gW, gB, splits, N))
+    if _Deferred.active and dY.shape[0] <= _Deferred.MAX_ROWS:
+        _Deferred.pending.append((X, dY, gW, gB, splits, N))      # the argument tuple of nv.wgrad_group
         return
     nv.gemm(X, dY, gW, bias=gB, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=splits, n=N)
 
@@ -398,7 +385,7 @@ class EmbedFn(torch.autograd.Function):
         s, arena = mod._st, mod._st_arena
         arena.attach_grads(s.emb_params, s.emb_lo, s.emb_hi)
         nv.embed_bwd(tokens, dout.contiguous(), ctx.rows.off, ctx.rows.len, s.pad_idx, s.g_emb)
-        flush_side_wgrads()      # the decoder's backward ends here: its deferred weight gradients overlap the encoder's
+        flush_deferred_wgrads()      # the decoder's backward ends here: its deferred weight gradients go out as one launch
         arena.grads_ready(s.emb_lo, s.emb_hi)
         return None, None, None, None
 

@@ -29,6 +29,8 @@ SIGNATURES = {
     "st_version": [],
     "st_gemm": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                 _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
+    "st_wgrad_group": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                       _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                    _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                    _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
@@ -216,6 +218,30 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
                         *(_drop(drop) if epi in (EPI_BF16_RELU, EPI_BF16_MASK) else _drop(None)))
     _check(rc, "st_gemm")
     return out
+
+
+def wgrad_group(problems):
+    """One launch for several weight gradients.  problems: iterable of (X [tokens, K_in] bf16, dY [tokens, N_out]
+    bf16, gW f32 [>= N_out, K_in], gB f32 [N_out] or None, splits, N_out) - the argument tuple of
+    ``functional.wgrad``; each is gW[n][k] += sum_m dY[m][n] X[m][k] (and gB[n] += sum_m dY[m][n])."""
+    problems = list(problems)
+    n = len(problems)
+    if n == 0:
+        return
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    X, dY, dW, dB = PA(), PA(), PA(), PA()
+    ldx, lddy, lddw, tokens, k_in, n_out, splits = IA(), IA(), IA(), IA(), IA(), IA(), IA()
+    for q, (x, dy, gw, gb, sp, rows) in enumerate(problems):
+        _mat(x, BF16, "X"), _mat(dy, BF16, "dY"), _mat(gw, F32, "gW")
+        if x.shape[0] != dy.shape[0] or gw.shape[0] < rows or gw.shape[1] < x.shape[1]:
+            raise ValueError("wgrad_group: problem %d has inconsistent shapes" % q)
+        _vec(gb, F32, rows, "gB")
+        X[q], dY[q], dW[q], dB[q] = x.data_ptr(), dy.data_ptr(), gw.data_ptr(), _p(gb)
+        ldx[q], lddy[q], lddw[q] = x.stride(0), dy.stride(0), gw.stride(0)
+        tokens[q], k_in[q], n_out[q], splits[q] = x.shape[0], x.shape[1], rows, sp
+    _tag("wgrad_group", n, sum(2.0 * pr[0].shape[0] * pr[0].shape[1] * pr[5] for pr in problems))
+    rc = load().st_wgrad_group(_stream(), n, X, ldx, dY, lddy, dW, lddw, dB, tokens, k_in, n_out, splits)
+    _check(rc, "st_wgrad_group")
 
 
 def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None,

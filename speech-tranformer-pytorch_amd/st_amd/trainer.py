@@ -24,7 +24,7 @@ import torch.nn as nn
 from .arena import arena_of
 from .dp import GradReducer
 from . import rng
-from .functional import side_wgrads
+from .functional import deferred_wgrads
 
 
 def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
@@ -50,7 +50,7 @@ class TrainStep:
         self._loss = self._gnorm = None
 
     # ---- the two halves of a step -------------------------------------------------------------
-    def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, side=False):
+    def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, captured=False):
         self.optimizer.zero_grad()
         rng.advance()                          # next step's dropout masks (an in-place device add: capturable)
         if hasattr(self.model, "forward_packed"):
@@ -63,9 +63,10 @@ class TrainStep:
         else:
             logits, _ = self.model(inputs, input_lengths, targets, target_lengths)
             loss = self.crit(logits.contiguous().view(-1, self.vocab_size), ground_truth.contiguous().view(-1))
-        # captured graph: the decoder's weight gradients fork onto a side stream (the eager path keeps one
-        # stream: its gradient-ready hooks assume a weight gradient is enqueued when the layer's backward returns)
-        with side_wgrads(side):
+        # the decoder's weight gradients are deferred into one grouped launch - unless eager gradient-ready hooks
+        # are live (they assume a weight gradient is enqueued when its layer's backward returns)
+        hooks_live = self.reducer is not None and not captured
+        with deferred_wgrads(not hooks_live):
             loss.backward()
         return loss.detach()
 
@@ -112,7 +113,7 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.detach()                       # bucket all-reduces are issued explicitly between the graphs
         with torch.cuda.graph(self._g_fb, pool=pool):
-            self._loss = self._forward_backward(*batch, side=True)
+            self._loss = self._forward_backward(*batch, captured=True)
         with torch.cuda.graph(self._g_opt, pool=pool):
             self._gnorm = self._clip_and_update()
         # capture only records; the step that triggered it is executed by the replay that follows

@@ -99,6 +99,11 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
     return out
 
 
+def wgrad_group(problems):
+    for x, dy, gw, gb, sp, rows in problems:
+        gemm(x, dy, gw, bias=gb, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=sp, n=rows)
+
+
 def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None,
             drop=None, drop_where=0):
     v = X.float() @ W.float().t() + bias
@@ -253,7 +258,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "wgrad_group", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16"]
 
 

@@ -418,3 +418,24 @@ def test_attention_dropout(case):
     # and the masks really are drawn: the dropout-free output differs
     o0 = run(nv.attn_fwd, nv.attn_bwd, "cuda", None)
     assert rel(o[0], o0[0]) > 5e-2
+
+
+def test_wgrad_group_matches_individual_launches():
+    """st_wgrad_group: many weight-gradient problems (different shapes, split counts, with / without a bias
+    gradient, more than one launch's worth) in one call == the same problems launched one by one."""
+    shapes = [(1206, 768, 256, 4, True), (1206, 256, 256, 2, True), (1206, 1024, 256, 4, True),
+              (1206, 256, 1024, 1, False), (333, 128, 80, 3, True), (50, 4344, 256, 1, False)] * 8      # 48 > GROUP_MAX
+    probs, ref = [], []
+    for q, (m, n, k, sp, with_b) in enumerate(shapes):
+        dy, x = cu(g(m, n, seed=10 + q)), cu(g(m, k, seed=60 + q))
+        init, b0 = g(n, k, seed=5, dtype=F32), g(1, n, seed=6, dtype=F32).view(-1)
+        gw, gb = cu(init.clone()), (cu(b0.clone()) if with_b else None)
+        probs.append((x, dy, gw, gb, sp, n))
+        rw, rb = cu(init.clone()), (cu(b0.clone()) if with_b else None)
+        nv.gemm(x, dy, rw, bias=rb, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=sp, n=n)
+        ref.append((rw, rb))
+    nv.wgrad_group(probs)
+    for q, ((_, _, gw, gb, _, _), (rw, rb)) in enumerate(zip(probs, ref)):
+        check(gw, rw, 1e-5, "wgrad_group dW problem %d" % q)       # same kernel body; only the atomic order differs
+        if gb is not None:
+            check(gb, rb, 1e-5, "wgrad_group db problem %d" % q)
