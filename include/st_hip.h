@@ -116,8 +116,8 @@ int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, co
  * probabilities (Attention.py:89); pass the same values to st_attn_bwd. */
 int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
                 int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
-                int H, int d_k, int max_q, int q_rows_total, int causal, float scale, const int* work, int n_work,
-                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+                int H, int d_k, int max_q, int max_k, int q_rows_total, int causal, float scale, const int* work,
+                int n_work, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
 /* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
  * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:

@@ -74,13 +74,13 @@ __device__ __forceinline__ void decode_item(const AttnArgs& a, int& b, int& h, i
 // ---- streamed [64 x DK] tiles ----------------------------------------------------------------------
 // LDS image: natural rows, stride DK + 8 elements (144 B / 80 B): ds_read_b128 row fragments over 16 rows
 // and the 4-row groups of ds_read_b64_tr_b16 are both bank-conflict free (DK = 64).
-template <int DK> struct TileGeo {
-  static constexpr int STR = DK + 8, E = TILE * STR, CPR = DK / 8, CH = DK / 32;   // CH chunks per thread
+template <int DK, int ROWS = TILE> struct TileGeo {
+  static constexpr int STR = DK + 8, E = ROWS * STR, CPR = DK / 8, CH = ROWS * CPR / 256;   // CH chunks per thread
 };
 
-template <int DK>
+template <int DK, int ROWS = TILE>
 struct Stage {
-  using G = TileGeo<DK>;
+  using G = TileGeo<DK, ROWS>;
   bf16x8 v[G::CH];
   // chunk id = tid + p*256 -> tile row id / CPR, 16-byte chunk id % CPR
   static __device__ __forceinline__ void offsets(uint32_t (&off)[G::CH], int ld) {
@@ -90,10 +90,10 @@ struct Stage {
       off[p] = ((uint32_t)(id / G::CPR) * (uint32_t)ld + (id % G::CPR) * 8) * 2u;
     }
   }
-  // rows r0 .. r0+63 of the utterance's column slice `base`; rows >= nvalid read row nvalid-1
+  // rows r0 .. r0+ROWS-1 of the utterance's column slice `base`; rows >= nvalid read row nvalid-1
   __device__ __forceinline__ void load(const uint32_t (&off)[G::CH], const bf16* __restrict__ base, int ld, int r0,
                                        int nvalid) {
-    if (r0 + TILE <= nvalid) {
+    if (r0 + ROWS <= nvalid) {
       const char* tb = reinterpret_cast<const char*>(base + (size_t)r0 * ld);
 #pragma unroll
       for (int p = 0; p < G::CH; ++p) v[p] = *reinterpret_cast<const bf16x8*>(tb + off[p]);
@@ -219,28 +219,33 @@ __device__ __forceinline__ uint32_t keep_mask16(const Drop& dr, int bh, int fixe
   return km;
 }
 
-template <int DK, bool DROP>
+// KS = 2 ("few queries, many keys": the decoder-encoder attention, <= 64 queries against ~1000 keys): the workgroup
+// owns 64 query rows and streams 128-key stages; waves 0,1 take the first 64 keys of a stage, waves 2,3 the second
+// and the two partial softmax states are merged through LDS at the end - half the serial tile chain per workgroup.
+template <int DK, bool DROP, int KS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
-  using G = TileGeo<DK>;
+  using G = TileGeo<DK, TILE * KS>;
   constexpr int NT = DK / 16;   // k-steps of the QK^T contraction
   constexpr int ND = DK / 32;   // 32-wide output column tiles
+  constexpr int ROWS = TILE * KS, QROWS = WG_ROWS / KS;
   __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];   // 2 buffers x (K tile, V tile)
 
   int b, h, tile;
   decode_item(a, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
-  const int q0 = tile * WG_ROWS;
+  const int q0 = tile * QROWS;
   if (q0 >= lq) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
-  const int q = q0 + wave * 32 + (l & 31);
+  const int qw = KS > 1 ? (wave & 1) : wave, kp = KS > 1 ? (wave >> 1) : 0;   // query block, key half
+  const int q = q0 + qw * 32 + (l & 31);
   const bool q_ok = q < lq;
   const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
   const float c2 = a.scale * 1.4426950408889634f;  // scores -> log2 domain
   const Drop dr = make_drop(a.drop);
   const int bh = b * a.H + h;
 
-  const int k_hi = a.causal ? min(lk, q0 + WG_ROWS) : lk;   // keys this workgroup can see
-  const int ntiles = (k_hi + TILE - 1) / TILE;
+  const int k_hi = a.causal ? min(lk, q0 + QROWS) : lk;   // keys this workgroup can see
+  const int ntiles = (k_hi + ROWS - 1) / ROWS;
   const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;
   const bf16* vbase = a.V + (size_t)a.k_off[b] * a.ldv + h * DK;
 
@@ -249,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   for (int t = 0; t < NT; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8);
 
   uint32_t offk[G::CH], offv[G::CH];
-  Stage<DK>::offsets(offk, a.ldk);
-  Stage<DK>::offsets(offv, a.ldv);
-  Stage<DK> sk[2], sv[2];
+  Stage<DK, ROWS>::offsets(offk, a.ldk);
+  Stage<DK, ROWS>::offsets(offv, a.ldv);
+  Stage<DK, ROWS> sk[2], sv[2];
 
   f32x16 o[ND];
 #pragma unroll
@@ -259,17 +264,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   float m = -INFINITY, lsum = 0.f;
 
   auto load = [&](int set, int it) {
-    sk[set].load(offk, kbase, a.ldk, it * TILE, lk);
-    sv[set].load(offv, vbase, a.ldv, it * TILE, lk);
+    sk[set].load(offk, kbase, a.ldk, it * ROWS, lk);
+    sv[set].load(offv, vbase, a.ldv, it * ROWS, lk);
   };
   auto store = [&](int set) {
     sk[set].store(smem + set * 2 * G::E);
     sv[set].store(smem + set * 2 * G::E + G::E);
   };
   auto compute = [&](int buf, int it) {
-    const bf16* ks = smem + buf * 2 * G::E;
+    const bf16* ks = smem + buf * 2 * G::E + kp * TILE * G::STR;   // this wave's 64 keys of the stage
     const bf16* vs = ks + G::E;
-    const int kt = it * TILE;
+    const int kt = it * ROWS + kp * TILE;
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       for (int t = 0; t < NT; ++t) s[kb] = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s[kb]);
     }
     // masks only on tiles that cross a sequence end or the diagonal (wave-uniform test)
-    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + wave * 32);
+    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + qw * 32);
     if (!full) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -339,38 +344,63 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   };
   stream_tiles(ntiles, load, store, compute);
 
-  const float ltot = lsum + wave_xor32(lsum);
+  float ltot = lsum + wave_xor32(lsum);
+  if (KS > 1) {   // merge the two key halves: (m, l, O) of waves 2,3 -> LDS -> waves 0,1
+    float* xch = reinterpret_cast<float*>(smem + 2 * 32 * DK) + qw * (2 + ND * 16) * 64 + l;   // behind the 2 store patches
+    if (kp == 1) {
+      xch[0] = m;
+      xch[64] = ltot;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(2 + d * 16 + r) * 64] = o[d][r];
+    }
+    __syncthreads();
+    if (kp == 1) return;
+    const float m1 = xch[0], l1 = xch[64];
+    const float mn = fmaxf(m, m1);
+    const float a0 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - mn);
+    ltot = ltot * a0 + l1 * a1;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + xch[(2 + d * 16 + r) * 64] * a1;
+    m = mn;
+  }
   const float inv = ltot > 0.f ? (DROP ? dr.scale : 1.f) / ltot : 0.f;
   if (q_ok && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
-  store_rows<DK>(smem + wave * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + wave * 32,
-                 min(32, lq - (q0 + wave * 32)));
+  store_rows<DK>(smem + qw * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32,
+                 min(32, lq - (q0 + qw * 32)));
 }
 
 // ---------------------------------------------------------------------------------------------
 // Backward, part 1: dQ (and delta = rowsum(dO * O)).  Same decomposition as the forward.
 //   P^T = exp2(S^T c2 - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta),  dQ^T += K^T dS^T
 // ---------------------------------------------------------------------------------------------
-template <int DK, bool DROP>
+template <int DK, bool DROP, int KS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-  using G = TileGeo<DK>;
+  using G = TileGeo<DK, TILE * KS>;
   constexpr int NT = DK / 16, ND = DK / 32;
+  constexpr int ROWS = TILE * KS, QROWS = WG_ROWS / KS;   // KS = 2: see attn_fwd_kernel
   __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];
 
   int b, h, tile;
   decode_item(a, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
-  const int q0 = tile * WG_ROWS;
+  const int q0 = tile * QROWS;
   if (q0 >= lq) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
-  const int q = q0 + wave * 32 + (l & 31);
+  const int qw = KS > 1 ? (wave & 1) : wave, kp = KS > 1 ? (wave >> 1) : 0;
+  const int q = q0 + qw * 32 + (l & 31);
   const bool q_ok = q < lq;
   const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
   const float c2 = a.scale * 1.4426950408889634f;
   const Drop dr = make_drop(a.drop);
   const int bh = b * a.H + h;
 
-  const int k_hi = a.causal ? min(lk, q0 + WG_ROWS) : lk;
-  const int ntiles = (k_hi + TILE - 1) / TILE;
+  const int k_hi = a.causal ? min(lk, q0 + QROWS) : lk;
+  const int ntiles = (k_hi + ROWS - 1) / ROWS;
   const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;
   const bf16* vbase = a.V + (size_t)a.k_off[b] * a.ldv + h * DK;
 
@@ -387,30 +417,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   }
   dl += wave_xor32(dl);
   const float lse = a.lse[(size_t)h * a.q_rows_total + qrow];
-  if (q_ok && hi == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
+  if (q_ok && hi == 0 && kp == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
 
   uint32_t offk[G::CH], offv[G::CH];
-  Stage<DK>::offsets(offk, a.ldk);
-  Stage<DK>::offsets(offv, a.ldv);
-  Stage<DK> sk[2], sv[2];
+  Stage<DK, ROWS>::offsets(offk, a.ldk);
+  Stage<DK, ROWS>::offsets(offv, a.ldv);
+  Stage<DK, ROWS> sk[2], sv[2];
 
   f32x16 dq[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) dq[d] = zero16();
 
   auto load = [&](int set, int it) {
-    sk[set].load(offk, kbase, a.ldk, it * TILE, lk);
-    sv[set].load(offv, vbase, a.ldv, it * TILE, lk);
+    sk[set].load(offk, kbase, a.ldk, it * ROWS, lk);
+    sv[set].load(offv, vbase, a.ldv, it * ROWS, lk);
   };
   auto store = [&](int set) {
     sk[set].store(smem + set * 2 * G::E);
     sv[set].store(smem + set * 2 * G::E + G::E);
   };
   auto compute = [&](int buf, int it) {
-    const bf16* ks = smem + buf * 2 * G::E;
+    const bf16* ks = smem + buf * 2 * G::E + kp * TILE * G::STR;
     const bf16* vs = ks + G::E;
-    const int kt = it * TILE;
-    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + wave * 32);   // no masks needed
+    const int kt = it * ROWS + kp * TILE;
+    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + qw * 32);   // no masks needed
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s = zero16(), dp = zero16();
@@ -445,8 +475,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
   };
   stream_tiles(ntiles, load, store, compute);
-  store_rows<DK>(smem + wave * 32 * DK, dq, a.scale, a.dQ + (size_t)a.q_off[b] * a.lddq + h * DK, a.lddq,
-                 q0 + wave * 32, min(32, lq - (q0 + wave * 32)));
+  if (KS > 1) {   // dQ of the two key halves: waves 2,3 -> LDS -> waves 0,1
+    float* xch = reinterpret_cast<float*>(smem + 2 * 32 * DK) + qw * (ND * 16) * 64 + l;
+    if (kp == 1) {
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 64] = dq[d][r];
+    }
+    __syncthreads();
+    if (kp == 1) return;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[d][r] += xch[(d * 16 + r) * 64];
+  }
+  store_rows<DK>(smem + qw * 32 * DK, dq, a.scale, a.dQ + (size_t)a.q_off[b] * a.lddq + h * DK, a.lddq,
+                 q0 + qw * 32, min(32, lq - (q0 + qw * 32)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -594,6 +639,9 @@ bool set_drop(AttnArgs& a, const unsigned* seed, unsigned salt, int thresh, floa
   return on;
 }
 
+// few queries against many keys (decoder-encoder attention): split the keys over the wave pairs
+bool key_split(int max_q, int max_k, int causal) { return !causal && max_q <= 64 && max_k >= 256; }
+
 // grid size and enumeration mode for one family of workgroups
 int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
   a.work = work;
@@ -606,7 +654,7 @@ int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
 
 extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                            void* O, int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off,
-                           const int* k_len, int B, int H, int d_k, int max_q, int q_rows_total, int causal,
+                           const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
                            float scale, const int* work, int n_work, const unsigned* drop_seed, unsigned drop_salt,
                            int drop_thresh, float drop_scale) {
   if (B <= 0 || H <= 0 || max_q <= 0 || (work && n_work <= 0)) return 0;
@@ -620,10 +668,15 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
-  if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 0, stream, a);
-  else if (d_k == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, stream, a);
-  else if (!drop) hipLaunchKernelGGL((attn_fwd_kernel<32, false>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, stream, a);
+  const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
+#define ST_FWD(DKK, DR) \
+  do { if (ks2) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a); \
+       else hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a); } while (0)
+  if (d_k == 64 && !drop) ST_FWD(64, false);
+  else if (d_k == 64) ST_FWD(64, true);
+  else if (!drop) ST_FWD(32, false);
+  else ST_FWD(32, true);
+#undef ST_FWD
   ST_CHECK_LAUNCH();
   return 0;
 }
@@ -650,10 +703,15 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   dim3 block(256);
   if ((parts & 1) && !(work_q && n_work_q <= 0)) {
     dim3 gq(plan(a, work_q, n_work_q, B, H, max_q));
-    if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, block, 0, stream, a);
-    else if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 0, stream, a);
-    else if (!drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<32, false>), gq, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<32, true>), gq, block, 0, stream, a);
+    const bool ks2 = key_split(max_q, max_k, causal);
+#define ST_DQ(DKK, DR) \
+  do { if (ks2) hipLaunchKernelGGL((attn_bwd_dq_kernel<DKK, DR, 2>), gq, block, 0, stream, a); \
+       else hipLaunchKernelGGL((attn_bwd_dq_kernel<DKK, DR, 1>), gq, block, 0, stream, a); } while (0)
+    if (d_k == 64 && !drop) ST_DQ(64, false);
+    else if (d_k == 64) ST_DQ(64, true);
+    else if (!drop) ST_DQ(32, false);
+    else ST_DQ(32, true);
+#undef ST_DQ
   }
   if ((parts & 2) && !(work_k && n_work_k <= 0)) {
     dim3 gk(plan(a, work_k, n_work_k, B, H, max_k));

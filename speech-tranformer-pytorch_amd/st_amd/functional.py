@@ -236,7 +236,7 @@ class MhaFn(torch.autograd.Function):
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         scale = 1.0 / math.sqrt(d // H)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
-                    scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop)
+                    scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop, max_k=k_rows.max_len)
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)

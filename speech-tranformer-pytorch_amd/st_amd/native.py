@@ -37,7 +37,7 @@ SIGNATURES = {
     "st_ln_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                   _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_float],
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
-                    _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                    _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -300,7 +300,10 @@ def _work(w):
     return w.data_ptr(), w.numel()
 
 
-def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None):
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None,
+             max_k=0):
+    """max_k (longest key sequence) only selects the kernel variant: <= 64 queries against >= 256 keys take
+    the key-split path."""
     """work: optional int32 device list of (b << 16) | q_tile, heaviest first (functional.attn_work)."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
         _mat(t, BF16, nm)
@@ -313,7 +316,7 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     _tag("attn_fwd", n_head, d_k, int(causal), q_len, k_len)
     rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
-                            k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), rows, int(causal),
+                            k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), rows, int(causal),
                             float(scale), *_work(work), *_drop(drop))
     _check(rc, "st_attn_fwd")
     return O

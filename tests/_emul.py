@@ -164,7 +164,8 @@ def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h):
     return q, k, v, s, slice(qo, qo + ql), slice(ko, ko + kl), cs
 
 
-def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None):
+def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None,
+             max_k=0):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):

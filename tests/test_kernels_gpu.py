@@ -209,6 +209,8 @@ ATTN_CASES = [
     (2, 4, 64, [50, 33], [1000, 517], False, True),
     (3, 4, 32, [10, 5, 8], [60, 31, 45], False, True),
     (2, 4, 64, None, [1000, 640], False, True),
+    (3, 4, 64, [64, 1, 40], [700, 256, 65], False, True),      # <= 64 queries, >= 256 keys: key-split kernels
+    (2, 4, 32, [20, 33], [300, 129], False, False),
 ]
 
 
@@ -222,7 +224,7 @@ def test_attention_fwd_bwd(case):
         meta = [mv(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
         O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
         lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device=dev)
-        fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], c["causal"], c["scale"])
+        fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], c["causal"], c["scale"], max_k=c["max_k"])
         delta = torch.zeros_like(lse)
         dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
         dK, dV = (torch.zeros(c["Mk"], c["d"], dtype=BF16, device=dev) for _ in range(2))
@@ -252,7 +254,8 @@ def test_attention_work_lists_match_plain_enumeration():
             meta = [cu(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
             O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
             lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device="cuda")
-            nv.attn_fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], causal, c["scale"], work=wq if use else None)
+            nv.attn_fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], causal, c["scale"], work=wq if use else None,
+                        max_k=c["max_k"])
             delta = torch.zeros_like(lse)
             dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
             dK, dV = (torch.zeros(c["Mk"], c["d"], dtype=BF16, device="cuda") for _ in range(2))
@@ -403,7 +406,7 @@ def test_attention_dropout(case):
         meta = [mv(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
         O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
         lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device=dev)
-        fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], c["causal"], c["scale"], drop=d)
+        fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], c["causal"], c["scale"], drop=d, max_k=c["max_k"])
         delta = torch.zeros_like(lse)
         dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device=dev)
         dK, dV = (torch.zeros(c["Mk"], c["d"], dtype=BF16, device=dev) for _ in range(2))

@@ -117,7 +117,7 @@ if "attn" in which:
         dK, dV = torch.empty(mk, d, dtype=BF16, device=dev), torch.empty(mk, d, dtype=BF16, device=dev)
         pairs = float((q_len.double() * k_len.double()).sum()) * (0.5 if causal else 1.0)
         fl = 4.0 * pairs * d
-        us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale, work=wq))
+        us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale, work=wq, max_k=maxk))
         report("attn fwd  " + name, us, fl)
         for part, nm in ((1, "dq "), (2, "dkv")):
             us = timeit(lambda: nv.attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, H, maxq,
