@@ -7,3 +7,4 @@ The product path (``speech-tranformer-pytorch_amd/``) never imports this
 package and fails loudly when its HIP library is missing.
 """
 from .speech_transformer_oracle import *  # noqa: F401,F403
+from . import beam_oracle  # noqa: F401  (beam-search decode restatement; parity unpinned - see its header)

@@ -97,3 +97,12 @@ def test_loss_heads_on_gpu(golden_dir):
     tgt = torch.randint(1, 12, (3, 6), generator=g).cuda()
     total, att, ctc = head(enc, torch.tensor([40, 33, 21]), dec, tgt, torch.tensor([6, 4, 5]), tgt)
     assert torch.isfinite(total)
+
+
+def test_beam_search_decode_gpu():
+    """transformer/Decode.py with the real kernels (KV cache, shared encoder keys, key-split attention) against
+    the oracle restatement of Beam.py / Decode.py - both the run-to-the-limit and the early-finisher case."""
+    from tests import test_decode_cpu as dc
+    assert dc.run_decode("cuda", 0.0, 12) == {12}
+    lengths = dc.run_decode("cuda", 3.0, 16)
+    assert len(lengths) > 1 or min(lengths) < 16
