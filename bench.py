@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
     ap.add_argument("--no-train-mode", action="store_true", help="skip the extra (untimed-region) training-mode pass")
+    ap.add_argument("--no-decode", action="store_true", help="skip the extra beam-search decode measurement")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
                                                             "the captured HIP graph of the step")
     args = ap.parse_args()
@@ -255,6 +256,25 @@ def main():
                               "x2 per layer) and 0.5 (front-end); same step otherwise"}
         model.eval()
 
+    # ---- beam-search decode (BASELINE config 5: beam 10, same model and batch; N = 1 only, outside the timed
+    # region): utterances/s and ms per decoder step with the KV cache.  Random weights never emit EOS, so every
+    # utterance runs the full step budget - stated in the note.
+    decode = None
+    if world == 1 and not args.no_decode:
+        from transformer.Decode import Decode
+        dsteps = 50
+        dec = Decode(U.AttrDict(beam_size=10, n_best=1, max_steps=dsteps), "cuda", model=model)
+        dec.decode_batch((xg[:4], in_len[:4]))                         # warm-up (layouts, allocator)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        hyps, _ = dec.decode_batch((xg, in_len))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t2
+        decode = {"utterances_per_s": round(BATCH / dt, 1), "ms_per_step": round(dt / dsteps * 1e3, 3),
+                  "frames_per_s": round(float(in_len.sum()) / dt, 1),
+                  "note": "transformer/Decode.py, beam 10, B = %d, %d decoder steps (random weights never emit "
+                          "EOS), KV cache, eager launches; includes the encoder pass" % (BATCH, len(hyps[0][0]))}
+
     out = None
     if rank == 0:
         flops = step_flops(in_len, tgt_len, C2)
@@ -277,6 +297,8 @@ def main():
         }
         if train_mode is not None:
             out["train_mode"] = train_mode
+        if decode is not None:
+            out["decode"] = decode
 
     # ---- CPU baseline: the oracle restatement on this box's host cores (rank 0, N = 1 only) -------
     # Runs in a child process with a hard timeout so that a slow / oversubscribed host can never

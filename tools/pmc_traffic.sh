@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 R=${1:-r01}
 cd /root/repo
-CMD="python bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-train-mode"
+CMD="python bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-train-mode --no-decode"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_${R}_fetch -o p -- $CMD > gpurun_out/pmc_${R}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_${R}_write -o p -- $CMD > gpurun_out/pmc_${R}_write.log 2>&1
 python tools/summarize_pmc.py gpurun_out/pmc_${R}_fetch/p_results.db gpurun_out/pmc_${R}_write/p_results.db gpurun_out/pmc_${R}_traffic
