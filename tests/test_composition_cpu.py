@@ -244,3 +244,44 @@ def run_encoder_padded_api(golden_dir, device):
 def test_encoder_padded_api_composition(golden_dir):
     with emulated_kernels():
         run_encoder_padded_api(golden_dir, "cpu")
+
+
+def run_wide_step(device, d_model=512, n_head=8, d_ff=1024, n_enc=2, n_dec=1):
+    """The BASELINE config 3 layer shape (d_model 512, 8 heads, d_k 64) on a small batch: loss, logits and every
+    gradient against the fp64 oracle.  Exercises the N = 512 LayerNorm-GEMM geometry and 8-head attention."""
+    import transformer.Models as M
+    import transformer.Utils as U
+    p = orc.xavier_init_(orc.make_params(80, 30, d_model, d_ff, n_enc, n_dec, 100, 20, dtype=torch.float64), seed=3)
+    batch = orc.synthetic_batch(3, 70, 9, 80, 30, seed=4, t_min=30, l_min=4)
+    truth = orc.train_step(p, {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}, n_head,
+                           d_model, 100, 1, 5.0)
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=20, num_enc_layer=n_enc,
+                          num_dec_layer=n_dec, n_heads=n_head, d_k=d_model // n_head, d_v=d_model // n_head,
+                          d_model=d_model, d_inner_hid=d_ff, dropout=0.0, vocab_size=30))
+    m = M.Transformer(cfg)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    m = m.eval().to(device)
+    L = int(batch["tgt_len"].max())
+    logits, _ = m(batch["x"].to(device), batch["in_len"], batch["tokens"][:, :L].to(device), batch["tgt_len"])
+    loss = torch.nn.CrossEntropyLoss(ignore_index=0)(logits.contiguous().view(-1, 30), batch["gt"][:, :L].reshape(-1).to(device))
+    loss.backward()
+    valid = (torch.arange(L).view(1, -1) < batch["tgt_len"].view(-1, 1))
+    assert rel(logits.detach().cpu()[valid], truth["logits"][valid]) < 2e-2
+    assert abs(loss.item() - truth["loss"].item()) < 2e-2 * truth["loss"].item()
+    rels, flat_g, flat_t = [], [], []
+    for n, q in m.named_parameters():
+        g, t = q.grad.detach().cpu(), truth["grads"][n]
+        assert torch.isfinite(g).all(), n
+        if "linear_k.bias" in n:
+            continue
+        rels.append(rel(g, t))
+        flat_g.append(g.double().reshape(-1))
+        flat_t.append(t.double().reshape(-1))
+    assert max(rels) < GRAD_TOL_TENSOR, max(rels)
+    assert sorted(rels)[len(rels) // 2] < GRAD_TOL_MEDIAN
+    assert rel(torch.cat(flat_g), torch.cat(flat_t)) < GRAD_TOL_GLOBAL
+
+
+def test_wide_step_composition():
+    with emulated_kernels():
+        run_wide_step("cpu")

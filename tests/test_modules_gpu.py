@@ -106,3 +106,8 @@ def test_beam_search_decode_gpu():
     assert dc.run_decode("cuda", 0.0, 12) == {12}
     lengths = dc.run_decode("cuda", 3.0, 16)
     assert len(lengths) > 1 or min(lengths) < 16
+
+
+def test_config3_layer_shape_step_gpu():
+    """d_model 512, 8 heads (BASELINE config 3's layer shape): full step against the fp64 oracle."""
+    comp.run_wide_step("cuda")
