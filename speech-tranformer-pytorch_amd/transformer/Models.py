@@ -158,7 +158,16 @@ class Transformer(nn.Module):
         return bundle(v_pad=v_pad, vocab_params=[w], vocab_lo=lo, vocab_hi=hi,
                       w_vocab=a.bf16(w, v_pad), g_w_vocab=a.grad_view(w, v_pad))
 
-    def forward_packed(self, inputs, inputs_pos, targets, targets_pos):
+    def forward_joint(self, inputs, inputs_pos, targets, targets_pos):
+        """For the joint CTC + attention objective (BASELINE config 4; transformer/Loss.py:CTCAttentionLoss):
+        -> (seq_logit [B, L, V], enc_output [B, T, d] fp32, zero past each length).  Both are differentiable;
+        the encoder receives the sum of the decoder's and the CTC branch's gradients through autograd."""
+        B, L = targets.shape
+        logits, t_rows, enc, in_rows = self.forward_packed(inputs, inputs_pos, targets, targets_pos, want_enc=True)
+        padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, t_rows.scatter_index(L), logits)
+        return padded.view(B, L, -1), F_.UnpackFn.apply(enc, in_rows, int(in_rows.max_len))
+
+    def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False):
         """The same computation with the logits left in the ragged layout the kernels produce:
         -> (logits [sum(targets_pos), V] fp32 (a column slice of a [*, v_pad] buffer), Rows of the target side).
         ``Rows.scatter_index(L)`` maps row r to its position b*L + t in the padded layout; trainer.TrainStep uses
@@ -178,6 +187,8 @@ class Transformer(nn.Module):
             enc, _ = self.encoder.forward_rows(inputs, inputs_pos, in_rows)
             dec, _ = self.decoder.forward_rows(targets, targets_pos, enc, in_rows, t_rows)
             logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self)       # [sum(tgt_len), v_pad]
+        if want_enc:
+            return logits[:, :self.vocab_size], t_rows, enc, in_rows
         return logits[:, :self.vocab_size], t_rows
 
     def forward(self, inputs, inputs_pos, targets=None, targets_pos=None):

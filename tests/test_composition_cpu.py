@@ -285,3 +285,63 @@ def run_wide_step(device, d_model=512, n_head=8, d_ff=1024, n_enc=2, n_dec=1):
 def test_wide_step_composition():
     with emulated_kernels():
         run_wide_step("cpu")
+
+
+def run_joint_ctc_step(device):
+    """BASELINE config 4: joint lambda * CTC + (1 - lambda) * attention loss (transformer/Loss.py:CTCAttentionLoss
+    on Transformer.forward_joint).  The encoder gets gradient from BOTH branches; everything is compared with the
+    same objective evaluated on the fp64 oracle's encoder / decoder."""
+    import torch.nn.functional as func
+    import transformer.Models as M
+    import transformer.Utils as U
+    from transformer.Loss import CTCAttentionLoss
+    d_model, n_head = 128, 4
+    p = orc.xavier_init_(orc.make_params(80, 30, d_model, 256, 2, 2, 100, 20, dtype=torch.float64), seed=5)
+    batch = orc.synthetic_batch(3, 70, 9, 80, 30, seed=6, t_min=40, l_min=4)
+    x, in_len, tokens, tgt_len, gt = (batch[k] for k in ("x", "in_len", "tokens", "tgt_len", "gt"))
+    L = int(tgt_len.max())
+    tokens, gt = tokens[:, :L], gt[:, :L]
+    head = CTCAttentionLoss(d_model, 30, ctc_weight=0.3)
+    # ---- fp64 truth
+    leaves = {k: (v.clone().requires_grad_(True) if not k.endswith(".pe") else v) for k, v in p.items()}
+    w64 = head.ctc_proj.weight.detach().double().clone().requires_grad_(True)
+    b64 = head.ctc_proj.bias.detach().double().clone().requires_grad_(True)
+    enc, _ = orc.encoder(leaves, x.double(), in_len, n_head)
+    dec, _, _ = orc.decoder(leaves, tokens, tgt_len, in_len, enc, n_head)
+    logits = func.linear(dec, leaves["tgt_word_proj.weight"])
+    att = orc.cross_entropy(logits, gt)
+    logp = func.log_softmax(func.linear(enc, w64, b64), -1).transpose(0, 1)
+    ctc = func.ctc_loss(logp, gt, in_len, tgt_len, blank=0, reduction="mean", zero_infinity=True)
+    truth = 0.3 * ctc + 0.7 * att
+    names = [k for k in leaves if not k.endswith(".pe")]
+    all_g = torch.autograd.grad(truth, [leaves[k] for k in names] + [w64, b64], allow_unused=True)
+    tg = dict(zip(names, all_g))
+    g_w64, g_b64 = all_g[-2], all_g[-1]
+    # ---- product
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=20, num_enc_layer=2,
+                          num_dec_layer=2, n_heads=n_head, d_k=32, d_v=32, d_model=d_model, d_inner_hid=256,
+                          dropout=0.0, vocab_size=30))
+    m = M.Transformer(cfg)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    m, head = m.eval().to(device), head.to(device)
+    logits_h, enc_h = m.forward_joint(x.to(device), in_len, tokens.to(device), tgt_len)
+    assert enc_h.shape == (3, int(in_len.max()), d_model) and logits_h.shape == (3, L, 30)
+    loss, att_h, ctc_h = head(enc_h, in_len, logits_h, gt.to(device), tgt_len, gt.to(device))
+    loss.backward()
+    assert abs(loss.item() - truth.item()) < 2e-2 * abs(truth.item()), (loss.item(), truth.item())
+    assert abs(ctc_h.item() - ctc.item()) < 2e-2 * abs(ctc.item())
+    rels = []
+    for n, q in m.named_parameters():
+        if "linear_k.bias" in n or tg[n] is None:
+            continue
+        assert q.grad is not None and torch.isfinite(q.grad).all(), n
+        rels.append((rel(q.grad.detach().cpu(), tg[n]), n))
+    assert max(rels)[0] < GRAD_TOL_TENSOR, max(rels)
+    assert sorted(rels)[len(rels) // 2][0] < GRAD_TOL_MEDIAN
+    assert rel(head.ctc_proj.weight.grad.cpu(), g_w64) < GRAD_TOL_MEDIAN       # the CTC head sees the bf16 encoder output
+    assert rel(head.ctc_proj.bias.grad.cpu(), g_b64) < GRAD_TOL_MEDIAN
+
+
+def test_joint_ctc_step_composition():
+    with emulated_kernels():
+        run_joint_ctc_step("cpu")

@@ -111,3 +111,8 @@ def test_beam_search_decode_gpu():
 def test_config3_layer_shape_step_gpu():
     """d_model 512, 8 heads (BASELINE config 3's layer shape): full step against the fp64 oracle."""
     comp.run_wide_step("cuda")
+
+
+def test_joint_ctc_attention_step_gpu():
+    """BASELINE config 4 objective: CTC head on the HIP encoder output + attention CE, gradients vs the fp64 oracle."""
+    comp.run_joint_ctc_step("cuda")
