@@ -140,6 +140,14 @@ int st_row_index(st_stream_t stream, const int* off, const int* len, int B, int 
 
 /* Padded fp32 features [B,T,F] -> bf16 row matrix (train.py:33, Models.py:42). */
 int st_pack_rows(st_stream_t stream, const float* x, int B, int T, int F, const int* off, const int* len, void* out);
+/* Feature front-end fused with the ragged pack (reference Dataset.py: cmvn :89-92, concat_frame :121-143,
+ * subsampling :145-153): raw padded fp32 features x [B,T,F] (in_len[b] valid frames) -> bf16 row matrix
+ * out [sum(out_len), ld >= F*(1+left+right)]; output row r of utterance b is frame r*interval with its left /
+ * right context blocks exactly where the reference writes them (right blocks indexed with the RIGHT width,
+ * :139-141; right <= left).  stats: per-utterance Kaldi CMVN statistics f32 [B, 2, F+1] or NULL. */
+int st_feat_stack(st_stream_t stream, const float* x, int B, int T, int F, const int* in_len, const float* stats,
+                  int left, int right, int interval, const int* out_off, const int* out_len, int max_out_len,
+                  void* out, int ld);
 /* bf16 row matrix -> padded fp32 [B,T,D], zero past len[b] (Encoder/Decoder return value). */
 int st_unpack_rows(st_stream_t stream, const void* x, int ld, int B, int T, int D, const int* off, const int* len,
                    float* out);

@@ -7,4 +7,5 @@ The product path (``speech-tranformer-pytorch_amd/``) never imports this
 package and fails loudly when its HIP library is missing.
 """
 from .speech_transformer_oracle import *  # noqa: F401,F403
+from . import feature_oracle  # noqa: F401  (CMVN / frame stacking / subsampling, Dataset.py)
 from . import beam_oracle  # noqa: F401  (beam-search decode restatement; parity unpinned - see its header)

@@ -186,6 +186,45 @@ __global__ void pack_grad_kernel(const float* __restrict__ g, int T, int D, cons
   }
 }
 
+// Feature front-end (reference Dataset.py: cmvn :89-92, concat_frame :121-143, subsampling :145-153) fused with
+// the ragged pack: raw padded fp32 features [B, T, F] -> bf16 row matrix [sum(out_len), F*(1+left+right)] in the
+// layout the encoder front-end GEMM consumes.  Output row r of utterance b is frame t = r * interval; block k of the
+// row follows the reference's write order (middle, then left contexts, then right contexts - the right blocks are
+// indexed with the RIGHT width as in Dataset.py:139-141; later writes win).  stats: per-utterance Kaldi CMVN
+// statistics [B, 2, F+1] (sums | count, sums of squares) or null.  One workgroup per output row.
+__global__ void feat_stack_kernel(const float* __restrict__ x, int T, int F, const int* __restrict__ in_len,
+                                  const float* __restrict__ stats, int left, int right, int interval,
+                                  const int* __restrict__ out_off, const int* __restrict__ out_len,
+                                  bf16* __restrict__ out, int ld) {
+  const int b = blockIdx.z, r = blockIdx.y;
+  if (r >= out_len[b]) return;
+  const int len = in_len[b], t = r * interval;
+  const int blocks = 1 + left + right;
+  const float* xb = x + (size_t)b * T * F;
+  const float* st = stats ? stats + (size_t)b * 2 * (F + 1) : nullptr;
+  const float cnt = st ? st[F] : 1.f;
+  bf16* dst = out + (size_t)(out_off[b] + r) * ld;
+  for (int c = threadIdx.x; c < blocks * F; c += blockDim.x) {
+    const int k = c / F, f = c - k * F;
+    int src = -1;                                   // frame feeding this element (-1: stays zero)
+    if (k == left) src = t;
+    for (int i = 0; i < left; ++i)
+      if (k == left - i - 1 && t >= i + 1) src = t - i - 1;
+    for (int i = 0; i < right; ++i)
+      if (k == right + i + 1 && t + i + 1 < len) src = t + i + 1;
+    float v = 0.f;
+    if (src >= 0) {
+      v = xb[(size_t)src * F + f];
+      if (st) {
+        const float mean = st[f] / cnt;
+        const float var = st[F + 1 + f] / cnt - mean * mean;
+        v = (v - mean) / sqrtf(var);
+      }
+    }
+    dst[c] = (bf16)v;
+  }
+}
+
 // Decoder input: out[off[b]+t] = E[tok[b,t]] + PE[t]   (Models.py:84 + repair R3; Embedding.py:26)
 __global__ void embed_pe_fwd_kernel(const long long* __restrict__ tok, int L, const float* __restrict__ emb,
                                     const float* __restrict__ pe, int D, const int* off, const int* len,
@@ -299,6 +338,17 @@ extern "C" int st_pack_rows(hipStream_t stream, const float* x, int B, int T, in
   if (B <= 0 || T <= 0) return 0;
   if (F & 3) return -1;
   hipLaunchKernelGGL(pack_rows_kernel, dim3(1, T, B), dim3(64), 0, stream, x, T, F, off, len, (bf16*)out);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_feat_stack(hipStream_t stream, const float* x, int B, int T, int F, const int* in_len,
+                             const float* stats, int left, int right, int interval, const int* out_off,
+                             const int* out_len, int max_out_len, void* out, int ld) {
+  if (B <= 0 || T <= 0 || max_out_len <= 0) return 0;
+  if (left < 0 || right < 0 || right > left || interval < 1 || ld < F * (1 + left + right)) return -1;
+  hipLaunchKernelGGL(feat_stack_kernel, dim3(1, max_out_len, B), dim3(128), 0, stream, x, T, F, in_len, stats, left,
+                     right, interval, out_off, out_len, (bf16*)out, ld);
   ST_CHECK_LAUNCH();
   return 0;
 }

@@ -46,6 +46,8 @@ SIGNATURES = {
     "st_colsum": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "st_feat_stack": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                      _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int],
     "st_unpack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_pack_grad": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int],
     "st_embed_pe_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
@@ -344,6 +346,24 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
                             int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),
                             *_work(work_k), *_drop(drop))
     _check(rc, "st_attn_bwd")
+
+
+def feat_stack(x, in_len, stats, left, right, interval, out_off, out_len, max_out_len, out):
+    """Raw padded features x fp32 [B, T, F] -> stacked / subsampled / normalised bf16 rows (Dataset.py front-end)."""
+    if not (x.is_cuda and x.dtype == F32 and x.is_contiguous() and x.dim() == 3):
+        raise ValueError("feat_stack: x must be a contiguous fp32 [B, T, F] tensor on the GPU")
+    B, T, F = x.shape
+    _vec(in_len, I32, B, "in_len"), _vec(out_off, I32, B, "out_off"), _vec(out_len, I32, B, "out_len")
+    _mat(out, BF16, "out")
+    if stats is not None and not (stats.is_cuda and stats.dtype == F32 and stats.is_contiguous()
+                                  and tuple(stats.shape) == (B, 2, F + 1)):
+        raise ValueError("feat_stack: stats must be fp32 [B, 2, F+1] on the GPU")
+    _tag("feat_stack", B, T, F)
+    rc = load().st_feat_stack(_stream(), x.data_ptr(), B, T, F, in_len.data_ptr(), _p(stats), int(left), int(right),
+                              int(interval), out_off.data_ptr(), out_len.data_ptr(), int(max_out_len), out.data_ptr(),
+                              out.stride(0))
+    _check(rc, "st_feat_stack")
+    return out
 
 
 def colsum(x, out):

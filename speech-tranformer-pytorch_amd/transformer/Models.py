@@ -52,16 +52,24 @@ class Encoder(nn.Module):
                       beta_in=a.master(ln.bias), g_w_in=a.grad_view(lin.weight), g_b_in=a.grad_view(lin.bias),
                       g_gamma_in=a.grad_view(ln.weight), g_beta_in=a.grad_view(ln.bias))
 
-    def forward_rows(self, inputs, inputs_length, rows=None):
-        """inputs [B, T, F] fp32 (zero past each length) -> (packed bf16 [sum(len), d], Rows)."""
-        _check_lengths(inputs_length, min(self.n_max_seq, inputs.shape[1]), "Encoder")
+    def forward_rows(self, inputs, inputs_length, rows=None, packed=None):
+        """inputs [B, T, F] fp32 (zero past each length) -> (packed bf16 [sum(len), d], Rows).
+        ``packed = (row_matrix bf16 [sum(len), F], Rows)``: features already in the ragged layout
+        (st_amd.features.stack_frames) - ``inputs`` / ``inputs_length`` are then ignored."""
         arena = arena_of(self)
         with arena.scope():
-            if rows is None:
-                rows = F_.Rows.packed(inputs_length, inputs.device)
+            if packed is not None:
+                xp, rows = packed
+                if rows.max_len > self.n_max_seq:
+                    raise ValueError("Encoder: utterance of %d frames exceeds max_inputs_length %d" % (rows.max_len, self.n_max_seq))
+            else:
+                _check_lengths(inputs_length, min(self.n_max_seq, inputs.shape[1]), "Encoder")
+                if rows is None:
+                    rows = F_.Rows.packed(inputs_length, inputs.device)
             rows.pos                                      # position table built before the first launch
-            xp = F_.PackFn.apply(inputs.float(), rows)
-            drop = rng.site(inputs.device, self.input_proj[2].p) if self.training else None   # Models.py:31: p = 0.5
+            if packed is None:
+                xp = F_.PackFn.apply(inputs.float(), rows)
+            drop = rng.site(xp.device, self.input_proj[2].p) if self.training else None   # Models.py:31: p = 0.5
             e = F_.FrontendFn.apply(xp, self.input_proj[0].weight, self, rows, drop)
             for layer in self.layer_stack:
                 e = layer.forward_rows(e, rows)

@@ -202,6 +202,28 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
             dV[ks, cs] = (pv.to(BF16).float().t() @ do).to(BF16)
 
 
+def feat_stack(x, in_len, stats, left, right, interval, out_off, out_len, max_out_len, out):
+    B, T, F = x.shape
+    for b in range(B):
+        n = int(in_len[b])
+        v = x[b, :n].double()
+        if stats is not None:
+            st = stats[b].double()
+            mean = st[0, :-1] / st[0, -1]
+            v = (v - mean) / torch.sqrt(st[1, :-1] / st[0, -1] - mean * mean)
+        v = v.float()
+        stk = torch.zeros(n, F * (1 + left + right))
+        stk[:, left * F:(left + 1) * F] = v
+        for i in range(left):
+            stk[i + 1:n, (left - i - 1) * F:(left - i) * F] = v[0:n - i - 1]
+        for i in range(right):
+            stk[0:n - i - 1, (right + i + 1) * F:(right + i + 2) * F] = v[i + 1:n]
+        sub = stk[::interval]
+        o = int(out_off[b])
+        out[o:o + sub.shape[0], :sub.shape[1]] = sub.to(BF16)
+    return out
+
+
 def colsum(x, out):
     out += x.float().sum(0)
     return out
@@ -259,7 +281,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "wgrad_group", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "wgrad_group", "feat_stack", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16"]
 
 

@@ -442,3 +442,9 @@ def test_wgrad_group_matches_individual_launches():
         check(gw, rw, 1e-5, "wgrad_group dW problem %d" % q)       # same kernel body; only the atomic order differs
         if gb is not None:
             check(gb, rb, 1e-5, "wgrad_group db problem %d" % q)
+
+
+def test_feat_stack_kernel():
+    """st_feat_stack (CMVN + frame stacking + subsampling + ragged pack) against the oracle restatement of Dataset.py."""
+    from tests import test_features_cpu as tf
+    tf.run_stack_frames("cuda")
