@@ -48,6 +48,31 @@ class Beam(object):
             self.all_scores.append(self.scores)
         return self.done
 
+    @staticmethod
+    def advance_batch(beams, word_lk):
+        """``advance`` for several beams that are at the same step, with ONE top-k launch and ONE host read (the
+        per-beam version costs a launch chain and a sync each).  word_lk: [len(beams), beam, num_words].
+        Returns the list of ``done`` flags; every beam ends up exactly as after ``beams[i].advance(word_lk[i])``."""
+        n, size, num_words = word_lk.shape
+        if len(beams[0].prev_ks) > 0:
+            scores = torch.stack([b.scores for b in beams])
+            beam_lk = (word_lk + scores.unsqueeze(2)).reshape(n, -1)
+        else:
+            beam_lk = word_lk[:, 0]
+        best_scores, best_ids = beam_lk.topk(size, 1, True, True)
+        prev_k = best_ids // num_words
+        next_y = best_ids - prev_k * num_words
+        done = (next_y[:, 0] == Constants.EOS).tolist()                           # the one synchronisation
+        for i, b in enumerate(beams):
+            b.all_scores.append(b.scores)
+            b.scores = best_scores[i]
+            b.prev_ks.append(prev_k[i])
+            b.next_ys.append(next_y[i])
+            if done[i]:
+                b.done = True
+                b.all_scores.append(b.scores)
+        return [b.done for b in beams]          # sticky, as advance() returns self.done
+
     def sort_scores(self):
         "Sort the scores."
         return torch.sort(self.scores, 0, True)
@@ -68,8 +93,13 @@ class Beam(object):
     def get_hypothesis(self, k):
         "Walk the back-pointers to rebuild hypothesis k (a list of token ids)."
         k = int(k)
+        if not self.prev_ks:
+            return []
+        # one device->host copy of the whole trellis instead of two reads per step
+        prev = torch.stack(self.prev_ks).tolist()
+        ys = torch.stack(self.next_ys[1:]).tolist()
         hyp = []
-        for j in range(len(self.prev_ks) - 1, -1, -1):
-            hyp.append(int(self.next_ys[j + 1][k]))
-            k = int(self.prev_ks[j][k])
+        for j in range(len(prev) - 1, -1, -1):
+            hyp.append(ys[j][k])
+            k = prev[j][k]
         return hyp[::-1]

@@ -115,21 +115,27 @@ class Decode(object):
             beams = [Beam(beam, dev) for _ in range(B)]
             active = list(range(B))
             caches = [torch.zeros(B * beam, self.max_steps, 2 * d, dtype=BF16, device=dev) for _ in dec.layer_stack]
+            koff = klen = None
+            max_k = 0
             for step in range(self.max_steps):
                 n = len(active) * beam
                 tokens = torch.cat([beams[b].next_ys[-1] for b in active])              # slot order = score order
-                idx = torch.tensor(active).repeat_interleave(beam)
-                koff = in_off_h[idx].to(dev, I32)
-                klen = in_len_h[idx].to(dev, I32)
+                if koff is None:                                                        # (re)built only when the batch shrinks
+                    idx = torch.tensor(active).repeat_interleave(beam)
+                    koff, klen = in_off_h[idx].to(dev, I32), in_len_h[idx].to(dev, I32)
+                    max_k = int(in_len_h[idx].max())
                 word_lk = self._step(tokens, step, [c[:n] for c in caches], cross, koff, klen,
-                                     int(in_len_h[idx].max())).view(len(active), beam, -1)
+                                     max_k).view(len(active), beam, -1)
+                done = Beam.advance_batch([beams[b] for b in active], word_lk)          # one top-k, one host read
                 still, origins = [], []
                 for i, b in enumerate(active):
-                    if not beams[b].advance(word_lk[i]):
+                    if not done[i]:
                         still.append(b)
                         origins.append(beams[b].get_current_origin() + i * beam)        # rows of the step's layout
                 if not still:
                     break
+                if len(still) != len(active):
+                    koff = None
                 # finished utterances leave the batch (Decode.py:112-165); surviving hypotheses inherit the
                 # cache rows of the hypothesis they extend
                 order = torch.cat(origins)

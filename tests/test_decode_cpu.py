@@ -55,6 +55,22 @@ def test_beam_class_matches_oracle_beam():
         assert a.get_current_state().tolist() == b.current_prefixes().tolist()
 
 
+def test_beam_advance_batch_equals_per_beam_advance():
+    from transformer.Beam import Beam
+    g = torch.Generator().manual_seed(1)
+    size, V, n = 3, 9, 4
+    one, many = [Beam(size, "cpu") for _ in range(n)], [Beam(size, "cpu") for _ in range(n)]
+    for step in range(6):
+        lk = torch.log_softmax(torch.randn(n, size, V, generator=g) * 3, -1)
+        d1 = [b.advance(lk[i]) for i, b in enumerate(one)]
+        d2 = Beam.advance_batch(many, lk)
+        assert d1 == d2
+        for a, b in zip(one, many):
+            assert torch.equal(a.scores, b.scores) and torch.equal(a.prev_ks[-1], b.prev_ks[-1])
+            assert torch.equal(a.next_ys[-1], b.next_ys[-1]) and a.done == b.done
+            assert [a.get_hypothesis(k) for k in range(size)] == [b.get_hypothesis(k) for k in range(size)]
+
+
 def run_decode(device, eos_boost, max_steps):
     from transformer.Decode import Decode
     from transformer.Utils import AttrDict
