@@ -165,6 +165,7 @@ class _Deferred:
     active = False
     pending = []
     MAX_ROWS = 4096     # only launches that cannot fill the GPU are worth deferring
+    SPLITS = 1          # per deferred problem (measured: 1 beats 2 and 4 - the group as a whole already fills the GPU)
 
 
 def flush_deferred_wgrads():
@@ -197,7 +198,8 @@ def wgrad(dY, X, gW, rows=None, gB=None):
     N = dY.shape[1] if rows is None else rows
     splits = _splits(dY.shape[0], N, X.shape[1])
     if _Deferred.active and dY.shape[0] <= _Deferred.MAX_ROWS:
-        _Deferred.pending.append((X, dY, gW, gB, splits, N))      # the argument tuple of nv.wgrad_group
+        # the group as a whole fills the GPU: no split-K per problem (fewer atomics, longer k-loops per workgroup)
+        _Deferred.pending.append((X, dY, gW, gB, _Deferred.SPLITS, N))      # the argument tuple of nv.wgrad_group
         return
     nv.gemm(X, dY, gW, bias=gB, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=splits, n=N)
 
