@@ -11,7 +11,7 @@ import json
 import sqlite3
 import sys
 
-CLASSES = [("gemm_wgrad", "gemm_sym_kernel<true, true"), ("gemm_dgrad", "gemm_sym_kernel<false, true"),
+CLASSES = [("gemm_wgrad", ("gemm_sym_kernel<true, true", "gemm_wgrad_group_kernel")), ("gemm_dgrad", "gemm_sym_kernel<false, true"),
            ("gemm_fwd", "gemm_sym_kernel<false, false"), ("gemm_ln", "gemm_ln_kernel"),
            ("attn_fwd", "attn_fwd_kernel"), ("attn_bwd_dq", "attn_bwd_dq_kernel"),
            ("attn_bwd_dkv", "attn_bwd_dkv_kernel"), ("ln_bwd", "ln_bwd_kernel")]
@@ -29,13 +29,14 @@ def main():
     out, lines = {}, ["# per-launch HBM traffic (bytes); FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as reported",
                       "%-16s %8s %14s %14s %14s" % ("kernel class", "launches", "read_bytes", "write_bytes", "total_bytes")]
     for cls, pat in CLASSES:
+        pats = pat if isinstance(pat, tuple) else (pat,)
         n = rd = wr = 0.0
         for name, (cnt, avg) in fetch.items():
-            if pat in name:
+            if any(q in name for q in pats):
                 n += cnt
                 rd += cnt * avg * 1024.0 * 2.0
         for name, (cnt, avg) in write.items():
-            if pat in name:
+            if any(q in name for q in pats):
                 wr += cnt * avg * 1024.0
         if n:
             out[cls] = {"launches": int(n), "read_bytes": rd / n, "write_bytes": wr / n, "bytes": (rd + wr) / n}
