@@ -116,3 +116,43 @@ def test_config3_layer_shape_step_gpu():
 def test_joint_ctc_attention_step_gpu():
     """BASELINE config 4 objective: CTC head on the HIP encoder output + attention CE, gradients vs the fp64 oracle."""
     comp.run_joint_ctc_step("cuda")
+
+
+def test_full_size_batch_split_invariance():
+    """BASELINE config 2 layer shapes at full utterance lengths (T up to 1000, L up to 50), where the fp64 oracle is
+    too slow to be the checker: the token-summed loss and every gradient of a ragged batch must equal the sum over
+    its utterances processed ONE AT A TIME (a size-independent property that exercises the packed layout, the
+    attention work lists, split-K / grouped weight gradients and the key-split kernels at production sizes)."""
+    import torch
+    from st_amd import synthetic
+    from st_amd.arena import arena_of
+    from transformer.Models import Transformer
+    from transformer.Utils import AttrDict, init_parameters
+
+    cfg = AttrDict(dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_layer=2, num_dec_layer=2,
+                        n_heads=4, d_k=64, d_v=64, d_model=256, d_inner_hid=1024, dropout=0.1, vocab_size=4337))
+    torch.manual_seed(0)
+    model = Transformer(cfg).cuda()
+    init_parameters(model)
+    model.eval()
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(6, 1000, 50, 80, 4337, seed=3, t_min=300, l_min=20)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=0, reduction="sum")
+
+    def run(sel):
+        arena = arena_of(model)
+        arena.zero_grads()
+        xs, ts, gs = x[sel].cuda(), tokens[sel].cuda(), gt[sel].cuda()
+        T, L = int(in_len[sel].max()), int(tgt_len[sel].max())
+        logits, _ = model(xs[:, :T], in_len[sel], ts[:, :L], tgt_len[sel])
+        loss = crit(logits.contiguous().view(-1, 4337), gs[:, :L].contiguous().view(-1))
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), arena.grad.detach().clone()
+
+    full_loss, full_grad = run(torch.arange(6))
+    parts = [run(torch.tensor([b])) for b in range(6)]
+    sum_loss, sum_grad = sum(p[0] for p in parts), sum(p[1] for p in parts)
+    assert abs(full_loss - sum_loss) <= 2e-3 * abs(sum_loss), (full_loss, sum_loss)
+    r = float((full_grad - sum_grad).norm() / sum_grad.norm())
+    # same bf16 roundings per utterance either way; only accumulation orders (split-K, atomics, tile order) differ
+    assert r < 5e-3, r
