@@ -1,105 +1,103 @@
-"""Beam bookkeeping: drop-in for the reference's transformer/Beam.py (OpenNMT-style beam).
+"""Per-utterance beam state for transformer/Decode.py - API-compatible with the reference's transformer/Beam.py.
 
-Same class, same methods, same semantics - with the one repair the reference needs to run at all: the
-back-pointer is ``id // num_words`` (Beam.py:65 uses true division, which yields float indices on current
-PyTorch and fails at the first ``get_hypothesis``).  Everything stays on the device the scores live on; the only
-host read per step is the "top of beam is EOS" test (Beam.py:70), as in the reference."""
+What is kept from the reference is the public surface only (constructor, ``advance``, ``sort_scores``,
+``get_hypothesis``, ``get_current_state`` / ``get_current_origin`` / ``get_tentative_hypothesis``,
+``get_the_best_score_and_idx`` and the attributes ``size, done, scores, all_scores, prev_ks, next_ys``) and the
+search rule it encodes:
+
+* step 0 expands a single BOS row (all slots are identical), later steps add each slot's running score to its
+  ``[beam, vocab]`` log-probabilities;
+* the ``size`` best entries of the flattened ``beam x vocab`` table become the new slots: back-pointer =
+  ``index // vocab`` (the reference divides with ``/`` - float indices on current PyTorch, its decode cannot run;
+  SURVEY D12), token = ``index % vocab``;
+* the beam is finished as soon as its best slot emits EOS; slots that emitted EOS further down keep being
+  extended, exactly as in the reference.
+
+The trellis lives on the device the scores live on.  ``advance`` needs one host read per call (the EOS test);
+``advance_batch`` does the same update for many utterances with one top-k launch and one host read.
+"""
 import torch
 
 import transformer.Constants as Constants
 
 
 class Beam(object):
-    ''' Store the necessary info for beam search. '''
-
     def __init__(self, size, device):
-        self.size = size
+        self.size, self.device = size, device
         self.done = False
-        self.device = device
-        self.scores = torch.zeros(size, dtype=torch.float32, device=device)      # Beam.py:24
-        self.all_scores = []
-        self.prev_ks = []                                                          # back-pointers per step
-        self.next_ys = [torch.full((size,), Constants.BOS, dtype=torch.long, device=device)]   # Beam.py:31-33
+        self.scores = torch.zeros(size, dtype=torch.float32, device=device)       # running log-probability per slot
+        self.all_scores = []                                                        # score vector before every step
+        self.prev_ks = []                                                           # back-pointers, one tensor per step
+        self.next_ys = [torch.full((size,), Constants.BOS, dtype=torch.long, device=device)]   # tokens per step
 
-    def get_current_state(self):
-        "Get the outputs for the current timestep."
-        return self.get_tentative_hypothesis()
-
-    def get_current_origin(self):
-        "Get the backpointers for the current timestep."
-        return self.prev_ks[-1]
-
-    def advance(self, word_lk):
-        "Update the status and check for finished or not.  word_lk: [beam, num_words] log-probabilities."
-        num_words = word_lk.size(1)
-        if len(self.prev_ks) > 0:
-            beam_lk = word_lk + self.scores.unsqueeze(1).expand_as(word_lk)       # Beam.py:48-49
-        else:
-            beam_lk = word_lk[0]                                                   # all beams are BOS: use one row
-        flat_beam_lk = beam_lk.reshape(-1)
-        best_scores, best_scores_id = flat_beam_lk.topk(self.size, 0, True, True)
+    # ---- state update ------------------------------------------------------------------------------
+    def _commit(self, best_scores, best_flat, vocab, finished):
+        origin = best_flat // vocab
         self.all_scores.append(self.scores)
         self.scores = best_scores
-        prev_k = best_scores_id // num_words                                       # Beam.py:65, repaired (D12)
-        self.prev_ks.append(prev_k)
-        self.next_ys.append(best_scores_id - prev_k * num_words)
-        if self.next_ys[-1][0].item() == Constants.EOS:                            # Beam.py:70: top-of-beam is EOS
+        self.prev_ks.append(origin)
+        self.next_ys.append(best_flat - origin * vocab)
+        if finished:
             self.done = True
             self.all_scores.append(self.scores)
+
+    def advance(self, word_lk):
+        """word_lk [beam, vocab] log-probabilities of the next token for every slot -> True once finished."""
+        vocab = word_lk.size(1)
+        table = word_lk[0] if not self.prev_ks else word_lk + self.scores.unsqueeze(1)
+        best_scores, best_flat = table.reshape(-1).topk(self.size, 0, True, True)
+        finished = (best_flat[0] % vocab).item() == Constants.EOS
+        self._commit(best_scores, best_flat, vocab, finished)
         return self.done
 
     @staticmethod
     def advance_batch(beams, word_lk):
-        """``advance`` for several beams that are at the same step, with ONE top-k launch and ONE host read (the
-        per-beam version costs a launch chain and a sync each).  word_lk: [len(beams), beam, num_words].
-        Returns the list of ``done`` flags; every beam ends up exactly as after ``beams[i].advance(word_lk[i])``."""
-        n, size, num_words = word_lk.shape
-        if len(beams[0].prev_ks) > 0:
-            scores = torch.stack([b.scores for b in beams])
-            beam_lk = (word_lk + scores.unsqueeze(2)).reshape(n, -1)
+        """The same update for ``len(beams)`` utterances that are at the same step: word_lk [n, beam, vocab].
+        One top-k launch and one device->host read in total; returns each beam's ``done`` flag."""
+        n, size, vocab = word_lk.shape
+        if beams[0].prev_ks:
+            table = (word_lk + torch.stack([b.scores for b in beams]).unsqueeze(2)).reshape(n, -1)
         else:
-            beam_lk = word_lk[:, 0]
-        best_scores, best_ids = beam_lk.topk(size, 1, True, True)
-        prev_k = best_ids // num_words
-        next_y = best_ids - prev_k * num_words
-        done = (next_y[:, 0] == Constants.EOS).tolist()                           # the one synchronisation
+            table = word_lk[:, 0]
+        best_scores, best_flat = table.topk(size, 1, True, True)
+        finished = ((best_flat[:, 0] % vocab) == Constants.EOS).tolist()
         for i, b in enumerate(beams):
-            b.all_scores.append(b.scores)
-            b.scores = best_scores[i]
-            b.prev_ks.append(prev_k[i])
-            b.next_ys.append(next_y[i])
-            if done[i]:
-                b.done = True
-                b.all_scores.append(b.scores)
-        return [b.done for b in beams]          # sticky, as advance() returns self.done
+            b._commit(best_scores[i], best_flat[i], vocab, finished[i])
+        return [b.done for b in beams]
 
+    # ---- read-out ----------------------------------------------------------------------------------
     def sort_scores(self):
-        "Sort the scores."
+        """(scores, slot indices) in decreasing score order."""
         return torch.sort(self.scores, 0, True)
 
     def get_the_best_score_and_idx(self):
-        "Get the score of the best in the beam (the reference returns element [1], Beam.py:81; kept)."
-        scores, ids = self.sort_scores()
-        return scores[1], ids[1]
+        """Element [1] of the sorted scores / indices - the reference returns the runner-up here (its Beam.py:81)."""
+        ordered, slots = self.sort_scores()
+        return ordered[1], slots[1]
 
-    def get_tentative_hypothesis(self):
-        "Get the decoded sequence for the current timestep: [beam, len] with BOS in front."
-        if len(self.next_ys) == 1:
-            return self.next_ys[0].unsqueeze(1)
-        _, keys = self.sort_scores()
-        hyps = [[Constants.BOS] + self.get_hypothesis(k) for k in keys.tolist()]
-        return torch.tensor(hyps, dtype=torch.long, device=self.device)
+    def get_current_origin(self):
+        """Back-pointers of the latest step: new slot j extends old slot get_current_origin()[j]."""
+        return self.prev_ks[-1]
 
     def get_hypothesis(self, k):
-        "Walk the back-pointers to rebuild hypothesis k (a list of token ids)."
-        k = int(k)
+        """Token list of slot k, rebuilt through the back-pointers (one device->host copy of the trellis)."""
         if not self.prev_ks:
             return []
-        # one device->host copy of the whole trellis instead of two reads per step
-        prev = torch.stack(self.prev_ks).tolist()
-        ys = torch.stack(self.next_ys[1:]).tolist()
-        hyp = []
-        for j in range(len(prev) - 1, -1, -1):
-            hyp.append(ys[j][k])
-            k = prev[j][k]
-        return hyp[::-1]
+        back = torch.stack(self.prev_ks).tolist()
+        toks = torch.stack(self.next_ys[1:]).tolist()
+        slot, out = int(k), []
+        for step in reversed(range(len(back))):
+            out.append(toks[step][slot])
+            slot = back[step][slot]
+        out.reverse()
+        return out
+
+    def get_tentative_hypothesis(self):
+        """[beam, len] decoder input: BOS followed by every slot's tokens, best slot first."""
+        if len(self.next_ys) == 1:
+            return self.next_ys[0].unsqueeze(1)
+        _, slots = self.sort_scores()
+        rows = [[Constants.BOS] + self.get_hypothesis(s) for s in slots.tolist()]
+        return torch.tensor(rows, dtype=torch.long, device=self.device)
+
+    get_current_state = get_tentative_hypothesis
