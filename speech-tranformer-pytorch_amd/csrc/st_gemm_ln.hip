@@ -114,7 +114,7 @@ __device__ __forceinline__ void ln_store_block(bf16* patch, bf16* gbase, int ld,
 
 // The row-wise epilogue.  `acc` holds x W^T for rows i_base + (lane & 31), columns wn*128 + ...; the
 // residual block (if any) already sits in the wave's patch (ln_stage_res).
-template <int N>
+template <int N, int DROPW>
 __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4], bool have_res, int i_base, int wm,
                                             int wn, bf16* patch, float* red) {
   constexpr int WN = Geo<N>::WN, WM = Geo<N>::WM;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
   const bool row_ok = i < a.M;
   const int nvalid = min(32, a.M - i_base);
   const Drop dr = make_drop(a.drop);
-  const bool drop_pre = dr.on() && a.drop_where == 1, drop_out = dr.on() && a.drop_where == 2;
+  constexpr bool drop_pre = DROPW == 1, drop_out = DROPW == 2;   // compile-time: the eval-mode epilogue carries no dropout code
   float sum = 0.f;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -205,7 +205,7 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
   });
 }
 
-template <int N>
+template <int N, int DROPW>
 __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
   using G = Geo<N>;
   __shared__ __attribute__((aligned(16))) bf16 smem[2 * G::BUF];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
-  ln_epilogue<N>(a, acc, a.res != nullptr, i_base, wm, wn, patch, red);
+  ln_epilogue<N, DROPW>(a, acc, a.res != nullptr, i_base, wm, wn, patch, red);
 }
 
 }  // namespace
@@ -311,8 +311,13 @@ extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void
   const bool drop = drop_seed != nullptr && drop_thresh > 0 && (drop_where == 1 || drop_where == 2);
   a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
   a.drop.scale = drop ? drop_scale : 1.f; a.drop_where = drop ? drop_where : 0;
-#define ST_LN(NN) \
-  hipLaunchKernelGGL((gemm_ln_kernel<NN>), dim3((M + Geo<NN>::BM - 1) / Geo<NN>::BM), dim3(256), 0, stream, a)
+#define ST_LN(NN)                                                                                               \
+  do {                                                                                                          \
+    const dim3 grid((M + Geo<NN>::BM - 1) / Geo<NN>::BM);                                                       \
+    if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<NN, 1>), grid, dim3(256), 0, stream, a);          \
+    else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<NN, 2>), grid, dim3(256), 0, stream, a);     \
+    else hipLaunchKernelGGL((gemm_ln_kernel<NN, 0>), grid, dim3(256), 0, stream, a);                            \
+  } while (0)
   if (N == 128) ST_LN(128);
   else if (N == 256) ST_LN(256);
   else if (N == 512) ST_LN(512);

@@ -122,7 +122,7 @@ template <int KG> struct SmemSize {
 };
 
 // One output tile (of one split) of one problem; `bid` is the workgroup's index within that problem's grid.
-template <bool XT, bool YT, int EPI, int KG>
+template <bool XT, bool YT, int EPI, int KG, bool DROP = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem_all) {
   const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0, tid = threadIdx.x & 255;
   bf16* smem = smem_all + grp * 4 * TILE_E;
@@ -342,15 +342,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
         const int jl = (wn * 2 + y) * 32 + 8 * g + 4 * hi;
         bf16x4 o;
         uint32_t bits = 0;
-        if (EPI == EPI_BF16_RELU) {
-          if (dr.on()) bits = dr.bits(drop_counter_rc(i0 + il, j0 + jl, a.N));   // wave-uniform branch, training only
-        }
+        if (EPI == EPI_BF16_RELU && DROP) bits = dr.bits(drop_counter_rc(i0 + il, j0 + jl, a.N));   // training only
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[x][y][4 * g + e] + bv[y][g][e];
           if (EPI == EPI_BF16_RELU) {
             v = fmaxf(v, 0.f);
-            if (dr.on()) v = dr.keep(bits, e) ? v * dr.scale : 0.f;
+            if (DROP) v = dr.keep(bits, e) ? v * dr.scale : 0.f;
           }
           if (EPI == EPI_BF16_MASK) v *= a.drop.scale;   // 1 unless the forward dropped h (SubLayers.py:25)
           o[e] = (bf16)v;
@@ -384,10 +382,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
   }
 }
 
-template <bool XT, bool YT, int EPI, int KG>
+template <bool XT, bool YT, int EPI, int KG, bool DROP = false>
 __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 smem_all[SmemSize<KG>::E];
-  gemm_body<XT, YT, EPI, KG>(a, blockIdx.x, smem_all);
+  gemm_body<XT, YT, EPI, KG, DROP>(a, blockIdx.x, smem_all);
 }
 
 // Several weight-gradient problems in ONE launch (the decoder's are ~20 workgroups each and pure latency when
@@ -420,6 +418,10 @@ template <bool XT, bool YT>
 int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
 #define ST_CASE(E, KG) \
   case E: hipLaunchKernelGGL((gemm_sym_kernel<XT, YT, E, KG>), grid, dim3(256 * KG), 0, stream, a); break;
+  if (epi == EPI_BF16_RELU && a.drop.seed != nullptr) {   // training-mode dropout: its own instantiation
+    hipLaunchKernelGGL((gemm_sym_kernel<XT, YT, EPI_BF16_RELU, 1, true>), grid, dim3(256), 0, stream, a);
+    return 0;
+  }
   switch (epi) {
     ST_CASE(EPI_BF16, 1) ST_CASE(EPI_BF16_RELU, 1) ST_CASE(EPI_F32, 1) ST_CASE(EPI_BF16_MASK, 1)
     ST_CASE(EPI_BF16_ADD, 1) ST_CASE(EPI_F32_ATOMIC, 1) ST_CASE(EPI_F32_ATOMIC_T, 2)
