@@ -17,7 +17,7 @@ namespace {
 // Each lane owns 8 consecutive columns (16-byte loads); a row takes N/8 lanes, so a wave streams
 // 64 / (N/8) rows at a time and two such row groups are in flight per iteration.
 // ---------------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool DROP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, int lddy,
                                                      const bf16* __restrict__ xhat, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const bf16* __restrict__ mask,
@@ -53,14 +53,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
       const int row = base + u * RPW + slot;
       float g[8], xh[8], s1 = 0.f, s2 = 0.f;
       uint32_t bits[2] = {0, 0};
-      if (dr.on()) {
+      if (DROP) {
         bits[0] = dr.bits(drop_counter_rc(row, c0, N));
         bits[1] = dr.bits(drop_counter_rc(row, c0 + 4, N));
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float d = (float)vdy[u][e];
-        if (dr.on()) d = dr.keep(bits[e >> 2], e & 3) ? d * dr.scale : 0.f;
+        if (DROP) d = dr.keep(bits[e >> 2], e & 3) ? d * dr.scale : 0.f;
         xh[e] = (float)vxh[u][e];
         g[e] = d * gm[e];
         s1 += g[e];
@@ -302,15 +302,17 @@ extern "C" int st_ln_bwd(hipStream_t stream, const void* dy, int lddy, const voi
   drop.seed = on ? drop_seed : nullptr; drop.salt = drop_salt; drop.thresh = on ? drop_thresh : 0;
   drop.scale = on ? drop_scale : 1.f;
   if (!(mask_scale > 0.f)) mask_scale = 1.f;
-#define ST_LN_BWD(NN)                                                                                         \
-  hipLaunchKernelGGL((ln_bwd_kernel<NN>), dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, lddy,          \
+#define ST_LN_BWD_(NN, DR)                                                                                    \
+  hipLaunchKernelGGL((ln_bwd_kernel<NN, DR>), dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, lddy,      \
                      (const bf16*)xhat, rstd, gamma, (const bf16*)mask, (bf16*)dx, lddx, dgamma, dbeta, dbias, M, \
                      drop, mask_scale)
+#define ST_LN_BWD(NN) do { if (on) ST_LN_BWD_(NN, true); else ST_LN_BWD_(NN, false); } while (0)
   if (N == 128) ST_LN_BWD(128);
   else if (N == 256) ST_LN_BWD(256);
   else if (N == 512) ST_LN_BWD(512);
   else return -2;
 #undef ST_LN_BWD
+#undef ST_LN_BWD_
   ST_CHECK_LAUNCH();
   return 0;
 }
