@@ -214,11 +214,22 @@ def _empty(rows, cols, like, dtype=BF16):
 
 
 # ------------------------------------------------------------------------------------------------
+class CrossGradAcc:
+    """Shared by the N decoder-encoder attentions of one forward pass (they all read the same encoder output):
+    their backward passes run in reverse layer order and add their encoder gradients into ``buf`` inside the
+    dgrad GEMM's epilogue; the N-th one returns the sum.  Saves N - 1 full-size adds and their launches."""
+    __slots__ = ("n", "seen", "buf")
+
+    def __init__(self, n: int):
+        self.n, self.seen, self.buf = n, 0, None
+
+
 class MhaFn(torch.autograd.Function):
     """out = LN(attn(x_q W_q, x_kv W_k, x_kv W_v) W_o + b_o + x_q)   (Attention.py:64-96, R2)."""
 
     @staticmethod
-    def forward(ctx, x_q, x_kv, anchor, mod, q_rows: Rows, k_rows: Rows, causal: bool, want_attn: bool, drop=None):
+    def forward(ctx, x_q, x_kv, anchor, mod, q_rows: Rows, k_rows: Rows, causal: bool, want_attn: bool, drop=None,
+                kv_acc=None):
         s = mod._st
         d, H = s.d_model, s.n_head
         Mq = x_q.shape[0]
@@ -245,6 +256,7 @@ class MhaFn(torch.autograd.Function):
         ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
+        ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers sum their encoder gradient into one buffer
         return out
 
     @staticmethod
@@ -285,10 +297,23 @@ class MhaFn(torch.autograd.Function):
             wgrad(dqkv, x_q, s.g_w_q, gB=s.g_b_q)
             dgrad(dqkv, s.w_q, dx_q, epi=nv.EPI_BF16_ADD, aux=ds)
             wgrad(dkv, x_kv, s.g_w_kv, gB=s.g_b_kv)
-            dx_kv = _empty(x_kv.shape[0], d, x_q)
-            dgrad(dkv, s.w_kv, dx_kv)
+            acc = ctx.kv_acc
+            if acc is None:
+                dx_kv = _empty(x_kv.shape[0], d, x_q)
+                dgrad(dkv, s.w_kv, dx_kv)
+            else:
+                # every decoder layer attends the same encoder output: instead of handing autograd N gradients
+                # to add, the GEMM epilogues accumulate into one buffer and the last layer to run (layer 0) returns it
+                if acc.buf is None:
+                    acc.buf = _empty(x_kv.shape[0], d, x_q)
+                    dgrad(dkv, s.w_kv, acc.buf)
+                else:
+                    dgrad(dkv, s.w_kv, acc.buf, epi=nv.EPI_BF16_ADD, aux=acc.buf)
+                acc.seen += 1
+                if acc.seen == acc.n:
+                    dx_kv, acc.buf, acc.seen = acc.buf, None, 0
         arena.grads_ready(s.lo, s.hi)
-        return dx_q, dx_kv, None, None, None, None, None, None, None
+        return dx_q, dx_kv, None, None, None, None, None, None, None, None
 
 
 class FfnFn(torch.autograd.Function):

@@ -76,12 +76,12 @@ class MultiHeadAttention(nn.Module):
         return rng.site(device, self.dropout.p) if self.training else None
 
     # ---- fast path: bf16 row matrices ----------------------------------------------------------
-    def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal):
+    def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal, kv_acc=None):
         """x_q [Mq, d] (and x_kv [Mk, d] for cross-attention, else None) bf16 row matrices."""
         arena = arena_of(self)
         with arena.scope():
             return F_.MhaFn.apply(x_q, x_kv, self.linear_q.weight, self, q_rows, k_rows, bool(causal), False,
-                                  self._drop(x_q.device))
+                                  self._drop(x_q.device), kv_acc)
 
     # ---- reference API -------------------------------------------------------------------------
     def forward(self, q, k, v, mask=None):

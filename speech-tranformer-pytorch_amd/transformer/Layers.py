@@ -30,9 +30,9 @@ class DecoderLayer(nn.Module):
         self.enc_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner_hid, dropout=dropout)
 
-    def forward_rows(self, y, enc, t_rows, in_rows):
+    def forward_rows(self, y, enc, t_rows, in_rows, kv_acc=None):
         s = self.slf_attn.forward_rows(y, None, t_rows, t_rows, True)
-        c = self.enc_attn.forward_rows(s, enc, t_rows, in_rows, False)
+        c = self.enc_attn.forward_rows(s, enc, t_rows, in_rows, False, kv_acc=kv_acc)
         return self.pos_ffn.forward_rows(c)
 
     def forward(self, inputs, enc_output, slf_attn_mask=None, dec_enc_attn_mask=None):

@@ -107,8 +107,10 @@ class Decoder(nn.Module):
             if t_rows is None:
                 t_rows = F_.Rows.packed(tgt_len, tokens.device)
             y = F_.EmbedFn.apply(self.tgt_word_emb.weight, self, tokens.contiguous(), t_rows)
+            # one accumulator for the encoder gradient of all layers (only when the encoder output needs one)
+            acc = F_.CrossGradAcc(len(self.layer_stack)) if enc_rows_mat.requires_grad else None
             for layer in self.layer_stack:
-                y = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows)
+                y = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows, acc)
         return y, t_rows
 
     def forward(self, outputs_data, outputs_pos, input_pos, enc_output, return_attns=False):
