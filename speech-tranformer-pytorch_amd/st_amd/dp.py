@@ -48,6 +48,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    from . import rng
+    rng.set_rank(rank)           # per-rank dropout streams
     return rank, local, world
 
 

@@ -21,15 +21,26 @@ from . import native as nv
 
 _seeds: Dict[str, torch.Tensor] = {}
 _salt = 0
+_rank_offset = 0      # data-parallel ranks draw different masks from the same torch seed (set_rank)
 
 
 def seed_tensor(device) -> torch.Tensor:
     key = str(torch.device(device))
     t = _seeds.get(key)
     if t is None:
-        t = torch.tensor([torch.initial_seed() & 0x7FFFFFFF], dtype=torch.int32, device=device)
+        t = torch.tensor([(torch.initial_seed() + _rank_offset) & 0x7FFFFFFF], dtype=torch.int32, device=device)
         _seeds[key] = t
     return t
+
+
+def set_rank(rank: int) -> None:
+    """Called by ``dp.init_from_env``: rank r's stream starts r * 0x9E3779B1 away from rank 0's, so the shards of a
+    data-parallel batch do not share dropout masks even when every rank called ``torch.manual_seed`` alike."""
+    global _rank_offset
+    delta = (int(rank) * 0x9E3779B1 - _rank_offset) & 0x7FFFFFFF
+    _rank_offset = (int(rank) * 0x9E3779B1) & 0x7FFFFFFF
+    for t in _seeds.values():
+        t.add_(delta)
 
 
 def manual_seed(seed: int) -> None:
@@ -37,7 +48,7 @@ def manual_seed(seed: int) -> None:
     global _salt
     _salt = 0
     for t in _seeds.values():
-        t.fill_(int(seed) & 0x7FFFFFFF)
+        t.fill_((int(seed) + _rank_offset) & 0x7FFFFFFF)
 
 
 def advance(device=None) -> None:
