@@ -30,7 +30,7 @@ namespace {
 #endif
 constexpr int BK = ST_GEMM_BK;
 constexpr int NS = BK + 8;    // natural tile row stride (144 B): conflict-free ds_read_b128 over 16 rows
-constexpr int CS_CM = 144;    // contraction-major tile row stride (128 + 16): the 4 c-rows of a tr read hit 4 bank groups
+constexpr int CS_CM = 128;    // contraction-major tile: unpadded c-rows, 64-byte groups XOR-swizzled by (c-row & 3) - see cm_col()
 constexpr int TILE_E = (128 * NS > BK * CS_CM) ? 128 * NS : BK * CS_CM;   // elements of either tile image
 constexpr int CH = BK / 16;   // 16-byte chunks per thread per operand tile
 constexpr int CPR = BK / 8;   // chunks per natural row
@@ -50,6 +50,12 @@ struct GemmArgs {
   int c_per_split, tiles_i, tiles_j, splits;
   DropArgs drop;   // EPI_BF16_RELU: dropout after the ReLU (SubLayers.py:25); EPI_BF16_MASK: .scale on the survivors
 };
+
+// Column of a contraction-major tile element after the swizzle: bits 5-6 of the column are XORed with (c-row & 3).
+// A ds_read_b64_tr_b16 wave-instruction touches, per 32 lanes, 4 consecutive c-rows x 2 column blocks of 32 bytes;
+// with 256-byte c-rows they would all sit on the same 16 banks - the XOR spreads them over all 64 (PMC showed 31 %
+// of the LDS cycles of the weight-gradient kernel as bank conflicts with a padded stride instead).
+__device__ __forceinline__ int cm_col(int crow, int col) { return col ^ ((crow & 3) << 5); }
 
 // This thread's share (4 x 16 bytes) of a 128 x 64 operand tile.  The byte offsets from the k-tile's
 // (wave-uniform) base are fixed for the whole kernel, so the inner loop carries no address arithmetic and no
@@ -98,7 +104,7 @@ struct Stage {
     for (int p = 0; p < CH; ++p) {
       const int id = tid + p * 256;
       if (!CM) *reinterpret_cast<bf16x8*>(tile + (id / CPR) * NS + (id % CPR) * 8) = v[p];
-      else *reinterpret_cast<bf16x8*>(tile + (id >> 4) * CS_CM + (id & 15) * 8) = v[p];
+      else *reinterpret_cast<bf16x8*>(tile + (id >> 4) * CS_CM + cm_col(id >> 4, (id & 15) * 8)) = v[p];
     }
   }
 };
@@ -107,7 +113,17 @@ template <bool CM>
 __device__ __forceinline__ bf16x8 read_frag(const bf16* tile, int blk_row0, int kk) {
   const int l = threadIdx.x & 63, hi = l >> 5;
   if (!CM) return frag_nat(tile, NS, blk_row0 + (l & 31), kk * 16 + hi * 8);
-  return frag_tr(tile, CS_CM, blk_row0, kk * 16 + hi * 8, kk * 16 + hi * 8 + 4);
+  // transposing read (st_common.cuh: frag_tr) on the swizzled image: c-rows ca + (t >> 2) and ca + 4 + (t >> 2)
+  const int t = l & 15, ca = kk * 16 + hi * 8 + (t >> 2);
+  const int col = blk_row0 + ((l >> 4) & 1) * 16 + 4 * (t & 3);
+  const bf16* pa = tile + ca * CS_CM + cm_col(ca, col);
+  const bf16* pb = tile + (ca + 4) * CS_CM + cm_col(ca + 4, col);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pa));
+  const bf16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((ST_LDS bf16x4*)(pb));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = up[0]; f[5] = up[1]; f[6] = up[2]; f[7] = up[3];
+  return f;
 }
 
 // KG = 2 (weight gradients): two 4-wave groups share one output tile, each taking half of the workgroup's
