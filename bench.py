@@ -74,6 +74,8 @@ def kernel_report(records):
                     pairs *= 0.5
                 flops = 4.0 * pairs * dk * H          # two contractions of the non-recomputed work per kernel
                 kind = "attn_fwd" if tag[0] == "attn_fwd" else {1: "attn_bwd_dq", 2: "attn_bwd_dkv", 3: "attn_bwd"}[tag[6]]
+                if kind == "attn_bwd":
+                    flops *= 2.0                      # dQ and dK/dV bodies in one launch
             elif tag[0] == "ln_bwd":
                 kind = "ln_bwd"
         a = agg.setdefault(kind, {"ms": 0.0, "launches": 0, "flops": 0.0})

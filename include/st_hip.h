@@ -41,7 +41,8 @@ enum {
   ST_EPI_BF16_MASK = 3,  /* D(bf16) = acc * (aux > 0)       ReLU backward            */
   ST_EPI_BF16_ADD = 4,   /* D(bf16) = acc + aux             residual-gradient add    */
   ST_EPI_F32_ATOMIC = 5, /* D(f32) += acc (atomic, split-K)                          */
-  ST_EPI_F32_ATOMIC_T = 6 /* D^T(f32)[j][i] += acc: weight gradients, coalesced atomics */
+  ST_EPI_F32_ATOMIC_T = 6, /* D^T(f32)[j][i] += acc: weight gradients, coalesced atomics */
+  ST_EPI_BF16_DELTA = 7  /* D(bf16) = acc, and delta[h][i] = sum_{j in head h} D(i,j) * aux(i,j) */
 };
 
 /* Training-mode dropout (nn.Dropout in Attention.py:89, SubLayers.py:25,27,
@@ -65,6 +66,8 @@ enum {
  * ST_EPI_F32_ATOMIC_T, where a non-NULL bias is the fp32 [N] bias-GRADIENT
  * accumulator: bias[j] += sum_c Y(j,c) (the column sums of dy, i.e. the
  * nn.Linear bias gradient, produced by the weight-gradient launch itself).
+ * ST_EPI_BF16_DELTA (the dgrad that produces the attention backward's dO = d(context), aux = the forward
+ * context O): `bias` is the fp32 OUTPUT delta [N / head, M] and `splits` carries the head width (32 or 64).
  * Dropout: ST_EPI_BF16_RELU drops after the ReLU (SubLayers.py:25);
  * ST_EPI_BF16_MASK multiplies the surviving (aux > 0) elements by drop_scale
  * (backward of the former; aux is the dropped activation). */
@@ -122,6 +125,7 @@ int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
 /* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
  * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:
  * parts & 1 = dQ (also writes delta), parts & 2 = dK/dV (reads delta); 3 = both.
+ * O == NULL: delta is an input (st_gemm ST_EPI_BF16_DELTA wrote it with dO) and parts == 3 runs as ONE launch.
  * work_q / work_k: optional work lists (see st_attn_fwd) over 128-query tiles
  * (dQ kernel) and 128-key tiles (dK/dV kernel). */
 int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,

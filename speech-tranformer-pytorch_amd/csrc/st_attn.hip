@@ -58,9 +58,9 @@ struct AttnArgs {
 };
 
 // blockIdx.x -> (utterance, head, tile)
-__device__ __forceinline__ void decode_item(const AttnArgs& a, int& b, int& h, int& tile) {
-  const int idx = blockIdx.x / a.H;
-  h = blockIdx.x % a.H;
+__device__ __forceinline__ void decode_item(const AttnArgs& a, int bid, int& b, int& h, int& tile) {
+  const int idx = bid / a.H;
+  h = bid % a.H;
   if (a.work) {
     const int w = a.work[idx];
     b = w >> 16;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];   // 2 buffers x (K tile, V tile)
 
   int b, h, tile;
-  decode_item(a, b, h, tile);
+  decode_item(a, blockIdx.x, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
   const int q0 = tile * QROWS;
   if (q0 >= lq) return;
@@ -379,14 +379,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 //   P^T = exp2(S^T c2 - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta),  dQ^T += K^T dS^T
 // ---------------------------------------------------------------------------------------------
 template <int DK, bool DROP, int KS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf16* smem) {
   using G = TileGeo<DK, TILE * KS>;
   constexpr int NT = DK / 16, ND = DK / 32;
   constexpr int ROWS = TILE * KS, QROWS = WG_ROWS / KS;   // KS = 2: see attn_fwd_kernel
-  __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];
 
   int b, h, tile;
-  decode_item(a, b, h, tile);
+  decode_item(a, bid, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
   const int q0 = tile * QROWS;
   if (q0 >= lq) return;
@@ -411,13 +410,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int col = h * DK + t * 16 + hi * 8;
     qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + col);
     dof[t] = *reinterpret_cast<const bf16x8*>(a.dO + qrow * a.lddo + col);
-    const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + qrow * a.ldo + col);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dl += (float)dof[t][e] * (float)of[e];
   }
-  dl += wave_xor32(dl);
+  if (a.O != nullptr) {   // delta = rowsum(dO * O) computed (and published) here ...
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + qrow * a.ldo + h * DK + t * 16 + hi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[t][e] * (float)of[e];
+    }
+    dl += wave_xor32(dl);
+    if (q_ok && hi == 0 && kp == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
+  } else {                // ... or already produced by the launch that wrote dO (st_gemm, ST_EPI_BF16_DELTA)
+    dl = a.delta[(size_t)h * a.q_rows_total + qrow];
+  }
   const float lse = a.lse[(size_t)h * a.q_rows_total + qrow];
-  if (q_ok && hi == 0 && kp == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
 
   uint32_t offk[G::CH], offv[G::CH];
   Stage<DK, ROWS>::offsets(offk, a.ldk);
@@ -494,6 +500,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                  q0 + qw * 32, min(32, lq - (q0 + qw * 32)));
 }
 
+template <int DK, bool DROP, int KS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[4 * TileGeo<DK, TILE * KS>::E];
+  attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward, part 2: dK, dV.  Each wave owns 32 keys (lane & 31) and loops over 64-query tiles
 // (Q rows, dO rows and the tile's 64 lse + 64 delta values).
@@ -501,14 +513,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 //   dV^T += dO^T P,   dP = dO V^T,   dS = P (dP - delta[q]),   dK^T += Q^T dS
 // ---------------------------------------------------------------------------------------------
 template <int DK, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf16* smem) {
   using G = TileGeo<DK>;
   constexpr int NT = DK / 16, ND = DK / 32;
   constexpr int BUF = 2 * G::E + 256;   // Q tile, dO tile, lse[64] + delta[64] (fp32, counted in bf16 elements)
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * BUF];
 
   int b, h, tile;
-  decode_item(a, b, h, tile);
+  decode_item(a, bid, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
   const int k0 = tile * WG_ROWS;
   if (k0 >= lk) return;
@@ -624,6 +635,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                  k0 + wave * 32, nrows);
 }
 
+template <int DK, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (2 * TileGeo<DK>::E + 256)];
+  attn_bwd_dkv_body<DK, DROP>(a, blockIdx.x, smem);
+}
+
+// dQ and dK/dV in ONE launch (possible when delta comes from the producer of dO: no kernel-to-kernel dependency
+// is left).  Workgroups [0, n_q) run the dQ body on the query-tile work list, the rest the dK/dV body on the
+// key-tile list; the long dK/dV items start while the dQ items drain.
+template <int DK, bool DROP, int KS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, AttnArgs ak, int n_q) {
+  constexpr int EQ = 4 * TileGeo<DK, TILE * KS>::E, EK = 2 * (2 * TileGeo<DK>::E + 256);
+  __shared__ __attribute__((aligned(16))) bf16 smem[EQ > EK ? EQ : EK];
+  if ((int)blockIdx.x < n_q) attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x, smem);
+  else attn_bwd_dkv_body<DK, DROP>(ak, blockIdx.x - n_q, smem);
+}
+
 int check_common(int d_k, int ldq, int ldk, int ldv) {
   if (d_k != 32 && d_k != 64) return -1;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7)) return -2;
@@ -691,7 +719,7 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   if (B <= 0 || H <= 0 || max_q <= 0 || max_k <= 0) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
-  if ((ldo & 7) || (lddo & 7) || (lddq & 7) || (lddk & 7) || (lddv & 7)) return -3;
+  if ((O && (ldo & 7)) || (lddo & 7) || (lddq & 7) || (lddk & 7) || (lddv & 7)) return -3;
   if (B > 32767) return -4;
   AttnArgs a = {};
   a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
@@ -701,9 +729,26 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   dim3 block(256);
-  if ((parts & 1) && !(work_q && n_work_q <= 0)) {
+  const bool ks2 = key_split(max_q, max_k, causal);
+  const bool run_q = (parts & 1) && !(work_q && n_work_q <= 0), run_k = (parts & 2) && !(work_k && n_work_k <= 0);
+  if (run_q && run_k && O == nullptr) {
+    // delta was produced together with dO (st_gemm, ST_EPI_BF16_DELTA): the two kernels are independent -> one launch
+    AttnArgs ak = a;
+    const int nq = plan(a, work_q, n_work_q, B, H, max_q), nk = plan(ak, work_k, n_work_k, B, H, max_k);
+    dim3 grid(nq + nk);
+#define ST_BWD(DKK, DR) \
+  do { if (ks2) hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a, ak, nq); \
+       else hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a, ak, nq); } while (0)
+    if (d_k == 64 && !drop) ST_BWD(64, false);
+    else if (d_k == 64) ST_BWD(64, true);
+    else if (!drop) ST_BWD(32, false);
+    else ST_BWD(32, true);
+#undef ST_BWD
+    ST_CHECK_LAUNCH();
+    return 0;
+  }
+  if (run_q) {
     dim3 gq(plan(a, work_q, n_work_q, B, H, max_q));
-    const bool ks2 = key_split(max_q, max_k, causal);
 #define ST_DQ(DKK, DR) \
   do { if (ks2) hipLaunchKernelGGL((attn_bwd_dq_kernel<DKK, DR, 2>), gq, block, 0, stream, a); \
        else hipLaunchKernelGGL((attn_bwd_dq_kernel<DKK, DR, 1>), gq, block, 0, stream, a); } while (0)
@@ -713,7 +758,7 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
     else ST_DQ(32, true);
 #undef ST_DQ
   }
-  if ((parts & 2) && !(work_k && n_work_k <= 0)) {
+  if (run_k) {
     dim3 gk(plan(a, work_k, n_work_k, B, H, max_k));
     if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, block, 0, stream, a);
     else if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, block, 0, stream, a);

@@ -38,7 +38,7 @@ constexpr int CPR = BK / 8;   // chunks per natural row
 __device__ __attribute__((aligned(16))) float g_zero_f32[4];
 
 enum Epi { EPI_BF16 = 0, EPI_BF16_RELU = 1, EPI_F32 = 2, EPI_BF16_MASK = 3, EPI_BF16_ADD = 4, EPI_F32_ATOMIC = 5,
-           EPI_F32_ATOMIC_T = 6 };
+           EPI_F32_ATOMIC_T = 6, EPI_BF16_DELTA = 7 };
 
 struct GemmArgs {
   const bf16* X; int ldx;
@@ -48,6 +48,7 @@ struct GemmArgs {
   const float* bias;
   const bf16* aux; int ldaux;
   int c_per_split, tiles_i, tiles_j, splits;
+  int head_dim;    // EPI_BF16_DELTA: columns per attention head (32 or 64)
   DropArgs drop;   // EPI_BF16_RELU: dropout after the ReLU (SubLayers.py:25); EPI_BF16_MASK: .scale on the survivors
 };
 
@@ -318,7 +319,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int j = jb + y * 32 + 8 * g + 4 * hi;
-      bv[y][g] = *reinterpret_cast<const f32x4*>((a.bias != nullptr && j < a.N) ? a.bias + j : g_zero_f32);
+      bv[y][g] = *reinterpret_cast<const f32x4*>((EPI != EPI_BF16_DELTA && a.bias != nullptr && j < a.N) ? a.bias + j
+                                                                                                           : g_zero_f32);
     }
   if (EPI == EPI_F32 || EPI == EPI_F32_ATOMIC) {   // logits (row-per-lane fp32 vectors)
 #pragma unroll
@@ -374,7 +376,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
   }
   // the mask / addend chunks this thread will need: requested before the barrier, all in flight together
   bf16x8 auxv[8];
-  if (EPI == EPI_BF16_MASK || EPI == EPI_BF16_ADD) {
+  if (EPI == EPI_BF16_MASK || EPI == EPI_BF16_ADD || EPI == EPI_BF16_DELTA) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int id = p * 256 + tid, i = i0 + (id >> 4), j = j0 + (id & 15) * 8;
@@ -393,6 +395,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
     } else if (EPI == EPI_BF16_ADD) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)auxv[p][e]);
+    } else if (EPI == EPI_BF16_DELTA) {
+      // delta[h][i] = sum over head h's columns of D(i, .) * aux(i, .): the attention backward's rowsum(dO * O),
+      // produced where dO is produced.  A head's columns sit in head_dim / 8 neighbouring lanes of one row.
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += (float)v[e] * (float)auxv[p][e];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      if (a.head_dim == 64) part += __shfl_xor(part, 4, 64);
+      const int cph = a.head_dim >> 3;   // 16-byte chunks per head
+      if (i < a.M && j < a.N && ((id & 15) % cph) == 0)
+        const_cast<float*>(a.bias)[(size_t)(j / a.head_dim) * a.M + i] = part;
     }
     if (i < a.M && j < a.N) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
   }
@@ -426,6 +440,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wgrad_group_kernel(GroupArgs g) {
   a.X = p.X; a.ldx = p.ldx; a.Y = p.Y; a.ldy = p.ldy; a.D = p.D; a.ldd = p.ldd;
   a.M = p.M; a.N = p.N; a.Kc = p.Kc; a.bias = p.bias; a.aux = nullptr; a.ldaux = 0;
   a.c_per_split = p.c_per_split; a.tiles_i = p.tiles_i; a.tiles_j = p.tiles_j; a.splits = p.splits;
+  a.head_dim = 0;
   a.drop.seed = nullptr; a.drop.salt = 0; a.drop.thresh = 0; a.drop.scale = 1.f;
   gemm_body<true, true, EPI_F32_ATOMIC_T, 2>(a, (int)blockIdx.x - g.first[pi], smem_all);
 }
@@ -440,7 +455,7 @@ int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
   }
   switch (epi) {
     ST_CASE(EPI_BF16, 1) ST_CASE(EPI_BF16_RELU, 1) ST_CASE(EPI_F32, 1) ST_CASE(EPI_BF16_MASK, 1)
-    ST_CASE(EPI_BF16_ADD, 1) ST_CASE(EPI_F32_ATOMIC, 1) ST_CASE(EPI_F32_ATOMIC_T, 2)
+    ST_CASE(EPI_BF16_ADD, 1) ST_CASE(EPI_F32_ATOMIC, 1) ST_CASE(EPI_F32_ATOMIC_T, 2) ST_CASE(EPI_BF16_DELTA, 1)
     default: return -1;
   }
 #undef ST_CASE
@@ -495,16 +510,18 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
                        void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi,
                        int splits, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
-  if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 6) return -1;
+  if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 7) return -1;
   if (x_cmajor && !y_cmajor) return -2;  // not needed by any caller
   // contraction-major operands are read in 8-row chunks: the caller guarantees the buffer is
   // padded (ld >= round_up(rows, 8)); rows beyond M / N only feed outputs that are never stored.
   if ((x_cmajor && ldx < ((M + 7) & ~7)) || (y_cmajor && ldy < ((N + 7) & ~7))) return -3;
   if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && ((ldd & 7) || (N & 7))) return -4;
-  if ((epi == EPI_BF16_MASK || epi == EPI_BF16_ADD) && (ldaux & 7)) return -5;
+  if ((epi == EPI_BF16_MASK || epi == EPI_BF16_ADD || epi == EPI_BF16_DELTA) && (ldaux & 7)) return -5;
+  if (epi == EPI_BF16_DELTA && (!bias || !aux || (splits != 32 && splits != 64) || (N % splits))) return -6;
+  GemmArgs a;
+  a.head_dim = epi == EPI_BF16_DELTA ? splits : 0;   // this epilogue takes the head width in the `splits` slot
   if (splits < 1) splits = 1;
   if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T) splits = 1;
-  GemmArgs a;
   a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
   a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux;
   const bool drop = epi == EPI_BF16_RELU && drop_seed != nullptr && drop_thresh > 0;

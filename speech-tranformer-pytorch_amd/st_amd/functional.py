@@ -272,8 +272,10 @@ class MhaFn(torch.autograd.Function):
         nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b_o)
         wgrad(ds, attn_ctx, s.g_w_o)
         dctx = _empty(Mq, d, x_q)
-        dgrad(ds, s.w_o, dctx)
         delta = torch.empty(H * Mq, dtype=F32, device=x_q.device)
+        # d(context) and, in the same launch, delta = rowsum(d(context) * context) per head: the two attention
+        # backward kernels then depend on nothing but finished buffers and run as ONE launch
+        nv.gemm(ds, s.w_o, dctx, epi=nv.EPI_BF16_DELTA, aux=attn_ctx, y_cmajor=True, delta=delta, head_dim=d // H)
         if x_kv is None:
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             # key rows past k_len (padded layout only) get no gradient: they must read as zeros
@@ -286,7 +288,7 @@ class MhaFn(torch.autograd.Function):
                 torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
         work_q, work_k = attn_work(q_rows, k_rows, ctx.causal)
-        nv.attn_bwd(Q, K, V, attn_ctx, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
+        nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
                     q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop)
         dx_q = _empty(Mq, d, x_q)
         dx_kv = None

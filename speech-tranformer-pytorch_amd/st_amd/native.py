@@ -19,7 +19,7 @@ import torch
 
 from . import build as _build
 
-EPI_BF16, EPI_BF16_RELU, EPI_F32, EPI_BF16_MASK, EPI_BF16_ADD, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T = range(7)
+EPI_BF16, EPI_BF16_RELU, EPI_F32, EPI_BF16_MASK, EPI_BF16_ADD, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T, EPI_BF16_DELTA = range(8)
 
 _c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 _c_uint = ctypes.c_uint
@@ -199,8 +199,10 @@ def _drop(d: Optional["Drop"]):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1,
-         m=None, n=None, kc=None, drop=None):
-    """out[i][j] (+)= sum_c X(i,c) Y(j,c).  ``*_cmajor``: that tensor is stored [c, rows]."""
+         m=None, n=None, kc=None, drop=None, delta=None, head_dim=0):
+    """out[i][j] (+)= sum_c X(i,c) Y(j,c).  ``*_cmajor``: that tensor is stored [c, rows].
+    EPI_BF16_DELTA: additionally delta[h][i] = sum over head h's ``head_dim`` columns of out(i, .) * aux(i, .)
+    (fp32 [N / head_dim, M]) - the attention backward's rowsum(dO * O), produced by the GEMM that produces dO."""
     _mat(X, BF16, "X"), _mat(Y, BF16, "Y")
     _mat(out, F32 if epi in (EPI_F32, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T) else BF16, "out")
     M = m if m is not None else (X.shape[1] if x_cmajor else X.shape[0])
@@ -210,8 +212,13 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
     if out.shape[0] < need[0] or out.shape[1] < need[1]:
         raise ValueError("gemm: out %s too small for %dx%d" % (tuple(out.shape), need[0], need[1]))
     _vec(bias, F32, N, "bias")
+    if epi == EPI_BF16_DELTA:
+        if head_dim not in (32, 64) or N % head_dim:
+            raise ValueError("gemm: EPI_BF16_DELTA needs head_dim in {32, 64} dividing N")
+        _vec(delta, F32, (N // head_dim) * M, "delta")
+        bias, splits = delta, head_dim          # the C-ABI passes them in the bias / splits slots of this epilogue
     ldaux = 0
-    if epi in (EPI_BF16_MASK, EPI_BF16_ADD):
+    if epi in (EPI_BF16_MASK, EPI_BF16_ADD, EPI_BF16_DELTA):
         _mat(aux, BF16, "aux")
         ldaux = aux.stride(0)
     _tag("gemm", int(x_cmajor), int(y_cmajor), M, N, Kc, epi)
@@ -327,20 +334,23 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
 def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
              parts=3, work_q=None, work_k=None, drop=None):
     """parts: 1 = dQ (+delta) kernel, 2 = dK/dV kernel (needs delta from part 1), 3 = both."""
-    for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
+    for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
         _mat(t, BF16, nm)
+    if O is not None:      # O = None: delta is an INPUT (produced with dO by gemm(..., epi=EPI_BF16_DELTA)); one launch
+        _mat(O, BF16, "O")
     B = q_off.numel()
     d_k = Q.shape[1] // n_head
     rows = Q.shape[0]
     _vec(lse, F32, n_head * rows, "lse"), _vec(delta, F32, n_head * rows, "delta")
-    if _TIMING is not None and parts == 3:   # profile the two kernels of the call separately
+    if _TIMING is not None and parts == 3 and O is not None:   # profile the two kernels of the call separately
         for part in (1, 2):
             attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal,
                      scale, parts=part, work_q=work_q, work_k=work_k, drop=drop)
         return
     _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts)
     rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
-                            O.data_ptr(), O.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(), delta.data_ptr(),
+                            _p(O), 0 if O is None else O.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(),
+                            delta.data_ptr(),
                             dQ.data_ptr(), dQ.stride(0), dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0),
                             q_off.data_ptr(), q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k,
                             int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),

@@ -68,7 +68,7 @@ def keep_qk(d, bh, nq, nk):
 
 
 def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1, m=None, n=None,
-         kc=None, drop=None):
+         kc=None, drop=None, delta=None, head_dim=0):
     Xl = (X.t() if x_cmajor else X).float()      # logical [M, Kc]
     Yl = (Y.t() if y_cmajor else Y).float()      # logical [N, Kc]
     M = m if m is not None else Xl.shape[0]
@@ -96,6 +96,9 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
         out[:N, :M] += acc.t()
     else:
         out[:M, :N] = acc.to(out.dtype)
+        if epi == nv.EPI_BF16_DELTA:
+            prod = out[:M, :N].float() * aux[:M, :N].float()
+            delta.view(N // head_dim, -1)[:, :M] = prod.view(M, N // head_dim, head_dim).sum(-1).t()
     return out
 
 
@@ -188,9 +191,12 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
         for h in range(n_head):
             q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h)
             p = torch.exp2(s / math.log(2.0) - lse.view(n_head, rows)[h, qs].unsqueeze(-1))
-            do, o = dO[qs, cs].float(), O[qs, cs].float()
-            dl = (do * o).sum(-1, keepdim=True)
-            delta.view(n_head, rows)[h, qs] = dl.squeeze(-1)
+            do = dO[qs, cs].float()
+            if O is not None:
+                dl = (do * O[qs, cs].float()).sum(-1, keepdim=True)
+                delta.view(n_head, rows)[h, qs] = dl.squeeze(-1)
+            else:
+                dl = delta.view(n_head, rows)[h, qs].unsqueeze(-1)
             dp = do @ v.t()
             pv = p
             if _on(drop):

@@ -448,3 +448,44 @@ def test_feat_stack_kernel():
     """st_feat_stack (CMVN + frame stacking + subsampling + ragged pack) against the oracle restatement of Dataset.py."""
     from tests import test_features_cpu as tf
     tf.run_stack_frames("cuda")
+
+
+@pytest.mark.parametrize("M,N,K,hd", [(333, 256, 256, 64), (1000, 128, 128, 32), (130, 512, 512, 64)])
+def test_gemm_dgrad_with_delta_epilogue(M, N, K, hd):
+    """ST_EPI_BF16_DELTA: the dgrad that produces d(context) also emits delta[h][i] = rowsum_h(d(context) * context)."""
+    dy, W, O = g(M, K, seed=1), g(K, N, seed=2, scale=K ** -0.5), g(M, N, seed=3)
+    H = N // hd
+    ref_d = torch.zeros(H * M, dtype=F32)
+    ref = em.gemm(dy, W, torch.zeros(M, N, dtype=BF16), aux=O, epi=nv.EPI_BF16_DELTA, y_cmajor=True, delta=ref_d,
+                  head_dim=hd)
+    got_d = torch.full((H * M,), float("nan"), dtype=F32, device="cuda")
+    got = nv.gemm(cu(dy), cu(W), torch.zeros(M, N, dtype=BF16, device="cuda"), aux=cu(O), epi=nv.EPI_BF16_DELTA,
+                  y_cmajor=True, delta=got_d, head_dim=hd)
+    check(got, ref, 1e-2, "dgrad+delta out")
+    # delta is a sum of products of bf16 values: compare against the kernel's OWN bf16 output to isolate the reduction
+    own = (got.float().cpu() * O.float()).view(M, H, hd).sum(-1).t().reshape(-1)
+    check(got_d, own, 1e-5, "dgrad+delta delta")
+
+
+@pytest.mark.parametrize("case", [(3, 4, 64, None, [200, 131, 64], False, True), (2, 4, 64, [50, 33], [1000, 517], False, True),
+                                  (2, 4, 32, None, [129, 70], True, True)])
+def test_attention_backward_single_launch(case):
+    """O = None: delta comes in precomputed and dQ + dK/dV run as one launch - identical results to the two-kernel path."""
+    c = _attn_case(*case, seed=31)
+    Q, K, V, dO = cu(c["Q"]), cu(c["K"]), cu(c["V"]), cu(c["dO"])
+    meta = [cu(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
+    O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
+    lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device="cuda")
+    nv.attn_fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], c["causal"], c["scale"], max_k=c["max_k"])
+    outs = []
+    for single in (False, True):
+        delta = torch.zeros_like(lse)
+        dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
+        dK, dV = (torch.zeros(c["Mk"], c["d"], dtype=BF16, device="cuda") for _ in range(2))
+        if single:
+            delta = outs[0][3].clone()
+        nv.attn_bwd(Q, K, V, None if single else O, dO, lse, delta, dQ, dK, dV, *meta, c["H"], c["max_q"], c["max_k"],
+                    c["causal"], c["scale"])
+        outs.append((dQ, dK, dV, delta))
+    for a, b, nm in zip(outs[0][:3], outs[1][:3], ("dQ", "dK", "dV")):
+        assert torch.equal(a, b), "single-launch backward changed %s" % nm
