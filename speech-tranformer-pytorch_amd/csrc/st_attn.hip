@@ -642,14 +642,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // dQ and dK/dV in ONE launch (possible when delta comes from the producer of dO: no kernel-to-kernel dependency
-// is left).  Workgroups [0, n_q) run the dQ body on the query-tile work list, the rest the dK/dV body on the
-// key-tile list; the long dK/dV items start while the dQ items drain.
+// is left).  Workgroups [0, n_k) run the dK/dV body on the key-tile work list (the heavier items: four
+// contractions per tile), the rest the dQ body on the query-tile list, which fills in as the dK/dV items drain.
 template <int DK, bool DROP, int KS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, AttnArgs ak, int n_q) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, AttnArgs ak, int n_k) {
   constexpr int EQ = 4 * TileGeo<DK, TILE * KS>::E, EK = 2 * (2 * TileGeo<DK>::E + 256);
   __shared__ __attribute__((aligned(16))) bf16 smem[EQ > EK ? EQ : EK];
-  if ((int)blockIdx.x < n_q) attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x, smem);
-  else attn_bwd_dkv_body<DK, DROP>(ak, blockIdx.x - n_q, smem);
+  if ((int)blockIdx.x < n_k) attn_bwd_dkv_body<DK, DROP>(ak, blockIdx.x, smem);
+  else attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x - n_k, smem);
 }
 
 int check_common(int d_k, int ldq, int ldk, int ldv) {
@@ -737,8 +737,8 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
     const int nq = plan(a, work_q, n_work_q, B, H, max_q), nk = plan(ak, work_k, n_work_k, B, H, max_k);
     dim3 grid(nq + nk);
 #define ST_BWD(DKK, DR) \
-  do { if (ks2) hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a, ak, nq); \
-       else hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a, ak, nq); } while (0)
+  do { if (ks2) hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a, ak, nk); \
+       else hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a, ak, nk); } while (0)
     if (d_k == 64 && !drop) ST_BWD(64, false);
     else if (d_k == 64) ST_BWD(64, true);
     else if (!drop) ST_BWD(32, false);
