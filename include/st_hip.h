@@ -98,6 +98,16 @@ int st_gemm_ln(st_stream_t stream, const void* X, int ldx, const void* W, int M,
                const float* pe, const int* pos, void* out, int ldo, void* xhat, float* rstd, void* pre,
                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int drop_where);
 
+/* Data-gradient GEMM + LayerNorm backward in one launch (the backward analogue of st_gemm_ln):
+ *   dy = bf16(dY W (+ aux)),  dx = LayerNorm-backward(dy; xhat, rstd, gamma),  dgamma/dbeta += ..., dbias += colsum(dx)
+ * dY bf16 [M, Kc], W bf16 [Kc, N] (ld ldw: an nn.Linear weight [out = Kc, in = N] as stored), N = d_model in
+ * {128, 256, 512}; identical to st_gemm(0, 1, .., ST_EPI_BF16[_ADD]) followed by st_ln_bwd, without dy going to
+ * HBM.  Used where a sublayer's input gradient is the previous sublayer's LayerNorm output gradient
+ * (SubLayers.py:25-27 -> Attention.py:94 backward, and so on down the stack). */
+int st_gemm_lnbwd(st_stream_t stream, const void* dY, int lddy, const void* W, int ldw, int M, int N, int Kc,
+                  const void* aux, int ldaux, const void* xhat, const float* rstd, const float* gamma, void* dx,
+                  int lddx, float* dgamma, float* dbeta, float* dbias);
+
 /* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
  * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).
  * mask (optional bf16 [M,N]): dx is zeroed where mask <= 0 (front-end ReLU,

@@ -34,6 +34,8 @@ SIGNATURES = {
     "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                    _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                    _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
+    "st_gemm_lnbwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int,
+                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_ln_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                   _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_float],
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -282,6 +284,26 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
                            *_drop(drop if drop_where in (1, 2) else None), int(drop_where))
     _check(rc, "st_gemm_ln")
     return out
+
+
+def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None):
+    """dx = LayerNorm-backward(bf16(dY W (+ aux)); xhat, rstd, gamma) in one launch; W is the nn.Linear weight
+    [Kc, N] as stored (contraction-major for this product).  == gemm(dY, W, tmp, y_cmajor=True[, ADD aux]) + ln_bwd."""
+    _mat(dY, BF16, "dY"), _mat(W, BF16, "W"), _mat(xhat, BF16, "xhat"), _mat(dx, BF16, "dx")
+    M, Kc = dY.shape
+    N = W.shape[1]
+    if W.shape[0] != Kc or xhat.stride(0) != N or xhat.shape[0] < M:
+        raise ValueError("gemm_lnbwd: inconsistent shapes")
+    if aux is not None:
+        _mat(aux, BF16, "aux")
+    _vec(rstd, F32, M, "rstd"), _vec(gamma, F32, N, "gamma")
+    _vec(dgamma, F32, N, "dgamma"), _vec(dbeta, F32, N, "dbeta"), _vec(dbias, F32, N, "dbias")
+    _tag("gemm_lnbwd", M, N, Kc)
+    rc = load().st_gemm_lnbwd(_stream(), dY.data_ptr(), dY.stride(0), W.data_ptr(), W.stride(0), M, N, Kc, _p(aux),
+                              0 if aux is None else aux.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                              dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias))
+    _check(rc, "st_gemm_lnbwd")
+    return dx
 
 
 def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None, drop=None, mask_scale=1.0):

@@ -136,6 +136,12 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
     return out
 
 
+def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None):
+    dy = torch.zeros(dY.shape[0], W.shape[1], dtype=BF16)
+    gemm(dY, W, dy, aux=aux, epi=nv.EPI_BF16_ADD if aux is not None else nv.EPI_BF16, y_cmajor=True)
+    return ln_bwd(dy, xhat[:dY.shape[0]], rstd, gamma, dx, dgamma, dbeta, dbias)
+
+
 def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None, drop=None, mask_scale=1.0):
     d, xh = dy.float(), xhat.float()
     if _on(drop):
@@ -287,7 +293,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "wgrad_group", "feat_stack", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16"]
 
 

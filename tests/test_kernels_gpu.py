@@ -489,3 +489,23 @@ def test_attention_backward_single_launch(case):
         outs.append((dQ, dK, dV, delta))
     for a, b, nm in zip(outs[0][:3], outs[1][:3], ("dQ", "dK", "dV")):
         assert torch.equal(a, b), "single-launch backward changed %s" % nm
+
+
+@pytest.mark.parametrize("M,N,K,with_aux", [(300, 128, 128, True), (1000, 256, 1024, True), (130, 256, 768, False),
+                                             (70, 512, 512, True), (999, 256, 256, True)])
+def test_gemm_lnbwd(M, N, K, with_aux):
+    """st_gemm_lnbwd == st_gemm (dgrad, + aux) followed by st_ln_bwd, in one launch."""
+    dY, W = g(M, K, seed=1), g(K, N, seed=2, scale=K ** -0.5)
+    aux = g(M, N, seed=3) if with_aux else None
+    xhat, rstd, gamma = g(M, N, seed=4), g(M, seed=5, dtype=F32).abs() + 0.5, 1 + 0.2 * g(N, seed=6, dtype=F32)
+
+    def run(fn, dev):
+        mv = (lambda t: None if t is None else t.to(dev))
+        dx = torch.zeros(M, N, dtype=BF16, device=dev)
+        acc = [torch.ones(N, dtype=F32, device=dev) for _ in range(3)]
+        fn(mv(dY), mv(W), mv(aux), mv(xhat), mv(rstd), mv(gamma), dx, acc[0], acc[1], acc[2])
+        return [dx] + acc
+
+    r, o = run(em.gemm_lnbwd, "cpu"), run(nv.gemm_lnbwd, "cuda")
+    for got, ref, nm, tol in zip(o, r, ("dx", "dgamma", "dbeta", "dbias"), (1.5e-2, 5e-3, 5e-3, 8e-3)):
+        check(got, ref, tol, "gemm_lnbwd %s %s" % ((M, N, K, with_aux), nm))
