@@ -431,8 +431,10 @@ struct GroupArgs {
   GroupProblem p[GROUP_MAX];
 };
 
-__global__ __launch_bounds__(512, 1) void gemm_wgrad_group_kernel(GroupArgs g) {
-  __shared__ __attribute__((aligned(16))) bf16 smem_all[SmemSize<2>::E];
+// Two 4-wave workgroups per CU, one k-range each (no intra-workgroup k split as in the single-problem launch): with
+// thousands of workgroups in a group, one workgroup's prologue and atomic epilogue hide behind its neighbour's k-loop.
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_group_kernel(GroupArgs g) {
+  __shared__ __attribute__((aligned(16))) bf16 smem_all[SmemSize<1>::E];
   int pi = 0;
   while (pi + 1 < g.n && (int)blockIdx.x >= g.first[pi + 1]) ++pi;   // workgroup-uniform
   const GroupProblem& p = g.p[pi];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(512, 1) void gemm_wgrad_group_kernel(GroupArgs g) {
   a.c_per_split = p.c_per_split; a.tiles_i = p.tiles_i; a.tiles_j = p.tiles_j; a.splits = p.splits;
   a.head_dim = 0;
   a.drop.seed = nullptr; a.drop.salt = 0; a.drop.thresh = 0; a.drop.scale = 1.f;
-  gemm_body<true, true, EPI_F32_ATOMIC_T, 2>(a, (int)blockIdx.x - g.first[pi], smem_all);
+  gemm_body<true, true, EPI_F32_ATOMIC_T, 1>(a, (int)blockIdx.x - g.first[pi], smem_all);
 }
 
 template <bool XT, bool YT>
@@ -500,7 +502,7 @@ extern "C" int st_wgrad_group(hipStream_t stream, int n, const void* const* X, c
       ++g.n;
     }
     if (g.n == 0) continue;
-    hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(g.first[g.n]), dim3(512), 0, stream, g);
+    hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(g.first[g.n]), dim3(256), 0, stream, g);
     ST_CHECK_LAUNCH();
   }
   return 0;

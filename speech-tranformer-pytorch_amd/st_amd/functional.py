@@ -155,17 +155,25 @@ def _splits(M: int, N: int, K: int) -> int:
 
 class _Deferred:
     """Weight-gradient launches produce nothing the rest of the backward pass reads (only parameter
-    gradients).  Inside ``deferred_wgrads()`` the decoder-sized ones (~20 workgroups each: pure launch latency
-    one by one, 36 of them per step) are therefore collected and issued as ONE grouped launch
-    (``st_wgrad_group``) once the decoder's backward is done (``flush_deferred_wgrads`` from EmbedFn.backward).
-    Measured on config 2: 36 launches x ~11 us -> one launch of ~30 us.  Moving that launch (or the individual
-    ones) to a second stream inside the captured graph was tried and is slower: a cross-queue dependency costs
-    ~50 us in a HIP graph, and the 8-wave workgroups of the grouped launch evict the encoder's backward from
-    whole CUs.  The operand tensors stay referenced by the list until the launch is enqueued."""
+    gradients).  Inside ``deferred_wgrads()`` they are therefore collected and issued as grouped launches
+    (``st_wgrad_group``): the decoder's when its backward is done (``flush_deferred_wgrads`` from
+    EmbedFn.backward), the encoder's on exit.  One by one the decoder-sized ones are pure launch latency
+    (~20 workgroups each, 36 per step) and the encoder-sized ones one round of ~250 workgroups whose prologue and
+    atomic epilogue nothing overlaps; grouped, ~2300 workgroups stream through the CUs back to back.
+    Measured on config 2: 1.15 ms in 32 launches -> ~0.55 ms in 2.  Moving the launches to
+    a second stream inside the captured graph was tried and is slower: a cross-queue dependency costs ~50 us in a
+    HIP graph.  The operand tensors stay referenced by the list until the launch is enqueued."""
     active = False
     pending = []
-    MAX_ROWS = 4096     # only launches that cannot fill the GPU are worth deferring
-    SPLITS = 1          # per deferred problem (measured: 1 beats 2 and 4 - the group as a whole already fills the GPU)
+    ROWS_PER_SPLIT = 3072     # ~48 k-steps per workgroup; measured on config 2 (24060 rows): 8 splits beat 4, 12 and 16
+
+    @staticmethod
+    def splits(rows: int) -> int:
+        """Power of two (the kernel's XCD-local tile walk keeps whole splits on one XCD); 1 for decoder-sized problems."""
+        want, s = max(1, round(rows / _Deferred.ROWS_PER_SPLIT)), 1
+        while s * 2 <= want:
+            s *= 2
+        return s
 
 
 def flush_deferred_wgrads():
@@ -175,8 +183,8 @@ def flush_deferred_wgrads():
 
 
 class deferred_wgrads:
-    """Context manager around loss.backward(): batch the small weight-gradient GEMMs into one grouped launch
-    (flushed at the end of the decoder's backward, or on exit)."""
+    """Context manager around loss.backward(): batch the weight-gradient GEMMs into grouped launches
+    (flushed at the end of the decoder's backward and on exit)."""
 
     def __init__(self, enable: bool = True):
         self.enable = enable
@@ -197,9 +205,8 @@ def wgrad(dY, X, gW, rows=None, gB=None):
     ``gB``: the same launch also accumulates the bias gradient gB[n] += sum_m dY[m][n]."""
     N = dY.shape[1] if rows is None else rows
     splits = _splits(dY.shape[0], N, X.shape[1])
-    if _Deferred.active and dY.shape[0] <= _Deferred.MAX_ROWS:
-        # the group as a whole fills the GPU: no split-K per problem (fewer atomics, longer k-loops per workgroup)
-        _Deferred.pending.append((X, dY, gW, gB, _Deferred.SPLITS, N))      # the argument tuple of nv.wgrad_group
+    if _Deferred.active:
+        _Deferred.pending.append((X, dY, gW, gB, _Deferred.splits(dY.shape[0]), N))   # the argument tuple of nv.wgrad_group
         return
     nv.gemm(X, dY, gW, bias=gB, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=splits, n=N)
 
@@ -224,12 +231,57 @@ class CrossGradAcc:
         self.n, self.seen, self.buf = n, 0, None
 
 
+class LnLink:
+    """Joins two consecutive sublayers S1 -> S2 of one forward pass so that S2's backward can run S1's LayerNorm
+    backward inside its own last dgrad GEMM (``nv.gemm_lnbwd``): S1 (the LayerNorm's owner) records what that needs
+    in its forward; S2's backward consumes it, leaves the result in ``ds`` and returns it as its input gradient;
+    S1's backward recognises that tensor and skips its own ``ln_bwd``.  Valid only while S1's output has S2 as its
+    single consumer (the layer stacks guarantee it); anything else arriving at S1 raises."""
+    __slots__ = ("ok", "st", "arena", "xhat", "rstd", "g_bias", "ds")
+
+    def __init__(self):
+        self.ok, self.ds = False, None
+
+    def offer(self, mod, xhat, rstd, g_bias):
+        """S1.forward: the LayerNorm output is used as is (no dropout / mask on it), so S2 may fuse its backward."""
+        self.ok, self.st, self.arena, self.xhat, self.rstd, self.g_bias = True, mod._st, mod._st_arena, xhat, rstd, g_bias
+
+    def fused_dgrad(self, dY, W, aux):
+        """S2.backward: d(S2 input) = dY W + aux, pushed through S1's LayerNorm backward in the same launch."""
+        st = self.st
+        self.arena.attach_grads(st.params, st.lo, st.hi)      # before the kernel accumulates into S1's slots
+        ds = _empty(dY.shape[0], W.shape[1], dY)
+        nv.gemm_lnbwd(dY, W, aux, self.xhat, self.rstd, st.gamma, ds, st.g_gamma, st.g_beta, self.g_bias)
+        self.ds = ds
+        return ds
+
+    def claim(self, dout):
+        """S1.backward: the already-normalised gradient if S2 produced it, else None (run ln_bwd as usual)."""
+        ds, self.ds = self.ds, None
+        if ds is None:
+            return None
+        if dout.data_ptr() != ds.data_ptr() or dout.shape != ds.shape:
+            raise RuntimeError("LnLink: the gradient reaching this sublayer is not the one its consumer fused the "
+                               "LayerNorm backward into (its output has more than one consumer?)")
+        return ds
+
+
+def _input_grad(link, dY, W, aux):
+    """The last GEMM of a sublayer's backward: its input gradient, fused with the upstream LayerNorm when linked."""
+    if link is not None and link.ok:
+        return link.fused_dgrad(dY, W, aux)
+    dx = _empty(dY.shape[0], W.shape[1], dY)
+    dgrad(dY, W, dx, epi=nv.EPI_BF16_ADD, aux=aux)
+    return dx
+
+
 class MhaFn(torch.autograd.Function):
     """out = LN(attn(x_q W_q, x_kv W_k, x_kv W_v) W_o + b_o + x_q)   (Attention.py:64-96, R2)."""
 
     @staticmethod
     def forward(ctx, x_q, x_kv, anchor, mod, q_rows: Rows, k_rows: Rows, causal: bool, want_attn: bool, drop=None,
-                kv_acc=None):
+                kv_acc=None, up=None, down=None):
+        """up / down: LnLink to the sublayer that produced x_q / that consumes the output (see LnLink)."""
         s = mod._st
         d, H = s.d_model, s.n_head
         Mq = x_q.shape[0]
@@ -257,6 +309,9 @@ class MhaFn(torch.autograd.Function):
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
         ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers sum their encoder gradient into one buffer
+        ctx.up, ctx.down = up, down
+        if down is not None:
+            down.offer(mod, xhat, rstd, s.g_b_o)
         return out
 
     @staticmethod
@@ -268,8 +323,10 @@ class MhaFn(torch.autograd.Function):
         Mq = x_q.shape[0]
         dout = dout.contiguous()
         arena.attach_grads(s.params, s.lo, s.hi)
-        ds = _empty(Mq, d, x_q)
-        nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b_o)
+        ds = ctx.down.claim(dout) if ctx.down is not None else None
+        if ds is None:
+            ds = _empty(Mq, d, x_q)
+            nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b_o)
         wgrad(ds, attn_ctx, s.g_w_o)
         dctx = _empty(Mq, d, x_q)
         delta = torch.empty(H * Mq, dtype=F32, device=x_q.device)
@@ -290,14 +347,13 @@ class MhaFn(torch.autograd.Function):
         work_q, work_k = attn_work(q_rows, k_rows, ctx.causal)
         nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
                     q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop)
-        dx_q = _empty(Mq, d, x_q)
         dx_kv = None
         if x_kv is None:
             wgrad(dqkv, x_q, s.g_w_qkv, gB=s.g_b_qkv)
-            dgrad(dqkv, s.w_qkv, dx_q, epi=nv.EPI_BF16_ADD, aux=ds)
+            dx_q = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dqkv, s.w_qkv, ds)
         else:
             wgrad(dqkv, x_q, s.g_w_q, gB=s.g_b_q)
-            dgrad(dqkv, s.w_q, dx_q, epi=nv.EPI_BF16_ADD, aux=ds)
+            dx_q = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dqkv, s.w_q, ds)
             wgrad(dkv, x_kv, s.g_w_kv, gB=s.g_b_kv)
             acc = ctx.kv_acc
             if acc is None:
@@ -315,15 +371,16 @@ class MhaFn(torch.autograd.Function):
                 if acc.seen == acc.n:
                     dx_kv, acc.buf, acc.seen = acc.buf, None, 0
         arena.grads_ready(s.lo, s.hi)
-        return dx_q, dx_kv, None, None, None, None, None, None, None, None
+        return dx_q, dx_kv, None, None, None, None, None, None, None, None, None, None
 
 
 class FfnFn(torch.autograd.Function):
     """out = LN(x + fc2(relu(fc1(x))))   (SubLayers.py:24-28)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mod, drop1=None, drop2=None):
-        """drop1: dropout after the ReLU (SubLayers.py:25); drop2: on the LayerNorm output (SubLayers.py:27)."""
+    def forward(ctx, x, anchor, mod, drop1=None, drop2=None, up=None, down=None):
+        """drop1: dropout after the ReLU (SubLayers.py:25); drop2: on the LayerNorm output (SubLayers.py:27);
+        up / down: LnLink to the sublayer that produced x / that consumes the output."""
         s = mod._st
         M, d = x.shape
         h = _empty(M, s.d_ff, x)
@@ -334,6 +391,9 @@ class FfnFn(torch.autograd.Function):
                    drop_where=2 if drop2 is not None else 0)
         ctx.save_for_backward(x, h, xhat, rstd)
         ctx.mod, ctx.drop1, ctx.drop2 = mod, drop1, drop2
+        ctx.up, ctx.down = up, down
+        if down is not None and drop2 is None:       # a dropped LayerNorm output keeps its own (mask-regenerating) ln_bwd
+            down.offer(mod, xhat, rstd, s.g_b2)
         return out
 
     @staticmethod
@@ -344,16 +404,17 @@ class FfnFn(torch.autograd.Function):
         M, d = x.shape
         dout = dout.contiguous()
         arena.attach_grads(s.params, s.lo, s.hi)
-        ds = _empty(M, d, x)
-        nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b2, drop=ctx.drop2)
+        ds = ctx.down.claim(dout) if ctx.down is not None else None
+        if ds is None:
+            ds = _empty(M, d, x)
+            nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b2, drop=ctx.drop2)
         wgrad(ds, h, s.g_w2)
         dh = _empty(M, s.d_ff, x)
         dgrad(ds, s.w2, dh, epi=nv.EPI_BF16_MASK, aux=h, drop=ctx.drop1)   # h is the dropped activation: 0 where dropped
         wgrad(dh, x, s.g_w1, gB=s.g_b1)
-        dx = _empty(M, d, x)
-        dgrad(dh, s.w1, dx, epi=nv.EPI_BF16_ADD, aux=ds)
+        dx = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dh, s.w1, ds)
         arena.grads_ready(s.lo, s.hi)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class FrontendFn(torch.autograd.Function):

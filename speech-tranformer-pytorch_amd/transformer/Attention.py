@@ -76,12 +76,13 @@ class MultiHeadAttention(nn.Module):
         return rng.site(device, self.dropout.p) if self.training else None
 
     # ---- fast path: bf16 row matrices ----------------------------------------------------------
-    def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal, kv_acc=None):
-        """x_q [Mq, d] (and x_kv [Mk, d] for cross-attention, else None) bf16 row matrices."""
+    def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal, kv_acc=None, up=None, down=None):
+        """x_q [Mq, d] (and x_kv [Mk, d] for cross-attention, else None) bf16 row matrices.
+        up / down: st_amd.functional.LnLink shared with the sublayer before / after this one (layer stacks only)."""
         arena = arena_of(self)
         with arena.scope():
             return F_.MhaFn.apply(x_q, x_kv, self.linear_q.weight, self, q_rows, k_rows, bool(causal), False,
-                                  self._drop(x_q.device), kv_acc)
+                                  self._drop(x_q.device), kv_acc, up, down)
 
     # ---- reference API -------------------------------------------------------------------------
     def forward(self, q, k, v, mask=None):

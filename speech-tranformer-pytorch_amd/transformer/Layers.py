@@ -1,8 +1,19 @@
 """Encoder / decoder layers (drop-in for reference transformer/Layers.py:8-44)."""
+import os
+
+import torch
 import torch.nn as nn
+
+from st_amd.functional import LnLink
 
 from transformer.Attention import MultiHeadAttention
 from transformer.SubLayers import PositionwiseFeedForward
+
+
+def _links(n):
+    """LnLinks only when a backward pass will follow."""
+    on = torch.is_grad_enabled() and not os.environ.get("ST_NO_LNLINK")     # the switch is for A/B timing only
+    return [LnLink() if on else None for _ in range(n)]
 
 
 class EncoderLayer(nn.Module):
@@ -13,8 +24,13 @@ class EncoderLayer(nn.Module):
         self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner_hid, dropout=dropout)
 
-    def forward_rows(self, x, rows):
-        return self.pos_ffn.forward_rows(self.slf_attn.forward_rows(x, None, rows, rows, False))
+    def forward_rows(self, x, rows, up=None):
+        """-> (output rows, LnLink the next layer may pass back as ``up``).  The links let each sublayer's backward
+        run the previous sublayer's LayerNorm backward inside its last GEMM; they require that nothing but the next
+        sublayer consumes the intermediate tensors, which holds inside the stacks."""
+        l1, l2 = _links(2)
+        a = self.slf_attn.forward_rows(x, None, rows, rows, False, up=up, down=l1)
+        return self.pos_ffn.forward_rows(a, up=l1, down=l2), l2
 
     def forward(self, inputs, slf_attn_mask=None):
         a, w = self.slf_attn(inputs, inputs, inputs, mask=slf_attn_mask)
@@ -30,10 +46,12 @@ class DecoderLayer(nn.Module):
         self.enc_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner_hid, dropout=dropout)
 
-    def forward_rows(self, y, enc, t_rows, in_rows, kv_acc=None):
-        s = self.slf_attn.forward_rows(y, None, t_rows, t_rows, True)
-        c = self.enc_attn.forward_rows(s, enc, t_rows, in_rows, False, kv_acc=kv_acc)
-        return self.pos_ffn.forward_rows(c)
+    def forward_rows(self, y, enc, t_rows, in_rows, kv_acc=None, up=None):
+        """-> (output rows, LnLink for the next layer); see EncoderLayer.forward_rows."""
+        l1, l2, l3 = _links(3)
+        s = self.slf_attn.forward_rows(y, None, t_rows, t_rows, True, up=up, down=l1)
+        c = self.enc_attn.forward_rows(s, enc, t_rows, in_rows, False, kv_acc=kv_acc, up=l1, down=l2)
+        return self.pos_ffn.forward_rows(c, up=l2, down=l3), l3
 
     def forward(self, inputs, enc_output, slf_attn_mask=None, dec_enc_attn_mask=None):
         s, w1 = self.slf_attn(inputs, inputs, inputs, mask=slf_attn_mask)

@@ -71,8 +71,9 @@ class Encoder(nn.Module):
                 xp = F_.PackFn.apply(inputs.float(), rows)
             drop = rng.site(xp.device, self.input_proj[2].p) if self.training else None   # Models.py:31: p = 0.5
             e = F_.FrontendFn.apply(xp, self.input_proj[0].weight, self, rows, drop)
+            link = None                         # FrontendFn's LayerNorm output is masked/offset: not linked
             for layer in self.layer_stack:
-                e = layer.forward_rows(e, rows)
+                e, link = layer.forward_rows(e, rows, link)
         return e, rows
 
     def forward(self, inputs, inputs_length, return_attns=False):
@@ -109,8 +110,9 @@ class Decoder(nn.Module):
             y = F_.EmbedFn.apply(self.tgt_word_emb.weight, self, tokens.contiguous(), t_rows)
             # one accumulator for the encoder gradient of all layers (only when the encoder output needs one)
             acc = F_.CrossGradAcc(len(self.layer_stack)) if enc_rows_mat.requires_grad else None
+            link = None
             for layer in self.layer_stack:
-                y = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows, acc)
+                y, link = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows, acc, link)
         return y, t_rows
 
     def forward(self, outputs_data, outputs_pos, input_pos, enc_output, return_attns=False):

@@ -37,12 +37,12 @@ class PositionwiseFeedForward(nn.Module):
                       g_w1=a.grad_view(f1.weight), g_b1=a.grad_view(f1.bias), g_w2=a.grad_view(f2.weight),
                       g_b2=a.grad_view(f2.bias), g_gamma=a.grad_view(ln.weight), g_beta=a.grad_view(ln.bias))
 
-    def forward_rows(self, x):
+    def forward_rows(self, x, up=None, down=None):
         d1 = rng.site(x.device, self.dropout1.p) if self.training else None      # SubLayers.py:25
         d2 = rng.site(x.device, self.dropout2.p) if self.training else None      # SubLayers.py:27 (after the LN)
         arena = arena_of(self)
         with arena.scope():
-            return F_.FfnFn.apply(x, self.fc1.weight, self, d1, d2)
+            return F_.FfnFn.apply(x, self.fc1.weight, self, d1, d2, up, down)
 
     def forward(self, inputs):
         shape = inputs.shape
