@@ -75,6 +75,18 @@ int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int l
             int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits,
             const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
+/* st_gemm whose Y operand (and bias) is a stack of equally shaped blocks lying y_block_stride (bias_block_stride)
+ * elements apart in memory - the same nn.Linear weight of consecutive identical layers as the parameter arena
+ * lays them out.  Forward (0,0): N = blocks * y_block_rows output columns, block b = rows [b * y_block_rows, ..);
+ * dgrad (0,1): Kc = blocks * y_block_rows, i.e. D = sum_b X[:, block b] W_b.  y_block_rows: a power of two >= 128
+ * (0 = plain st_gemm).  Used for the decoder-encoder attention of ALL decoder layers at once: their key/value
+ * projections of the encoder output (Attention.py:75-76, one launch instead of one per layer) and the matching
+ * input gradient.  Not available for the split-K / DELTA epilogues. */
+int st_gemm_stacked(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
+                    void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits,
+                    const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int y_block_rows,
+                    long y_block_stride, long bias_block_stride);
+
 /* n weight-gradient problems in ONE launch (the decoder's are ~20 workgroups
  * each: launched one by one they are pure latency).  Problem q:
  *   dW[q][N_out, K_in] (f32, ld lddw) += dY[q]^T X[q],  db[q][N_out] += colsum(dY[q])   (db or db[q] may be NULL)

@@ -49,6 +49,10 @@ struct GemmArgs {
   const bf16* aux; int ldaux;
   int c_per_split, tiles_i, tiles_j, splits;
   int head_dim;    // EPI_BF16_DELTA: columns per attention head (32 or 64)
+  // Y (and the bias) may be a stack of equally spaced blocks - the same weight of consecutive identical layers as it
+  // lies in the parameter arena: row r of the stack is row (r & (2^yseg_shift - 1)) of block r >> yseg_shift, blocks
+  // yseg_extra + 2^yseg_shift * ldy elements apart (bias blocks: bias_extra + 2^yseg_shift).  yseg_shift = 31: one block.
+  int yseg_shift; long yseg_extra, bias_extra;
   DropArgs drop;   // EPI_BF16_RELU: dropout after the ReLU (SubLayers.py:25); EPI_BF16_MASK: .scale on the survivors
 };
 
@@ -186,16 +190,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
   Addr<YT> ady;
   adx.init(tid, a.ldx, i0, a.M);
   ady.init(tid, a.ldy, j0, a.N);
+  // block of a stacked Y this tile / k-tile reads (tiles never straddle blocks: block rows are a multiple of 128)
+  const bf16* const Yn = a.Y + (YT ? 0 : (long)(j0 >> a.yseg_shift) * a.yseg_extra);
+  auto ybase = [&](int c0) { return YT ? a.Y + (long)(c0 >> a.yseg_shift) * a.yseg_extra : Yn; };
   // two k-tiles in flight in registers (A: even tiles, B: odd tiles) + one in LDS being consumed
   Stage<XT> ax, bx;
   Stage<YT> ay, by;
   auto loadA = [&](int kt) {
     ax.load(tid, adx, a.X, a.ldx, c_begin + kt * BK, c_end);
-    ay.load(tid, ady, a.Y, a.ldy, c_begin + kt * BK, c_end);
+    ay.load(tid, ady, ybase(c_begin + kt * BK), a.ldy, c_begin + kt * BK, c_end);
   };
   auto loadB = [&](int kt) {
     bx.load(tid, adx, a.X, a.ldx, c_begin + kt * BK, c_end);
-    by.load(tid, ady, a.Y, a.ldy, c_begin + kt * BK, c_end);
+    by.load(tid, ady, ybase(c_begin + kt * BK), a.ldy, c_begin + kt * BK, c_end);
   };
   auto storeA = [&]() { ax.store(tid, xs(0)); ay.store(tid, ys(0)); };
   auto storeB = [&]() { bx.store(tid, xs(1)); by.store(tid, ys(1)); };
@@ -319,8 +326,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int j = jb + y * 32 + 8 * g + 4 * hi;
-      bv[y][g] = *reinterpret_cast<const f32x4*>((EPI != EPI_BF16_DELTA && a.bias != nullptr && j < a.N) ? a.bias + j
-                                                                                                           : g_zero_f32);
+      bv[y][g] = *reinterpret_cast<const f32x4*>((EPI != EPI_BF16_DELTA && a.bias != nullptr && j < a.N)
+                                                     ? a.bias + j + (YT ? 0 : (long)(j >> a.yseg_shift) * a.bias_extra)
+                                                     : g_zero_f32);
     }
   if (EPI == EPI_F32 || EPI == EPI_F32_ATOMIC) {   // logits (row-per-lane fp32 vectors)
 #pragma unroll
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_group_kernel(GroupArgs g) {
   a.X = p.X; a.ldx = p.ldx; a.Y = p.Y; a.ldy = p.ldy; a.D = p.D; a.ldd = p.ldd;
   a.M = p.M; a.N = p.N; a.Kc = p.Kc; a.bias = p.bias; a.aux = nullptr; a.ldaux = 0;
   a.c_per_split = p.c_per_split; a.tiles_i = p.tiles_i; a.tiles_j = p.tiles_j; a.splits = p.splits;
-  a.head_dim = 0;
+  a.head_dim = 0; a.yseg_shift = 31; a.yseg_extra = 0; a.bias_extra = 0;
   a.drop.seed = nullptr; a.drop.salt = 0; a.drop.thresh = 0; a.drop.scale = 1.f;
   gemm_body<true, true, EPI_F32_ATOMIC_T, 1>(a, (int)blockIdx.x - g.first[pi], smem_all);
 }
@@ -508,10 +516,19 @@ extern "C" int st_wgrad_group(hipStream_t stream, int n, const void* const* X, c
   return 0;
 }
 
-extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
-                       void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi,
-                       int splits, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale) {
+extern "C" int st_gemm_stacked(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y,
+                               int ldy, void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux,
+                               int ldaux, int epi, int splits, const unsigned* drop_seed, unsigned drop_salt,
+                               int drop_thresh, float drop_scale, int y_block_rows, long y_block_stride,
+                               long bias_block_stride) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
+  int yseg_shift = 31;
+  if (y_block_rows > 0) {   // power-of-two multiple of 128 rows per block; forward and dgrad operands only
+    if (y_block_rows < 128 || (y_block_rows & (y_block_rows - 1)) || x_cmajor || (y_block_stride & 7) ||
+        (bias_block_stride & 3)) return -7;
+    if (epi == EPI_F32_ATOMIC || epi == EPI_F32_ATOMIC_T || epi == EPI_BF16_DELTA) return -7;
+    yseg_shift = __builtin_ctz(y_block_rows);
+  }
   if ((ldx & 7) || (ldy & 7) || (N & 3) || epi < 0 || epi > 7) return -1;
   if (x_cmajor && !y_cmajor) return -2;  // not needed by any caller
   // contraction-major operands are read in 8-row chunks: the caller guarantees the buffer is
@@ -526,6 +543,10 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T) splits = 1;
   a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
   a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux;
+  a.yseg_shift = yseg_shift;
+  // per block: what the plain row stride does not already cover (rows run along the contraction axis for dgrad)
+  a.yseg_extra = y_block_rows > 0 ? y_block_stride - (long)y_block_rows * ldy : 0;
+  a.bias_extra = y_block_rows > 0 ? bias_block_stride - (long)y_block_rows : 0;
   const bool drop = epi == EPI_BF16_RELU && drop_seed != nullptr && drop_thresh > 0;
   a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
   a.drop.scale = (drop || epi == EPI_BF16_MASK) && drop_scale > 0.f ? drop_scale : 1.f;
@@ -537,4 +558,11 @@ extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const voi
   if (rc) return rc;
   ST_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
+                       void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi,
+                       int splits, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale) {
+  return st_gemm_stacked(stream, x_cmajor, y_cmajor, X, ldx, Y, ldy, D, ldd, M, N, Kc, bias, aux, ldaux, epi, splits,
+                         drop_seed, drop_salt, drop_thresh, drop_scale, 0, 0, 0);
 }

@@ -231,6 +231,72 @@ class CrossGradAcc:
         self.n, self.seen, self.buf = n, 0, None
 
 
+class CrossKv:
+    """The key/value projections of the encoder output for ALL decoder layers (Attention.py:75-76 of every
+    decoder-encoder attention) as one GEMM, and their input gradient as one GEMM: the layers' [2d, d] weights are
+    equally spaced in the parameter arena, so ``st_gemm_stacked`` reads them as one [n * 2d, d] operand.  Takes 2n
+    full-size launches out of the decoder's (latency-bound) chain.  Layer l reads columns [l * 2d, (l + 1) * 2d) of
+    ``kv`` and writes its dK | dV into the same columns of ``dkv``; the last layer to run backward (layer 0) hands
+    ``dkv`` to CrossKvFn.backward as THE gradient of ``kv`` (the other layers return None for it)."""
+    __slots__ = ("mods", "n", "w_stride", "b_stride", "seen", "dkv")
+
+    def __init__(self, mods, w_stride, b_stride):
+        self.mods, self.n, self.w_stride, self.b_stride, self.seen, self.dkv = mods, len(mods), w_stride, b_stride, 0, None
+
+    @staticmethod
+    def plan(mods):
+        """-> CrossKv for these decoder-encoder attention modules, or None when one GEMM cannot serve them
+        (different shapes, unequal spacing, live gradient-ready hooks that expect per-layer weight gradients)."""
+        if len(mods) < 2:
+            return None
+        a = mods[0]._st_arena
+        if a is None or any(m._st_arena is not a for m in mods) or a._grad_ready_cb is not None:
+            return None
+        d = mods[0]._st.d_model
+        if any(m._st.d_model != d or m._st.n_head != mods[0]._st.n_head for m in mods) or (2 * d) & (2 * d - 1) or d < 64:
+            return None
+        w_off = [a.offset[id(m.linear_k.weight)] for m in mods]
+        b_off = [a.offset[id(m.linear_k.bias)] for m in mods]
+        ws, bs = w_off[1] - w_off[0], b_off[1] - b_off[0]
+        if ws <= 0 or bs <= 0 or any(w_off[i + 1] - w_off[i] != ws or b_off[i + 1] - b_off[i] != bs for i in range(len(mods) - 1)):
+            return None
+        return CrossKv(list(mods), ws, bs)
+
+
+class CrossKvSlot:
+    """What layer ``idx`` is handed instead of a CrossGradAcc: its column block of the shared CrossKv buffers."""
+    __slots__ = ("state", "idx")
+
+    def __init__(self, state, idx):
+        self.state, self.idx = state, idx
+
+
+class CrossKvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, anchor, state: CrossKv):
+        s0 = state.mods[0]._st
+        kv = _empty(enc.shape[0], state.n * 2 * s0.d_model, enc)
+        nv.gemm(enc, s0.w_kv, kv, bias=s0.b_kv, stack=(state.n, state.w_stride, state.b_stride))
+        ctx.save_for_backward(enc)
+        ctx.state = state
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        enc, = ctx.saved_tensors
+        state = ctx.state
+        s0 = state.mods[0]._st
+        w = 2 * s0.d_model
+        dkv = dkv.contiguous()
+        for l, m in enumerate(state.mods):
+            s = m._st
+            m._st_arena.attach_grads(s.params, s.lo, s.hi)
+            wgrad(dkv[:, l * w:(l + 1) * w], enc, s.g_w_kv, gB=s.g_b_kv)
+        d_enc = _empty(enc.shape[0], s0.d_model, enc)
+        nv.gemm(dkv, s0.w_kv, d_enc, y_cmajor=True, stack=(state.n, state.w_stride, 0))
+        return d_enc, None, None
+
+
 class LnLink:
     """Joins two consecutive sublayers S1 -> S2 of one forward pass so that S2's backward can run S1's LayerNorm
     backward inside its own last dgrad GEMM (``nv.gemm_lnbwd``): S1 (the LayerNorm's owner) records what that needs
@@ -294,8 +360,11 @@ class MhaFn(torch.autograd.Function):
         else:
             qkv = _empty(Mq, d, x_q)
             nv.gemm(x_q, s.w_q, qkv, bias=s.b_q)
-            kvbuf = _empty(x_kv.shape[0], 2 * d, x_q)
-            nv.gemm(x_kv, s.w_kv, kvbuf, bias=s.b_kv)
+            if isinstance(kv_acc, CrossKvSlot):       # x_kv is CrossKv's buffer: this layer's K | V are already in it
+                kvbuf = x_kv[:, kv_acc.idx * 2 * d:(kv_acc.idx + 1) * 2 * d]
+            else:
+                kvbuf = _empty(x_kv.shape[0], 2 * d, x_q)
+                nv.gemm(x_kv, s.w_kv, kvbuf, bias=s.b_kv)
             Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
         attn_ctx = _empty(Mq, d, x_q)
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
@@ -308,7 +377,7 @@ class MhaFn(torch.autograd.Function):
         ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
-        ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers sum their encoder gradient into one buffer
+        ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers share one encoder-gradient buffer (or CrossKv's)
         ctx.up, ctx.down = up, down
         if down is not None:
             down.offer(mod, xhat, rstd, s.g_b_o)
@@ -341,8 +410,15 @@ class MhaFn(torch.autograd.Function):
         else:
             Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
             dqkv = _empty(Mq, d, x_q)
-            dkv = _empty(x_kv.shape[0], 2 * d, x_q) if k_rows.dense else \
-                torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
+            slot = ctx.kv_acc if isinstance(ctx.kv_acc, CrossKvSlot) else None
+            if slot is not None:
+                st = slot.state
+                if st.dkv is None:
+                    st.dkv = _empty(*x_kv.shape, x_q) if k_rows.dense else torch.zeros_like(x_kv)
+                dkv = st.dkv[:, slot.idx * 2 * d:(slot.idx + 1) * 2 * d]
+            else:
+                dkv = _empty(x_kv.shape[0], 2 * d, x_q) if k_rows.dense else \
+                    torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
         work_q, work_k = attn_work(q_rows, k_rows, ctx.causal)
         nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
@@ -354,14 +430,20 @@ class MhaFn(torch.autograd.Function):
         else:
             wgrad(dqkv, x_q, s.g_w_q, gB=s.g_b_q)
             dx_q = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dqkv, s.w_q, ds)
-            wgrad(dkv, x_kv, s.g_w_kv, gB=s.g_b_kv)
             acc = ctx.kv_acc
-            if acc is None:
+            if slot is not None:
+                # weight and input gradients of all layers' K/V projections: CrossKvFn.backward, from the whole dkv
+                st.seen += 1
+                if st.seen == st.n:
+                    dx_kv, st.dkv, st.seen = st.dkv, None, 0
+            elif acc is None:
+                wgrad(dkv, x_kv, s.g_w_kv, gB=s.g_b_kv)
                 dx_kv = _empty(x_kv.shape[0], d, x_q)
                 dgrad(dkv, s.w_kv, dx_kv)
             else:
                 # every decoder layer attends the same encoder output: instead of handing autograd N gradients
                 # to add, the GEMM epilogues accumulate into one buffer and the last layer to run (layer 0) returns it
+                wgrad(dkv, x_kv, s.g_w_kv, gB=s.g_b_kv)
                 if acc.buf is None:
                     acc.buf = _empty(x_kv.shape[0], d, x_q)
                     dgrad(dkv, s.w_kv, acc.buf)

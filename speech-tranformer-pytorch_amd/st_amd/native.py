@@ -23,12 +23,16 @@ EPI_BF16, EPI_BF16_RELU, EPI_F32, EPI_BF16_MASK, EPI_BF16_ADD, EPI_F32_ATOMIC, E
 
 _c_int, _c_float, _c_void_p, _c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 _c_uint = ctypes.c_uint
+_c_long = ctypes.c_long
 
 # name -> argtypes (restype is int everywhere); must mirror include/st_hip.h exactly.
 SIGNATURES = {
     "st_version": [],
     "st_gemm": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                 _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
+    "st_gemm_stacked": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
+                        _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int,
+                        _c_float, _c_int, _c_long, _c_long],
     "st_wgrad_group": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                        _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
@@ -201,8 +205,11 @@ def _drop(d: Optional["Drop"]):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1,
-         m=None, n=None, kc=None, drop=None, delta=None, head_dim=0):
+         m=None, n=None, kc=None, drop=None, delta=None, head_dim=0, stack=None):
     """out[i][j] (+)= sum_c X(i,c) Y(j,c).  ``*_cmajor``: that tensor is stored [c, rows].
+    ``stack = (blocks, stride, bias_stride)``: Y (and bias) is the FIRST of ``blocks`` equally shaped blocks lying
+    ``stride`` (``bias_stride``) elements apart - the same weight of consecutive identical layers in the parameter
+    arena; the operand is their vertical stack (more output columns forward, a longer contraction for dgrad).
     EPI_BF16_DELTA: additionally delta[h][i] = sum over head h's ``head_dim`` columns of out(i, .) * aux(i, .)
     (fp32 [N / head_dim, M]) - the attention backward's rowsum(dO * O), produced by the GEMM that produces dO."""
     _mat(X, BF16, "X"), _mat(Y, BF16, "Y")
@@ -210,10 +217,18 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
     M = m if m is not None else (X.shape[1] if x_cmajor else X.shape[0])
     N = n if n is not None else (Y.shape[1] if y_cmajor else Y.shape[0])
     Kc = kc if kc is not None else (X.shape[0] if x_cmajor else X.shape[1])
+    blocks, block_rows, y_stride, b_stride = 1, 0, 0, 0
+    if stack is not None:
+        blocks, y_stride, b_stride = stack
+        block_rows = Y.shape[0]
+        if y_cmajor:
+            Kc = blocks * block_rows
+        else:
+            N = blocks * block_rows
     need = (N, M) if epi == EPI_F32_ATOMIC_T else (M, N)
     if out.shape[0] < need[0] or out.shape[1] < need[1]:
         raise ValueError("gemm: out %s too small for %dx%d" % (tuple(out.shape), need[0], need[1]))
-    _vec(bias, F32, N, "bias")
+    _vec(bias, F32, N // blocks if not y_cmajor else N, "bias")
     if epi == EPI_BF16_DELTA:
         if head_dim not in (32, 64) or N % head_dim:
             raise ValueError("gemm: EPI_BF16_DELTA needs head_dim in {32, 64} dividing N")
@@ -224,9 +239,15 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
         _mat(aux, BF16, "aux")
         ldaux = aux.stride(0)
     _tag("gemm", int(x_cmajor), int(y_cmajor), M, N, Kc, epi)
-    rc = load().st_gemm(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0),
-                        out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux, epi, splits,
-                        *(_drop(drop) if epi in (EPI_BF16_RELU, EPI_BF16_MASK) else _drop(None)))
+    dropargs = _drop(drop) if epi in (EPI_BF16_RELU, EPI_BF16_MASK) else _drop(None)
+    if stack is None:
+        rc = load().st_gemm(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(),
+                            Y.stride(0), out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux, epi, splits,
+                            *dropargs)
+    else:
+        rc = load().st_gemm_stacked(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(),
+                                    Y.stride(0), out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux,
+                                    epi, splits, *dropargs, block_rows, y_stride, b_stride)
     _check(rc, "st_gemm")
     return out
 

@@ -108,11 +108,18 @@ class Decoder(nn.Module):
             if t_rows is None:
                 t_rows = F_.Rows.packed(tgt_len, tokens.device)
             y = F_.EmbedFn.apply(self.tgt_word_emb.weight, self, tokens.contiguous(), t_rows)
-            # one accumulator for the encoder gradient of all layers (only when the encoder output needs one)
-            acc = F_.CrossGradAcc(len(self.layer_stack)) if enc_rows_mat.requires_grad else None
             link = None
-            for layer in self.layer_stack:
-                y, link = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows, acc, link)
+            ckv = F_.CrossKv.plan([layer.enc_attn for layer in self.layer_stack])
+            if ckv is not None:
+                # the K/V projections of the encoder output for all layers: one GEMM now (and one in the backward)
+                kv = F_.CrossKvFn.apply(enc_rows_mat, self.layer_stack[0].enc_attn.linear_k.weight, ckv)
+                for l, layer in enumerate(self.layer_stack):
+                    y, link = layer.forward_rows(y, kv, t_rows, in_rows, F_.CrossKvSlot(ckv, l), link)
+            else:
+                # one accumulator for the encoder gradient of all layers (only when the encoder output needs one)
+                acc = F_.CrossGradAcc(len(self.layer_stack)) if enc_rows_mat.requires_grad else None
+                for layer in self.layer_stack:
+                    y, link = layer.forward_rows(y, enc_rows_mat, t_rows, in_rows, acc, link)
         return y, t_rows
 
     def forward(self, outputs_data, outputs_pos, input_pos, enc_output, return_attns=False):

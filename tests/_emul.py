@@ -68,7 +68,12 @@ def keep_qk(d, bh, nq, nk):
 
 
 def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1, m=None, n=None,
-         kc=None, drop=None, delta=None, head_dim=0):
+         kc=None, drop=None, delta=None, head_dim=0, stack=None):
+    if stack is not None:       # Y / bias: the first of `blocks` equally spaced blocks (st_gemm_stacked)
+        blocks, y_stride, b_stride = stack
+        Y = torch.as_strided(Y, (blocks, Y.shape[0], Y.shape[1]), (y_stride, Y.stride(0), 1)).reshape(-1, Y.shape[1])
+        if bias is not None:
+            bias = torch.as_strided(bias, (blocks, bias.shape[0]), (b_stride, 1)).reshape(-1)
     Xl = (X.t() if x_cmajor else X).float()      # logical [M, Kc]
     Yl = (Y.t() if y_cmajor else Y).float()      # logical [N, Kc]
     M = m if m is not None else Xl.shape[0]

@@ -509,3 +509,35 @@ def test_gemm_lnbwd(M, N, K, with_aux):
     r, o = run(em.gemm_lnbwd, "cpu"), run(nv.gemm_lnbwd, "cuda")
     for got, ref, nm, tol in zip(o, r, ("dx", "dgamma", "dbeta", "dbias"), (1.5e-2, 5e-3, 5e-3, 8e-3)):
         check(got, ref, tol, "gemm_lnbwd %s %s" % ((M, N, K, with_aux), nm))
+
+
+@pytest.mark.parametrize("M,blocks,rows,K", [(700, 3, 256, 128), (1206, 6, 512, 256), (77, 2, 128, 80)])
+def test_gemm_stacked_weights(M, blocks, rows, K):
+    """st_gemm_stacked: the Y operand (and bias) is `blocks` equally spaced [rows, K] blocks inside a larger buffer
+    (how the parameter arena holds the same weight of consecutive layers) == the same GEMMs on the gathered stack,
+    forward (more output columns) and dgrad (longer contraction)."""
+    ldy = (K + 7) // 8 * 8
+    w_stride, b_stride = rows * ldy + 4096 + 64, rows + 192
+    arena_w = cu(g(1, blocks * w_stride + 128, seed=1, scale=K ** -0.5).view(-1))
+    arena_b = cu(g(1, blocks * b_stride + 64, seed=2, dtype=F32).view(-1))
+    W0 = torch.as_strided(arena_w, (rows, K), (ldy, 1), 64)                 # block 0 starts 64 elements in
+    b0 = arena_b[32:32 + rows]
+    Wcat = torch.cat([torch.as_strided(arena_w, (rows, K), (ldy, 1), 64 + l * w_stride) for l in range(blocks)]).contiguous()
+    bcat = torch.cat([arena_b[32 + l * b_stride:32 + l * b_stride + rows] for l in range(blocks)]).contiguous()
+    x = cu(g(M, K, seed=3))
+    Kp = ldy
+    xp = torch.zeros(M, Kp, dtype=BF16, device="cuda")
+    xp[:, :K] = x
+    out, ref = torch.empty(M, blocks * rows, dtype=BF16, device="cuda"), torch.empty(M, blocks * rows, dtype=BF16, device="cuda")
+    nv.gemm(xp[:, :K], W0, out, bias=b0, stack=(blocks, w_stride, b_stride))
+    wc = torch.zeros(blocks * rows, Kp, dtype=BF16, device="cuda")
+    wc[:, :K] = Wcat
+    nv.gemm(xp[:, :K], wc[:, :K], ref, bias=bcat)
+    assert torch.equal(out, ref), "stacked forward differs from the gathered GEMM"
+    # dgrad: dx[M, K] = dy[M, blocks * rows] @ stack (+ aux)
+    if K % 8 == 0:
+        dy, aux = cu(g(M, blocks * rows, seed=4)), cu(g(M, K, seed=5))
+        dx, dref = torch.empty(M, K, dtype=BF16, device="cuda"), torch.empty(M, K, dtype=BF16, device="cuda")
+        nv.gemm(dy, W0, dx, y_cmajor=True, stack=(blocks, w_stride, 0), epi=nv.EPI_BF16_ADD, aux=aux)
+        nv.gemm(dy, Wcat, dref, y_cmajor=True, epi=nv.EPI_BF16_ADD, aux=aux)
+        assert torch.equal(dx, dref), "stacked dgrad differs from the gathered GEMM"
