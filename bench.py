@@ -65,8 +65,8 @@ def kernel_report(records):
                 flops = 2.0 * M * N * K
             elif tag[0] == "wgrad_group":      # several weight gradients in one launch; tag = (name, n, flops)
                 kind, flops = "gemm_wgrad", float(tag[2])
-            elif tag[0] == "gemm_ln":
-                kind, flops = "gemm_ln", 2.0 * tag[1] * tag[2] * tag[3]
+            elif tag[0] in ("gemm_ln", "gemm_lnbwd"):
+                kind, flops = tag[0], 2.0 * tag[1] * tag[2] * tag[3]
             elif tag[0] in ("attn_fwd", "attn_bwd"):
                 H, dk, causal, ql, kl = tag[1:6]
                 pairs = float((ql.double() * kl.double()).sum().item())
@@ -252,8 +252,13 @@ def main():
             loss_t, _ = step_t(xg, in_len, tg, tgt_len, gg)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        step_t.use_graph = False
+        native.timing_start()
+        step_t(xg, in_len, tg, tgt_len, gg)
+        agg_t = kernel_report(native.timing_stop())
         train_mode = {"ms_per_step": round(dt / args.steps * 1e3, 3), "value": round(frames * args.steps / dt, 1),
                       "unit": "frames/s", "loss": round(loss_t.item(), 4),
+                      "kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(agg_t.items(), key=lambda kv: -kv[1]["ms"])[:8]},
                       "note": "model.train(): in-kernel counter-based dropout, p = 0.1 (attention probabilities, FFN "
                               "x2 per layer) and 0.5 (front-end); same step otherwise"}
         model.eval()

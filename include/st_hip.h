@@ -115,10 +115,12 @@ int st_gemm_ln(st_stream_t stream, const void* X, int ldx, const void* W, int M,
  * dY bf16 [M, Kc], W bf16 [Kc, N] (ld ldw: an nn.Linear weight [out = Kc, in = N] as stored), N = d_model in
  * {128, 256, 512}; identical to st_gemm(0, 1, .., ST_EPI_BF16[_ADD]) followed by st_ln_bwd, without dy going to
  * HBM.  Used where a sublayer's input gradient is the previous sublayer's LayerNorm output gradient
- * (SubLayers.py:25-27 -> Attention.py:94 backward, and so on down the stack). */
+ * (SubLayers.py:25-27 -> Attention.py:94 backward, and so on down the stack).  drop_*: the forward dropped the
+ * LayerNorm output (st_gemm_ln with drop_where = 2, SubLayers.py:27); the same mask is regenerated here. */
 int st_gemm_lnbwd(st_stream_t stream, const void* dY, int lddy, const void* W, int ldw, int M, int N, int Kc,
                   const void* aux, int ldaux, const void* xhat, const float* rstd, const float* gamma, void* dx,
-                  int lddx, float* dgamma, float* dbeta, float* dbias);
+                  int lddx, float* dgamma, float* dbeta, float* dbias, const unsigned* drop_seed, unsigned drop_salt,
+                  int drop_thresh, float drop_scale);
 
 /* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
  * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).

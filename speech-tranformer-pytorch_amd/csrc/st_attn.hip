@@ -197,26 +197,37 @@ __device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float
 // ---------------------------------------------------------------------------------------------
 // Forward.  Each wave owns 32 query rows (lane & 31); key / value tiles are streamed.
 // ---------------------------------------------------------------------------------------------
-// 16-bit keep mask of one lane's 16 accumulator registers: register r <-> pair (fixed, var0 + acc_row(r, hi)).
+// Keep decisions of one lane's 16 accumulator registers: register r <-> pair (fixed, var0 + acc_row(r, hi)).
 // FIXED_IS_Q: the lane's own index is the query (forward / dQ: registers run over keys), else it is the key.
 template <bool FIXED_IS_Q>
-__device__ __forceinline__ uint32_t keep_mask16(const Drop& dr, int bh, int fixed, int var0, int hi) {
-  uint32_t km = 0;
+__device__ __forceinline__ void keep16(const Drop& dr, int bh, int fixed, int var0, int hi, bool (&keep)[16]) {
+  // Lanes l and l ^ 1 hold neighbouring fixed indices (2f, 2f + 1: tile origins are even) and therefore need the SAME
+  // eight hashes (a 2 x 2 block serves both).  Each computes four - the even lane register groups g = 0, 1, the odd
+  // lane g = 2, 3 - and fetches the other four from its neighbour with a DPP move (the hash costs two quarter-rate
+  // v_mul_lo_u32; this halves what dropout adds to the VALU-bound softmax).
+  const int par = threadIdx.x & 1, fx = fixed & 1;
+  uint32_t own[4], nb[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int v = var0 + 8 * g + 4 * hi;   // 4 consecutive indices v .. v+3 (v % 4 == 0): two 2 x 2 blocks
+  for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-      const uint32_t bits = FIXED_IS_Q ? dr.bits(drop_counter_qk(bh, fixed, v + 2 * hb))
-                                       : dr.bits(drop_counter_qk(bh, v + 2 * hb, fixed));
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int byte = FIXED_IS_Q ? 2 * (fixed & 1) + e : 2 * e + (fixed & 1);
-        if (dr.keep(bits, byte)) km |= 1u << (4 * g + 2 * hb + e);
-      }
+      const int v = var0 + 8 * (2 * par + gi) + 4 * hi + 2 * hb;
+      own[gi * 2 + hb] = FIXED_IS_Q ? dr.bits(drop_counter_qk(bh, fixed, v)) : dr.bits(drop_counter_qk(bh, v, fixed));
     }
-  }
-  return km;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) nb[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)own[j], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int j = (g & 1) * 2 + hb;
+      uint32_t bits = ((g >> 1) == par) ? own[j] : nb[j];
+      // byte of (q, k) inside its block = 2 * (q & 1) + (k & 1); this lane's two elements differ in the variable index
+      bits >>= FIXED_IS_Q ? 16 * fx : 8 * fx;
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        keep[4 * g + 2 * hb + e] = (int)((bits >> (FIXED_IS_Q ? 8 * e : 16 * e)) & 0xffu) >= dr.thresh;
+    }
 }
 
 // KS = 2 ("few queries, many keys": the decoder-encoder attention, <= 64 queries against ~1000 keys): the workgroup
@@ -325,10 +336,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     if (DROP) {   // dropped probabilities leave the normaliser untouched; the 1/(1-p) scale is folded into `inv`
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const uint32_t km = keep_mask16<true>(dr, bh, q, kt + kb * 32, hi);
+        bool keep[16];
+        keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (!((km >> r) & 1u)) s[kb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[kb][r] = keep[r] ? s[kb][r] : 0.f;
       }
     }
     // O^T += V^T P^T : A operand = V^T (transposing LDS read), B operand = P^T (own registers)
@@ -465,9 +476,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
         }
       }
       if (DROP) {   // dS = P (M dP / (1-p) - delta)
-        const uint32_t km = keep_mask16<true>(dr, bh, q, kt + kb * 32, hi);
+        bool keep[16];
+        keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] = ((km >> r) & 1u) ? dp[r] * dr.scale : 0.f;
+        for (int r = 0; r < 16; ++r) dp[r] = keep[r] ? dp[r] * dr.scale : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * (dp[r] - dl);
@@ -583,11 +595,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
         s = mfma32(rd_nat<DK>(qs, qb * 32 + (l & 31), t), kf[t], s);
         dp = mfma32(rd_nat<DK>(dos, qb * 32 + (l & 31), t), vf[t], dp);
       }
-      uint32_t km = 0xffffu;
+      bool keep[16];
       if (DROP) {   // dS = P (M dP / (1-p) - delta), and dV takes the dropped, rescaled P
-        km = keep_mask16<false>(dr, bh, key, qt + qb * 32, hi);
+        keep16<false>(dr, bh, key, qt + qb * 32, hi, keep);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] = ((km >> r) & 1u) ? dp[r] * dr.scale : 0.f;
+        for (int r = 0; r < 16; ++r) dp[r] = keep[r] ? dp[r] * dr.scale : 0.f;
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -612,7 +624,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
       for (int r = 0; r < 16; ++r) {
         p[r] = __builtin_amdgcn_exp2f(s[r]);
         s[r] = p[r] * dp[r];
-        if (DROP) p[r] = ((km >> r) & 1u) ? p[r] * dr.scale : 0.f;
+        if (DROP) p[r] = keep[r] ? p[r] * dr.scale : 0.f;
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {

@@ -36,6 +36,7 @@ struct LnBwdArgs {
   const float* gamma;           // [N]
   bf16* out; int ldo;           // dx [M, N]
   float* dgamma; float* dbeta; float* dbias;   // [N] each, atomically accumulated (nullable)
+  DropArgs drop;                // the forward dropped the LayerNorm OUTPUT (SubLayers.py:27): dy <- dy * keep / (1 - p)
 };
 
 template <int N> struct Geo {
@@ -133,7 +134,7 @@ __device__ __forceinline__ bf16x8 frag_w(const bf16* tile, int col0, int kk) {
 // wave-private [32][128] patch, 16-byte chunks XOR-swizzled by the row: element (row, col)
 __device__ __forceinline__ int patch_at(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)); }
 
-template <int N>
+template <int N, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
   using G = Geo<N>;
   __shared__ __attribute__((aligned(16))) bf16 smem[G::SMEM_E];
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
   const int i = i_base + r;
   const bool row_ok = i < a.M;
   const float* gm = a.gamma + wn * 128;
+  const Drop dr = make_drop(a.drop);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -241,10 +243,13 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
       if (a.aux) ad4 = *reinterpret_cast<const bf16x4*>(p2 + at);
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(gm + jl);
       bf16x4 dy4;
+      uint32_t bits = 0;
+      if (DROP) bits = dr.bits(drop_counter_rc(i, wn * 128 + jl, N));   // the mask st_gemm_ln drew (drop_where = 2)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         dy4[e] = (bf16)(acc[b][4 * g + e] + (float)ad4[e]);       // the rounding the two-kernel path stores
-        const float d = (float)dy4[e];
+        float d = (float)dy4[e];
+        if (DROP) d = dr.keep(bits, e) ? d * dr.scale : 0.f;
         const float gg = d * g4[e];
         acc[b][4 * g + e] = gg;                                    // keep g = dy * gamma
         s1 += gg;
@@ -284,10 +289,17 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
     const bf16x8 dyv = *reinterpret_cast<const bf16x8*>(p2 + rr * 128 + ((cc ^ (rr & 15)) << 3));
     const bf16x8 xv = *reinterpret_cast<const bf16x8*>(p1 + rr * 128 + ((cc ^ (rr & 15)) << 3));
     if (rr < nvalid) {
+      uint32_t bits[2] = {0, 0};
+      if (DROP) {
+        bits[0] = dr.bits(drop_counter_rc(i_base + rr, wn * 128 + cc * 8, N));
+        bits[1] = dr.bits(drop_counter_rc(i_base + rr, wn * 128 + cc * 8 + 4, N));
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        ab[e] += (float)dyv[e];
-        ag[e] += (float)dyv[e] * (float)xv[e];
+        float d = (float)dyv[e];
+        if (DROP) d = dr.keep(bits[e >> 2], e & 3) ? d * dr.scale : 0.f;
+        ab[e] += d;
+        ag[e] += d * (float)xv[e];
       }
     }
   }
@@ -351,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
 
 extern "C" int st_gemm_lnbwd(hipStream_t stream, const void* dY, int lddy, const void* W, int ldw, int M, int N, int Kc,
                              const void* aux, int ldaux, const void* xhat, const float* rstd, const float* gamma,
-                             void* dx, int lddx, float* dgamma, float* dbeta, float* dbias) {
+                             void* dx, int lddx, float* dgamma, float* dbeta, float* dbias, const unsigned* drop_seed,
+                             unsigned drop_salt, int drop_thresh, float drop_scale) {
   if (M <= 0) return 0;
   if ((lddy & 7) || (ldw & 7) || (lddx & 7) || (Kc & 7) || (aux && (ldaux & 7)) || !xhat || !rstd || !gamma || !dx) return -1;
   if (ldw < N) return -2;
@@ -359,8 +372,15 @@ extern "C" int st_gemm_lnbwd(hipStream_t stream, const void* dY, int lddy, const
   a.X = (const bf16*)dY; a.ldx = lddy; a.W = (const bf16*)W; a.ldw = ldw; a.M = M; a.Kc = Kc;
   a.aux = (const bf16*)aux; a.ldaux = ldaux; a.xhat = (const bf16*)xhat; a.rstd = rstd; a.gamma = gamma;
   a.out = (bf16*)dx; a.ldo = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
-#define ST_LB(NN) \
-  hipLaunchKernelGGL((gemm_lnbwd_kernel<NN>), dim3((M + Geo<NN>::BM - 1) / Geo<NN>::BM), dim3(256), 0, stream, a)
+  const bool drop = drop_seed != nullptr && drop_thresh > 0;
+  a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
+  a.drop.scale = drop ? drop_scale : 1.f;
+#define ST_LB(NN)                                                                                                  \
+  do {                                                                                                             \
+    const dim3 grid((M + Geo<NN>::BM - 1) / Geo<NN>::BM);                                                          \
+    if (drop) hipLaunchKernelGGL((gemm_lnbwd_kernel<NN, true>), grid, dim3(256), 0, stream, a);                    \
+    else hipLaunchKernelGGL((gemm_lnbwd_kernel<NN, false>), grid, dim3(256), 0, stream, a);                        \
+  } while (0)
   if (N == 128) ST_LB(128);
   else if (N == 256) ST_LB(256);
   else if (N == 512) ST_LB(512);

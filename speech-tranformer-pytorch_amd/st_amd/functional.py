@@ -303,21 +303,22 @@ class LnLink:
     in its forward; S2's backward consumes it, leaves the result in ``ds`` and returns it as its input gradient;
     S1's backward recognises that tensor and skips its own ``ln_bwd``.  Valid only while S1's output has S2 as its
     single consumer (the layer stacks guarantee it); anything else arriving at S1 raises."""
-    __slots__ = ("ok", "st", "arena", "xhat", "rstd", "g_bias", "ds")
+    __slots__ = ("ok", "st", "arena", "xhat", "rstd", "g_bias", "drop", "ds")
 
     def __init__(self):
         self.ok, self.ds = False, None
 
-    def offer(self, mod, xhat, rstd, g_bias):
-        """S1.forward: the LayerNorm output is used as is (no dropout / mask on it), so S2 may fuse its backward."""
+    def offer(self, mod, xhat, rstd, g_bias, drop=None):
+        """S1.forward: what S2 needs to run this LayerNorm's backward (drop: dropout applied to the LN output)."""
         self.ok, self.st, self.arena, self.xhat, self.rstd, self.g_bias = True, mod._st, mod._st_arena, xhat, rstd, g_bias
+        self.drop = drop
 
     def fused_dgrad(self, dY, W, aux):
         """S2.backward: d(S2 input) = dY W + aux, pushed through S1's LayerNorm backward in the same launch."""
         st = self.st
         self.arena.attach_grads(st.params, st.lo, st.hi)      # before the kernel accumulates into S1's slots
         ds = _empty(dY.shape[0], W.shape[1], dY)
-        nv.gemm_lnbwd(dY, W, aux, self.xhat, self.rstd, st.gamma, ds, st.g_gamma, st.g_beta, self.g_bias)
+        nv.gemm_lnbwd(dY, W, aux, self.xhat, self.rstd, st.gamma, ds, st.g_gamma, st.g_beta, self.g_bias, drop=self.drop)
         self.ds = ds
         return ds
 
@@ -474,8 +475,8 @@ class FfnFn(torch.autograd.Function):
         ctx.save_for_backward(x, h, xhat, rstd)
         ctx.mod, ctx.drop1, ctx.drop2 = mod, drop1, drop2
         ctx.up, ctx.down = up, down
-        if down is not None and drop2 is None:       # a dropped LayerNorm output keeps its own (mask-regenerating) ln_bwd
-            down.offer(mod, xhat, rstd, s.g_b2)
+        if down is not None:
+            down.offer(mod, xhat, rstd, s.g_b2, drop2)
         return out
 
     @staticmethod

@@ -39,7 +39,8 @@ SIGNATURES = {
                    _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                    _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
     "st_gemm_lnbwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int,
-                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
+                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                      _c_void_p, _c_uint, _c_int, _c_float],
     "st_ln_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                   _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_float],
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -307,9 +308,10 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
     return out
 
 
-def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None):
+def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, drop=None):
     """dx = LayerNorm-backward(bf16(dY W (+ aux)); xhat, rstd, gamma) in one launch; W is the nn.Linear weight
-    [Kc, N] as stored (contraction-major for this product).  == gemm(dY, W, tmp, y_cmajor=True[, ADD aux]) + ln_bwd."""
+    [Kc, N] as stored (contraction-major for this product).  == gemm(dY, W, tmp, y_cmajor=True[, ADD aux]) + ln_bwd.
+    drop: the forward dropped the LayerNorm output (gemm_ln drop_where = 2)."""
     _mat(dY, BF16, "dY"), _mat(W, BF16, "W"), _mat(xhat, BF16, "xhat"), _mat(dx, BF16, "dx")
     M, Kc = dY.shape
     N = W.shape[1]
@@ -322,7 +324,7 @@ def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias
     _tag("gemm_lnbwd", M, N, Kc)
     rc = load().st_gemm_lnbwd(_stream(), dY.data_ptr(), dY.stride(0), W.data_ptr(), W.stride(0), M, N, Kc, _p(aux),
                               0 if aux is None else aux.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                              dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias))
+                              dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias), *_drop(drop))
     _check(rc, "st_gemm_lnbwd")
     return dx
 

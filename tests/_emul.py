@@ -141,10 +141,10 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
     return out
 
 
-def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None):
+def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, drop=None):
     dy = torch.zeros(dY.shape[0], W.shape[1], dtype=BF16)
     gemm(dY, W, dy, aux=aux, epi=nv.EPI_BF16_ADD if aux is not None else nv.EPI_BF16, y_cmajor=True)
-    return ln_bwd(dy, xhat[:dY.shape[0]], rstd, gamma, dx, dgamma, dbeta, dbias)
+    return ln_bwd(dy, xhat[:dY.shape[0]], rstd, gamma, dx, dgamma, dbeta, dbias, drop=drop)
 
 
 def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=None, drop=None, mask_scale=1.0):

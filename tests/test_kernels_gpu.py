@@ -491,24 +491,27 @@ def test_attention_backward_single_launch(case):
         assert torch.equal(a, b), "single-launch backward changed %s" % nm
 
 
-@pytest.mark.parametrize("M,N,K,with_aux", [(300, 128, 128, True), (1000, 256, 1024, True), (130, 256, 768, False),
-                                             (70, 512, 512, True), (999, 256, 256, True)])
-def test_gemm_lnbwd(M, N, K, with_aux):
-    """st_gemm_lnbwd == st_gemm (dgrad, + aux) followed by st_ln_bwd, in one launch."""
+@pytest.mark.parametrize("M,N,K,with_aux,p", [(300, 128, 128, True, 0), (1000, 256, 1024, True, 0), (130, 256, 768, False, 0),
+                                               (70, 512, 512, True, 0), (999, 256, 256, True, 0),
+                                               (999, 256, 768, True, 0.1), (130, 128, 256, True, 0.3), (200, 512, 512, False, 0.2)])
+def test_gemm_lnbwd(M, N, K, with_aux, p):
+    """st_gemm_lnbwd == st_gemm (dgrad, + aux) followed by st_ln_bwd, in one launch; p > 0: the LayerNorm output was
+    dropped in the forward (the mask is regenerated from the same counters as st_ln_bwd's)."""
+    dn, de = _drops(11, p) if p else (None, None)
     dY, W = g(M, K, seed=1), g(K, N, seed=2, scale=K ** -0.5)
     aux = g(M, N, seed=3) if with_aux else None
     xhat, rstd, gamma = g(M, N, seed=4), g(M, seed=5, dtype=F32).abs() + 0.5, 1 + 0.2 * g(N, seed=6, dtype=F32)
 
-    def run(fn, dev):
+    def run(fn, dev, d):
         mv = (lambda t: None if t is None else t.to(dev))
         dx = torch.zeros(M, N, dtype=BF16, device=dev)
         acc = [torch.ones(N, dtype=F32, device=dev) for _ in range(3)]
-        fn(mv(dY), mv(W), mv(aux), mv(xhat), mv(rstd), mv(gamma), dx, acc[0], acc[1], acc[2])
+        fn(mv(dY), mv(W), mv(aux), mv(xhat), mv(rstd), mv(gamma), dx, acc[0], acc[1], acc[2], drop=d)
         return [dx] + acc
 
-    r, o = run(em.gemm_lnbwd, "cpu"), run(nv.gemm_lnbwd, "cuda")
+    r, o = run(em.gemm_lnbwd, "cpu", de), run(nv.gemm_lnbwd, "cuda", dn)
     for got, ref, nm, tol in zip(o, r, ("dx", "dgamma", "dbeta", "dbias"), (1.5e-2, 5e-3, 5e-3, 8e-3)):
-        check(got, ref, tol, "gemm_lnbwd %s %s" % ((M, N, K, with_aux), nm))
+        check(got, ref, tol, "gemm_lnbwd %s %s" % ((M, N, K, with_aux, p), nm))
 
 
 @pytest.mark.parametrize("M,blocks,rows,K", [(700, 3, 256, 128), (1206, 6, 512, 256), (77, 2, 128, 80)])
