@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
     ap.add_argument("--no-train-mode", action="store_true", help="skip the extra (untimed-region) training-mode pass")
     ap.add_argument("--no-decode", action="store_true", help="skip the extra beam-search decode measurement")
+    ap.add_argument("--force-dp", action="store_true", help="N = 1 only: run the data-parallel code path (split backward "
+                    "graphs, bucketed RCCL all-reduce) on a one-rank group - its overhead without a second GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
                                                             "the captured HIP graph of the step")
     args = ap.parse_args()
@@ -167,7 +169,12 @@ def main():
     model = model.eval().cuda()                   # eval(): every Dropout is identity; autograd still runs
     arena = arena_of(model)
     dp.broadcast_parameters(arena)                # train_multi.py:176
-    reducer = dp.GradReducer(arena, wire_dtype=torch.bfloat16 if args.wire_bf16 else None) if world > 1 else None
+    if args.force_dp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    reducer = dp.GradReducer(arena, wire_dtype=torch.bfloat16 if args.wire_bf16 else None,
+                             force=args.force_dp) if (world > 1 or args.force_dp) else None
     optim = ScheduledOptim(model, C2["d_model"], U.AttrDict(n_warmup_steps=12000))
     step = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
 
@@ -320,11 +327,16 @@ def main():
         except Exception as e:  # noqa: BLE001 - the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
                                    "sample": "CPU baseline did not finish within %ds (%s)" % (args.cpu_timeout, type(e).__name__)}
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which a pipe would otherwise deliver at exit - AFTER this line
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)        # the last line of stdout
 
 
 if __name__ == "__main__":

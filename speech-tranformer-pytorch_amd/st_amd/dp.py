@@ -134,9 +134,11 @@ class GradReducer:
     """Bucketed, backward-overlapped gradient averaging over a flat gradient buffer."""
 
     def __init__(self, arena, group=None, bucket_bytes: int = 32 << 20, wire_dtype: Optional[torch.dtype] = None,
-                 overlap: bool = True):
+                 overlap: bool = True, force: bool = False):
+        """force: run the collectives even on a one-rank group (tests of the launch / stream ordering on one GPU)."""
         self.arena, self.group = arena, group
         self.world = world_size(group)
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.wire_dtype, self.overlap = wire_dtype, overlap
         total = arena.total
         per = max(1, bucket_bytes // 4)
@@ -150,10 +152,10 @@ class GradReducer:
         self._filled = [0] * len(self.buckets)
         self._fired = [False] * len(self.buckets)
         self._work = []
-        backend = dist.get_backend(group) if self.world > 1 else "none"
+        backend = dist.get_backend(group) if self.active else "none"
         self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
         self.exposed_wait_s = 0.0
-        if self.world > 1:
+        if self.active:
             arena.set_grad_ready_callback(self._on_ready)
 
     # ---- called from the autograd engine thread as gradient slices land ------------------------
@@ -187,15 +189,25 @@ class GradReducer:
 
     def reduce_all(self) -> None:
         """All-reduce every bucket now (in production order) and finish the average."""
-        if self.world == 1:
+        if not self.active:
             return
         self._fired = [False] * len(self.buckets)
         self.synchronize()
 
+    def fire_from(self, lo: int) -> None:
+        """Explicit mode (after :meth:`detach`): start the all-reduce of every bucket that lies wholly at or above
+        element ``lo`` - the gradients there are final (e.g. the decoder's, once its backward graph has been
+        replayed) and their exchange overlaps whatever is launched next; :meth:`synchronize` does the rest."""
+        if not self.active:
+            return
+        for i, (blo, _) in enumerate(self.buckets):
+            if blo >= lo and not self._fired[i]:
+                self._fire(i)
+
     def synchronize(self) -> None:
         """Flush buckets that never filled, wait for every all-reduce and finish the
         average; afterwards ``arena.grad`` holds the rank-mean gradient."""
-        if self.world == 1:
+        if not self.active:
             return
         for i in range(len(self.buckets)):
             if not self._fired[i]:

@@ -12,13 +12,18 @@ HIP-graph mode (``use_graph=True``): the step launches ~600 small kernels; the d
 GPU time).  The step is therefore captured once per batch signature (same tensors, same
 lengths - what bench.py and a bucketed loader produce) into a HIP graph and replayed; the
 Noam rate is a device scalar updated before each replay.  With data parallelism the
-gradient all-reduce stays eager between two graphs (forward+backward | clip+Adam).
+gradient all-reduce stays eager BETWEEN graphs, and the backward is cut at the encoder
+output into two of them: forward + loss + decoder backward | encoder backward | clip+Adam.
+The decoder's and the vocabulary projection's gradients (the tail ~2/3 of the flat buffer)
+are final after the first graph, so their RCCL all-reduce runs while the second graph - the
+encoder's backward, ~40 % of the step - is executing.
 """
 from __future__ import annotations
 
 from typing import Optional
 
 import torch
+import torch.distributed
 import torch.nn as nn
 
 from .arena import arena_of
@@ -46,8 +51,9 @@ class TrainStep:
         self.global_step = 0
         self.use_graph, self.graph_warmup = use_graph, graph_warmup
         self._sig, self._seen = None, 0
-        self._g_fb = self._g_opt = None
+        self._g_fb = self._g_enc = self._g_opt = None
         self._loss = self._gnorm = None
+        self._cut = None
 
     # ---- the two halves of a step -------------------------------------------------------------
     def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, captured=False):
@@ -69,6 +75,35 @@ class TrainStep:
         with deferred_wgrads(not hooks_live):
             loss.backward()
         return loss.detach()
+
+    # ---- data-parallel graph mode: the backward in two captures -----------------------------------
+    def _forward_decoder_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth):
+        """zero_grad, forward, loss, and the backward down to the encoder output (weight gradients of the decoder
+        flushed).  Leaves (encoder output, its gradient) in ``self._cut`` for :meth:`_encoder_backward`."""
+        self.optimizer.zero_grad()
+        rng.advance()
+        logits, t_rows, enc, enc_leaf = self.model.forward_packed(inputs, input_lengths, targets, target_lengths,
+                                                                  cut_encoder=True)
+        truth = ground_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ground_truth.shape[1]))
+        loss = self.crit(logits, truth)
+        with deferred_wgrads(True):
+            loss.backward()
+        self._cut = (enc, enc_leaf.grad)
+        return loss.detach()
+
+    def _encoder_backward(self):
+        enc, d_enc = self._cut
+        self._cut = None
+        with deferred_wgrads(True):
+            enc.backward(d_enc)
+
+    def _decoder_grad_start(self) -> int:
+        """First element of the flat gradient buffer that the encoder's backward no longer touches."""
+        arena = arena_of(self.model)
+        enc = {id(p) for p in self.model.encoder.parameters()}
+        cut = max(arena.offset[i] + arena.size[i] for i in enc)
+        others = [arena.offset[id(p)] for p in arena.params if id(p) not in enc]
+        return cut if not others or min(others) >= cut else arena.total      # interleaved layout: nothing fires early
 
     def _clip_and_update(self):
         grad_norm = clip_grad_norm_flat(arena_of(self.model), self.max_grad_norm)
@@ -93,7 +128,7 @@ class TrainStep:
         sig = (inputs.data_ptr(), targets.data_ptr(), ground_truth.data_ptr(), tuple(inputs.shape),
                tuple(targets.shape), input_lengths.cpu().numpy().tobytes(), target_lengths.cpu().numpy().tobytes())
         if sig != self._sig:
-            self._sig, self._seen, self._g_fb, self._g_opt = sig, 0, None, None
+            self._sig, self._seen, self._g_fb, self._g_enc, self._g_opt = sig, 0, None, None, None
         if self._g_fb is None:
             self._seen += 1
             if self._seen <= self.graph_warmup:          # lazy init (arena, layouts, allocator) happens eagerly
@@ -101,7 +136,11 @@ class TrainStep:
             self._capture(batch)
         self.optimizer.update_learning_rate(self.global_step)
         self._g_fb.replay()
-        if self.reducer is not None:
+        if self._g_enc is not None:
+            self.reducer.fire_from(self._dec_lo)      # decoder-side buckets: exchanged while the encoder's backward runs
+            self._g_enc.replay()
+            self.reducer.synchronize()
+        elif self.reducer is not None:
             self.reducer.reduce_all()
         self._g_opt.replay()
         return self._loss, self._gnorm
@@ -110,10 +149,24 @@ class TrainStep:
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        split = self.reducer is not None and self.reducer.active and hasattr(self.model, "forward_packed") \
+            and hasattr(self.model, "encoder")
         if self.reducer is not None:
             self.reducer.detach()                       # bucket all-reduces are issued explicitly between the graphs
-        with torch.cuda.graph(self._g_fb, pool=pool):
-            self._loss = self._forward_backward(*batch, captured=True)
-        with torch.cuda.graph(self._g_opt, pool=pool):
+        # ProcessGroupNCCL's watchdog thread polls the events of outstanding collectives (hipEventQuery); under the
+        # default "global" capture mode that call from ANOTHER thread aborts the process ("operation not permitted
+        # when stream is capturing").  With a process group alive, only this thread's unsafe calls are policed.
+        mode = dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}
+        if split:
+            self._g_enc, self._dec_lo = torch.cuda.CUDAGraph(), self._decoder_grad_start()
+            with torch.cuda.graph(self._g_fb, pool=pool, **mode):
+                self._loss = self._forward_decoder_backward(*batch)
+            with torch.cuda.graph(self._g_enc, pool=pool, **mode):
+                self._encoder_backward()
+        else:
+            self._g_enc = None
+            with torch.cuda.graph(self._g_fb, pool=pool, **mode):
+                self._loss = self._forward_backward(*batch, captured=True)
+        with torch.cuda.graph(self._g_opt, pool=pool, **mode):
             self._gnorm = self._clip_and_update()
         # capture only records; the step that triggered it is executed by the replay that follows

@@ -186,7 +186,7 @@ class Transformer(nn.Module):
         padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, t_rows.scatter_index(L), logits)
         return padded.view(B, L, -1), F_.UnpackFn.apply(enc, in_rows, int(in_rows.max_len))
 
-    def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False):
+    def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False):
         """The same computation with the logits left in the ragged layout the kernels produce:
         -> (logits [sum(targets_pos), V] fp32 (a column slice of a [*, v_pad] buffer), Rows of the target side).
         ``Rows.scatter_index(L)`` maps row r to its position b*L + t in the padded layout; trainer.TrainStep uses
@@ -204,8 +204,13 @@ class Transformer(nn.Module):
         F_.attn_work(t_rows, in_rows, False)      # decoder-encoder attention
         with arena.scope():
             enc, _ = self.encoder.forward_rows(inputs, inputs_pos, in_rows)
-            dec, _ = self.decoder.forward_rows(targets, targets_pos, enc, in_rows, t_rows)
+            # cut_encoder: the decoder runs on a detached leaf, so that the backward can be taken in two calls -
+            # loss.backward() (decoder; leaves d(enc) in enc_leaf.grad), then enc.backward(enc_leaf.grad)
+            enc_in = enc.detach().requires_grad_(True) if cut_encoder else enc
+            dec, _ = self.decoder.forward_rows(targets, targets_pos, enc_in, in_rows, t_rows)
             logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self)       # [sum(tgt_len), v_pad]
+        if cut_encoder:
+            return logits[:, :self.vocab_size], t_rows, enc, enc_in
         if want_enc:
             return logits[:, :self.vocab_size], t_rows, enc, in_rows
         return logits[:, :self.vocab_size], t_rows

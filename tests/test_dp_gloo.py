@@ -30,7 +30,7 @@ class Toy(nn.Module):
         return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
 
 
-def _worker(rank, world, port, wire_bf16, out_q):
+def _worker(rank, world, port, wire_bf16, out_q, explicit=False):
     import sys
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(here, "speech-tranformer-pytorch_amd"))
@@ -50,10 +50,15 @@ def _worker(rank, world, port, wire_bf16, out_q):
     x = torch.randn(8, 16, generator=g)
     y = torch.randn(8, 8, generator=g)
     sl = slice(rank * 4, rank * 4 + 4)
+    if explicit:                               # HIP-graph mode: no hooks, the trainer fires ranges itself
+        red.detach()
     for step in range(2):                      # second step: buckets re-arm, grads re-zeroed
         flat.zero_grad()
         loss = ((model(x[sl]) - y[sl]) ** 2).mean()
         loss.backward()
+        if explicit:
+            red.fire_from(flat.total // 2)     # the tail buckets first (TrainStep: after the decoder's backward graph)
+            assert any(red._fired) and not all(red._fired)
         red.synchronize()
     mean_loss = dp.allreduce_mean(loss.detach())
     if rank == 0:
@@ -64,12 +69,12 @@ def _worker(rank, world, port, wire_bf16, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire_bf16", [False, True])
-def test_bucketed_allreduce_matches_shard_average(wire_bf16):
+@pytest.mark.parametrize("wire_bf16,explicit", [(False, False), (True, False), (False, True)])
+def test_bucketed_allreduce_matches_shard_average(wire_bf16, explicit):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, wire_bf16, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, wire_bf16, q, explicit)) for r in range(world)]
     for p in procs:
         p.start()
     params, grads, mean_loss = q.get(timeout=120)

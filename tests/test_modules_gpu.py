@@ -188,3 +188,54 @@ def test_training_actually_learns():
     assert all(math.isfinite(v) for v in losses)
     assert losses[0] > 0.8 * math.log(30)
     assert min(losses[-20:]) < 1.0 and sum(losses[-20:]) / 20 < losses[0] / 3, (losses[0], losses[-20:])
+
+
+def test_split_backward_graphs_with_reducer_match_single_graph():
+    """Data-parallel graph mode cuts the backward at the encoder output (two captures, the decoder-side all-reduce
+    issued in between).  On a ONE-rank RCCL group (collectives really launched, averaging over 1 rank) the loss,
+    gradient norm and updated parameters must equal the single-graph step's."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from st_amd import dp, synthetic
+    from st_amd.arena import arena_of
+    from st_amd.trainer import TrainStep
+    from transformer.Models import Transformer
+    from transformer.Optim import ScheduledOptim
+    from transformer.Utils import AttrDict, init_parameters
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg = AttrDict(dict(feature_dim=80, max_inputs_length=200, max_target_length=32, num_enc_layer=2,
+                            num_dec_layer=2, n_heads=4, d_k=32, d_v=32, d_model=128, d_inner_hid=256, dropout=0.0,
+                            vocab_size=30))
+        inputs, targets, in_len, tgt_len, truth = synthetic.make_batch(4, 160, 20, 80, 30, seed=1, t_min=60, l_min=6)
+        results = []
+        for with_reducer in (False, True):
+            torch.manual_seed(0)
+            model = Transformer(cfg).cuda()
+            init_parameters(model)
+            model.eval()
+            opt = ScheduledOptim(model, 128, AttrDict(n_warmup_steps=4000))
+            red = dp.GradReducer(arena_of(model), bucket_bytes=64 << 10, force=True) if with_reducer else None
+            step = TrainStep(model, opt, 30, 5.0, reducer=red, use_graph=True, graph_warmup=1)
+            x, t, gt = inputs.cuda(), targets.cuda(), truth.cuda()
+            out = []
+            for _ in range(4):
+                loss, gnorm = step(x, in_len, t, tgt_len, gt)
+                out.append((float(loss), float(gnorm)))
+            if with_reducer:
+                assert step._g_enc is not None and 0 < step._dec_lo < arena_of(model).total
+                assert len(red.buckets) > 4
+            results.append(([l for l, _ in out], [g for _, g in out], arena_of(model).flat.detach().float().cpu().clone()))
+        (l0, g0, p0), (l1, g1, p1) = results
+        for a, b in zip(l0 + g0, l1 + g1):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (l0, l1, g0, g1)
+        assert float((p0 - p1).norm() / p0.norm()) < 5e-3
+    finally:
+        dist.destroy_process_group()
