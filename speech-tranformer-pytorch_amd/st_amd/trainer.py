@@ -142,7 +142,8 @@ class TrainStep:
             self.reducer.synchronize()
         elif self.reducer is not None:
             self.reducer.reduce_all()
-        self._g_opt.replay()
+        if self._g_opt is not None:
+            self._g_opt.replay()
         return self._loss, self._gnorm
 
     def _capture(self, batch):
@@ -163,10 +164,16 @@ class TrainStep:
                 self._loss = self._forward_decoder_backward(*batch)
             with torch.cuda.graph(self._g_enc, pool=pool, **mode):
                 self._encoder_backward()
-        else:
+        elif self.reducer is not None and self.reducer.active:
             self._g_enc = None
             with torch.cuda.graph(self._g_fb, pool=pool, **mode):
                 self._loss = self._forward_backward(*batch, captured=True)
+        else:                                           # nothing happens between backward and the update: ONE graph
+            self._g_enc = self._g_opt = None
+            with torch.cuda.graph(self._g_fb, pool=pool, **mode):
+                self._loss = self._forward_backward(*batch, captured=True)
+                self._gnorm = self._clip_and_update()
+            return
         with torch.cuda.graph(self._g_opt, pool=pool, **mode):
             self._gnorm = self._clip_and_update()
         # capture only records; the step that triggered it is executed by the replay that follows
