@@ -9,7 +9,8 @@
 // byte round trip) and without the second launch.  Where it applies: the gradient a sublayer hands to the
 // sublayer before it - dx = dh W1 + ds out of the feed-forward (transformer/SubLayers.py:25-27 backward) feeding
 // the LayerNorm of the attention sublayer (transformer/Attention.py:94 backward), and so on down the stack.
-// `dy` is rounded to bf16 exactly where the two-kernel path stores it, so the results match that path.
+// `dy` is rounded to bf16 once, as acc + aux (the two-kernel path rounds the GEMM result and then the sum: its dy
+// differs from this one by that double rounding, ~0.3 bf16 ulp rms - 3e-3 of the step's gradient norm, measured).
 //
 // Structure = st_gemm_ln.hip (256 threads, 32 * (4 / (N / 128)) x N tile, wave block 32 rows x 128 columns with the
 // accumulator transposed: row statistics are lane-local) with the weight tile contraction-major (read with
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
       if (DROP) bits = dr.bits(drop_counter_rc(i, wn * 128 + jl, N));   // the mask st_gemm_ln drew (drop_where = 2)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        dy4[e] = (bf16)(acc[b][4 * g + e] + (float)ad4[e]);       // the rounding the two-kernel path stores
+        dy4[e] = (bf16)(acc[b][4 * g + e] + (float)ad4[e]);       // one rounding (see the header)
         float d = (float)dy4[e];
         if (DROP) d = dr.keep(bits, e) ? d * dr.scale : 0.f;
         const float gg = d * g4[e];

@@ -21,6 +21,7 @@ from . import native as nv
 
 _seeds: Dict[str, torch.Tensor] = {}
 _salt = 0
+_manual = None        # seed set by manual_seed(): also used by seed tensors created afterwards
 _rank_offset = 0      # data-parallel ranks draw different masks from the same torch seed (set_rank)
 
 
@@ -28,7 +29,8 @@ def seed_tensor(device) -> torch.Tensor:
     key = str(torch.device(device))
     t = _seeds.get(key)
     if t is None:
-        t = torch.tensor([(torch.initial_seed() + _rank_offset) & 0x7FFFFFFF], dtype=torch.int32, device=device)
+        base = torch.initial_seed() if _manual is None else _manual
+        t = torch.tensor([(base + _rank_offset) & 0x7FFFFFFF], dtype=torch.int32, device=device)
         _seeds[key] = t
     return t
 
@@ -45,8 +47,8 @@ def set_rank(rank: int) -> None:
 
 def manual_seed(seed: int) -> None:
     """Re-seed every device's dropout stream (and restart the salt counter)."""
-    global _salt
-    _salt = 0
+    global _salt, _manual
+    _salt, _manual = 0, int(seed)
     for t in _seeds.values():
         t.fill_((int(seed) + _rank_offset) & 0x7FFFFFFF)
 
