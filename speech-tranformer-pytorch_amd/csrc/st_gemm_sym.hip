@@ -291,6 +291,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
 #pragma unroll
         for (int t = 0; t < 16; ++t) cs[y][t] += xch[(64 + y * 16 + t) * 64];
     }
+    // the bf16 epilogues stage the tile in the same LDS: every wave must have read its hand-over block first
+    if (EPI != EPI_F32_ATOMIC_T) __syncthreads();
   }
   if (EPI == EPI_F32_ATOMIC_T) {
     // D^T[j][i] += acc: the lane index i is the contiguous axis of dW -> coalesced fp32 atomics
@@ -461,6 +463,12 @@ int launch(hipStream_t stream, const GemmArgs& a, int epi, dim3 grid) {
   case E: hipLaunchKernelGGL((gemm_sym_kernel<XT, YT, E, KG>), grid, dim3(256 * KG), 0, stream, a); break;
   if (epi == EPI_BF16_RELU && a.drop.seed != nullptr) {   // training-mode dropout: its own instantiation
     hipLaunchKernelGGL((gemm_sym_kernel<XT, YT, EPI_BF16_RELU, 1, true>), grid, dim3(256), 0, stream, a);
+    return 0;
+  }
+  // few output tiles and a long contraction (the vocabulary projection's input gradient: 20 tiles, K = 4344): the two
+  // wave groups of an 8-wave workgroup take half of K each
+  if (epi == EPI_BF16 && a.tiles_i * a.tiles_j <= 128 && a.Kc >= 2048) {
+    hipLaunchKernelGGL((gemm_sym_kernel<XT, YT, EPI_BF16, 2>), grid, dim3(512), 0, stream, a);
     return 0;
   }
   switch (epi) {

@@ -70,7 +70,8 @@ def test_probe_mfma_layout():
 
 
 # ---- GEMM family ---------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 256, 80), (1000, 768, 256), (257, 1024, 256), (77, 256, 1024)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 256, 80), (1000, 768, 256), (257, 1024, 256), (77, 256, 1024),
+                                     (200, 256, 2304), (1206, 256, 4344)])     # long K, few tiles: the 8-wave split-K variant
 @pytest.mark.parametrize("epi", [nv.EPI_BF16, nv.EPI_BF16_RELU, nv.EPI_F32])
 def test_gemm_forward(M, N, K, epi):
     X, W, b = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5), g(N, seed=3, dtype=F32)
@@ -93,7 +94,7 @@ def test_gemm_strided_operands():
     assert ob[:, :d].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 256, 1024), (333, 768, 256), (64, 4344, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 256, 1024), (333, 768, 256), (64, 4344, 256), (1206, 4344, 256)])
 @pytest.mark.parametrize("epi", [nv.EPI_BF16, nv.EPI_BF16_MASK, nv.EPI_BF16_ADD])
 def test_gemm_dgrad(M, N, K, epi):
     """dx[M,K] = dy[M,N] W[N,K] (W read contraction-major through the transposing LDS read)."""
