@@ -52,7 +52,7 @@ struct Stage {
   static constexpr int CHUNKS = ROWS * 4;                 // [ROWS][4 chunks]
   static constexpr int CH = (CHUNKS + 255) / 256;         // per thread (ROWS = 32: threads 128.. duplicate 0..127)
   bf16x8 v[CH];
-  static __device__ __forceinline__ int chunk_id(int p) { return (threadIdx.x + p * 256) % CHUNKS; }
+  static __device__ __forceinline__ int chunk_id(int p) { return ((threadIdx.x & 255) + p * 256) % CHUNKS; }   // & 255: the 4-wave group's thread id
   static __device__ __forceinline__ void offsets(uint32_t (&off)[CH], int ld, int row0, int nrows) {
 #pragma unroll
     for (int p = 0; p < CH; ++p) {
@@ -205,12 +205,17 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
   });
 }
 
-template <int N, int DROPW>
-__global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
+// KG = 2 (decoder-sized M, long K: ~20 workgroups whose k-loop is a serial latency chain): 8 waves, the second
+// 4-wave group takes the second half of K with its own LDS buffers and hands its accumulators to the first through
+// LDS; the first group alone runs the LayerNorm epilogue.  One such workgroup per CU.
+template <int N, int DROPW, int KG>
+__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : 2) void gemm_ln_kernel(GemmLnArgs a) {
   using G = Geo<N>;
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * G::BUF];
+  __shared__ __attribute__((aligned(16))) bf16 smem_all[KG * 2 * G::BUF];
   __shared__ float red[2 * 4 * 32];
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+  const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
+  bf16* smem = smem_all + grp * 2 * G::BUF;
+  const int wave = (threadIdx.x >> 6) & 3, l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
   const int wm = wave / G::WN, wn = wave % G::WN;
   const int i0 = blockIdx.x * G::BM, i_base = i0 + wm * 32;
   auto xs = [&](int buf) { return smem + buf * G::BUF; };
@@ -226,8 +231,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
   // two k-tiles in flight in registers (A: even tiles, B: odd tiles) + one in LDS being consumed
   Stage<G::BM> ax, bx;
   Stage<N> ay, by;
-  auto loadA = [&](int kt) { ax.load(offx, a.X, kt * BK, a.K); ay.load(offy, a.W, kt * BK, a.K); };
-  auto loadB = [&](int kt) { bx.load(offx, a.X, kt * BK, a.K); by.load(offy, a.W, kt * BK, a.K); };
+  // this group's k-range [k_begin, k_end): both groups run the same number of k-tiles (surplus tiles read zeros)
+  const int nk = ((a.K + BK - 1) / BK + KG - 1) / KG;
+  const int k_begin = grp * nk * BK, k_end = min(a.K, k_begin + nk * BK);
+  auto loadA = [&](int kt) { ax.load(offx, a.X, k_begin + kt * BK, k_end); ay.load(offy, a.W, k_begin + kt * BK, k_end); };
+  auto loadB = [&](int kt) { bx.load(offx, a.X, k_begin + kt * BK, k_end); by.load(offy, a.W, k_begin + kt * BK, k_end); };
   auto storeA = [&]() { ax.store(xs(0)); ay.store(ys(0)); };
   auto storeB = [&]() { bx.store(xs(1)); by.store(ys(1)); };
   auto compute = [&](int buf) {
@@ -241,7 +249,6 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
       for (int b = 0; b < 4; ++b) acc[b] = mfma32(yf[b], xf, acc[b]);
     }
   };
-  const int nk = (a.K + BK - 1) / BK;
   loadA(0);
   if (nk > 1) loadB(1);
   storeA();
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
   // this lane's 8 residual chunks of the wave's [32][128] block (chunk id = p*64 + lane -> row id >> 4,
   // 16-byte column chunk id & 15): requested now, parked in the wave's patch after the k-loop
   bf16x8 resv[8];
-  if (a.res) {
+  if (a.res && grp == 0) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int id = p * 64 + l, rr = min(i_base + (id >> 4), a.M - 1), c = id & 15;
@@ -281,6 +288,22 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(GemmLnArgs a) {
     }
   }
   __syncthreads();   // the patches reuse the operand buffers
+  if (KG > 1) {   // group 1 -> LDS ([register][lane]: conflict-free both ways) -> group 0
+    float* xch = reinterpret_cast<float*>(smem_all) + wave * (64 * 64) + l;
+    if (grp == 1) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xch[(b * 16 + t) * 64] = acc[b][t];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[b][t] += xch[(b * 16 + t) * 64];
+    __syncthreads();   // (the four remaining waves) every hand-over block is read before a patch overwrites it
+  }
   bf16* patch = smem + wave * 4096;
   if (a.res) {
 #pragma unroll
@@ -311,16 +334,18 @@ extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void
   const bool drop = drop_seed != nullptr && drop_thresh > 0 && (drop_where == 1 || drop_where == 2);
   a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
   a.drop.scale = drop ? drop_scale : 1.f; a.drop_where = drop ? drop_where : 0;
-#define ST_LN(NN)                                                                                               \
-  do {                                                                                                          \
-    const dim3 grid((M + Geo<NN>::BM - 1) / Geo<NN>::BM);                                                       \
-    if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<NN, 1>), grid, dim3(256), 0, stream, a);          \
-    else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<NN, 2>), grid, dim3(256), 0, stream, a);     \
-    else hipLaunchKernelGGL((gemm_ln_kernel<NN, 0>), grid, dim3(256), 0, stream, a);                            \
+#define ST_LN(NN, KG)                                                                                              \
+  do {                                                                                                             \
+    const dim3 grid((M + Geo<NN>::BM - 1) / Geo<NN>::BM), blk(256 * KG);                                           \
+    if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<NN, 1, KG>), grid, blk, 0, stream, a);               \
+    else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<NN, 2, KG>), grid, blk, 0, stream, a);          \
+    else hipLaunchKernelGGL((gemm_ln_kernel<NN, 0, KG>), grid, blk, 0, stream, a);                                 \
   } while (0)
-  if (N == 128) ST_LN(128);
-  else if (N == 256) ST_LN(256);
-  else if (N == 512) ST_LN(512);
+  // few workgroups and a long contraction: split K inside an 8-wave workgroup (N = 512 would not fit its LDS)
+  const bool split = N <= 256 && K >= 512 && (M + Geo<256>::BM - 1) / Geo<256>::BM <= 128;
+  if (N == 128) { if (split) ST_LN(128, 2); else ST_LN(128, 1); }
+  else if (N == 256) { if (split) ST_LN(256, 2); else ST_LN(256, 1); }
+  else if (N == 512) ST_LN(512, 1);
   else return -3;
 #undef ST_LN
   ST_CHECK_LAUNCH();
