@@ -41,18 +41,21 @@ struct GemmLnArgs {
 
 // Geometry: WM x WN waves, each 32 rows x 128 columns (4 MFMA tiles).  N = 128: 4 x 1 (BM = 128),
 // N = 256: 2 x 2 (BM = 64), N = 512: 1 x 4 (BM = 32).
-template <int N> struct Geo {
-  static constexpr int WN = N / 128, WM = 4 / WN, BM = 32 * WM;
+// TALL (N = 256, encoder-sized M): 8 waves, 4 x 2, BM = 128 - twice the rows per weight tile that goes through LDS and
+// two waves per SIMD inside ONE workgroup (M / 64 = 376 tiles leave 136 of the 256 CUs with a single 4-wave workgroup).
+template <int N, bool TALL = false> struct Geo {
+  static constexpr int WN = N / 128, WM = (TALL ? 8 : 4) / WN, BM = 32 * WM, NT = 64 * WM * WN;
   static constexpr int XE = BM * NS, YE = N * NS, BUF = XE + YE;
+  static constexpr int SMEM_E = 2 * BUF > WM * WN * 4096 ? 2 * BUF : WM * WN * 4096;   // operand double buffer | one patch per wave
 };
 
 // This thread's 16-byte chunks of a ROWS x 32 operand tile: fixed byte offsets from the k-tile base.
-template <int ROWS>
+template <int ROWS, int NT = 256>   // NT: threads that cooperate on a tile (a 4-wave group, or all 8 waves of a TALL workgroup)
 struct Stage {
   static constexpr int CHUNKS = ROWS * 4;                 // [ROWS][4 chunks]
-  static constexpr int CH = (CHUNKS + 255) / 256;         // per thread (ROWS = 32: threads 128.. duplicate 0..127)
+  static constexpr int CH = (CHUNKS + NT - 1) / NT;       // per thread (ROWS = 32: threads 128.. duplicate 0..127)
   bf16x8 v[CH];
-  static __device__ __forceinline__ int chunk_id(int p) { return ((threadIdx.x & 255) + p * 256) % CHUNKS; }   // & 255: the 4-wave group's thread id
+  static __device__ __forceinline__ int chunk_id(int p) { return ((threadIdx.x & (NT - 1)) + p * NT) % CHUNKS; }
   static __device__ __forceinline__ void offsets(uint32_t (&off)[CH], int ld, int row0, int nrows) {
 #pragma unroll
     for (int p = 0; p < CH; ++p) {
@@ -114,10 +117,10 @@ __device__ __forceinline__ void ln_store_block(bf16* patch, bf16* gbase, int ld,
 
 // The row-wise epilogue.  `acc` holds x W^T for rows i_base + (lane & 31), columns wn*128 + ...; the
 // residual block (if any) already sits in the wave's patch (ln_stage_res).
-template <int N, int DROPW>
+template <int N, int DROPW, bool TALL>
 __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4], bool have_res, int i_base, int wm,
                                             int wn, bf16* patch, float* red) {
-  constexpr int WN = Geo<N>::WN, WM = Geo<N>::WM;
+  constexpr int WN = Geo<N, TALL>::WN, WM = Geo<N, TALL>::WM;
   const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
   const int i = i_base + r;
   const bool row_ok = i < a.M;
@@ -208,14 +211,15 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
 // KG = 2 (decoder-sized M, long K: ~20 workgroups whose k-loop is a serial latency chain): 8 waves, the second
 // 4-wave group takes the second half of K with its own LDS buffers and hands its accumulators to the first through
 // LDS; the first group alone runs the LayerNorm epilogue.  One such workgroup per CU.
-template <int N, int DROPW, int KG>
-__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : 2) void gemm_ln_kernel(GemmLnArgs a) {
-  using G = Geo<N>;
-  __shared__ __attribute__((aligned(16))) bf16 smem_all[KG * 2 * G::BUF];
-  __shared__ float red[2 * 4 * 32];
+template <int N, int DROPW, int KG, bool TALL = false>
+__global__ __launch_bounds__((TALL ? 512 : 256 * KG), ((KG > 1 || TALL) ? 1 : 2)) void gemm_ln_kernel(GemmLnArgs a) {
+  static_assert(!(TALL && KG > 1), "one or the other");
+  using G = Geo<N, TALL>;
+  __shared__ __attribute__((aligned(16))) bf16 smem_all[KG > 1 ? KG * 2 * G::BUF : G::SMEM_E];
+  __shared__ float red[2 * G::WM * G::WN * 32];
   const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
   bf16* smem = smem_all + grp * 2 * G::BUF;
-  const int wave = (threadIdx.x >> 6) & 3, l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+  const int wave = (threadIdx.x >> 6) & (G::WM * G::WN - 1), l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
   const int wm = wave / G::WN, wn = wave % G::WN;
   const int i0 = blockIdx.x * G::BM, i_base = i0 + wm * 32;
   auto xs = [&](int buf) { return smem + buf * G::BUF; };
@@ -225,12 +229,14 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : 2) void gemm_ln_kernel(GemmL
 #pragma unroll
   for (int b = 0; b < 4; ++b) acc[b] = zero16();
 
-  uint32_t offx[Stage<G::BM>::CH], offy[Stage<N>::CH];
-  Stage<G::BM>::offsets(offx, a.ldx, i0, a.M);
-  Stage<N>::offsets(offy, a.K, 0, N);
+  using SX = Stage<G::BM, G::NT>;
+  using SY = Stage<N, G::NT>;
+  uint32_t offx[SX::CH], offy[SY::CH];
+  SX::offsets(offx, a.ldx, i0, a.M);
+  SY::offsets(offy, a.K, 0, N);
   // two k-tiles in flight in registers (A: even tiles, B: odd tiles) + one in LDS being consumed
-  Stage<G::BM> ax, bx;
-  Stage<N> ay, by;
+  SX ax, bx;
+  SY ay, by;
   // this group's k-range [k_begin, k_end): both groups run the same number of k-tiles (surplus tiles read zeros)
   const int nk = ((a.K + BK - 1) / BK + KG - 1) / KG;
   const int k_begin = grp * nk * BK, k_end = min(a.K, k_begin + nk * BK);
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : 2) void gemm_ln_kernel(GemmL
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
-  ln_epilogue<N, DROPW>(a, acc, a.res != nullptr, i_base, wm, wn, patch, red);
+  ln_epilogue<N, DROPW, TALL>(a, acc, a.res != nullptr, i_base, wm, wn, patch, red);
 }
 
 }  // namespace
@@ -343,7 +349,16 @@ extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void
   } while (0)
   // few workgroups and a long contraction: split K inside an 8-wave workgroup (N = 512 would not fit its LDS)
   const bool split = N <= 256 && K >= 512 && (M + Geo<256>::BM - 1) / Geo<256>::BM <= 128;
+  // more 64-row tiles than CUs, but fewer than two rounds of them: 128-row tiles on 8 waves (see Geo)
+  // (measured, M = 24060: K = 1024 32.7 -> 30.1 us; K = 256 16.8 -> 17.1 us, so only for the long contraction)
+  const bool tall = N == 256 && K >= 512 && M > 64 * 256 && M <= 128 * 256;
   if (N == 128) { if (split) ST_LN(128, 2); else ST_LN(128, 1); }
+  else if (N == 256 && tall) {
+    const dim3 grid((M + 127) / 128), blk(512);
+    if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<256, 1, 1, true>), grid, blk, 0, stream, a);
+    else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<256, 2, 1, true>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_ln_kernel<256, 0, 1, true>), grid, blk, 0, stream, a);
+  }
   else if (N == 256) { if (split) ST_LN(256, 2); else ST_LN(256, 1); }
   else if (N == 512) ST_LN(512, 1);
   else return -3;

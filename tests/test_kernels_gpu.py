@@ -131,7 +131,8 @@ def test_gemm_wgrad(M, N, K, splits):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1000, 256, 256), (130, 256, 1024), (70, 512, 512), (500, 256, 80),
-                                     (1206, 256, 1024), (1206, 256, 544), (700, 128, 1000), (9000, 256, 1024)])   # K >= 512, M <= 8192: 8-wave K split
+                                     (1206, 256, 1024), (1206, 256, 544), (700, 128, 1000), (9000, 256, 1024),   # K >= 512, M <= 8192: 8-wave K split
+                                     (16500, 256, 544)])                                                        # 8-wave 128-row tiles
 @pytest.mark.parametrize("variant", ["res", "relu_pe"])
 def test_gemm_ln(M, N, K, variant):
     X, W = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5)
