@@ -40,20 +40,21 @@ struct LnBwdArgs {
   DropArgs drop;                // the forward dropped the LayerNorm OUTPUT (SubLayers.py:27): dy <- dy * keep / (1 - p)
 };
 
-template <int N> struct Geo {
-  static constexpr int WN = N / 128, WM = 4 / WN, BM = 32 * WM;
+// TALL (N = 256, encoder-sized M, long contraction): 8 waves, 4 x 2, BM = 128 - as in st_gemm_ln.hip.
+template <int N, bool TALL = false> struct Geo {
+  static constexpr int WN = N / 128, WM = (TALL ? 8 : 4) / WN, BM = 32 * WM, NT = 64 * WM * WN;
   static constexpr int XE = BM * NS, YE = BK * N, BUF = XE + YE;
-  static constexpr int SMEM_E = 2 * BUF > 4 * 2 * 4096 ? 2 * BUF : 4 * 2 * 4096;   // operand buffers | 2 patches per wave
+  static constexpr int SMEM_E = 2 * BUF > WM * WN * 2 * 4096 ? 2 * BUF : WM * WN * 2 * 4096;   // operand buffers | 2 patches per wave
 };
 
 __device__ __forceinline__ int cm_col(int crow, int col) { return col ^ ((crow & 3) << 5); }
 
 // X tile: BM x 32, natural
-template <int ROWS>
+template <int ROWS, int NT = 256>
 struct StageX {
-  static constexpr int CHUNKS = ROWS * 4, CH = (CHUNKS + 255) / 256;
+  static constexpr int CHUNKS = ROWS * 4, CH = (CHUNKS + NT - 1) / NT;
   bf16x8 v[CH];
-  static __device__ __forceinline__ int chunk_id(int p) { return (threadIdx.x + p * 256) % CHUNKS; }
+  static __device__ __forceinline__ int chunk_id(int p) { return (threadIdx.x + p * NT) % CHUNKS; }
   static __device__ __forceinline__ void offsets(uint32_t (&off)[CH], int ld, int row0, int nrows) {
 #pragma unroll
     for (int p = 0; p < CH; ++p) {
@@ -84,14 +85,14 @@ struct StageX {
 };
 
 // W tile: 32 c-rows x N, contraction-major, swizzled
-template <int N>
+template <int N, int NT = 256>
 struct StageW {
-  static constexpr int CPR = N / 8, CH = BK * CPR / 256;
+  static constexpr int CPR = N / 8, CH = BK * CPR / NT;
   bf16x8 v[CH];
   static __device__ __forceinline__ void offsets(uint32_t (&off)[CH], int ld) {
 #pragma unroll
     for (int p = 0; p < CH; ++p) {
-      const int id = threadIdx.x + p * 256;
+      const int id = threadIdx.x + p * NT;
       off[p] = ((uint32_t)(id / CPR) * (uint32_t)ld + (id % CPR) * 8) * 2u;
     }
   }
@@ -104,7 +105,7 @@ struct StageW {
     } else {
 #pragma unroll
       for (int p = 0; p < CH; ++p) {
-        const bool ok = c0 + (int)((threadIdx.x + p * 256) / CPR) < c_end;
+        const bool ok = c0 + (int)((threadIdx.x + p * NT) / CPR) < c_end;
         v[p] = *reinterpret_cast<const bf16x8*>(ok ? kb + off[p] : reinterpret_cast<const char*>(g_zero_lb));
       }
     }
@@ -112,7 +113,7 @@ struct StageW {
   __device__ __forceinline__ void store(bf16* tile) const {
 #pragma unroll
     for (int p = 0; p < CH; ++p) {
-      const int id = threadIdx.x + p * 256, crow = id / CPR;
+      const int id = threadIdx.x + p * NT, crow = id / CPR;
       *reinterpret_cast<bf16x8*>(tile + crow * N + cm_col(crow, (id % CPR) * 8)) = v[p];
     }
   }
@@ -135,11 +136,11 @@ __device__ __forceinline__ bf16x8 frag_w(const bf16* tile, int col0, int kk) {
 // wave-private [32][128] patch, 16-byte chunks XOR-swizzled by the row: element (row, col)
 __device__ __forceinline__ int patch_at(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)); }
 
-template <int N, bool DROP>
-__global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
-  using G = Geo<N>;
+template <int N, bool DROP, bool TALL = false>
+__global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd_kernel(LnBwdArgs a) {
+  using G = Geo<N, TALL>;
   __shared__ __attribute__((aligned(16))) bf16 smem[G::SMEM_E];
-  __shared__ float red[2 * 4 * 32];
+  __shared__ float red[2 * G::WM * G::WN * 32];
   __shared__ float csum[3][G::WM][N];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
   const int wm = wave / G::WN, wn = wave % G::WN;
@@ -151,11 +152,13 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) acc[b] = zero16();
 
-  uint32_t offx[StageX<G::BM>::CH], offw[StageW<N>::CH];
-  StageX<G::BM>::offsets(offx, a.ldx, i0, a.M);
-  StageW<N>::offsets(offw, a.ldw);
-  StageX<G::BM> ax, bx;
-  StageW<N> aw, bw;
+  using SX = StageX<G::BM, G::NT>;
+  using SW = StageW<N, G::NT>;
+  uint32_t offx[SX::CH], offw[SW::CH];
+  SX::offsets(offx, a.ldx, i0, a.M);
+  SW::offsets(offw, a.ldw);
+  SX ax, bx;
+  SW aw, bw;
   auto loadA = [&](int kt) { ax.load(offx, a.X, kt * BK, a.Kc); aw.load(offw, a.W, a.ldw, kt * BK, a.Kc); };
   auto loadB = [&](int kt) { bx.load(offx, a.X, kt * BK, a.Kc); bw.load(offw, a.W, a.ldw, kt * BK, a.Kc); };
   auto storeA = [&]() { ax.store(xs(0)); aw.store(ys(0)); };
@@ -265,14 +268,14 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
   if (G::WN > 1) {
     if (hi == 0) {
       red[(wm * G::WN + wn) * 32 + r] = s1;
-      red[128 + (wm * G::WN + wn) * 32 + r] = s2;
+      red[G::WM * G::WN * 32 + (wm * G::WN + wn) * 32 + r] = s2;
     }
     __syncthreads();
     s1 = s2 = 0.f;
 #pragma unroll
     for (int w = 0; w < G::WN; ++w) {
       s1 += red[(wm * G::WN + w) * 32 + r];
-      s2 += red[128 + (wm * G::WN + w) * 32 + r];
+      s2 += red[G::WM * G::WN * 32 + (wm * G::WN + w) * 32 + r];
     }
   }
   const float m1 = s1 * (1.f / N), m2 = s2 * (1.f / N);
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void gemm_lnbwd_kernel(LnBwdArgs a) {
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < N; c += 256) {
+  for (int c = threadIdx.x; c < N; c += G::NT) {
     float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int w = 0; w < G::WM; ++w) { t0 += csum[0][w][c]; t1 += csum[1][w][c]; t2 += csum[2][w][c]; }
@@ -376,6 +379,15 @@ extern "C" int st_gemm_lnbwd(hipStream_t stream, const void* dY, int lddy, const
   const bool drop = drop_seed != nullptr && drop_thresh > 0;
   a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
   a.drop.scale = drop ? drop_scale : 1.f;
+  // more 64-row tiles than CUs but fewer than two rounds of them, long contraction: 128-row tiles on 8 waves
+  // (measured like st_gemm_ln: helps K >= 512 only)
+  if (N == 256 && Kc >= 512 && M > 64 * 256 && M <= 128 * 256) {
+    const dim3 grid((M + 127) / 128);
+    if (drop) hipLaunchKernelGGL((gemm_lnbwd_kernel<256, true, true>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_lnbwd_kernel<256, false, true>), grid, dim3(512), 0, stream, a);
+    ST_CHECK_LAUNCH();
+    return 0;
+  }
 #define ST_LB(NN)                                                                                                  \
   do {                                                                                                             \
     const dim3 grid((M + Geo<NN>::BM - 1) / Geo<NN>::BM);                                                          \

@@ -496,7 +496,8 @@ def test_attention_backward_single_launch(case):
 
 @pytest.mark.parametrize("M,N,K,with_aux,p", [(300, 128, 128, True, 0), (1000, 256, 1024, True, 0), (130, 256, 768, False, 0),
                                                (70, 512, 512, True, 0), (999, 256, 256, True, 0),
-                                               (999, 256, 768, True, 0.1), (130, 128, 256, True, 0.3), (200, 512, 512, False, 0.2)])
+                                               (999, 256, 768, True, 0.1), (130, 128, 256, True, 0.3), (200, 512, 512, False, 0.2),
+                                               (16500, 256, 768, True, 0), (16450, 256, 512, True, 0.1)])      # 8-wave 128-row tiles
 def test_gemm_lnbwd(M, N, K, with_aux, p):
     """st_gemm_lnbwd == st_gemm (dgrad, + aux) followed by st_ln_bwd, in one launch; p > 0: the LayerNorm output was
     dropped in the forward (the mask is regenerated from the same counters as st_ln_bwd's)."""
