@@ -655,11 +655,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
 // dQ and dK/dV in ONE launch (possible when delta comes from the producer of dO: no kernel-to-kernel dependency
 // is left).  Workgroups [0, n_k) run the dK/dV body on the key-tile work list (the heavier items: four
-// contractions per tile), the rest the dQ body on the query-tile list, which fills in as the dK/dV items drain.
+// contractions per tile), the rest the dQ body on the query-tile list, which fills in as the dK/dV items drain
+// (the key-split variant KS = 2 orders them the other way round, see below).
 template <int DK, bool DROP, int KS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, AttnArgs ak, int n_k) {
   constexpr int EQ = 4 * TileGeo<DK, TILE * KS>::E, EK = 2 * (2 * TileGeo<DK>::E + 256);
   __shared__ __attribute__((aligned(16))) bf16 smem[EQ > EK ? EQ : EK];
+  if (KS > 1) {
+    // few queries against many keys (decoder-encoder attention): the dQ items are the long serial chains here (one
+    // workgroup streams all keys of an utterance), so they are dispatched first and the one-tile dK/dV items fill in
+    // around them (27.2 -> 23.3 us at config 2)
+    const int n_q = (int)gridDim.x - n_k;
+    if ((int)blockIdx.x < n_q) attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x, smem);
+    else attn_bwd_dkv_body<DK, DROP>(ak, blockIdx.x - n_q, smem);
+    return;
+  }
   if ((int)blockIdx.x < n_k) attn_bwd_dkv_body<DK, DROP>(ak, blockIdx.x, smem);
   else attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x - n_k, smem);
 }

@@ -120,7 +120,7 @@ if "attn" in which:
         us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale, work=wq, max_k=maxk))
         report("attn fwd  " + name, us, fl)
         for part, nm in ((1, "dq "), (2, "dkv"), (3, "all")):
-            us = timeit(lambda: nv.attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, H, maxq,
+            us = timeit(lambda: nv.attn_bwd(Q, K, V, None if part == 3 else O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, H, maxq,
                                             maxk, causal, scale, parts=part, work_q=wq, work_k=wk))
             report("attn bwd %s " % nm + name, us, fl)
 
