@@ -87,6 +87,22 @@ if "gemm" in which:
         rstd = torch.empty(m, dtype=F32, device=dev)
         us = timeit(lambda: nv.gemm_ln(X, W, b, res, gm, bt, out, xh, rstd))
         report("gemm_ln %-8s [%d,%d]" % (tag, m, k), us, 2.0 * m * d * k, 2.0 * (m * k + 3 * m * d))
+    for (m, k, tag) in [(M, 1024, "dh*W1"), (M, 768, "dqkv*Wqkv"), (Md, 1024, "dec dh*W1"), (Md, 256, "dec dq*Wq")]:
+        dY, W, aux, xh = rnd(m, k), rnd(k, d), rnd(m, d), rnd(m, d)
+        rstd, gm = rnd(m, dtype=F32).abs() + 0.5, rnd(d, dtype=F32)
+        dx, acc = torch.empty(m, d, dtype=BF16, device=dev), [torch.zeros(d, dtype=F32, device=dev) for _ in range(3)]
+        us = timeit(lambda: nv.gemm_lnbwd(dY, W, aux, xh, rstd, gm, dx, acc[0], acc[1], acc[2]))
+        report("gemm_lnbwd %-10s [%d,%d]" % (tag, m, k), us, 2.0 * m * d * k, 2.0 * (m * k + 3 * m * d))
+    # the encoder's weight gradients as the step issues them: 6 layers x (qkv, wo, w1, w2) in ONE grouped launch
+    from st_amd.functional import _Deferred
+    probs, fl = [], 0.0
+    for _ in range(6):
+        for (n, k) in ((768, 256), (256, 256), (1024, 256), (256, 1024)):
+            probs.append((rnd(M, k), rnd(M, n), torch.zeros(n, k, dtype=F32, device=dev), torch.zeros(n, dtype=F32, device=dev),
+                          _Deferred.splits(M), n))
+            fl += 2.0 * M * n * k
+    us = timeit(lambda: nv.wgrad_group(probs), n=5)
+    report("wgrad_group encoder (24 problems)", us, fl, 0.0)
 
 if "attn" in which:
     def offs(lens):
