@@ -567,10 +567,11 @@ class VocabFn(torch.autograd.Function):
     """logits = dec W_vocab^T, fp32, columns padded to a multiple of 8 (Models.py:145,151)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mod):
+    def forward(ctx, x, anchor, mod, mask_pad=False):
+        """mask_pad: the padding columns (zero weight rows -> logit 0) come out as -1e30 instead."""
         s = mod._st
         logits = torch.empty(x.shape[0], s.v_pad, dtype=F32, device=x.device)
-        nv.gemm(x, s.w_vocab, logits, epi=nv.EPI_F32)
+        nv.gemm(x, s.w_vocab, logits, epi=nv.EPI_F32, bias=s.pad_bias if mask_pad else None)
         ctx.save_for_backward(x)
         ctx.mod = mod
         return logits
@@ -586,7 +587,7 @@ class VocabFn(torch.autograd.Function):
         dx = _empty(x.shape[0], x.shape[1], x)
         dgrad(dl, s.w_vocab, dx)
         arena.grads_ready(s.vocab_lo, s.vocab_hi)
-        return dx, None, None
+        return dx, None, None, None
 
 
 class PackFn(torch.autograd.Function):

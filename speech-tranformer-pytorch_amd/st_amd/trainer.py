@@ -63,7 +63,7 @@ class TrainStep:
             # loss over the valid tokens only: the kernels' ragged logits rows against the matching ground-truth
             # entries.  Identical to train.py:40 on the padded [B, L, V] tensor: its padded positions carry
             # ground truth 0 = ignore_index, and the mean is over non-ignored tokens either way.
-            logits, t_rows = self.model.forward_packed(inputs, input_lengths, targets, target_lengths)
+            logits, t_rows = self.model.forward_packed(inputs, input_lengths, targets, target_lengths, padded_logits=True)
             truth = ground_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ground_truth.shape[1]))
             loss = self.crit(logits, truth)
         else:
@@ -83,7 +83,7 @@ class TrainStep:
         self.optimizer.zero_grad()
         rng.advance()
         logits, t_rows, enc, enc_leaf = self.model.forward_packed(inputs, input_lengths, targets, target_lengths,
-                                                                  cut_encoder=True)
+                                                                  cut_encoder=True, padded_logits=True)
         truth = ground_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ground_truth.shape[1]))
         loss = self.crit(logits, truth)
         with deferred_wgrads(True):

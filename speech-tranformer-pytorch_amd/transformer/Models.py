@@ -174,7 +174,11 @@ class Transformer(nn.Module):
         w = self.tgt_word_proj.weight
         v_pad = (self.vocab_size + 7) // 8 * 8
         lo, hi = a.span([w])
-        return bundle(v_pad=v_pad, vocab_params=[w], vocab_lo=lo, vocab_hi=hi,
+        # additive mask of the padded vocabulary columns: -1e30 there makes log-softmax over the whole padded row equal
+        # to log-softmax over the vocabulary (their probability is exactly 0), so a loss can read the buffer in place
+        pad_bias = torch.zeros(v_pad, dtype=torch.float32, device=w.device)
+        pad_bias[self.vocab_size:] = -1e30
+        return bundle(v_pad=v_pad, vocab_params=[w], vocab_lo=lo, vocab_hi=hi, pad_bias=pad_bias,
                       w_vocab=a.bf16(w, v_pad), g_w_vocab=a.grad_view(w, v_pad))
 
     def forward_joint(self, inputs, inputs_pos, targets, targets_pos):
@@ -186,7 +190,8 @@ class Transformer(nn.Module):
         padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, t_rows.scatter_index(L), logits)
         return padded.view(B, L, -1), F_.UnpackFn.apply(enc, in_rows, int(in_rows.max_len))
 
-    def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False):
+    def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False,
+                       padded_logits=False):
         """The same computation with the logits left in the ragged layout the kernels produce:
         -> (logits [sum(targets_pos), V] fp32 (a column slice of a [*, v_pad] buffer), Rows of the target side).
         ``Rows.scatter_index(L)`` maps row r to its position b*L + t in the padded layout; trainer.TrainStep uses
@@ -208,12 +213,16 @@ class Transformer(nn.Module):
             # loss.backward() (decoder; leaves d(enc) in enc_leaf.grad), then enc.backward(enc_leaf.grad)
             enc_in = enc.detach().requires_grad_(True) if cut_encoder else enc
             dec, _ = self.decoder.forward_rows(targets, targets_pos, enc_in, in_rows, t_rows)
-            logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self)       # [sum(tgt_len), v_pad]
+            # padded_logits: return the whole [*, v_pad] buffer with the padding columns at -1e30 (a cross-entropy over it
+            # equals the one over the vocabulary, and neither the column slice nor its gradient is ever copied)
+            logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self, padded_logits)   # [sum(tgt_len), v_pad]
+        if not padded_logits:
+            logits = logits[:, :self.vocab_size]
         if cut_encoder:
-            return logits[:, :self.vocab_size], t_rows, enc, enc_in
+            return logits, t_rows, enc, enc_in
         if want_enc:
-            return logits[:, :self.vocab_size], t_rows, enc, in_rows
-        return logits[:, :self.vocab_size], t_rows
+            return logits, t_rows, enc, in_rows
+        return logits, t_rows
 
     def forward(self, inputs, inputs_pos, targets=None, targets_pos=None):
         """inputs [B, T, F]; inputs_pos [B] input lengths; targets [B, L] tokens;
