@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_k
 
 // Several weight-gradient problems in ONE launch (the decoder's are ~20 workgroups each and pure latency when
 // launched one by one).  The descriptors travel in the kernel-argument segment - no device-side table.
-constexpr int GROUP_MAX = 40;
+constexpr int GROUP_MAX = 48;   // 48 descriptors = 3.6 KB of the 4 KB kernel-argument segment; the decoder's group is 43 problems
 struct GroupProblem {
   const bf16* X; const bf16* Y; float* D; float* bias;
   int ldx, ldy, ldd, M, N, Kc, c_per_split, tiles_i, tiles_j, splits;

@@ -430,7 +430,7 @@ def test_wgrad_group_matches_individual_launches():
     """st_wgrad_group: many weight-gradient problems (different shapes, split counts, with / without a bias
     gradient, more than one launch's worth) in one call == the same problems launched one by one."""
     shapes = [(1206, 768, 256, 4, True), (1206, 256, 256, 2, True), (1206, 1024, 256, 4, True),
-              (1206, 256, 1024, 1, False), (333, 128, 80, 3, True), (50, 4344, 256, 1, False)] * 8      # 48 > GROUP_MAX
+              (1206, 256, 1024, 1, False), (333, 128, 80, 3, True), (50, 4344, 256, 1, False)] * 9      # 54 > GROUP_MAX
     probs, ref = [], []
     for q, (m, n, k, sp, with_b) in enumerate(shapes):
         dy, x = cu(g(m, n, seed=10 + q)), cu(g(m, k, seed=60 + q))
