@@ -193,6 +193,13 @@ int st_embed_bwd(st_stream_t stream, const long long* tok, int B, int L, const v
 /* fp32 master parameters -> bf16 shadow, n a multiple of 8. */
 int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);
 
+/* clip_grad_norm_ + Adam over the flat fp32 parameter buffer in one pass (train.py:45-46, transformer/Optim.py:
+ * Adam(betas = (beta1, beta2), eps)): g *= min(1, max_norm / (*gnorm + 1e-6)) (gnorm NULL: no clipping), then the
+ * update of torch.optim.Adam at step count *step (already incremented) and learning rate *lr - all three device
+ * scalars.  n: elements, a multiple of 4; p, g, m (exp_avg), v (exp_avg_sq): fp32 [n]. */
+int st_adam_clip(st_stream_t stream, long long n, float* p, float* g, float* m, float* v, const float* lr,
+                 const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps);
+
 /* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
 int st_probe_tr16(st_stream_t stream, const void* in, void* out);
 int st_probe_mfma(st_stream_t stream, const void* A, const void* Bt, float* D);

@@ -264,6 +264,40 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict
   }
 }
 
+// Global-norm gradient clipping + Adam over the flat parameter arena, one pass (train.py:45-46: clip_grad_norm_ then
+// ScheduledOptim.step; Adam(betas, eps) of transformer/Optim.py).  Same arithmetic as torch's fused Adam kernel
+// (bias corrections from the step count, denom = sqrt(v) / sqrt(bc2) + eps, p -= lr / bc1 * m / denom); the clipped
+// gradient is written back, as clip_grad_norm_ leaves it.  lr / step / gnorm are device scalars, so a captured graph
+// replays with the current learning rate.
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, size_t n4, const float* lr_p,
+                                                        const float* step_p, const float* gnorm_p, float max_norm,
+                                                        float beta1, float beta2, float eps) {
+  const float lr = *lr_p, step = *step_p;
+  const float coef = gnorm_p ? fminf(max_norm / (*gnorm_p + 1e-6f), 1.0f) : 1.0f;
+  const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
+  const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 gg = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 mm = *reinterpret_cast<const f32x4*>(m + i * 4);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i * 4);
+    f32x4 pp = *reinterpret_cast<const f32x4*>(p + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gg[e] * coef;
+      gg[e] = ge;
+      mm[e] = mm[e] + (1.0f - beta1) * (ge - mm[e]);          // lerp(m, g, 1 - beta1), as torch
+      vv[e] = beta2 * vv[e] + (1.0f - beta2) * ge * ge;
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pp[e] -= step_size * mm[e] / denom;
+    }
+    *reinterpret_cast<f32x4*>(g + i * 4) = gg;
+    *reinterpret_cast<f32x4*>(m + i * 4) = mm;
+    *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+    *reinterpret_cast<f32x4*>(p + i * 4) = pp;
+  }
+}
+
 // ---- hardware probes (tests/test_probe_gpu.py): pin the fragment layouts the kernels rely on -------
 __global__ void probe_tr16_kernel(const bf16* in, bf16* out) {
   __shared__ __attribute__((aligned(16))) bf16 tile[16 * 64];
@@ -398,6 +432,19 @@ extern "C" int st_cast_bf16(hipStream_t stream, const float* src, void* dst, lon
   int blocks = (int)((n8 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, stream, src, (bf16*)dst, n8);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_adam_clip(hipStream_t stream, long long n, float* p, float* g, float* m, float* v, const float* lr,
+                            const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps) {
+  if (n <= 0) return 0;
+  if ((n & 3) || !p || !g || !m || !v || !lr || !step) return -1;
+  const size_t n4 = (size_t)n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, lr, step, gnorm, max_norm, beta1,
+                     beta2, eps);
   ST_CHECK_LAUNCH();
   return 0;
 }

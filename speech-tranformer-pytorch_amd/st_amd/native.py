@@ -62,6 +62,8 @@ SIGNATURES = {
     "st_embed_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                      _c_void_p],
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
+    "st_adam_clip": [_c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                     _c_float, _c_float, _c_float, _c_float],
     "st_probe_tr16": [_c_void_p, _c_void_p, _c_void_p],
     "st_probe_mfma": [_c_void_p, _c_void_p, _c_void_p, _c_void_p],
 }
@@ -493,6 +495,18 @@ def cast_bf16(src, dst):
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     _check(load().st_cast_bf16(_stream(), src.data_ptr(), dst.data_ptr(), src.numel()), "st_cast_bf16")
     return dst
+
+
+def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps):
+    """In place: g *= min(1, max_norm / (gnorm + 1e-6)); (p, m, v) <- Adam(p, g, m, v; lr, step).  lr / step / gnorm are
+    0-dim fp32 device tensors (gnorm None: no clipping)."""
+    for t in (p, g, m, v):
+        assert t.is_cuda and t.dtype == F32 and t.is_contiguous() and t.numel() == p.numel()
+    for t in (lr, step) + ((gnorm,) if gnorm is not None else ()):
+        assert t.is_cuda and t.dtype == F32 and t.numel() == 1
+    _check(load().st_adam_clip(_stream(), p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr.data_ptr(),
+                               step.data_ptr(), _p(gnorm), float(max_norm), float(beta1), float(beta2), float(eps)),
+           "st_adam_clip")
 
 
 def probe_tr16(inp, out):

@@ -106,6 +106,11 @@ class TrainStep:
         return cut if not others or min(others) >= cut else arena.total      # interleaved layout: nothing fires early
 
     def _clip_and_update(self):
+        if getattr(self.optimizer, "arena", None) is not None:
+            # global norm (one reduction over the flat buffer), then clip + Adam as one pass (st_adam_clip)
+            grad_norm = torch.linalg.vector_norm(arena_of(self.model).grad)
+            self.optimizer.step_captured(grad_norm=grad_norm, max_norm=self.max_grad_norm)
+            return grad_norm
         grad_norm = clip_grad_norm_flat(arena_of(self.model), self.max_grad_norm)
         self.optimizer.step_captured()
         return grad_norm

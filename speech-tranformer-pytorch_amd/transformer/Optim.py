@@ -34,9 +34,27 @@ class ScheduledOptim(object):
         self.update_learning_rate(global_step)
         self.optimizer.step()
 
-    def step_captured(self):
-        """The update alone (rate already set with update_learning_rate) - what a HIP graph captures."""
-        self.optimizer.step()
+    def step_captured(self, grad_norm=None, max_norm=None):
+        """The update alone (rate already set with update_learning_rate) - what a HIP graph captures.
+        With ``grad_norm`` (device scalar: the global gradient norm) and ``max_norm`` on the flat-arena path, gradient
+        clipping (train.py:45) and the Adam update are ONE pass over the buffers (``st_adam_clip``: the arithmetic of
+        torch's fused Adam, on this optimizer's own state tensors - ``state_dict`` is unchanged)."""
+        group = self.optimizer.param_groups[0]
+        plain = not (group["weight_decay"] or group["amsgrad"] or group["maximize"])
+        if self.arena is None or grad_norm is None or not plain:
+            self.optimizer.step()
+            return
+        from st_amd import native as nv
+        p = group["params"][0]
+        st = self.optimizer.state[p]
+        if len(st) == 0:                 # what torch.optim.Adam creates lazily on its first step (capturable / fused)
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        st["step"].add_(1)
+        beta1, beta2 = group["betas"]
+        nv.adam_clip(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], self.lr_tensor, st["step"], grad_norm, max_norm,
+                     beta1, beta2, group["eps"])
 
     def zero_grad(self):
         if self.arena is not None:

@@ -107,6 +107,16 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
     return out
 
 
+def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps):
+    coef = 1.0 if gnorm is None else min(float(max_norm) / (float(gnorm) + 1e-6), 1.0)
+    g.mul_(coef)
+    m.lerp_(g, 1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    t = float(step)
+    bc1, bc2 = 1.0 - beta1 ** t, 1.0 - beta2 ** t
+    p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-float(lr) / bc1)
+
+
 def wgrad_group(problems):
     for x, dy, gw, gb, sp, rows in problems:
         gemm(x, dy, gw, bias=gb, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=sp, n=rows)
@@ -298,7 +308,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16"]
 
 

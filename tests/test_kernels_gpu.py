@@ -548,3 +548,32 @@ def test_gemm_stacked_weights(M, blocks, rows, K):
         nv.gemm(dy, W0, dx, y_cmajor=True, stack=(blocks, w_stride, 0), epi=nv.EPI_BF16_ADD, aux=aux)
         nv.gemm(dy, Wcat, dref, y_cmajor=True, epi=nv.EPI_BF16_ADD, aux=aux)
         assert torch.equal(dx, dref), "stacked dgrad differs from the gathered GEMM"
+
+
+def test_adam_clip_matches_torch_clip_and_fused_adam():
+    """st_adam_clip == clip_grad_norm_ (global norm over the flat buffer) followed by torch.optim.Adam(fused, capturable)
+    with a device learning-rate tensor, over several steps with a changing rate (the Noam schedule) and gradients both
+    above and below the clipping threshold."""
+    n, max_norm = 40000, 5.0
+    torch.manual_seed(3)
+    p0 = torch.randn(n, device="cuda")
+    pa, pb = p0.clone(), torch.nn.Parameter(p0.clone())
+    lr_t = torch.zeros((), device="cuda")
+    opt = torch.optim.Adam([pb], lr=lr_t, betas=(0.9, 0.98), eps=1e-9, fused=True, capturable=True)
+    m, v, step = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros((), device="cuda")
+    for it in range(6):
+        g = torch.randn(n, device="cuda") * (0.2 if it % 2 else 0.002)        # norm 40 (clipped) / 0.4 (not clipped)
+        lr_t.fill_(1e-3 * (it + 1))
+        ga = g.clone()
+        gnorm = torch.linalg.vector_norm(ga)
+        step.add_(1)
+        nv.adam_clip(pa, ga, m, v, lr_t, step, gnorm, max_norm, 0.9, 0.98, 1e-9)
+        pb.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pb], max_norm)
+        opt.step()
+        check(ga, pb.grad, 1e-6, "adam_clip clipped gradient, step %d" % it)
+        check(pa, pb.detach(), 2e-6, "adam_clip parameters, step %d" % it)
+    st = opt.state[pb]
+    check(m, st["exp_avg"], 1e-6, "adam_clip exp_avg")
+    check(v, st["exp_avg_sq"], 1e-6, "adam_clip exp_avg_sq")
+    assert float(step) == float(st["step"])
