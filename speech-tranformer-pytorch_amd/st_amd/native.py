@@ -144,7 +144,9 @@ def load(build_if_missing: bool = True):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (torch.cuda.current_stream() builds a Stream object
+    per call: ~8 us of host time, measurable in the eager decode loop's ~100 launches per step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _check(rc: int, what: str) -> None:

@@ -31,12 +31,11 @@ class Beam(object):
         self.next_ys = [torch.full((size,), Constants.BOS, dtype=torch.long, device=device)]   # tokens per step
 
     # ---- state update ------------------------------------------------------------------------------
-    def _commit(self, best_scores, best_flat, vocab, finished):
-        origin = best_flat // vocab
+    def _commit(self, best_scores, origin, token, finished):
         self.all_scores.append(self.scores)
         self.scores = best_scores
         self.prev_ks.append(origin)
-        self.next_ys.append(best_flat - origin * vocab)
+        self.next_ys.append(token)
         if finished:
             self.done = True
             self.all_scores.append(self.scores)
@@ -46,8 +45,9 @@ class Beam(object):
         vocab = word_lk.size(1)
         table = word_lk[0] if not self.prev_ks else word_lk + self.scores.unsqueeze(1)
         best_scores, best_flat = table.reshape(-1).topk(self.size, 0, True, True)
-        finished = (best_flat[0] % vocab).item() == Constants.EOS
-        self._commit(best_scores, best_flat, vocab, finished)
+        origin = best_flat // vocab
+        token = best_flat - origin * vocab
+        self._commit(best_scores, origin, token, token[0].item() == Constants.EOS)
         return self.done
 
     @staticmethod
@@ -60,9 +60,11 @@ class Beam(object):
         else:
             table = word_lk[:, 0]
         best_scores, best_flat = table.topk(size, 1, True, True)
-        finished = ((best_flat[:, 0] % vocab) == Constants.EOS).tolist()
-        for i, b in enumerate(beams):
-            b._commit(best_scores[i], best_flat[i], vocab, finished[i])
+        origin = best_flat // vocab                      # back-pointers and tokens of every utterance in two launches
+        token = best_flat - origin * vocab
+        finished = (token[:, 0] == Constants.EOS).tolist()
+        for i, (b, sc, og, tk) in enumerate(zip(beams, best_scores.unbind(0), origin.unbind(0), token.unbind(0))):
+            b._commit(sc, og, tk, finished[i])
         return [b.done for b in beams]
 
     # ---- read-out ----------------------------------------------------------------------------------
