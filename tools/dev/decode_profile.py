@@ -22,5 +22,5 @@ rec.decode_batch((x, il))
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
 print(s.getvalue()[:4500])
