@@ -1,6 +1,4 @@
 """Encoder / decoder layers (drop-in for reference transformer/Layers.py:8-44)."""
-import os
-
 import torch
 import torch.nn as nn
 
@@ -12,7 +10,7 @@ from transformer.SubLayers import PositionwiseFeedForward
 
 def _links(n):
     """LnLinks only when a backward pass will follow."""
-    on = torch.is_grad_enabled() and not os.environ.get("ST_NO_LNLINK")     # the switch is for A/B timing only
+    on = torch.is_grad_enabled()
     return [LnLink() if on else None for _ in range(n)]
 
 
