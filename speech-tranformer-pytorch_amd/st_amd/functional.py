@@ -250,7 +250,17 @@ class CrossKv:
         if len(mods) < 2:
             return None
         a = mods[0]._st_arena
-        if a is None or any(m._st_arena is not a for m in mods) or a._grad_ready_cb is not None:
+        if a is None or a._grad_ready_cb is not None:
+            return None
+        cached = getattr(mods[0], "_st_crosskv", None)           # the layout check is done once per arena
+        if cached is None or cached[0] is not a:
+            cached = (a, CrossKv._strides(mods, a))
+            mods[0]._st_crosskv = cached
+        return None if cached[1] is None else CrossKv(list(mods), *cached[1])
+
+    @staticmethod
+    def _strides(mods, a):
+        if any(m._st_arena is not a for m in mods):
             return None
         d = mods[0]._st.d_model
         if any(m._st.d_model != d or m._st.n_head != mods[0]._st.n_head for m in mods) or (2 * d) & (2 * d - 1) or d < 64:
@@ -260,7 +270,7 @@ class CrossKv:
         ws, bs = w_off[1] - w_off[0], b_off[1] - b_off[0]
         if ws <= 0 or bs <= 0 or any(w_off[i + 1] - w_off[i] != ws or b_off[i + 1] - b_off[i] != bs for i in range(len(mods) - 1)):
             return None
-        return CrossKv(list(mods), ws, bs)
+        return ws, bs
 
 
 class CrossKvSlot:
