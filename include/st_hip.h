@@ -183,12 +183,13 @@ int st_unpack_rows(st_stream_t stream, const void* x, int ld, int B, int T, int 
 int st_pack_grad(st_stream_t stream, const float* g, int B, int T, int D, const int* off, const int* len, void* out,
                  int ld);
 
-/* Decoder input: out[off[b]+t] = emb[tok[b,t]] + pe[t]  (Models.py:84,87 with repair R3). */
-int st_embed_pe_fwd(st_stream_t stream, const long long* tok, int B, int L, const float* emb, const float* pe, int D,
-                    const int* off, const int* len, void* out);
-/* demb[tok] += dy (f32 atomics); row pad_idx receives nothing (Models.py:74). */
+/* Decoder input: out[off[b]+t] = emb[tok[b,t]] + pe[t]  (Models.py:84,87 with repair R3).  emb has V rows; a token id
+   outside [0, V) traps the kernel (nn.Embedding's device assert). */
+int st_embed_pe_fwd(st_stream_t stream, const long long* tok, int B, int L, const float* emb, int V, const float* pe,
+                    int D, const int* off, const int* len, void* out);
+/* demb[tok] += dy (f32 atomics); row pad_idx receives nothing (Models.py:74); ids outside [0, V) trap. */
 int st_embed_bwd(st_stream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
-                 const int* off, const int* len, int pad_idx, float* demb);
+                 const int* off, const int* len, int pad_idx, float* demb, int V);
 
 /* fp32 master parameters -> bf16 shadow, n a multiple of 8. */
 int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);

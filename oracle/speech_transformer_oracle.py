@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
 
-Every function restates, in plain functional PyTorch on CPU tensors, what one
+Every function restates, in plain functional PyTorch (device-agnostic: the tests run it in float64 on the
+CPU for the small configurations and, unchanged, in float64 ON THE GPU for the benchmark-sized ones), what one
 reference symbol computes; the docstring cites the reference file:line it
 follows (paths relative to the reference checkout).  Parameters are looked up
 in a flat ``dict`` keyed by the *reference's own* ``state_dict`` names, so a
@@ -154,7 +155,7 @@ def multi_head_attention(p: Params, pre: str, q: torch.Tensor, k: torch.Tensor, 
     vh = split(F.linear(v, p[pre + "linear_v.weight"], p[pre + "linear_v.bias"]))
     scores = torch.matmul(qh, kh.transpose(2, 3)).div_(math.sqrt(dk))      # in place, as Attention.py:82-87
     if mask is not None:
-        scores.masked_fill_(mask.unsqueeze(1), float("-inf"))
+        scores.masked_fill_(mask.unsqueeze(1).to(scores.device), float("-inf"))   # masks are built on the host (Utils.py:41-70)
     attn = _dropout(torch.softmax(scores, dim=-1), "attn")                  # Attention.py:89
     ctx = torch.matmul(attn, vh).transpose(1, 2).contiguous().view(bsz, lq, d)
     out = F.linear(ctx, p[pre + "output_linear.weight"], p[pre + "output_linear.bias"])
@@ -253,7 +254,7 @@ def cross_entropy(logits: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     lp = torch.log_softmax(logits.reshape(-1, v), dim=-1)
     t = gt.reshape(-1)
     keep = t != PAD
-    nll = -lp[torch.arange(t.numel()), t]
+    nll = -lp[torch.arange(t.numel(), device=t.device), t]
     return (nll * keep).sum() / keep.sum()
 
 

@@ -226,12 +226,15 @@ __global__ void feat_stack_kernel(const float* __restrict__ x, int T, int F, con
 }
 
 // Decoder input: out[off[b]+t] = E[tok[b,t]] + PE[t]   (Models.py:84 + repair R3; Embedding.py:26)
-__global__ void embed_pe_fwd_kernel(const long long* __restrict__ tok, int L, const float* __restrict__ emb,
+// A token id outside [0, V) traps (nn.Embedding device-asserts on it): reading / accumulating at emb + id * D would
+// silently touch neighbouring slots of the flat parameter / gradient arena.
+__global__ void embed_pe_fwd_kernel(const long long* __restrict__ tok, int L, const float* __restrict__ emb, int V,
                                     const float* __restrict__ pe, int D, const int* off, const int* len,
                                     bf16* __restrict__ out) {
   const int b = blockIdx.z, t = blockIdx.y;
   if (t >= len[b]) return;
   const long long id = tok[(size_t)b * L + t];
+  if (id < 0 || id >= V) __builtin_trap();
   const float* e = emb + (size_t)id * D;
   const float* p = pe + (size_t)t * D;
   bf16* dst = out + (size_t)(off[b] + t) * D;
@@ -245,11 +248,12 @@ __global__ void embed_pe_fwd_kernel(const long long* __restrict__ tok, int L, co
 
 // dE[tok] += dy ; the padding_idx row (Models.py:74, Constants.PAD) never receives gradient.
 __global__ void embed_bwd_kernel(const long long* __restrict__ tok, int L, const bf16* __restrict__ dy, int ld, int D,
-                                 const int* off, const int* len, int pad_idx, float* demb) {
+                                 const int* off, const int* len, int pad_idx, float* demb, int V) {
   const int b = blockIdx.z, t = blockIdx.y;
   if (t >= len[b]) return;
   const long long id = tok[(size_t)b * L + t];
   if (id == pad_idx) return;
+  if (id < 0 || id >= V) __builtin_trap();
   const bf16* src = dy + (size_t)(off[b] + t) * ld;
   float* dst = demb + (size_t)id * D;
   for (int f = threadIdx.x; f < D; f += blockDim.x) atomicAdd(dst + f, (float)src[f]);
@@ -407,20 +411,21 @@ extern "C" int st_pack_grad(hipStream_t stream, const float* g, int B, int T, in
   return 0;
 }
 
-extern "C" int st_embed_pe_fwd(hipStream_t stream, const long long* tok, int B, int L, const float* emb,
+extern "C" int st_embed_pe_fwd(hipStream_t stream, const long long* tok, int B, int L, const float* emb, int V,
                                const float* pe, int D, const int* off, const int* len, void* out) {
   if (B <= 0 || L <= 0) return 0;
-  if (D & 3) return -1;
-  hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(1, L, B), dim3(64), 0, stream, tok, L, emb, pe, D, off, len, (bf16*)out);
+  if ((D & 3) || V <= 0) return -1;
+  hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(1, L, B), dim3(64), 0, stream, tok, L, emb, V, pe, D, off, len, (bf16*)out);
   ST_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int st_embed_bwd(hipStream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
-                            const int* off, const int* len, int pad_idx, float* demb) {
+                            const int* off, const int* len, int pad_idx, float* demb, int V) {
   if (B <= 0 || L <= 0) return 0;
+  if (V <= 0) return -1;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(1, L, B), dim3(64), 0, stream, tok, L, (const bf16*)dy, ld, D, off, len,
-                     pad_idx, demb);
+                     pad_idx, demb, V);
   ST_CHECK_LAUNCH();
   return 0;
 }

@@ -57,10 +57,10 @@ SIGNATURES = {
                       _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int],
     "st_unpack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_pack_grad": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int],
-    "st_embed_pe_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p,
-                        _c_void_p],
+    "st_embed_pe_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                        _c_void_p, _c_void_p],
     "st_embed_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
-                     _c_void_p],
+                     _c_void_p, _c_int],
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
     "st_adam_clip": [_c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_float, _c_float, _c_float, _c_float],
@@ -476,8 +476,8 @@ def embed_pe_fwd(tok, emb, pe, off, length, out):
     _mat(emb, F32, "emb"), _mat(pe, F32, "pe"), _mat(out, BF16, "out")
     D = emb.shape[1]
     assert emb.stride(0) == D and pe.stride(0) == D and out.stride(0) == D and pe.shape[0] >= L
-    _check(load().st_embed_pe_fwd(_stream(), tok.data_ptr(), B, L, emb.data_ptr(), pe.data_ptr(), D, off.data_ptr(),
-                                  length.data_ptr(), out.data_ptr()), "st_embed_pe_fwd")
+    _check(load().st_embed_pe_fwd(_stream(), tok.data_ptr(), B, L, emb.data_ptr(), emb.shape[0], pe.data_ptr(), D,
+                                  off.data_ptr(), length.data_ptr(), out.data_ptr()), "st_embed_pe_fwd")
     return out
 
 
@@ -488,7 +488,7 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     D = demb.shape[1]
     assert demb.stride(0) == D
     _check(load().st_embed_bwd(_stream(), tok.data_ptr(), B, L, dy.data_ptr(), dy.stride(0), D, off.data_ptr(),
-                               length.data_ptr(), int(pad_idx), demb.data_ptr()), "st_embed_bwd")
+                               length.data_ptr(), int(pad_idx), demb.data_ptr(), demb.shape[0]), "st_embed_bwd")
     return demb
 
 

@@ -152,6 +152,9 @@ class TrainStep:
         return self._loss, self._gnorm
 
     def _capture(self, batch):
+        if hasattr(self.optimizer, "_flat_state") and getattr(self.optimizer, "arena", None) is not None:
+            self.optimizer._flat_state()      # Adam's lazily created state must exist BEFORE the capture (a captured
+                                              # zero-fill would reset it on every replay)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -318,14 +318,19 @@ def emulated_kernels():
     saved = {n: getattr(nv, n) for n in _NAMES}
     saved_req = st_arena.ParamArena._require_gpu
     saved_drop = nv.Drop
+    import transformer.Optim as st_optim
+    saved_cpu_arena = st_optim.ScheduledOptim._allow_cpu_arena
     try:
         nv.Drop = Drop
+        st_optim.ScheduledOptim._allow_cpu_arena = True     # flat-arena Adam (st_adam_clip emulation) on CPU tensors
         for n in _NAMES:
-            setattr(nv, n, globals()[n])
+            setattr(nv, n, torch.no_grad()(globals()[n]))    # raw kernels know nothing of autograd (the grouped
+                                                              # weight gradients are flushed outside backward())
         st_arena.ParamArena._require_gpu = staticmethod(lambda dev: None)
         yield
     finally:
         for n, f in saved.items():
             setattr(nv, n, f)
         nv.Drop = saved_drop
+        st_optim.ScheduledOptim._allow_cpu_arena = saved_cpu_arena
         st_arena.ParamArena._require_gpu = saved_req

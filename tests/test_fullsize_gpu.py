@@ -1,0 +1,138 @@
+"""-m gpu: parity of the TIMED object at the BENCHMARKED sizes.
+
+BASELINE config 2 exactly as ``bench.py`` builds it (6+6 layers, d_model 256, 4 heads, d_ff 1024, V 4337, B = 32,
+seed-0 synthetic batch: 24,060 packed frame rows / 1,206 target rows, 8-way split grouped weight gradients) and
+BASELINE config 3's real depth (12+6 layers, d_model 512, 8 heads, the 4-utterance per-GPU shard of DP = 8) run
+through ``st_amd.trainer.TrainStep`` and are compared with ``oracle.train_step`` evaluated in float64 ON THE GPU
+(the oracle is plain device-agnostic torch; the [32, 4, 1000, 1000] fp64 score tensors are 1 GB each on a 288 GB
+part): loss, logits of the valid rows, EVERY gradient tensor, the pre-clip gradient norm and the post-step weights
+(train.py:25-46).  Tolerances are SURVEY.md section 8c's (bf16 activations / fp32 accumulate against fp64 truth):
+logits rel-L2 <= 2e-2, per-tensor gradient rel-L2 <= 8e-2, the analytically zero ``linear_k.bias`` by absolute
+bound.  The per-tensor table is written to ``gpurun_out/parity_<config>.txt`` (and shown when an assertion fails).
+"""
+import os
+
+import pytest
+import torch
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+C2 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_layer=6, num_dec_layer=6, n_heads=4,
+          d_k=64, d_v=64, d_model=256, d_inner_hid=1024, dropout=0.1, vocab_size=4337)
+C3 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_layer=12, num_dec_layer=6, n_heads=8,
+          d_k=64, d_v=64, d_model=512, d_inner_hid=1024, dropout=0.1, vocab_size=4337)
+
+LOGIT_TOL, GRAD_TOL_TENSOR, GRAD_TOL_MEDIAN, GRAD_TOL_GLOBAL = 2e-2, 8e-2, 4e-2, 3e-2
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_norm=5.0):
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import synthetic
+    from st_amd.arena import arena_of
+    from st_amd.trainer import TrainStep
+    from transformer.Optim import ScheduledOptim
+
+    torch.manual_seed(0)
+    model = M.Transformer(U.AttrDict(cfg))
+    U.init_parameters(model)                       # train.py:116
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.eval().cuda()                    # eval(): every Dropout is the identity (the oracle's parity mode)
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(32, 1000, 50, cfg["feature_dim"], cfg["vocab_size"], seed=0,
+                                                          t_min=500, l_min=25)
+    x, tokens, in_len, tgt_len, gt = x[:n_utts], tokens[:n_utts], in_len[:n_utts], tgt_len[:n_utts], gt[:n_utts]
+    if n_utts == 32:
+        assert int(in_len.sum()) == 24060 and int(tgt_len.sum()) == 1206
+    xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()
+    L = int(tgt_len.max())
+
+    # ---- fp64 truth on the GPU ---------------------------------------------------------------------------------
+    p64 = {k: v.double().cuda() for k, v in w.items()}
+    b64 = {"x": xg.double(), "in_len": in_len, "tokens": tg, "tgt_len": tgt_len, "gt": gg}
+    truth = orc.train_step(p64, b64, cfg["n_heads"], cfg["d_model"], warmup, 1, max_grad_norm)
+    torch.cuda.synchronize()
+
+    # ---- the product: logits (no-grad forward, same kernels), then ONE TrainStep call ------------------------------
+    with torch.no_grad():
+        lg, t_rows = model.forward_packed(xg, in_len, tg[:, :L], tgt_len)
+    valid = (torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)).cuda()
+    logit_rel = rel(lg.double(), truth["logits"][valid])       # ragged rows are utterance-major == masked-select order
+    before = arena_of(model).flat.detach().clone()
+    opt = ScheduledOptim(model, cfg["d_model"], U.AttrDict(n_warmup_steps=warmup))
+    step = TrainStep(model, opt, cfg["vocab_size"], max_grad_norm, use_graph=use_graph, graph_warmup=0)
+    loss, gnorm = step(xg, in_len, tg, tgt_len, gg)
+    torch.cuda.synchronize()
+    loss, gnorm = float(loss), float(gnorm)
+    arena = arena_of(model)
+    coef = min(1.0, max_grad_norm / (gnorm + 1e-6))        # st_adam_clip scaled the gradients in place
+    lr = truth["lr"]
+
+    rows, fg, ft, dev_sum, n_el = [], [], [], 0.0, 0
+    kbias = []
+    for n, p in model.named_parameters():
+        g = arena.grad_view(p).detach().double() / coef
+        t = truth["grads"][n]
+        if "linear_k.bias" in n:                          # analytically zero (softmax shift invariance)
+            q = truth["grads"][n.replace("linear_k", "linear_q")].abs().max().item()
+            kbias.append((g.abs().max().item(), q, n))
+            continue
+        rows.append((rel(g, t), n, t.norm().item()))
+        fg.append(g.reshape(-1))
+        ft.append(t.reshape(-1))
+        off = arena.offset[id(p)]
+        old = before[off:off + p.numel()].double()
+        u = (p.detach().double().reshape(-1) - old) / lr
+        ut = (truth["params"][n].reshape(-1) - p64[n].reshape(-1)) / lr
+        dev_sum += (u - ut).abs().sum().item()
+        n_el += p.numel()
+    glob = rel(torch.cat(fg), torch.cat(ft))
+    rows.sort(reverse=True)
+    med = rows[len(rows) // 2][0]
+    lines = ["# %s: TrainStep(use_graph=%s) vs oracle.train_step in fp64 on the GPU" % (tag, use_graph),
+             "loss %.6f (oracle %.6f, rel %.2e)  grad_norm %.5f (oracle %.5f, rel %.2e)  logits rel-L2 %.3e"
+             % (loss, truth["loss"].item(), abs(loss - truth["loss"].item()) / truth["loss"].item(), gnorm,
+                truth["grad_norm"].item(), abs(gnorm - truth["grad_norm"].item()) / truth["grad_norm"].item(), logit_rel),
+             "gradients: global rel-L2 %.3e, per-tensor median %.3e, max %.3e; mean |u - u_ref| of the Adam update %.4f"
+             % (glob, med, rows[0][0], dev_sum / n_el),
+             "per-tensor rel-L2 (worst first):"]
+    lines += ["  %.3e  %-58s |g| = %.3e" % r for r in rows]
+    lines += ["  linear_k.bias |g|max %.2e vs linear_q.bias |g|max %.2e  %s" % k for k in kbias]
+    report = "\n".join(lines)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_%s.txt" % tag), "w") as f:
+        f.write(report + "\n")
+    head = "\n".join(lines[:12])
+    assert logit_rel < LOGIT_TOL, head
+    assert abs(loss - truth["loss"].item()) < 2e-2 * truth["loss"].item(), head
+    assert abs(gnorm - truth["grad_norm"].item()) < 2e-2 * truth["grad_norm"].item(), head
+    assert glob < GRAD_TOL_GLOBAL and med < GRAD_TOL_MEDIAN, head
+    assert rows[0][0] < GRAD_TOL_TENSOR, head
+    for g, q, n in kbias:
+        assert g < 2.5e-1 * q + 1e-6, (n, g, q)
+    assert dev_sum / n_el < 0.08, head          # a sign flip of an Adam first-step update costs 2
+    return report
+
+
+def test_config2_trainstep_full_size_vs_fp64_oracle():
+    """BASELINE config 2 at the benchmarked size (B = 32, 24,060 rows, 6+6 layers), eager TrainStep."""
+    run_step_parity(C2, 32, "c2_b32")
+
+
+def test_config2_trainstep_graph_full_size_vs_fp64_oracle():
+    """The same step replayed from the HIP graph bench.py times."""
+    run_step_parity(C2, 32, "c2_b32_graph", use_graph=True)
+
+
+def test_config3_depth_trainstep_vs_fp64_oracle():
+    """BASELINE config 3's depth and width (12+6 layers, d_model 512, 8 heads) on its per-GPU shard (4 utterances)."""
+    run_step_parity(C3, 4, "c3_b4")
