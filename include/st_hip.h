@@ -42,7 +42,8 @@ enum {
   ST_EPI_BF16_ADD = 4,   /* D(bf16) = acc + aux             residual-gradient add    */
   ST_EPI_F32_ATOMIC = 5, /* D(f32) += acc (atomic, split-K)                          */
   ST_EPI_F32_ATOMIC_T = 6, /* D^T(f32)[j][i] += acc: weight gradients, coalesced atomics */
-  ST_EPI_BF16_DELTA = 7  /* D(bf16) = acc, and delta[h][i] = sum_{j in head h} D(i,j) * aux(i,j) */
+  ST_EPI_BF16_DELTA = 7  /* D(bf16) = acc, and delta[h][i] = sum_{j in head h} D(i,j) * (aux(i,j) + aux2(i,j)); aux2
+                            (nullable, bf16, ld = ldaux) = st_attn_fwd's Ores: what rounding O to bf16 dropped */
 };
 
 /* Training-mode dropout (nn.Dropout in Attention.py:89, SubLayers.py:25,27,
@@ -73,7 +74,7 @@ enum {
  * (backward of the former; aux is the dropped activation). */
 int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy, void* D,
             int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits,
-            const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+            const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, const void* aux2);
 
 /* st_gemm whose Y operand (and bias) is a stack of equally shaped blocks lying y_block_stride (bias_block_stride)
  * elements apart in memory - the same nn.Linear weight of consecutive identical layers as the parameter arena
@@ -142,7 +143,7 @@ int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, co
  * of every utterance up to max_q.  drop_*: dropout on the attention
  * probabilities (Attention.py:89); pass the same values to st_attn_bwd. */
 int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
-                int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
+                int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
                 int H, int d_k, int max_q, int max_k, int q_rows_total, int causal, float scale, const int* work,
                 int n_work, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 

@@ -40,6 +40,8 @@ struct AttnArgs {
   const bf16* K; int ldk;
   const bf16* V; int ldv;
   bf16* O; int ldo;               // forward: output; backward: forward output (for delta)
+  bf16* Ores;                     // forward, optional: bf16(O_fp32 - bf16(O_fp32)), same layout as O - with it the
+                                  // backward's delta = rowsum(dO * (O + Ores)) sees O to ~16 mantissa bits
   const bf16* dO; int lddo;
   bf16* dQ; int lddq;
   bf16* dK; int lddk;
@@ -53,6 +55,10 @@ struct AttnArgs {
   int H;
   int q_rows_total;
   int causal;
+  int psplit;                     // forward: P enters the P V product as two bf16 terms (hi + lo): the context, and with it
+                                  // the backward's delta = rowsum(dO * O), is then consistent with the fp32 P the backward
+                                  // recomputes - sum_k dS(q, k) = 0 to ~2^-16 instead of ~2^-9 (matters where the keys
+                                  // are nearly identical and dQ / dK are differences of almost equal terms); small-Lq only
   float scale;                    // 1/sqrt(d_k)
   DropArgs drop;                  // attention-probability dropout (Attention.py:89), training mode only
 };
@@ -169,7 +175,7 @@ __device__ __forceinline__ void stream_tiles(int ntiles, L load, S store, C comp
 // Store a transposed accumulator tile (lane = row, registers = DK columns) as coalesced rows:
 // through a wave-private [32][DK] LDS patch so HBM sees whole DK*2-byte row segments instead of
 // 64 scattered 8-byte writes per instruction.  `patch` is this wave's private 32*DK elements.
-template <int DK>
+template <int DK, bool RESID = false>
 __device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float mul, bf16* gbase, int ld, int row0,
                                            int nvalid_rows) {
   constexpr int ND = DK / 32, CPR = DK / 8;
@@ -180,7 +186,10 @@ __device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float
     for (int g = 0; g < 4; ++g) {
       bf16x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[d][4 * g + e] * mul);
+      for (int e = 0; e < 4; ++e) {
+        const float x = acc[d][4 * g + e] * mul;
+        v[e] = RESID ? (bf16)(x - (float)(bf16)x) : (bf16)x;      // RESID: what the bf16 rounding of x dropped
+      }
       const int col = d * 32 + 8 * g + 4 * hi;
       *reinterpret_cast<bf16x4*>(patch + r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7)) = v;
     }
@@ -349,8 +358,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       for (int hf = 0; hf < 2; ++hf) {
         const bf16x8 pf = pack_acc8(s[kb], 8 * hf);
         const int base = kb * 32 + 16 * hf + 4 * hi;
+        if (a.psplit) {   // (workgroup-uniform)
+          bf16x8 pl;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
+          for (int j = 0; j < 8; ++j) pl[j] = (bf16)(s[kb][8 * hf + j] - (float)pf[j]);
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            const bf16x8 vf = rd_tr<DK>(vs, d * 32, base);
+            o[d] = mfma32(vf, pf, o[d]);
+            o[d] = mfma32(vf, pl, o[d]);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < ND; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
+        }
       }
   };
   stream_tiles(ntiles, load, store, compute);
@@ -383,6 +404,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   if (q_ok && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
   store_rows<DK>(smem + qw * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32,
                  min(32, lq - (q0 + qw * 32)));
+  if (a.Ores)
+    store_rows<DK, true>(smem + qw * 32 * DK, o, inv, a.Ores + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32,
+                         min(32, lq - (q0 + qw * 32)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -703,7 +727,7 @@ int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
 }  // namespace
 
 extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                           void* O, int ldo, float* lse, const int* q_off, const int* q_len, const int* k_off,
+                           void* O, int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off,
                            const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
                            float scale, const int* work, int n_work, const unsigned* drop_seed, unsigned drop_salt,
                            int drop_thresh, float drop_scale) {
@@ -714,9 +738,10 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   if (B > 32767) return -4;
   AttnArgs a = {};
   a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
-  a.O = (bf16*)O; a.ldo = ldo; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
+  a.O = (bf16*)O; a.ldo = ldo; a.Ores = (bf16*)Ores; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
+  a.psplit = (Ores != nullptr && max_q <= 64) ? 1 : 0;     // the decoder's attentions, when a backward will follow
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
 #define ST_FWD(DKK, DR) \

@@ -47,6 +47,7 @@ struct GemmArgs {
   int M, N, Kc;
   const float* bias;
   const bf16* aux; int ldaux;
+  const bf16* aux2;   // EPI_BF16_DELTA, optional: second addend of the delta factor (aux + aux2), ld = ldaux
   int c_per_split, tiles_i, tiles_j, splits;
   int head_dim;    // EPI_BF16_DELTA: columns per attention head (32 or 64)
   // Y (and the bias) may be a stack of equally spaced blocks - the same weight of consecutive identical layers as it
@@ -385,12 +386,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
       }
   }
   // the mask / addend chunks this thread will need: requested before the barrier, all in flight together
-  bf16x8 auxv[8];
+  bf16x8 auxv[8], auxw[8];
   if (EPI == EPI_BF16_MASK || EPI == EPI_BF16_ADD || EPI == EPI_BF16_DELTA) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int id = p * 256 + tid, i = i0 + (id >> 4), j = j0 + (id & 15) * 8;
       auxv[p] = gload8(a.aux + (size_t)i * a.ldaux + j, i < a.M && j < a.N);
+      if (EPI == EPI_BF16_DELTA) auxw[p] = gload8(a.aux2 + (size_t)i * a.ldaux + j, a.aux2 != nullptr && i < a.M && j < a.N);
     }
   }
   __syncthreads();
@@ -410,7 +412,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
       // produced where dO is produced.  A head's columns sit in head_dim / 8 neighbouring lanes of one row.
       float part = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part += (float)v[e] * (float)auxv[p][e];
+      for (int e = 0; e < 8; ++e) part += (float)v[e] * ((float)auxv[p][e] + (float)auxw[p][e]);
       part += __shfl_xor(part, 1, 64);
       part += __shfl_xor(part, 2, 64);
       if (a.head_dim == 64) part += __shfl_xor(part, 4, 64);
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_group_kernel(GroupArgs g) {
   const GroupProblem& p = g.p[pi];
   GemmArgs a;
   a.X = p.X; a.ldx = p.ldx; a.Y = p.Y; a.ldy = p.ldy; a.D = p.D; a.ldd = p.ldd;
-  a.M = p.M; a.N = p.N; a.Kc = p.Kc; a.bias = p.bias; a.aux = nullptr; a.ldaux = 0;
+  a.M = p.M; a.N = p.N; a.Kc = p.Kc; a.bias = p.bias; a.aux = nullptr; a.ldaux = 0; a.aux2 = nullptr;
   a.c_per_split = p.c_per_split; a.tiles_i = p.tiles_i; a.tiles_j = p.tiles_j; a.splits = p.splits;
   a.head_dim = 0; a.yseg_shift = 31; a.yseg_extra = 0; a.bias_extra = 0;
   a.drop.seed = nullptr; a.drop.salt = 0; a.drop.thresh = 0; a.drop.scale = 1.f;
@@ -524,11 +526,12 @@ extern "C" int st_wgrad_group(hipStream_t stream, int n, const void* const* X, c
   return 0;
 }
 
-extern "C" int st_gemm_stacked(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y,
-                               int ldy, void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux,
-                               int ldaux, int epi, int splits, const unsigned* drop_seed, unsigned drop_salt,
-                               int drop_thresh, float drop_scale, int y_block_rows, long y_block_stride,
-                               long bias_block_stride) {
+namespace {
+int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y,
+              int ldy, void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux,
+              int ldaux, int epi, int splits, const unsigned* drop_seed, unsigned drop_salt,
+              int drop_thresh, float drop_scale, int y_block_rows, long y_block_stride,
+              long bias_block_stride, const void* aux2) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
   int yseg_shift = 31;
   if (y_block_rows > 0) {   // power-of-two multiple of 128 rows per block; forward and dgrad operands only
@@ -551,6 +554,7 @@ extern "C" int st_gemm_stacked(hipStream_t stream, int x_cmajor, int y_cmajor, c
   if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T) splits = 1;
   a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
   a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux;
+  a.aux2 = epi == EPI_BF16_DELTA ? (const bf16*)aux2 : nullptr;
   a.yseg_shift = yseg_shift;
   // per block: what the plain row stride does not already cover (rows run along the contraction axis for dgrad)
   a.yseg_extra = y_block_rows > 0 ? y_block_stride - (long)y_block_rows * ldy : 0;
@@ -568,9 +572,21 @@ extern "C" int st_gemm_stacked(hipStream_t stream, int x_cmajor, int y_cmajor, c
   return 0;
 }
 
+}  // namespace
+
+extern "C" int st_gemm_stacked(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y,
+                               int ldy, void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux,
+                               int ldaux, int epi, int splits, const unsigned* drop_seed, unsigned drop_salt,
+                               int drop_thresh, float drop_scale, int y_block_rows, long y_block_stride,
+                               long bias_block_stride) {
+  return gemm_impl(stream, x_cmajor, y_cmajor, X, ldx, Y, ldy, D, ldd, M, N, Kc, bias, aux, ldaux, epi, splits, drop_seed,
+                   drop_salt, drop_thresh, drop_scale, y_block_rows, y_block_stride, bias_block_stride, nullptr);
+}
+
 extern "C" int st_gemm(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y, int ldy,
                        void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi,
-                       int splits, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale) {
-  return st_gemm_stacked(stream, x_cmajor, y_cmajor, X, ldx, Y, ldy, D, ldd, M, N, Kc, bias, aux, ldaux, epi, splits,
-                         drop_seed, drop_salt, drop_thresh, drop_scale, 0, 0, 0);
+                       int splits, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale,
+                       const void* aux2) {
+  return gemm_impl(stream, x_cmajor, y_cmajor, X, ldx, Y, ldy, D, ldd, M, N, Kc, bias, aux, ldaux, epi, splits,
+                   drop_seed, drop_salt, drop_thresh, drop_scale, 0, 0, 0, aux2);
 }

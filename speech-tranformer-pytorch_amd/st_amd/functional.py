@@ -378,14 +378,17 @@ class MhaFn(torch.autograd.Function):
                 nv.gemm(x_kv, s.w_kv, kvbuf, bias=s.b_kv)
             Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
         attn_ctx = _empty(Mq, d, x_q)
+        # what rounding the context to bf16 drops (kept only when a backward follows): delta = rowsum(dO * O) is a
+        # difference partner of dP in dS = P (dP - delta); with O to ~16 bits the two stay consistent
+        ores = _empty(Mq, d, x_q) if any(ctx.needs_input_grad) else None      # (grad mode is off inside forward())
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         scale = 1.0 / math.sqrt(d // H)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
-                    scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop, max_k=k_rows.max_len)
+                    scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
-        ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd)
+        ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
         ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers share one encoder-gradient buffer (or CrossKv's)
@@ -396,7 +399,7 @@ class MhaFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd = ctx.saved_tensors
+        x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores = ctx.saved_tensors
         mod, q_rows, k_rows = ctx.mod, ctx.q_rows, ctx.k_rows
         s, arena = mod._st, mod._st_arena
         d, H = s.d_model, s.n_head
@@ -412,7 +415,7 @@ class MhaFn(torch.autograd.Function):
         delta = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         # d(context) and, in the same launch, delta = rowsum(d(context) * context) per head: the two attention
         # backward kernels then depend on nothing but finished buffers and run as ONE launch
-        nv.gemm(ds, s.w_o, dctx, epi=nv.EPI_BF16_DELTA, aux=attn_ctx, y_cmajor=True, delta=delta, head_dim=d // H)
+        nv.gemm(ds, s.w_o, dctx, epi=nv.EPI_BF16_DELTA, aux=attn_ctx, y_cmajor=True, delta=delta, head_dim=d // H, aux2=ores)
         if x_kv is None:
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             # key rows past k_len (padded layout only) get no gradient: they must read as zeros

@@ -29,7 +29,7 @@ _c_long = ctypes.c_long
 SIGNATURES = {
     "st_version": [],
     "st_gemm": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
-                _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
+                _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p],
     "st_gemm_stacked": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
                         _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int,
                         _c_float, _c_int, _c_long, _c_long],
@@ -43,7 +43,7 @@ SIGNATURES = {
                       _c_void_p, _c_uint, _c_int, _c_float],
     "st_ln_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                   _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_float],
-    "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+    "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -210,13 +210,14 @@ def _drop(d: Optional["Drop"]):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1,
-         m=None, n=None, kc=None, drop=None, delta=None, head_dim=0, stack=None):
+         m=None, n=None, kc=None, drop=None, delta=None, head_dim=0, stack=None, aux2=None):
     """out[i][j] (+)= sum_c X(i,c) Y(j,c).  ``*_cmajor``: that tensor is stored [c, rows].
     ``stack = (blocks, stride, bias_stride)``: Y (and bias) is the FIRST of ``blocks`` equally shaped blocks lying
     ``stride`` (``bias_stride``) elements apart - the same weight of consecutive identical layers in the parameter
     arena; the operand is their vertical stack (more output columns forward, a longer contraction for dgrad).
-    EPI_BF16_DELTA: additionally delta[h][i] = sum over head h's ``head_dim`` columns of out(i, .) * aux(i, .)
-    (fp32 [N / head_dim, M]) - the attention backward's rowsum(dO * O), produced by the GEMM that produces dO."""
+    EPI_BF16_DELTA: additionally delta[h][i] = sum over head h's ``head_dim`` columns of out(i, .) * (aux + aux2)(i, .)
+    (fp32 [N / head_dim, M]) - the attention backward's rowsum(dO * O), produced by the GEMM that produces dO;
+    ``aux2`` (optional) = attn_fwd's ``ores``, the part of O its bf16 rounding dropped."""
     _mat(X, BF16, "X"), _mat(Y, BF16, "Y")
     _mat(out, F32 if epi in (EPI_F32, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T) else BF16, "out")
     M = m if m is not None else (X.shape[1] if x_cmajor else X.shape[0])
@@ -243,12 +244,16 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
     if epi in (EPI_BF16_MASK, EPI_BF16_ADD, EPI_BF16_DELTA):
         _mat(aux, BF16, "aux")
         ldaux = aux.stride(0)
+        if aux2 is not None:
+            _mat(aux2, BF16, "aux2")
+            if epi != EPI_BF16_DELTA or aux2.stride(0) != ldaux or aux2.shape != aux.shape:
+                raise ValueError("gemm: aux2 goes with EPI_BF16_DELTA and must have aux's shape and stride")
     _tag("gemm", int(x_cmajor), int(y_cmajor), M, N, Kc, epi)
     dropargs = _drop(drop) if epi in (EPI_BF16_RELU, EPI_BF16_MASK) else _drop(None)
     if stack is None:
         rc = load().st_gemm(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(),
                             Y.stride(0), out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux, epi, splits,
-                            *dropargs)
+                            *dropargs, _p(aux2))
     else:
         rc = load().st_gemm_stacked(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(),
                                     Y.stride(0), out.data_ptr(), out.stride(0), M, N, Kc, _p(bias), _p(aux), ldaux,
@@ -359,12 +364,17 @@ def _work(w):
 
 
 def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None,
-             max_k=0):
+             max_k=0, ores=None):
     """max_k (longest key sequence) only selects the kernel variant: <= 64 queries against >= 256 keys take
     the key-split path."""
-    """work: optional int32 device list of (b << 16) | q_tile, heaviest first (functional.attn_work)."""
+    """work: optional int32 device list of (b << 16) | q_tile, heaviest first (functional.attn_work).
+    ores (optional, bf16, O's shape and stride): receives bf16(O_fp32 - bf16(O_fp32))."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
         _mat(t, BF16, nm)
+    if ores is not None:
+        _mat(ores, BF16, "ores")
+        if ores.stride(0) != O.stride(0) or ores.shape != O.shape:
+            raise ValueError("attn_fwd: ores must have O's shape and stride")
     B = q_off.numel()
     d_k = Q.shape[1] // n_head
     for t, nm in ((q_off, "q_off"), (q_len, "q_len"), (k_off, "k_off"), (k_len, "k_len")):
@@ -373,7 +383,7 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     _vec(lse, F32, n_head * rows, "lse")
     _tag("attn_fwd", n_head, d_k, int(causal), q_len, k_len)
     rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
-                            O.data_ptr(), O.stride(0), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
+                            O.data_ptr(), O.stride(0), _p(ores), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
                             k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), rows, int(causal),
                             float(scale), *_work(work), *_drop(drop))
     _check(rc, "st_attn_fwd")

@@ -68,7 +68,7 @@ def keep_qk(d, bh, nq, nk):
 
 
 def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmajor=False, splits=1, m=None, n=None,
-         kc=None, drop=None, delta=None, head_dim=0, stack=None):
+         kc=None, drop=None, delta=None, head_dim=0, stack=None, aux2=None):
     if stack is not None:       # Y / bias: the first of `blocks` equally spaced blocks (st_gemm_stacked)
         blocks, y_stride, b_stride = stack
         Y = torch.as_strided(Y, (blocks, Y.shape[0], Y.shape[1]), (y_stride, Y.stride(0), 1)).reshape(-1, Y.shape[1])
@@ -102,7 +102,8 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
     else:
         out[:M, :N] = acc.to(out.dtype)
         if epi == nv.EPI_BF16_DELTA:
-            prod = out[:M, :N].float() * aux[:M, :N].float()
+            o_hi = aux[:M, :N].float() + (aux2[:M, :N].float() if aux2 is not None else 0.0)
+            prod = out[:M, :N].float() * o_hi
             delta.view(N // head_dim, -1)[:, :M] = prod.view(M, N // head_dim, head_dim).sum(-1).t()
     return out
 
@@ -189,7 +190,7 @@ def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h):
 
 
 def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None,
-             max_k=0):
+             max_k=0, ores=None):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):
@@ -197,10 +198,20 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
             p = torch.softmax(s, -1)
             if _on(drop):   # the kernel drops un-normalised weights and folds 1/(1-p) into the final 1/l
                 p = p * keep_qk(drop, b * n_head + h, *s.shape)
-                O[qs, cs] = (p.to(BF16).float() @ v * drop.scale).to(BF16)
+                o32 = p.to(BF16).float() @ v * drop.scale
+                O[qs, cs] = o32.to(BF16)
+                if ores is not None:
+                    ores[qs, cs] = (o32 - O[qs, cs].float()).to(BF16)
                 lse.view(n_head, rows)[h, qs] = torch.logsumexp(s, -1) / math.log(2.0)
                 continue
-            O[qs, cs] = (p.to(BF16).float() @ v).to(BF16)
+            if ores is not None and max_q <= 64:     # the kernel's psplit mode: P as hi + lo bf16 terms
+                hi = p.to(BF16).float()
+                o32 = (hi + (p - hi).to(BF16).float()) @ v
+            else:
+                o32 = p.to(BF16).float() @ v
+            O[qs, cs] = o32.to(BF16)
+            if ores is not None:
+                ores[qs, cs] = (o32 - O[qs, cs].float()).to(BF16)
             lse.view(n_head, rows)[h, qs] = torch.logsumexp(s, -1) / math.log(2.0)
     return O
 

@@ -15,10 +15,12 @@ import oracle as orc
 from tests._emul import emulated_kernels
 
 
-# bf16 activations / fp32 accumulate against fp64 truth.  The reference itself under bf16 autocast
-# shows a per-tensor median of 3.5e-2; small decoder q/k projections, whose
-# gradient is a difference of nearly equal bf16-rounded terms (dP - delta), reach ~1e-1.
-GRAD_TOL_TENSOR, GRAD_TOL_MEDIAN, GRAD_TOL_GLOBAL = 1.5e-1, 4e-2, 3e-2
+# bf16 activations / fp32 accumulate against fp64 truth: SURVEY.md section 8c's tolerances.  (Round 1 needed 1.5e-1
+# per tensor for the decoder's q / k projections, whose gradient is a difference of nearly equal terms dP - delta; since
+# the attention forward hands the backward O to ~16 bits (Ores) and multiplies P in as hi + lo for the small-Lq
+# attentions, delta is consistent with the recomputed P and those tensors sit at 5e-2 - the level the reference itself
+# shows under bf16 autocast, profiles/r02_reference_bf16_floor.txt.)
+GRAD_TOL_TENSOR, GRAD_TOL_MEDIAN, GRAD_TOL_GLOBAL = 8e-2, 4e-2, 3e-2
 
 
 def rel(a, b):

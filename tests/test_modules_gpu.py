@@ -234,8 +234,17 @@ def test_split_backward_graphs_with_reducer_match_single_graph():
                 assert len(red.buckets) > 4
             results.append(([l for l, _ in out], [g for _, g in out], arena_of(model).flat.detach().float().cpu().clone()))
         (l0, g0, p0), (l1, g1, p1) = results
-        for a, b in zip(l0 + g0, l1 + g1):
-            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (l0, l1, g0, g1)
+        # Step 1 starts from identical weights: the two paths (one graph with grouped weight gradients and the stacked
+        # K/V GEMM | eager hooks, then split graphs around the all-reduce) differ by kernel-composition rounding only
+        # (measured 4e-4 on the gradient).  Later steps see weights that differ in the sign of a few Adam updates and
+        # the tiny learning rate puts most updates below bf16 resolution - a handful of shadow weights crossing a
+        # rounding boundary moves the loss by ~1e-4 - so they are compared at 1e-3 / 1e-2 (a lost bucket or a race
+        # between an all-reduce and the atomics of a weight gradient shows up as O(1) in the gradient norm).
+        assert abs(l0[0] - l1[0]) <= 1e-4 * abs(l0[0]) and abs(g0[0] - g1[0]) <= 2e-3 * g0[0], (l0, l1, g0, g1)
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 1e-3 * abs(a), (l0, l1)
+        for a, b in zip(g0, g1):
+            assert abs(a - b) <= 1e-2 * abs(a), (g0, g1)
         assert float((p0 - p1).norm() / p0.norm()) < 5e-3
     finally:
         dist.destroy_process_group()
@@ -303,3 +312,57 @@ def test_lnlink_rejects_a_foreign_gradient():
     with pytest.raises(RuntimeError, match="LnLink"):
         link.claim(torch.zeros(4, 8, device="cuda"))
     assert LnLink().claim(torch.zeros(1, device="cuda")) is None
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_trainstep_vs_oracle_gpu(golden_dir, use_graph):
+    """The timed object (TrainStep, eager and HIP-graph replay) against fixture F7: loss, pre-clip gradient norm, Noam
+    rate, clip + Adam arithmetic, post-step weights (train.py:25-46)."""
+    comp.run_trainstep_vs_oracle(golden_dir, "cuda", use_graph=use_graph)
+
+
+def test_dp_shards_vs_golden_gpu(golden_dir):
+    """Fixture F8 (8-shard gradient average of train_multi.py) against the HIP path run shard by shard."""
+    comp.run_dp_shards_vs_golden(golden_dir, "cuda")
+
+
+def test_optimizer_checkpoint_resume_gpu(golden_dir):
+    """Reference-format optimizer checkpoint <-> the flat fused Adam on the GPU; the Noam rate keeps moving after a
+    resume, for both update paths (torch's fused Adam through ``step`` and ``st_adam_clip`` through ``step_captured``)."""
+    import copy
+    import torch
+    import transformer.Utils as U
+    from transformer.Optim import ScheduledOptim
+    from transformer.Utils import learn_rate
+    _, w, _ = comp._load_c1(golden_dir)
+
+    def one_step(m, opt, s, clip_path):
+        opt.zero_grad()
+        g = torch.Generator().manual_seed(s)
+        for p in m.parameters():
+            p.grad.copy_(torch.randn(p.shape, generator=g))
+        if clip_path:
+            opt.update_learning_rate(s)
+            opt.step_captured(grad_norm=torch.linalg.vector_norm(opt.arena.grad), max_norm=1e9)
+        else:
+            opt.step(s)
+
+    for clip_path in (False, True):
+        m = comp._build(w, device="cuda")
+        opt = ScheduledOptim(m, 128, U.AttrDict(n_warmup_steps=100))
+        for s in (1, 2):
+            one_step(m, opt, s, clip_path)
+        sd = opt.state_dict()
+        assert len(sd["state"]) == 90 and isinstance(sd["param_groups"][0]["lr"], float)
+        m2 = comp._build({k: v.detach().clone() for k, v in m.state_dict().items()}, device="cuda")
+        opt2 = ScheduledOptim(m2, 128, U.AttrDict(n_warmup_steps=100))
+        opt2.load_state_dict(copy.deepcopy(sd))
+        one_step(m, opt, 3, clip_path)
+        one_step(m2, opt2, 3, clip_path)
+        assert abs(float(opt2.lr_tensor) - learn_rate(128, 100, 3)) < 1e-6 * learn_rate(128, 100, 3)
+        for (n, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+            assert torch.allclose(a, b, rtol=0, atol=1e-7), n
+        before = [p.detach().clone() for p in m2.parameters()]
+        one_step(m2, opt2, 60, clip_path)
+        moved = max((p.detach() - b).abs().max().item() for p, b in zip(m2.parameters(), before))
+        assert moved > 5 * learn_rate(128, 100, 3)          # lr(60) = 20 x lr(3): the schedule is alive after the resume
