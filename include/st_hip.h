@@ -88,6 +88,14 @@ int st_gemm_stacked(st_stream_t stream, int x_cmajor, int y_cmajor, const void* 
                     const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int y_block_rows,
                     long y_block_stride, long bias_block_stride);
 
+/* Weight-stationary streaming GEMM for the short-contraction products (csrc/st_gemm_ws.hip): D (bf16) = epi(X W^T + bias)
+ * with K = 256, N a multiple of 256, X [M, K] and W [N, K] natural.  epi: 0 = identity, 1 = ReLU (+ dropout, as
+ * ST_EPI_BF16_RELU).  w_block_rows > 0: W / bias are stacks of equally spaced blocks as in st_gemm_stacked
+ * (w_block_rows a power-of-two multiple of 256).  Replaces st_gemm(0, 0, ...) for Attention.py:74-76, SubLayers.py:25. */
+int st_gemm_ws(st_stream_t stream, const void* X, int ldx, const void* W, int ldw, void* D, int ldd, int M, int N, int K,
+               const float* bias, int epi, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh,
+               float drop_scale, int w_block_rows, long w_block_stride, long bias_block_stride);
+
 /* n weight-gradient problems in ONE launch (the decoder's are ~20 workgroups
  * each: launched one by one they are pure latency).  Problem q:
  *   dW[q][N_out, K_in] (f32, ld lddw) += dY[q]^T X[q],  db[q][N_out] += colsum(dY[q])   (db or db[q] may be NULL)

@@ -33,6 +33,8 @@ SIGNATURES = {
     "st_gemm_stacked": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
                         _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int,
                         _c_float, _c_int, _c_long, _c_long],
+    "st_gemm_ws": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                   _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_int, _c_long, _c_long],
     "st_wgrad_group": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                        _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
@@ -260,6 +262,32 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
                                     epi, splits, *dropargs, block_rows, y_stride, b_stride)
     _check(rc, "st_gemm")
     return out
+
+
+def gemm_ws(X, W, out, bias=None, relu=False, drop=None, stack=None):
+    """out = act(X W^T + bias) through the weight-stationary streaming kernel (K = 256, N % 256 == 0); stack as in gemm()."""
+    _mat(X, BF16, "X"), _mat(W, BF16, "W"), _mat(out, BF16, "out")
+    M, K = X.shape
+    N = W.shape[0]
+    blocks, block_rows, w_stride, b_stride = 1, 0, 0, 0
+    if stack is not None:
+        blocks, w_stride, b_stride = stack
+        block_rows = W.shape[0]
+        N = blocks * block_rows
+    if out.shape[0] < M or out.shape[1] < N:
+        raise ValueError("gemm_ws: out %s too small for %dx%d" % (tuple(out.shape), M, N))
+    _vec(bias, F32, N // blocks, "bias")
+    _tag("gemm", 0, 0, M, N, K, EPI_BF16_RELU if relu else EPI_BF16)
+    rc = load().st_gemm_ws(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
+                           M, N, K, _p(bias), int(relu), *(_drop(drop) if relu else _drop(None)), block_rows, w_stride, b_stride)
+    _check(rc, "st_gemm_ws")
+    return out
+
+
+def ws_ok(M, N, K, stack=None):
+    """Shapes the weight-stationary kernel takes (and where it pays: encoder-sized M)."""
+    rows = N if stack is None else N
+    return K == 256 and rows % 256 == 0 and M >= 4096
 
 
 def wgrad_group(problems):
