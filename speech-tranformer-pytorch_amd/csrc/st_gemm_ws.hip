@@ -27,10 +27,16 @@
 //     vmcnt counter with loads and may retire out of order with them, so a wave that did both would have to wait for
 //     its stores' acknowledgements before trusting a counted wait for its DMAs.
 //
-// LDS images ([rows][512 B] chunk, [rows][512 B] patch, [32][256 B] weight staging): 16-byte slots XOR-swizzled by
-// (row & 15): conflict-free ds_read_b128 / ds_write_b64 over the 16-lane groups.  LDS-DMA writes lane-linear, so the
-// swizzle of the chunk image is applied to the per-lane SOURCE address and to the read address
-// (cdna_hip_programming.md 5.4 rule 21).
+// The kernel is instruction-ISSUE bound, not MFMA- or memory-bound (s_memtime per phase: a SIMD issues one instruction
+// per ~4 cycles whatever its kind, so a 32-cycle MFMA pays for at most ~7 other instructions of the SIMD's two waves):
+// everything around the 16 MFMAs of a chunk is kept to a minimum -
+//   * chunk image [row / 16][32 k-slices][row % 16] x 16 B: the 16 fragment reads of a lane are ONE base register plus
+//     immediates (k-step kk at + 512 kk) and each 16-lane group reads one full 256-byte bank row (conflict-free);
+//     LDS-DMA writes lane-linear, so the image is produced by the per-lane SOURCE address (64-byte pieces of 16 rows
+//     per instruction);
+//   * the bias enters as the C operand of the first MFMA (no accumulator initialisation, no add);
+//   * LDS-DMA source offsets, patch and store offsets are per-lane constants computed once.
+// Patch and weight-staging images: 16-byte slots XOR-swizzled by (row & 15) (conflict-free 8 / 16-byte accesses).
 #include "st_common.cuh"
 #include <stdlib.h>
 #include <type_traits>
@@ -61,7 +67,6 @@ struct WsArgs {
 };
 
 __device__ __attribute__((aligned(16))) float g_zero_ws[4];
-__device__ unsigned long long g_ws_prof[8][4];   // dev instrumentation (ST_WS_DBG & 16): cycles per phase, workgroup 0
 
 template <int EPI, bool DROP>
 __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(WsArgs a) {
@@ -74,18 +79,29 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(WsArgs a) {
   if (nch <= 0) return;
   const bool loader = wave < 4;      // (wave-uniform) LDS-DMA issue | global stores
 
-  // ---- LDS-DMA: loader wave w moves rows 8w .. 8w+7 of every chunk (four 1 KB instructions) ----------------------
-  const int s = l & 31;                                            // 16-byte slot of the LDS row this lane fills
+  // ---- LDS-DMA: loader wave w fills LDS bytes [4096 w, 4096 (w + 1)) of every chunk image (four 1 KB instructions).
+  // Image piece (row, c) - the 16 bytes of k-slice c of chunk row `row` - lives at ((row >> 4) * 32 + c) * 256 +
+  // (row & 15) * 16; instruction q = 4 w + j covers pieces c = 4 (q & 7) + (lane >> 4), row = 16 (q >> 3) + (lane & 15).
   const unsigned lds0 = lds_addr(smem);
+  unsigned voff[4];                                                // byte offset of this lane's source piece from the chunk's row 0
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = 4 * wave + j;
+    voff[j] = (unsigned)((16 * (q >> 3) + (l & 15)) * a.ldx + (4 * (q & 7) + (l >> 4)) * 8) * 2u;
+  }
   auto issue = [&](int ci) {
     const int g = rank + min(ci, nch - 1) * a.ranks;               // beyond the end: re-load the last chunk (keeps vmcnt counted)
     const unsigned dst = lds0 + (unsigned)(ci % WS_NB) * WS_SLOT + (unsigned)wave * 4096u;
+    const char* base = reinterpret_cast<const char*>(a.X) + (size_t)g * WS_CH * a.ldx * 2;
+    if ((g + 1) * WS_CH <= a.M) {          // (uniform) whole chunk inside the matrix
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rr = 8 * wave + 2 * j + hi;                        // row within the chunk
-      const int c = (s & 16) | ((s ^ rr) & 15);                    // source slot = swizzle^-1 of the LDS slot
-      const int row = min(g * WS_CH + rr, a.M - 1);
-      lds_dma16(a.X + (size_t)row * a.ldx + c * 8, dst + 1024u * j);
+      for (int j = 0; j < 4; ++j) lds_dma16(base + voff[j], dst + 1024u * j);
+    } else {                               // rows past the end are clamped onto the last row (never stored)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = 4 * wave + j, row = min(g * WS_CH + 16 * (q >> 3) + (l & 15), a.M - 1);
+        lds_dma16(a.X + (size_t)row * a.ldx + (4 * (q & 7) + (l >> 4)) * 8, dst + 1024u * j);
+      }
     }
   };
   if (loader) {
@@ -118,23 +134,23 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(WsArgs a) {
         wf[h * 8 + kk] = *reinterpret_cast<const bf16x8*>(stage + r * 256 + (((2 * kk + hi) ^ (r & 15)) << 4));
     }
   }
-  f32x4 bv[4];
+  f32x16 bias16;                       // the accumulator's C input: bias of column n0 + acc_row(t, hi) in register t
 #pragma unroll
-  for (int gq = 0; gq < 4; ++gq)
-    bv[gq] = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + wblk * a.bias_extra + n0 + 8 * gq + 4 * hi : g_zero_ws);
+  for (int gq = 0; gq < 4; ++gq) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + wblk * a.bias_extra + n0 + 8 * gq + 4 * hi : g_zero_ws);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias16[4 * gq + e] = b4[e];
+  }
   // the compiler's own loads are retired HERE, so that it places no s_waitcnt vmcnt() of its own inside the loop (it
   // cannot see the LDS-DMAs and would drain them)
 #pragma unroll
   for (int kk = 0; kk < WS_K / 16; ++kk) touch(wf[kk]);
-#pragma unroll
-  for (int gq = 0; gq < 4; ++gq) touch(bv[gq]);
+  touch(bias16);
   __syncthreads();                   // every wave has read its weight image: the staging area becomes ring slots 4, 5
   if (loader) issue(4);
 
-  // fragment read offsets of this lane: row r, k-step kk -> slot ((2kk + hi) ^ r) & 15 (+ 16 for kk >= 8)
-  int rd[8];
-#pragma unroll
-  for (int k7 = 0; k7 < 8; ++k7) rd[k7] = r * 512 + ((k7 ^ ((r >> 1) & 7)) << 5) + ((hi ^ (r & 1)) << 4);
+  // fragment reads of this lane (chunk row r, k-slice 2 kk + hi): rdbase + 512 kk
+  const int rdbase = (r >> 4) * 8192 + (r & 15) * 16 + hi * 256;
   char* const patch0 = smem + WS_NB * WS_SLOT;
   const Drop dr = make_drop(a.drop);
   // store(c): thread t of waves 4-7 moves 16-byte pieces id = j * 256 + t (row id >> 5, slot id & 31) of the patch
@@ -154,25 +170,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(WsArgs a) {
     ep[gq] = r * 512 + (((c & 16) | ((c ^ r) & 15)) << 4) + hi * 8;
   }
 
-  unsigned long long pw = 0, pr = 0, pc = 0, pn = 0;
-  const bool prof = (a.dbg & 16) && blockIdx.x == 0;
   // One pipeline step: [barrier] DMA(ci + 5) | store(ci - 2) | MFMA(ci) -> cur || epilogue(ci - 1) <- prev.
   // MMA / EPI are compile-time so that the steady state is ONE basic block: the scheduler can then place the
   // epilogue's VALU work and LDS writes in the issue slots between the 16 dependent MFMAs.
   auto step = [&](auto mma_c, auto epi_c, int ci, f32x16& cur, const f32x16& prev) {
     constexpr bool MMA = decltype(mma_c)::value, EPI_ON = decltype(epi_c)::value;
-    const unsigned long long t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-    if (loader) {
+    if (loader && !(a.dbg & 2)) {
       // chunk ci's loads have landed once at most the 4 * 4 younger ones (chunks ci+1 .. ci+4) are outstanding
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS_NB - 2) * 4) : "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's patch writes have reached the LDS
     __builtin_amdgcn_s_barrier();    // chunk ci is in LDS; patch (ci-1) & 1 is complete; everybody is done with chunk ci-1
     asm volatile("" ::: "memory");
-    const unsigned long long t1 = prof ? __builtin_amdgcn_s_memtime() : 0;
     if (loader) {
       if (!(a.dbg & 2)) issue(ci + WS_NB - 1);         // into the slot chunk ci-1 occupied
-    } else if (ci >= 2) {            // store(ci - 2): 256 threads x 4 x 16 B = the 32 x 512 B patch, whole rows
+    } else if (ci >= 2 && !(a.dbg & 1)) {            // store(ci - 2): 256 threads x 4 x 16 B = the 32 x 512 B patch, whole rows
       const char* pt = patch0 + (ci & 1) * WS_PATCH;
       const int grow = (rank + (ci - 2) * a.ranks) * WS_CH;
       bf16* drow = a.D + (size_t)grow * a.ldd + slice * 256;
@@ -180,7 +192,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(WsArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const bf16x8*>(pt + sp[j]);
       if (grow + WS_CH <= a.M) {     // (workgroup-uniform) the whole chunk is inside the matrix: no per-row guards
-        if (!(a.dbg & 1))
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x8*>(drow + so[j]) = v[j];
       } else {
@@ -189,56 +200,60 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(WsArgs a) {
           if (grow + ((j * 256 + st) >> 5) < a.M) *reinterpret_cast<bf16x8*>(drow + so[j]) = v[j];
       }
     }
-    const unsigned long long t2 = prof ? __builtin_amdgcn_s_memtime() : 0;
     bf16x8 xf[WS_K / 16];
     if (MMA) {
       const char* xs = smem + (ci % WS_NB) * WS_SLOT;
       if (a.dbg & 4) {
 #pragma unroll
         for (int kk = 0; kk < WS_K / 16; ++kk) xf[kk] = wf[(kk + 1) & 15];
-      } else
+      } else {
 #pragma unroll
-      for (int kk = 0; kk < WS_K / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8*>(xs + rd[kk & 7] + (kk >> 3) * 256);
-      cur = zero16();
+        for (int kk = 0; kk < WS_K / 16; ++kk) xf[kk] = *reinterpret_cast<const bf16x8*>(xs + rdbase + kk * 512);
+      }
       if (a.dbg & 8) {
 #pragma unroll
         for (int kk = 0; kk < WS_K / 16; ++kk) asm volatile("" :: "v"(xf[kk]));
-      } else
+        cur = bias16;
+      } else {
+      // two independent accumulator chains (even / odd k-steps): a dependent MFMA cannot issue before its
+      // predecessor's result is back, which is longer than the 32-cycle issue interval
+      f32x16 c0 = mfma32(wf[0], xf[0], bias16), c1 = mfma32(wf[1], xf[1], zero16());
 #pragma unroll
-      for (int kk = 0; kk < WS_K / 16; ++kk) cur = mfma32(wf[kk], xf[kk], cur);
+      for (int kk = 2; kk < WS_K / 16; kk += 2) {
+        c0 = mfma32(wf[kk], xf[kk], c0);
+        c1 = mfma32(wf[kk + 1], xf[kk + 1], c1);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) cur[t] = c0[t] + c1[t];
+      }
     }
-    if (EPI_ON) {                    // epilogue(ci - 1): row = lane & 31 of that chunk, columns n0 + acc_row(t, hi)
+    if (EPI_ON && !(a.dbg & 16)) {                    // epilogue(ci - 1): row = lane & 31 of that chunk, columns n0 + acc_row(t, hi)
       char* pt = patch0 + ((ci - 1) & 1) * WS_PATCH;
       const int grow = (rank + (ci - 1) * a.ranks) * WS_CH;
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        bf16x4 o;
         uint32_t bits = 0;
         if (EPI == WS_RELU && DROP) bits = dr.bits(drop_counter_rc(grow + r, n0 + 8 * gq + 4 * hi, a.N));
+        f32x4 v4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = prev[4 * gq + e] + bv[gq][e];
+          float v = prev[4 * gq + e];
           if (EPI == WS_RELU) {
             v = fmaxf(v, 0.f);
             if (DROP) v = dr.keep(bits, e) ? v * dr.scale : 0.f;
           }
-          o[e] = (bf16)v;
+          v4[e] = v;
         }
-        *reinterpret_cast<bf16x4*>(pt + ep[gq]) = o;
+        *reinterpret_cast<bf16x4*>(pt + ep[gq]) = __builtin_convertvector(v4, bf16x4);
       }
     }
     if (MMA && EPI_ON) {             // 16 x { 1 MFMA, a few epilogue VALU }, an LDS write every fourth slot
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, EPI == WS_RELU ? 2 : 1, 0);
         if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
-    }
-    if (prof) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-      pw += t1 - t0; pr += t2 - t1; pc += t3 - t2; ++pn;
     }
   };
   using T_ = std::integral_constant<bool, true>;
@@ -259,14 +274,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(WsArgs a) {
   }
   step(F_{}, F_{}, nch + 1, acc_a, acc_b);         // store(nch - 1)
   if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) DMAs must not outlive the workgroup's LDS
-  if (prof && l == 0) { g_ws_prof[wave][0] = pw; g_ws_prof[wave][1] = pr; g_ws_prof[wave][2] = pc; g_ws_prof[wave][3] = pn; }
 }
 
 }  // namespace
-
-extern "C" int st_ws_prof_read(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_prof), sizeof(unsigned long long) * 32);
-}
 
 extern "C" int st_gemm_ws(hipStream_t stream, const void* X, int ldx, const void* W, int ldw, void* D, int ldd, int M,
                           int N, int K, const float* bias, int epi, const unsigned* drop_seed, unsigned drop_salt,
