@@ -203,6 +203,45 @@ __device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float
   }
 }
 
+// The same for a value AND what its bf16 rounding dropped (O, Ores), in ONE pass: both images are written to two
+// patches, one LDS wait, both are read back and stored - half the dependent LDS round trips of two store_rows calls
+// (the attention epilogue is a latency tail: every wave of the workgroup is in it at the same time).
+template <int DK>
+__device__ __forceinline__ void store_rows_pair(bf16* patch_hi, bf16* patch_lo, const f32x16* acc, float mul, bf16* g_hi,
+                                                bf16* g_lo, int ld, int row0, int nvalid_rows) {
+  constexpr int ND = DK / 32, CPR = DK / 8;
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 vh, vl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = acc[d][4 * g + e] * mul;
+        vh[e] = (bf16)x;
+        vl[e] = (bf16)(x - (float)vh[e]);
+      }
+      const int col = d * 32 + 8 * g + 4 * hi;
+      const int at = r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7);
+      *reinterpret_cast<bf16x4*>(patch_hi + at) = vh;
+      *reinterpret_cast<bf16x4*>(patch_lo + at) = vl;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 32 * CPR / 64; ++p) {
+    const int id = p * 64 + l, rr = id / CPR, c = id % CPR;
+    const int at = rr * DK + ((c ^ (rr & (CPR - 1))) << 3);
+    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(patch_hi + at);
+    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(patch_lo + at);
+    if (rr < nvalid_rows) {
+      *reinterpret_cast<bf16x8*>(g_hi + (size_t)(row0 + rr) * ld + c * 8) = vh;
+      *reinterpret_cast<bf16x8*>(g_lo + (size_t)(row0 + rr) * ld + c * 8) = vl;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Forward.  Each wave owns 32 query rows (lane & 31); key / value tiles are streamed.
 // ---------------------------------------------------------------------------------------------
@@ -402,11 +441,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
   const float inv = ltot > 0.f ? (DROP ? dr.scale : 1.f) / ltot : 0.f;
   if (q_ok && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
-  store_rows<DK>(smem + qw * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32,
-                 min(32, lq - (q0 + qw * 32)));
-  if (a.Ores)
-    store_rows<DK, true>(smem + qw * 32 * DK, o, inv, a.Ores + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32,
-                         min(32, lq - (q0 + qw * 32)));
+  if (a.Ores)      // (the tile buffers are free: the lo patches lie behind the hi patches / the key-split exchange area)
+    store_rows_pair<DK>(smem + qw * 32 * DK, smem + (KS == 1 ? 4 * 32 * DK : 256 * DK) + qw * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK,
+                        a.Ores + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32, min(32, lq - (q0 + qw * 32)));
+  else
+    store_rows<DK>(smem + qw * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32,
+                   min(32, lq - (q0 + qw * 32)));
 }
 
 // ---------------------------------------------------------------------------------------------

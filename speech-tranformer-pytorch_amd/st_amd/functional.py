@@ -211,6 +211,15 @@ def wgrad(dY, X, gW, rows=None, gB=None):
     nv.gemm(X, dY, gW, bias=gB, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=splits, n=N)
 
 
+def linear_fwd(x, w, out, bias, relu=False, drop=None, stack=None):
+    """out = act(x w^T + bias): the weight-stationary streaming kernel for encoder-sized inputs of width 256
+    (st_gemm_ws), the tiled kernel otherwise."""
+    n = w.shape[0] * (stack[0] if stack is not None else 1)
+    if nv.ws_ok(x.shape[0], n, x.shape[1]) and (stack is None or (w.shape[0] % 256 == 0 and not (w.shape[0] // 256) & (w.shape[0] // 256 - 1))):
+        return nv.gemm_ws(x, w, out, bias=bias, relu=relu, drop=drop, stack=stack)
+    return nv.gemm(x, w, out, bias=bias, epi=nv.EPI_BF16_RELU if relu else nv.EPI_BF16, drop=drop, stack=stack)
+
+
 def dgrad(dY, W, out, epi=nv.EPI_BF16, aux=None, kc=None, drop=None):
     """out[m][k] = sum_n dY[m][n] W[n][k]  (+ aux | masked by aux > 0, survivors scaled by drop.scale)."""
     return nv.gemm(dY, W, out, epi=epi, aux=aux, y_cmajor=True, kc=kc, drop=drop)
@@ -286,7 +295,7 @@ class CrossKvFn(torch.autograd.Function):
     def forward(ctx, enc, anchor, state: CrossKv):
         s0 = state.mods[0]._st
         kv = _empty(enc.shape[0], state.n * 2 * s0.d_model, enc)
-        nv.gemm(enc, s0.w_kv, kv, bias=s0.b_kv, stack=(state.n, state.w_stride, state.b_stride))
+        linear_fwd(enc, s0.w_kv, kv, s0.b_kv, stack=(state.n, state.w_stride, state.b_stride))
         ctx.save_for_backward(enc)
         ctx.state = state
         return kv
@@ -365,7 +374,7 @@ class MhaFn(torch.autograd.Function):
         self_attn = x_kv is None
         if self_attn:
             qkv = _empty(Mq, 3 * d, x_q)
-            nv.gemm(x_q, s.w_qkv, qkv, bias=s.b_qkv)
+            linear_fwd(x_q, s.w_qkv, qkv, s.b_qkv)
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             kvbuf = None
         else:
@@ -380,6 +389,8 @@ class MhaFn(torch.autograd.Function):
         attn_ctx = _empty(Mq, d, x_q)
         # what rounding the context to bf16 drops (kept only when a backward follows): delta = rowsum(dO * O) is a
         # difference partner of dP in dS = P (dP - delta); with O to ~16 bits the two stay consistent
+        # (every attention takes it: at config 3's depth the late ENCODER layers' keys are nearly identical across
+        # positions too, and their q / k gradients come out 5x off without it - tests/test_fullsize_gpu.py)
         ores = _empty(Mq, d, x_q) if any(ctx.needs_input_grad) else None      # (grad mode is off inside forward())
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         scale = 1.0 / math.sqrt(d // H)
@@ -480,7 +491,7 @@ class FfnFn(torch.autograd.Function):
         s = mod._st
         M, d = x.shape
         h = _empty(M, s.d_ff, x)
-        nv.gemm(x, s.w1, h, bias=s.b1, epi=nv.EPI_BF16_RELU, drop=drop1)
+        linear_fwd(x, s.w1, h, s.b1, relu=True, drop=drop1)
         out, xhat = _empty(M, d, x), _empty(M, d, x)
         rstd = torch.empty(M, dtype=F32, device=x.device)
         nv.gemm_ln(h, s.w2, s.b2, x, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS, drop=drop2,

@@ -284,10 +284,10 @@ def gemm_ws(X, W, out, bias=None, relu=False, drop=None, stack=None):
     return out
 
 
-def ws_ok(M, N, K, stack=None):
-    """Shapes the weight-stationary kernel takes (and where it pays: encoder-sized M)."""
-    rows = N if stack is None else N
-    return K == 256 and rows % 256 == 0 and M >= 4096
+def ws_ok(M, N, K):
+    """Shapes the weight-stationary kernel takes, and where it pays (measured on MI355X, tools/dev/ws_bench.py: 1.2-1.4x
+    over the tiled kernel from ~16 k rows up, on par at 7 k, so only encoder-sized row counts are routed to it)."""
+    return K == 256 and N % 256 == 0 and M >= 12288
 
 
 def wgrad_group(problems):

@@ -108,6 +108,10 @@ def gemm(X, Y, out, bias=None, aux=None, epi=nv.EPI_BF16, x_cmajor=False, y_cmaj
     return out
 
 
+def gemm_ws(X, W, out, bias=None, relu=False, drop=None, stack=None):
+    return gemm(X, W, out, bias=bias, epi=nv.EPI_BF16_RELU if relu else nv.EPI_BF16, drop=drop, stack=stack)
+
+
 def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps):
     coef = 1.0 if gnorm is None else min(float(max_norm) / (float(gnorm) + 1e-6), 1.0)
     g.mul_(coef)
@@ -319,7 +323,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16"]
 
 

@@ -577,3 +577,56 @@ def test_adam_clip_matches_torch_clip_and_fused_adam():
     check(m, st["exp_avg"], 1e-6, "adam_clip exp_avg")
     check(v, st["exp_avg_sq"], 1e-6, "adam_clip exp_avg_sq")
     assert float(step) == float(st["step"])
+
+
+# ---- st_gemm_ws: the weight-stationary streaming GEMM -------------------------------------------------------
+@pytest.mark.parametrize("M,N", [(32, 256), (33, 256), (1206, 768), (4097, 1024), (24060, 768), (13000, 256)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_gemm_ws_forward(M, N, relu):
+    """K = 256, N a multiple of 256; ragged last chunk (M % 32 != 0), one chunk, many chunks per workgroup, strided
+    input / output views (column slices of wider buffers)."""
+    K = 256
+    x, W, b = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5), g(N, seed=3, dtype=F32)
+    ref = em.gemm(x, W, torch.zeros(M, N, dtype=BF16), bias=b, epi=nv.EPI_BF16_RELU if relu else nv.EPI_BF16)
+    xw = torch.zeros(M, K + 64, dtype=BF16, device="cuda")
+    xw[:, 8:8 + K] = cu(x)
+    ow = torch.full((M + 3, N + 128), float("nan"), dtype=BF16, device="cuda")
+    out = nv.gemm_ws(xw[:, 8:8 + K], cu(W), ow[:M, 64:64 + N], bias=cu(b), relu=relu)
+    check(out, ref, 1e-2, "gemm_ws %dx%d relu=%d" % (M, N, relu))
+    assert torch.isnan(ow[M:].float()).all() and torch.isnan(ow[:, :64].float()).all() and torch.isnan(ow[:, 64 + N:].float()).all(), \
+        "gemm_ws wrote outside its output view"
+    nb = nv.gemm_ws(cu(x), cu(W), torch.empty(M, N, dtype=BF16, device="cuda"), relu=relu)       # no bias
+    check(nb, em.gemm(x, W, torch.zeros(M, N, dtype=BF16), epi=nv.EPI_BF16_RELU if relu else nv.EPI_BF16), 1e-2, "gemm_ws no bias")
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_gemm_ws_relu_dropout_mask(p):
+    """The ReLU + dropout epilogue draws the SAME counter-based mask as st_gemm's (the backward regenerates it there)."""
+    M, N, K = 13001, 1024, 256
+    x, W, b = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5), g(N, seed=3, dtype=F32)
+    dn, de = _drops(11, p)
+    ref = em.gemm(x, W, torch.zeros(M, N, dtype=BF16), bias=b, epi=nv.EPI_BF16_RELU, drop=de)
+    out = nv.gemm_ws(cu(x), cu(W), torch.zeros(M, N, dtype=BF16, device="cuda"), bias=cu(b), relu=True, drop=dn)
+    check(out, ref, 1e-2, "gemm_ws relu+dropout p=%g" % p)
+    _zero_pattern_equal(out, ref, "gemm_ws relu+dropout p=%g" % p)
+    tiled = nv.gemm(cu(x), cu(W), torch.zeros(M, N, dtype=BF16, device="cuda"), bias=cu(b), epi=nv.EPI_BF16_RELU, drop=dn)
+    _zero_pattern_equal(out, tiled, "gemm_ws vs st_gemm dropout mask")
+
+
+def test_gemm_ws_stacked_weights():
+    """Stacked weights (the decoder-encoder K/V projections of all layers, read in place from the arena) == the
+    gathered GEMM, and == st_gemm_stacked."""
+    M, blocks, rows, K = 13000, 6, 512, 256
+    w_stride, b_stride = rows * K + 4096 + 64, rows + 192
+    arena_w = cu(g(1, blocks * w_stride + 128, seed=1, scale=K ** -0.5).view(-1))
+    arena_b = cu(g(1, blocks * b_stride + 64, seed=2, dtype=F32).view(-1))
+    W0 = torch.as_strided(arena_w, (rows, K), (K, 1), 64)
+    b0 = arena_b[32:32 + rows]
+    Wcat = torch.cat([torch.as_strided(arena_w, (rows, K), (K, 1), 64 + l * w_stride) for l in range(blocks)]).contiguous()
+    bcat = torch.cat([arena_b[32 + l * b_stride:32 + l * b_stride + rows] for l in range(blocks)]).contiguous()
+    x = cu(g(M, K, seed=3))
+    out = nv.gemm_ws(x, W0, torch.empty(M, blocks * rows, dtype=BF16, device="cuda"), bias=b0, stack=(blocks, w_stride, b_stride))
+    ref = nv.gemm_ws(x, Wcat, torch.empty(M, blocks * rows, dtype=BF16, device="cuda"), bias=bcat)
+    assert torch.equal(out, ref), "stacked gemm_ws differs from the gathered one"
+    tiled = nv.gemm(x, W0, torch.empty(M, blocks * rows, dtype=BF16, device="cuda"), bias=b0, stack=(blocks, w_stride, b_stride))
+    check(out, tiled, 5e-3, "gemm_ws vs st_gemm_stacked")
