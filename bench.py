@@ -86,8 +86,10 @@ def kernel_report(records):
 
 
 def cpu_worker(args):
-    """Child process: time the CPU oracle (fp32, dropout off) on the first --cpu-utts utterances of the
-    benchmark batch, same seeded weights as the GPU model; prints the cpu_baseline JSON object."""
+    """Child process: time the CPU oracle (fp32) on the first --cpu-utts utterances (default: all 32) of the benchmark
+    batch, same seeded weights as the GPU model; dropout OFF (the parity mode) and dropout ON (how train.py:21 runs the
+    reference: p = 0.1 in the layers, 0.5 in the front-end; masks drawn with torch.bernoulli as nn.Dropout does).
+    Prints the cpu_baseline JSON object."""
     import oracle as orc
     import transformer.Models as M
     import transformer.Utils as U
@@ -110,8 +112,10 @@ def cpu_worker(args):
     leaves = {k: (v.requires_grad_(True) if not k.endswith(".pe") else v) for k, v in p.items()}
     params = [v for k, v in leaves.items() if not k.endswith(".pe")]
     opt = torch.optim.Adam(params, lr=orc.noam_lr(C2["d_model"], 12000, 1), betas=(0.9, 0.98), eps=1e-9)
-    times, loss = [], None
-    for _ in range(args.cpu_steps + 1):       # first step is the warm-up
+    frames = int(in_len[:n].sum())
+    t_start = time.perf_counter()
+
+    def one_step():
         t = time.perf_counter()
         opt.zero_grad()
         logits, _ = orc.transformer(leaves, b["x"], b["in_len"], b["tokens"], b["tgt_len"], C2["n_heads"])
@@ -119,14 +123,32 @@ def cpu_worker(args):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
-        times.append(time.perf_counter() - t)
+        return time.perf_counter() - t, loss.item()
+
+    def bernoulli(site, shape):       # nn.Dropout: keep / (1 - p), p = 0.5 in the front-end (Models.py:31), 0.1 elsewhere
+        pr = 0.5 if site == "front" else C2["dropout"]
+        return torch.empty(shape).bernoulli_(1.0 - pr).div_(1.0 - pr)
+
+    times, loss = [], None
+    for _ in range(args.cpu_steps + 1):       # first step is the warm-up
+        dt, loss = one_step()
+        times.append(dt)
     med = sorted(times[1:])[len(times[1:]) // 2]
-    frames = int(in_len[:n].sum())
-    print(json.dumps({"value": round(frames / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-                      "sec_per_step": round(med, 3),
-                      "sample": "%d steps (after 1 warm-up) of the oracle restatement (fwd + CE + autograd bwd + clip + "
-                                "torch Adam) on the first %d of the 32 utterances (%d valid frames), fp32, dropout "
-                                "off, torch %d threads; loss %.4f" % (args.cpu_steps, n, frames, cores, loss.item())}))
+    out = {"value": round(frames / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sec_per_step": round(med, 3),
+           "sample": "%d steps (after 1 warm-up) of the oracle restatement (fwd + CE + autograd bwd + clip + torch Adam) "
+                     "on the first %d of the 32 utterances (%d valid frames), fp32, dropout off, torch %d threads; loss "
+                     "%.4f" % (args.cpu_steps, n, frames, cores, loss)}
+    # dropout ON, while the time budget lasts (the GPU number must not wait for it)
+    if time.perf_counter() - t_start + 2.5 * med * 2 < args.cpu_timeout - 20:
+        with orc.dropout_masks(bernoulli):
+            td = [one_step()[0] for _ in range(2)]
+        out["dropout_on"] = {"value": round(frames / min(td), 1), "unit": "frames/s", "sec_per_step": round(min(td), 3),
+                             "sample": "best of 2 steps with Bernoulli masks at every nn.Dropout site of the reference "
+                                       "(train.py:21 model.train())"}
+    else:
+        out["dropout_on"] = None
+    print(json.dumps(out))
 
 
 def main():
@@ -136,8 +158,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--cpu-utts", type=int, default=8, help="utterances of the batch the CPU baseline is timed on")
-    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-utts", type=int, default=32, help="utterances of the batch the CPU baseline is timed on")
+    ap.add_argument("--cpu-timeout", type=int, default=200)
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many utterances of the seed-0 batch "
+                    "split contiguously over the ranks (SURVEY 8e: 32 -> 4 per GPU at N = 8) instead of 32 per GPU")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
@@ -178,8 +202,19 @@ def main():
     optim = ScheduledOptim(model, C2["d_model"], U.AttrDict(n_warmup_steps=12000))
     step = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
 
-    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"],
-                                                          seed=rank, t_min=T_MIN, l_min=L_MIN)
+    def shard(global_batch):
+        """global_batch = 0: weak scaling, 32 utterances per GPU (seed = rank, train_multi.py:136-139 keeps the per-rank
+        batch fixed); else the seed-0 batch's first `global_batch` utterances split contiguously by rank."""
+        if not global_batch:
+            return synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"], seed=rank, t_min=T_MIN,
+                                        l_min=L_MIN)
+        full = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"], seed=0, t_min=T_MIN, l_min=L_MIN)
+        per = global_batch // world
+        return tuple(t[rank * per:(rank + 1) * per] for t in full)
+
+    if args.global_batch and (args.global_batch % world or args.global_batch > BATCH):
+        raise SystemExit("--global-batch must be a multiple of the rank count and <= %d" % BATCH)
+    x, tokens, in_len, tgt_len, gt = shard(args.global_batch)
     xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()          # inputs resident in HBM before timing
 
     def run(n):
@@ -207,6 +242,42 @@ def main():
     elapsed, frames = el.item(), frames.item()
     ms_step = elapsed / args.steps * 1e3
 
+    # ---- SURVEY 8d's protocol next to the contract's back-to-back mean: a device sync at both edges of EVERY step,
+    # median of the per-step wall times; then the same with use_graph off (every kernel launched from Python: what a
+    # loader whose batches never repeat a length signature gets today)
+    def synced_median(n):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            step(xg, in_len, tg, tgt_len, gg)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t)
+        return sorted(ts)[len(ts) // 2] * 1e3
+    ms_median = synced_median(max(args.steps, 5))
+    eager_ms = None
+    if not args.no_graph:
+        step.use_graph = False
+        run(2)
+        eager_ms = synced_median(max(args.steps // 2, 5))
+        step.use_graph = True
+    exposed_ms = None
+    if reducer is not None and reducer.active:
+        # exposed gradient exchange = step time with the reducer minus the same step without any exchange (timing only)
+        plain = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=None, use_graph=not args.no_graph)
+        for _ in range(4):
+            plain(xg, in_len, tg, tgt_len, gg)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            plain(xg, in_len, tg, tgt_len, gg)
+        barrier()
+        t_plain = torch.tensor([(time.perf_counter() - t1) / args.steps * 1e3], device="cuda")
+        if world > 1:
+            dist.all_reduce(t_plain, op=dist.ReduceOp.MAX)
+        exposed_ms = round(ms_step - t_plain.item(), 3)
+        dp.broadcast_parameters(arena)            # the un-exchanged steps let the replicas drift: re-align them
+
     # ---- roofline pass: per-launch HIP events on the launch stream (outside the timed region) ----
     step.use_graph = False                      # per-launch events need real launches, not a graph replay
     native.timing_start()
@@ -230,19 +301,46 @@ def main():
     # HBM bytes per launch of that kernel class from the PMC passes (tools/pmc_traffic.sh: separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950 read correction applied); the summary
     # travels with the repo under profiles/ because counters cannot be collected inside the timed run.
-    traffic = None
+    traffic, traffic_src = None, None
     pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
     if pmc:
         with open(pmc[-1]) as f:
-            traffic = json.load(f).get(dom, {}).get("bytes")
+            pj = json.load(f)
+        traffic = pj.get(dom, {}).get("bytes")
+        traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload at git %s)" % (
+            os.path.basename(pmc[-1]), pj.get("git_sha", "unrecorded"))
     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": None if traffic is None else round(traffic),
+                "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // 2,
                 "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
     kernels = {k: {"ms_per_step": round(v["ms"] / 2, 3), "launches": v["launches"] // 2,
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] else None}
                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    # HBM side (SURVEY 8d "report both"): algorithmic bytes per step of the streaming kernels and of the GEMM / attention
+    # classes (operands once, bf16 activations) -> achieved GB/s and its fraction of the 8 TB/s peak
+    rows_e, rows_d, d_m, d_ff, n_e, n_d = float(in_len.sum()), float(tgt_len.sum()), C2["d_model"], C2["d_inner_hid"], \
+        C2["num_enc_layer"], C2["num_dec_layer"]
+    hbm_bytes = {
+        "st_adam_clip": 32.0 * arena.total,                               # p, g, m, v read + written (fp32)
+        "st_cast_bf16": 6.0 * arena.total,
+        "st_pack_rows": rows_e * C2["feature_dim"] * (4 + 2),
+        "ln_bwd": 3 * 6.0 * rows_e * d_m,                                 # dy, xhat in, dx out (3 launches, encoder-sized bound)
+        "st_embed_pe_fwd": rows_d * d_m * (4 + 4 + 2), "st_embed_bwd": rows_d * d_m * (2 + 8),
+        # per encoder layer: q/k/v (in d, out 3d), fc1 (in d, out d_ff) + the stacked K/V projection (in d, out 2 d n_dec)
+        "gemm_fwd": 2.0 * rows_e * (n_e * (4 * d_m + d_m + d_ff) + d_m + 2 * d_m * n_d),
+        "gemm_ln": 2.0 * rows_e * n_e * ((d_m + d_m + 2 * d_m) + (d_ff + d_m + 2 * d_m)),     # X, residual in; out, xhat
+        "gemm_lnbwd": 2.0 * rows_e * n_e * ((3 * d_m + 3 * d_m) + (d_ff + 3 * d_m)),           # dY, aux, xhat in; dx out
+        "gemm_dgrad": 2.0 * rows_e * n_e * ((d_m + 2 * d_m) + (d_m + 2 * d_ff)),               # delta / mask epilogues
+        "gemm_wgrad": 2.0 * rows_e * n_e * (2 * (4 * d_m) + 2 * (d_m + d_ff)) + 4.0 * 2 * arena.total,
+        "attn_fwd": 2.0 * rows_e * n_e * (3 * d_m + 2 * d_m),
+        "attn_bwd": 2.0 * rows_e * n_e * (3 * d_m + d_m + 3 * d_m),
+    }
+    for k, nbytes in hbm_bytes.items():
+        if k in kernels and kernels[k]["ms_per_step"] > 0:
+            gbs = nbytes / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
+            kernels[k]["hbm_gbs"] = round(gbs, 1)
+            kernels[k]["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 3)
 
     # ---- training mode (model.train(): dropout 0.1 in every layer, 0.5 in the front-end, as train.py:21 runs
     # the reference) - a second, separately timed pass; the headline above stays the dropout-free parity step
@@ -289,6 +387,32 @@ def main():
                   "note": "transformer/Decode.py, beam 10, B = %d, %d decoder steps (random weights never emit "
                           "EOS), KV cache, eager launches; includes the encoder pass" % (BATCH, len(hyps[0][0]))}
 
+    # ---- N > 1, default (weak) mode: also time the SPECIFIED partition - the global B = 32 batch of BASELINE config 2
+    # split contiguously over the ranks (4 utterances per GPU at N = 8, SURVEY 8e / north star) - in the same run
+    strong = None
+    if world > 1 and not args.global_batch and BATCH % world == 0:
+        try:
+            xs, ts, ils, tls, gs = shard(BATCH)
+            xsg, tsg, gsg = xs.cuda(), ts.cuda(), gs.cuda()
+            step_s = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
+            for _ in range(max(args.warmup, 4)):
+                step_s(xsg, ils, tsg, tls, gsg)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_s(xsg, ils, tsg, tls, gsg)
+            barrier()
+            ts_ = torch.tensor([time.perf_counter() - t1], device="cuda")
+            fr = torch.tensor([float(ils.sum())], device="cuda")
+            dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+            dist.all_reduce(fr, op=dist.ReduceOp.SUM)
+            strong = {"value": round(fr.item() * args.steps / ts_.item(), 1), "unit": "frames/s", "scaling": "strong",
+                      "ms_per_step": round(ts_.item() / args.steps * 1e3, 3), "global_batch": BATCH,
+                      "per_gpu_batch": BATCH // world,
+                      "note": "the seed-0 batch of BASELINE config 2 split contiguously by rank (SURVEY 8e)"}
+        except Exception as e:  # noqa: BLE001 - the headline line must still be printed
+            strong = {"error": "%s: %s" % (type(e).__name__, e)}
+
     out = None
     if rank == 0:
         flops = step_flops(in_len, tgt_len, C2)
@@ -296,11 +420,15 @@ def main():
             "metric": "frames/sec/step (80-d fbank, 6+6L d256) at 1/2/4/8 MI355X vs CPU ref",
             "value": round(frames * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 6+6L d256 h4 dff1024 V4337, 80-d fbank, B=32 per GPU, "
+            "ms_per_step_median_synced": round(ms_median, 3),
+            "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
+            "allreduce_exposed_ms": exposed_ms,
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 6+6L d256 h4 dff1024 V4337, 80-d fbank, %s, "
                                    "T<=1000 (%d valid frames on rank 0), L<=50; fwd+CE+bwd+clip+Adam, dropout off"
-                                   % int(in_len.sum()),
-                       "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                                   % (("global B=%d split %d per GPU (strong scaling, SURVEY 8e)" % (args.global_batch, args.global_batch // world))
+                                      if args.global_batch else "B=32 per GPU (weak scaling, train_multi.py:136-139)", int(in_len.sum())),
+                       "global_batch": args.global_batch or BATCH * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
                        "wire": "bf16" if args.wire_bf16 else "fp32"},
             "loss": round(loss.item(), 4), "grad_norm": round(gnorm.item(), 4),
@@ -309,6 +437,8 @@ def main():
             "kernel_ms_per_step": round(total_ms / 2, 3),
             "roofline": roofline, "kernels": kernels,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if train_mode is not None:
             out["train_mode"] = train_mode
         if decode is not None:
@@ -321,8 +451,8 @@ def main():
         import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-steps",
-                                str(args.cpu_steps), "--cpu-utts", str(args.cpu_utts)], capture_output=True, text=True,
-                               timeout=args.cpu_timeout)
+                                str(args.cpu_steps), "--cpu-utts", str(args.cpu_utts), "--cpu-timeout",
+                                str(args.cpu_timeout)], capture_output=True, text=True, timeout=args.cpu_timeout)
             out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001 - the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port",

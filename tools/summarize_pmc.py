@@ -12,7 +12,7 @@ import sqlite3
 import sys
 
 CLASSES = [("gemm_wgrad", ("gemm_sym_kernel<true, true", "gemm_wgrad_group_kernel")), ("gemm_dgrad", "gemm_sym_kernel<false, true"),
-           ("gemm_fwd", "gemm_sym_kernel<false, false"), ("gemm_ln", "gemm_ln_kernel"), ("gemm_lnbwd", "gemm_lnbwd_kernel"),
+           ("gemm_fwd", ("gemm_sym_kernel<false, false", "gemm_ws_kernel")), ("gemm_ln", "gemm_ln_kernel"), ("gemm_lnbwd", "gemm_lnbwd_kernel"),
            ("attn_fwd", "attn_fwd_kernel"), ("attn_bwd_dq", "attn_bwd_dq_kernel"),
            ("attn_bwd_dkv", "attn_bwd_dkv_kernel"), ("attn_bwd", "attn_bwd_kernel"), ("ln_bwd", "ln_bwd_kernel")]
 
@@ -43,6 +43,8 @@ def main():
             lines.append("%-16s %8d %14.0f %14.0f %14.0f" % (cls, n, rd / n, wr / n, (rd + wr) / n))
     with open(sys.argv[3] + ".txt", "w") as f:
         f.write("\n".join(lines) + "\n")
+    import os
+    out["git_sha"] = os.environ.get("GIT_SHA", "unrecorded")      # the GPU box has no .git: the caller passes the SHA
     with open(sys.argv[3] + ".json", "w") as f:
         json.dump(out, f, indent=1)
 
