@@ -7,11 +7,15 @@ over ranks], global-norm clip, Noam-Adam update.  The per-step ``.item()`` syncs
 the reference (train.py:31-32,42) are not reproduced: lengths are taken on the host
 (where the loader produced them) and the loss / grad-norm come back as device tensors.
 
-HIP-graph mode (``use_graph=True``): the step launches ~600 small kernels; the decoder half
+HIP-graph mode (``use_graph=True``): the step launches ~190 kernels; the decoder half
 (M ~ 1.2k rows) is launch-bound from Python (~10 us of host time per launch vs 2-4 us of
-GPU time).  The step is therefore captured once per batch signature (same tensors, same
-lengths - what bench.py and a bucketed loader produce) into a HIP graph and replayed; the
-Noam rate is a device scalar updated before each replay.  With data parallelism the
+GPU time).  The step is therefore captured per batch SIGNATURE (same tensors, same length
+vectors) into a HIP graph and replayed; the Noam rate is a device scalar updated before each
+replay.  Up to ``max_graphs`` signatures are kept (least recently used evicted), each with
+its own memory pool and with references to the ragged layouts its kernels read by address,
+so a loader that cycles through a set of pre-collated batches (bench.py; an epoch over a
+bucketed, cached dataset) replays, and one whose length vectors never repeat runs the eager
+path - whose ms/step bench.py reports next to the replay figure.  With data parallelism the
 gradient all-reduce stays eager BETWEEN graphs, and the backward is cut at the encoder
 output into two of them: forward + loss + decoder backward | encoder backward | clip+Adam.
 The decoder's and the vocabulary projection's gradients (the tail ~2/3 of the flat buffer)
@@ -20,6 +24,7 @@ encoder's backward, ~40 % of the step - is executing.
 """
 from __future__ import annotations
 
+import collections
 from typing import Optional
 
 import torch
@@ -43,14 +48,16 @@ def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
 
 class TrainStep:
     def __init__(self, model: nn.Module, optimizer, vocab_size: int, max_grad_norm: float,
-                 reducer: Optional[GradReducer] = None, use_graph: bool = False, graph_warmup: int = 2):
+                 reducer: Optional[GradReducer] = None, use_graph: bool = False, graph_warmup: int = 2,
+                 max_graphs: int = 8):
         self.model, self.optimizer = model, optimizer
         self.vocab_size, self.max_grad_norm = vocab_size, max_grad_norm
         self.crit = nn.CrossEntropyLoss(ignore_index=0)          # train.py:120
         self.reducer = reducer
         self.global_step = 0
-        self.use_graph, self.graph_warmup = use_graph, graph_warmup
-        self._sig, self._seen = None, 0
+        self.use_graph, self.graph_warmup, self.max_graphs = use_graph, graph_warmup, max_graphs
+        self._graphs = collections.OrderedDict()      # signature -> captured step (LRU)
+        self._seen = collections.OrderedDict()        # signature -> eager sightings before the capture
         self._g_fb = self._g_enc = self._g_opt = None
         self._loss = self._gnorm = None
         self._cut = None
@@ -132,32 +139,46 @@ class TrainStep:
 
         sig = (inputs.data_ptr(), targets.data_ptr(), ground_truth.data_ptr(), tuple(inputs.shape),
                tuple(targets.shape), input_lengths.cpu().numpy().tobytes(), target_lengths.cpu().numpy().tobytes())
-        if sig != self._sig:
-            self._sig, self._seen, self._g_fb, self._g_enc, self._g_opt = sig, 0, None, None, None
-        if self._g_fb is None:
-            self._seen += 1
-            if self._seen <= self.graph_warmup:          # lazy init (arena, layouts, allocator) happens eagerly
+        cap = self._graphs.get(sig)
+        if cap is None:
+            n = self._seen.get(sig, 0) + 1
+            self._seen[sig] = n
+            while len(self._seen) > 64:
+                self._seen.popitem(last=False)
+            if n <= self.graph_warmup:                   # lazy init (arena, layouts, allocator) happens eagerly
                 return self._eager(batch)
-            self._capture(batch)
+            cap = self._capture(batch)
+            self._graphs[sig] = cap
+            self._seen.pop(sig, None)
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.popitem(last=False)         # least recently used: its graphs, pool and pinned layouts go
+        self._graphs.move_to_end(sig)
+        self._g_fb, self._g_enc, self._g_opt, self._dec_lo = cap.g_fb, cap.g_enc, cap.g_opt, cap.dec_lo     # (introspection / tests)
         self.optimizer.update_learning_rate(self.global_step)
-        self._g_fb.replay()
-        if self._g_enc is not None:
-            self.reducer.fire_from(self._dec_lo)      # decoder-side buckets: exchanged while the encoder's backward runs
-            self._g_enc.replay()
+        cap.g_fb.replay()
+        if cap.g_enc is not None:
+            self.reducer.fire_from(cap.dec_lo)           # decoder-side buckets: exchanged while the encoder's backward runs
+            cap.g_enc.replay()
             self.reducer.synchronize()
         elif self.reducer is not None:
             self.reducer.reduce_all()
-        if self._g_opt is not None:
-            self._g_opt.replay()
-        return self._loss, self._gnorm
+        if cap.g_opt is not None:
+            cap.g_opt.replay()
+        return cap.loss, cap.gnorm
 
     def _capture(self, batch):
         if hasattr(self.optimizer, "_flat_state") and getattr(self.optimizer, "arena", None) is not None:
             self.optimizer._flat_state()      # Adam's lazily created state must exist BEFORE the capture (a captured
                                               # zero-fill would reset it on every replay)
         torch.cuda.synchronize()
-        pool = torch.cuda.graph_pool_handle()
-        self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        cap = _Captured()
+        # the captured kernels read the ragged layouts (offsets, lengths, positions, attention work lists, scatter
+        # index) by ADDRESS: pin the layout objects of this batch for as long as its graphs live (the layout cache may
+        # be flushed by other shapes meanwhile)
+        if hasattr(self.model, "prepare_layouts"):
+            cap.keep = self.model.prepare_layouts(batch[1], batch[3], batch[2].shape[1], batch[0].device)
+        pool = torch.cuda.graph_pool_handle()           # one pool per signature: replays of different signatures interleave freely
+        cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         split = self.reducer is not None and self.reducer.active and hasattr(self.model, "forward_packed") \
             and hasattr(self.model, "encoder")
         if self.reducer is not None:
@@ -167,21 +188,30 @@ class TrainStep:
         # when stream is capturing").  With a process group alive, only this thread's unsafe calls are policed.
         mode = dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}
         if split:
-            self._g_enc, self._dec_lo = torch.cuda.CUDAGraph(), self._decoder_grad_start()
-            with torch.cuda.graph(self._g_fb, pool=pool, **mode):
-                self._loss = self._forward_decoder_backward(*batch)
-            with torch.cuda.graph(self._g_enc, pool=pool, **mode):
+            cap.g_enc, cap.dec_lo = torch.cuda.CUDAGraph(), self._decoder_grad_start()
+            with torch.cuda.graph(cap.g_fb, pool=pool, **mode):
+                cap.loss = self._forward_decoder_backward(*batch)
+            with torch.cuda.graph(cap.g_enc, pool=pool, **mode):
                 self._encoder_backward()
         elif self.reducer is not None and self.reducer.active:
-            self._g_enc = None
-            with torch.cuda.graph(self._g_fb, pool=pool, **mode):
-                self._loss = self._forward_backward(*batch, captured=True)
+            with torch.cuda.graph(cap.g_fb, pool=pool, **mode):
+                cap.loss = self._forward_backward(*batch, captured=True)
         else:                                           # nothing happens between backward and the update: ONE graph
-            self._g_enc = self._g_opt = None
-            with torch.cuda.graph(self._g_fb, pool=pool, **mode):
-                self._loss = self._forward_backward(*batch, captured=True)
-                self._gnorm = self._clip_and_update()
-            return
-        with torch.cuda.graph(self._g_opt, pool=pool, **mode):
-            self._gnorm = self._clip_and_update()
+            cap.g_opt = None
+            with torch.cuda.graph(cap.g_fb, pool=pool, **mode):
+                cap.loss = self._forward_backward(*batch, captured=True)
+                cap.gnorm = self._clip_and_update()
+            return cap
+        with torch.cuda.graph(cap.g_opt, pool=pool, **mode):
+            cap.gnorm = self._clip_and_update()
         # capture only records; the step that triggered it is executed by the replay that follows
+        return cap
+
+
+class _Captured:
+    """One batch signature's captured step: its graph(s), static result tensors and pinned ragged layouts."""
+    __slots__ = ("g_fb", "g_enc", "g_opt", "loss", "gnorm", "dec_lo", "keep")
+
+    def __init__(self):
+        self.g_fb = self.g_enc = self.g_opt = self.loss = self.gnorm = self.keep = None
+        self.dec_lo = 0

@@ -197,6 +197,20 @@ class Transformer(nn.Module):
         padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, t_rows.scatter_index(L), logits)
         return padded.view(B, L, -1), F_.UnpackFn.apply(enc, in_rows, int(in_rows.max_len))
 
+    def prepare_layouts(self, inputs_pos, targets_pos, l_max, device):
+        """Every ragged layout of a batch (row offsets / lengths, position tables, the scatter index of the padded target
+        layout, the attention work lists) and its host->device copies, set up BEFORE the first kernel launch of a step -
+        and before a HIP-graph capture, whose kernels then hold these tensors by address (trainer.TrainStep pins the
+        returned objects).  -> (input Rows, target Rows)"""
+        in_rows = F_.Rows.packed(inputs_pos, device)
+        t_rows = F_.Rows.packed(targets_pos, device)
+        t_rows.scatter_index(l_max)
+        in_rows.pos, t_rows.pos
+        F_.attn_work(in_rows, in_rows, False)     # encoder self-attention
+        F_.attn_work(t_rows, t_rows, True)        # decoder self-attention (causal)
+        F_.attn_work(t_rows, in_rows, False)      # decoder-encoder attention
+        return in_rows, t_rows
+
     def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False,
                        padded_logits=False):
         """The same computation with the logits left in the ragged layout the kernels produce:
@@ -206,14 +220,7 @@ class Transformer(nn.Module):
         if self.return_attns:
             raise NotImplementedError("HIP path: attention maps are not materialised (config.return_attns must be falsy)")
         arena = arena_of(self)
-        # every ragged layout (and its host->device copies) is set up before the first kernel launch
-        in_rows = F_.Rows.packed(inputs_pos, inputs.device)
-        t_rows = F_.Rows.packed(targets_pos, inputs.device)
-        t_rows.scatter_index(targets.shape[1])
-        in_rows.pos, t_rows.pos
-        F_.attn_work(in_rows, in_rows, False)     # encoder self-attention
-        F_.attn_work(t_rows, t_rows, True)        # decoder self-attention (causal)
-        F_.attn_work(t_rows, in_rows, False)      # decoder-encoder attention
+        in_rows, t_rows = self.prepare_layouts(inputs_pos, targets_pos, targets.shape[1], inputs.device)
         with arena.scope():
             enc, _ = self.encoder.forward_rows(inputs, inputs_pos, in_rows)
             # cut_encoder: the decoder runs on a detached leaf, so that the backward can be taken in two calls -

@@ -366,3 +366,45 @@ def test_optimizer_checkpoint_resume_gpu(golden_dir):
         one_step(m2, opt2, 60, clip_path)
         moved = max((p.detach() - b).abs().max().item() for p, b in zip(m2.parameters(), before))
         assert moved > 5 * learn_rate(128, 100, 3)          # lr(60) = 20 x lr(3): the schedule is alive after the resume
+
+
+def test_graph_cache_serves_a_cycle_of_batches():
+    """A loader that cycles through several pre-collated batches (different length vectors): TrainStep keeps one captured
+    step per signature (LRU, layouts pinned) and must follow the eager trajectory; the layout cache may be flushed in
+    between (the graphs hold the ragged layouts by address)."""
+    import torch
+    from st_amd import functional as F_, synthetic
+    from st_amd.arena import arena_of
+    from st_amd.trainer import TrainStep
+    from transformer.Models import Transformer
+    from transformer.Optim import ScheduledOptim
+    from transformer.Utils import AttrDict, init_parameters
+
+    cfg = AttrDict(dict(feature_dim=80, max_inputs_length=200, max_target_length=32, num_enc_layer=2,
+                        num_dec_layer=2, n_heads=4, d_k=32, d_v=32, d_model=128, d_inner_hid=256, dropout=0.0,
+                        vocab_size=30))
+    batches = []
+    for seed in (1, 2, 3):
+        x, t, il, tl, gt = synthetic.make_batch(4, 160, 20, 80, 30, seed=seed, t_min=60, l_min=6)
+        batches.append((x.cuda(), il, t.cuda(), tl, gt.cuda()))
+    results = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        model = Transformer(cfg).cuda()
+        init_parameters(model)
+        model.eval()
+        opt = ScheduledOptim(model, 128, AttrDict(n_warmup_steps=4000))
+        step = TrainStep(model, opt, 30, 5.0, use_graph=use_graph, graph_warmup=1, max_graphs=2)
+        out = []
+        for i in range(12):
+            if i == 7:
+                F_._ROWS_CACHE.clear()          # e.g. an evaluation pass over other shapes in between
+            loss, gnorm = step(*batches[i % 3])
+            out.append((float(loss), float(gnorm)))
+        if use_graph:
+            assert len(step._graphs) == 2       # three signatures, two slots: least recently used evicted and re-captured
+        results.append((out, arena_of(model).flat.detach().float().cpu().clone()))
+    (o0, p0), (o1, p1) = results
+    for (l0, g0), (l1, g1) in zip(o0, o1):
+        assert abs(l0 - l1) <= 1e-3 * abs(l0) and abs(g0 - g1) <= 1e-2 * abs(g0), (o0, o1)
+    assert float((p0 - p1).norm() / p0.norm()) < 5e-3
