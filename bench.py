@@ -385,7 +385,8 @@ def main():
         decode = {"utterances_per_s": round(BATCH / dt, 1), "ms_per_step": round(dt / dsteps * 1e3, 3),
                   "frames_per_s": round(float(in_len.sum()) / dt, 1),
                   "note": "transformer/Decode.py, beam 10, B = %d, %d decoder steps (random weights never emit "
-                          "EOS), KV cache, eager launches; includes the encoder pass" % (BATCH, len(hyps[0][0]))}
+                          "EOS), KV cache, device-side beams, one HIP-graph replay per step; includes the encoder pass"
+                          % (BATCH, len(hyps[0][0]))}
 
     # ---- N > 1, default (weak) mode: also time the SPECIFIED partition - the global B = 32 batch of BASELINE config 2
     # split contiguously over the ranks (4 utterances per GPU at N = 8, SURVEY 8e / north star) - in the same run

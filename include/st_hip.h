@@ -200,6 +200,12 @@ int st_embed_pe_fwd(st_stream_t stream, const long long* tok, int B, int L, cons
 int st_embed_bwd(st_stream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
                  const int* off, const int* len, int pad_idx, float* demb, int V);
 
+/* Beam-search decode (transformer/Decode.py with a KV cache): cache bf16 [L][n][S][W]; for every layer, position
+   t <= *step (device scalar) and utterance (beam consecutive hypothesis rows), row u*beam+s <- row order[u*beam+s]
+   (device int64 [n], a row of the same utterance: Beam.py:65 back-pointers), in place. */
+int st_cache_reorder(st_stream_t stream, void* cache, const long long* order, const long long* step, int L, int n, int S,
+                     int W, int beam);
+
 /* fp32 master parameters -> bf16 shadow, n a multiple of 8. */
 int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);
 

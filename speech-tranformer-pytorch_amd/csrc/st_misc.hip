@@ -430,6 +430,42 @@ extern "C" int st_embed_bwd(hipStream_t stream, const long long* tok, int B, int
   return 0;
 }
 
+// Beam-search decode: hypotheses inherit the self-attention K|V history of the hypothesis they extend (Decode.py re-runs
+// the whole prefix instead; Beam.py:65 back-pointers).  cache [L][n][S][W] bf16; for every layer, every position
+// t <= *step and every utterance (beam consecutive rows): row u*beam+s <- old row order[u*beam+s] (same utterance),
+// in place: a workgroup holds the utterance's beam rows of one position in registers between its loads and stores.
+__global__ __launch_bounds__(256) void cache_reorder_kernel(bf16* cache, const long long* __restrict__ order,
+                                                            const long long* __restrict__ step, int n, int S, int W, int beam) {
+  const int t = blockIdx.x, u = blockIdx.y, l = blockIdx.z;
+  if (t > (int)*step) return;
+  const int cpr = W / 8, total = beam * cpr;          // 16-byte chunks per row / per utterance
+  bf16x8 v[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int id = p * 256 + threadIdx.x;
+    if (id < total) {
+      const long long src = order[u * beam + id / cpr];
+      v[p] = *reinterpret_cast<const bf16x8*>(cache + (((size_t)l * n + src) * S + t) * W + (id % cpr) * 8);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int id = p * 256 + threadIdx.x;
+    if (id < total)
+      *reinterpret_cast<bf16x8*>(cache + (((size_t)l * n + u * beam + id / cpr) * S + t) * W + (id % cpr) * 8) = v[p];
+  }
+}
+
+extern "C" int st_cache_reorder(hipStream_t stream, void* cache, const long long* order, const long long* step, int L,
+                                int n, int S, int W, int beam) {
+  if (L <= 0 || n <= 0 || S <= 0) return 0;
+  if ((W & 7) || beam <= 0 || (n % beam) || beam * (W / 8) > 2048) return -1;
+  hipLaunchKernelGGL(cache_reorder_kernel, dim3(S, n / beam, L), dim3(256), 0, stream, (bf16*)cache, order, step, n, S, W, beam);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int st_cast_bf16(hipStream_t stream, const float* src, void* dst, long long n) {
   if (n <= 0) return 0;
   if (n & 7) return -1;

@@ -64,6 +64,7 @@ SIGNATURES = {
     "st_embed_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                      _c_void_p, _c_int],
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
+    "st_cache_reorder": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int],
     "st_adam_clip": [_c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_float, _c_float, _c_float, _c_float],
     "st_probe_tr16": [_c_void_p, _c_void_p, _c_void_p],
@@ -528,6 +529,18 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     _check(load().st_embed_bwd(_stream(), tok.data_ptr(), B, L, dy.data_ptr(), dy.stride(0), D, off.data_ptr(),
                                length.data_ptr(), int(pad_idx), demb.data_ptr(), demb.shape[0]), "st_embed_bwd")
     return demb
+
+
+def cache_reorder(cache, order, step, beam):
+    """cache bf16 [L, n, S, W] (contiguous): rows of every utterance re-gathered by ``order`` (int64 [n], device) for the
+    positions <= step (int64 [1], device) - see st_cache_reorder."""
+    if not (cache.is_cuda and cache.dtype == BF16 and cache.is_contiguous() and cache.dim() == 4):
+        raise ValueError("cache_reorder: cache must be a contiguous bf16 [L, n, S, W] tensor on the GPU")
+    L, n, S, W = cache.shape
+    _vec(order, I64, n, "order"), _vec(step, I64, 1, "step")
+    _check(load().st_cache_reorder(_stream(), cache.data_ptr(), order.data_ptr(), step.data_ptr(), L, n, S, W, int(beam)),
+           "st_cache_reorder")
+    return cache
 
 
 def cast_bf16(src, dst):

@@ -10,8 +10,15 @@ with the log-softmax of the last position, an utterance leaves the batch when th
 * the encoder output is **not repeated per beam** (Decode.py:57-66): the encoder-decoder keys / values are
   projected once per utterance and every hypothesis's attention points its (offset, length) at its utterance's rows.
 
-One decode step is a chain of small launches (attention with one query row per hypothesis); it reuses the
-training kernels through the C-ABI (``st_gemm``, ``st_gemm_ln``, ``st_attn_fwd``).  The reference's constructor
+* the **beam state lives on the device** (scores, back-pointers, tokens, finished flags as [.., B, beam] tensors; the
+  arithmetic of transformer/Beam.py for all utterances in one top-k) and so do the step counter and the cache length,
+  so ONE decoder step - ~60 launches - is captured into a HIP graph after the first step and replayed; the host reads
+  the finished flags every 8 steps.  A finished utterance keeps its rows and is frozen (the reference drops it from
+  the batch, Decode.py:112-165: identical results); hypotheses inherit their parent's K|V history through
+  ``st_cache_reorder`` (the back-pointers of Beam.py:65 applied to the cache).
+
+One decode step reuses the training kernels through the C-ABI (``st_gemm``, ``st_gemm_ln``, ``st_attn_fwd``: the
+hypotheses of one utterance are one ``beam``-query problem of the key-split attention kernel).  The reference's constructor
 cannot run (obsolete ``Transformer(...)`` signature, undefined ``prob_projection``): pass the model."""
 import math
 
@@ -31,64 +38,87 @@ class Decode(object):
     ''' Beam search over a trained Transformer. '''
 
     def __init__(self, opt, device, model=None):
-        """opt: attribute-style (beam_size, n_best, [max_steps=100]); model: a transformer.Models.Transformer on
-        ``device`` (the reference loads a checkpoint here with an API that no longer exists)."""
+        """opt: attribute-style (beam_size, n_best, [max_steps=100], [use_graph]); model: a transformer.Models.Transformer
+        on ``device`` (the reference loads a checkpoint here with an API that no longer exists)."""
         if model is None:
             raise NotImplementedError("Decode(HIP): pass the Transformer instance (the reference's checkpoint loader "
                                       "calls an obsolete constructor and cannot run)")
         self.opt, self.device = opt, device
         self.model = model.to(device).eval()
-        self.max_steps = int(getattr(opt, "max_steps", 100))
+        self.max_steps = int(getattr(opt, "max_steps", None) or 100)
+        ug = getattr(opt, "use_graph", None)
+        self.use_graph = torch.device(device).type == "cuda" if ug is None else bool(ug)
 
-    # ---- one decoder step for `n` hypotheses -----------------------------------------------------
+    # ---- one decoder step for all n = B * beam hypotheses; everything that changes from step to step is DEVICE state ---
     @torch.no_grad()
-    def _step(self, tokens, step, caches, cross, hyp_koff, hyp_klen, max_k):
-        """tokens [n] int64 (last token of every hypothesis), step = its position; caches[l] bf16
-        [n, max_steps, 2d] (self-attention K|V of positions < step, already in hypothesis order);
-        cross[l] = bf16 [enc_rows, 2d]; hyp_koff / hyp_klen int32 [n]: the utterance rows each hypothesis attends.
-        -> log-probabilities [n, V] fp32; the step's K|V are written into the caches."""
+    def _step(self, st):
+        """-> log-probabilities [n, V] fp32 of the next token; writes the step's self-attention K|V into the caches.
+        ``st`` (a _DecodeState) holds: tokens [n] int64, step [1] int64, c_len [n] int32 (= step + 1), caches
+        [L, n, S, 2d], the per-utterance encoder keys / values ``cross[l]`` and the attention layouts."""
         dec = self.model.decoder
-        n, d = tokens.numel(), dec.d_model
-        dev = tokens.device
-        st = dec._st
-        x = (st.emb[tokens] + st.pe[step]).to(BF16)                                 # Models.py:84,87 (repair R3)
-        q_off = torch.arange(n, dtype=I32, device=dev)
-        q_len = torch.ones(n, dtype=I32, device=dev)
-        c_off = q_off * self.max_steps                                               # cache rows of hypothesis j
-        c_len = torch.full((n,), step + 1, dtype=I32, device=dev)
-        lse = torch.empty(dec.layer_stack[0].slf_attn.n_head * n, dtype=F32, device=dev)
+        n, d, S = st.n, dec.d_model, self.max_steps
+        dst = dec._st
+        x = (dst.emb.index_select(0, st.tokens) + dst.pe.index_select(0, st.step)).to(BF16)   # Models.py:84,87 (repair R3)
         for l, layer in enumerate(dec.layer_stack):
             # -- masked self-attention over the cache (the causal mask is implicit: only the past is cached)
             s = layer.slf_attn._st
             H = s.n_head
             scale = 1.0 / math.sqrt(d // H)
-            qkv = torch.empty(n, 3 * d, dtype=BF16, device=dev)
+            qkv = torch.empty(n, 3 * d, dtype=BF16, device=x.device)
             nv.gemm(x, s.w_qkv, qkv, bias=s.b_qkv)
-            caches[l][:, step] = qkv[:, d:]
-            kv = caches[l].view(n * self.max_steps, 2 * d)
-            ctx = torch.empty(n, d, dtype=BF16, device=dev)
-            nv.attn_fwd(qkv[:, :d], kv[:, :d], kv[:, d:], ctx, lse, q_off, q_len, c_off, c_len, H, 1, False, scale,
-                        max_k=step + 1)
-            y = torch.empty(n, d, dtype=BF16, device=dev)
+            st.caches[l].index_copy_(1, st.step, qkv[:, d:].unsqueeze(1))
+            kv = st.caches[l].view(n * S, 2 * d)
+            ctx = torch.empty(n, d, dtype=BF16, device=x.device)
+            nv.attn_fwd(qkv[:, :d], kv[:, :d], kv[:, d:], ctx, st.lse, st.q_off, st.q_one, st.c_off, st.c_len, H, 1, False,
+                        scale, max_k=S)
+            y = torch.empty(n, d, dtype=BF16, device=x.device)
             nv.gemm_ln(ctx, s.w_o, s.b_o, x, s.gamma, s.beta, y, None, None, eps=LN_EPS)
-            # -- encoder-decoder attention: keys / values projected once per utterance
+            # -- encoder-decoder attention: keys / values projected once per utterance; the beam's hypotheses of one
+            #    utterance are consecutive rows = ONE attention problem of `beam` queries (one pass over its keys)
             s = layer.enc_attn._st
-            q = torch.empty(n, d, dtype=BF16, device=dev)
+            q = torch.empty(n, d, dtype=BF16, device=x.device)
             nv.gemm(y, s.w_q, q, bias=s.b_q)
-            nv.attn_fwd(q, cross[l][:, :d], cross[l][:, d:], ctx, lse, q_off, q_len, hyp_koff, hyp_klen, H, 1, False,
-                        scale, max_k=max_k)
-            z = torch.empty(n, d, dtype=BF16, device=dev)
+            nv.attn_fwd(q, st.cross[l][:, :d], st.cross[l][:, d:], ctx, st.lse, st.u_off, st.u_len, st.k_off, st.k_len, H,
+                        st.beam, False, scale, max_k=st.max_k)
+            z = torch.empty(n, d, dtype=BF16, device=x.device)
             nv.gemm_ln(ctx, s.w_o, s.b_o, y, s.gamma, s.beta, z, None, None, eps=LN_EPS)
             # -- position-wise feed-forward
             s = layer.pos_ffn._st
-            h = torch.empty(n, s.d_ff, dtype=BF16, device=dev)
+            h = torch.empty(n, s.d_ff, dtype=BF16, device=x.device)
             nv.gemm(z, s.w1, h, bias=s.b1, epi=nv.EPI_BF16_RELU)
-            x = torch.empty(n, d, dtype=BF16, device=dev)
+            x = torch.empty(n, d, dtype=BF16, device=x.device)
             nv.gemm_ln(h, s.w2, s.b2, z, s.gamma, s.beta, x, None, None, eps=LN_EPS)
         ms = self.model._st
-        logits = torch.empty(n, ms.v_pad, dtype=F32, device=dev)
+        logits = torch.empty(n, ms.v_pad, dtype=F32, device=x.device)
         nv.gemm(x, ms.w_vocab, logits, epi=nv.EPI_F32)
         return torch.log_softmax(logits[:, :self.model.vocab_size], dim=-1)         # the undefined `prob_projection`
+
+    @torch.no_grad()
+    def _advance(self, st, word_lk):
+        """Beam.advance (Beam.py:43-74) for every utterance at once, on the device: top-k over beam x vocab of
+        score + log-probability, back-pointer = index // vocab, token = index % vocab, an utterance is finished once
+        the top of its beam emits EOS - after which its state is frozen (the reference removes it from the batch,
+        Decode.py:112-165; here it keeps its rows and is ignored).  Step 0 expands slot 0 only (Beam.py:48-51): the
+        other slots start at -inf.  Then the caches follow the back-pointers and the step counters advance."""
+        B, beam, V = st.B, st.beam, word_lk.shape[-1]
+        table = (word_lk.view(B, beam, V) + st.scores.unsqueeze(2)).view(B, beam * V)
+        best_scores, best_flat = table.topk(beam, 1, True, True)
+        origin = best_flat // V
+        token = best_flat - origin * V
+        live = ~st.done                                                     # utterances that advance in this step
+        lv = live.unsqueeze(1)
+        st.hist_scores.index_copy_(0, st.step, st.scores.unsqueeze(0))
+        st.scores.copy_(torch.where(lv, best_scores, st.scores))
+        origin = torch.where(lv, origin, st.slot_ids)
+        st.back.index_copy_(0, st.step, origin.unsqueeze(0))
+        st.toks.index_copy_(0, st.step, token.unsqueeze(0))
+        st.tokens.copy_(torch.where(lv, token, st.tokens.view(B, beam)).view(-1))
+        st.lengths.add_(live.to(st.lengths.dtype))
+        st.done.logical_or_(live & (token[:, 0] == Constants.EOS))
+        order = (origin + st.row0).view(-1)
+        nv.cache_reorder(st.caches, order, st.step, beam)
+        st.step.add_(1)
+        st.c_len.add_(1)
 
     @torch.no_grad()
     def decode_batch(self, src_batch):
@@ -103,49 +133,81 @@ class Decode(object):
             t_max = int(in_len.max())
             enc, in_rows = model.encoder.forward_rows(inputs[:, :t_max], in_len)        # packed [sum T, d]
             dec = model.decoder
-            d = dec.d_model
-            cross = []
+            d, S, n = dec.d_model, self.max_steps, B * beam
+            if S > dec.position_enc.pe.shape[1]:
+                raise ValueError("Decode: max_steps %d exceeds the decoder's positional-encoding table" % S)
+            st = _DecodeState()
+            st.B, st.beam, st.n = B, beam, n
+            st.cross = []
             for layer in dec.layer_stack:                                               # once per utterance
                 s = layer.enc_attn._st
                 kv = torch.empty(enc.shape[0], 2 * d, dtype=BF16, device=dev)
                 nv.gemm(enc, s.w_kv, kv, bias=s.b_kv)
-                cross.append(kv)
-            in_off_h, in_len_h = in_rows.off.cpu(), in_rows.len.cpu()
+                st.cross.append(kv)
+            H = dec.layer_stack[0].slf_attn.n_head
+            ar = torch.arange(n, dtype=I32, device=dev)
+            st.q_off, st.q_one, st.c_off = ar, torch.ones(n, dtype=I32, device=dev), ar * S
+            st.c_len = torch.ones(n, dtype=I32, device=dev)
+            st.u_off = torch.arange(B, dtype=I32, device=dev) * beam
+            st.u_len = torch.full((B,), beam, dtype=I32, device=dev)
+            st.k_off, st.k_len, st.max_k = in_rows.off, in_rows.len, int(in_rows.max_len)
+            st.lse = torch.empty(H * n, dtype=F32, device=dev)
+            st.caches = torch.zeros(len(dec.layer_stack), n, S, 2 * d, dtype=BF16, device=dev)
+            st.tokens = torch.full((n,), Constants.BOS, dtype=torch.long, device=dev)
+            st.step = torch.zeros(1, dtype=torch.long, device=dev)
+            st.scores = torch.full((B, beam), float("-inf"), dtype=F32, device=dev)
+            st.scores[:, 0] = 0.0
+            st.done = torch.zeros(B, dtype=torch.bool, device=dev)
+            st.lengths = torch.zeros(B, dtype=torch.long, device=dev)
+            st.hist_scores = torch.zeros(S, B, beam, dtype=F32, device=dev)
+            st.back = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
+            st.toks = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
+            st.slot_ids = torch.arange(beam, device=dev).unsqueeze(0).expand(B, beam).contiguous()
+            st.row0 = (torch.arange(B, device=dev) * beam).unsqueeze(1)
 
-            beams = [Beam(beam, dev) for _ in range(B)]
-            active = list(range(B))
-            caches = [torch.zeros(B * beam, self.max_steps, 2 * d, dtype=BF16, device=dev) for _ in dec.layer_stack]
-            koff = klen = None
-            max_k = 0
-            for step in range(self.max_steps):
-                n = len(active) * beam
-                tokens = torch.cat([beams[b].next_ys[-1] for b in active])              # slot order = score order
-                if koff is None:                                                        # (re)built only when the batch shrinks
-                    idx = torch.tensor(active).repeat_interleave(beam)
-                    koff, klen = in_off_h[idx].to(dev, I32), in_len_h[idx].to(dev, I32)
-                    max_k = int(in_len_h[idx].max())
-                word_lk = self._step(tokens, step, [c[:n] for c in caches], cross, koff, klen,
-                                     max_k).view(len(active), beam, -1)
-                done = Beam.advance_batch([beams[b] for b in active], word_lk)          # one top-k, one host read
-                still, origins = [], []
-                for i, b in enumerate(active):
-                    if not done[i]:
-                        still.append(b)
-                        origins.append(beams[b].get_current_origin() + i * beam)        # rows of the step's layout
-                if not still:
+            def one_step():
+                self._advance(st, self._step(st))
+
+            graph, steps_done = None, 0
+            while steps_done < S:
+                if self.use_graph and steps_done == 1:
+                    # step 0 ran eagerly (kernel modules loaded, allocator warm); every later step is a replay of ONE
+                    # captured step: the position, the cache length, the tokens and the beams are device state
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        one_step()
+                if graph is not None:
+                    graph.replay()
+                else:
+                    one_step()
+                steps_done += 1
+                # the EOS test of Beam.py:70 lives on the device; the host looks at it every few steps only
+                if (steps_done % 8 == 0 or not self.use_graph) and bool(st.done.all()):
                     break
-                if len(still) != len(active):
-                    koff = None
-                # finished utterances leave the batch (Decode.py:112-165); surviving hypotheses inherit the
-                # cache rows of the hypothesis they extend
-                order = torch.cat(origins)
-                for l in range(len(caches)):
-                    caches[l][:order.numel(), :step + 1] = caches[l][:n].index_select(0, order)[:, :step + 1]
-                active = still
 
+        # ---- per-utterance Beam objects (the reference's read-out API) from the device trellis -------------------------
+        lengths, done = st.lengths.tolist(), st.done.tolist()
         all_hyp, all_scores = [], []
         for b in range(B):
-            scores, tail_idxs = beams[b].sort_scores()
+            bm = Beam(beam, dev)
+            t = lengths[b]
+            bm.prev_ks = list(st.back[:t, b].unbind(0))
+            bm.next_ys += list(st.toks[:t, b].unbind(0))
+            bm.all_scores = list(st.hist_scores[:t, b].unbind(0))
+            if t:
+                bm.all_scores[0] = torch.zeros(beam, dtype=F32, device=dev)     # Beam.py:24: the initial scores are zeros
+            bm.scores = st.scores[b]
+            bm.done = done[b]
+            if bm.done:
+                bm.all_scores.append(bm.scores)
+            scores, tail_idxs = bm.sort_scores()
             all_scores += [scores[:n_best]]
-            all_hyp += [[beams[b].get_hypothesis(i) for i in tail_idxs[:n_best].tolist()]]
+            all_hyp += [[bm.get_hypothesis(i) for i in tail_idxs[:n_best].tolist()]]
+        self.beams = None
         return all_hyp, all_scores
+
+
+class _DecodeState(object):
+    """Device-resident state of one decode_batch call (attribute bag)."""
+    pass

@@ -318,13 +318,19 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     return demb
 
 
+def cache_reorder(cache, order, step, beam):
+    t = int(step.reshape(-1)[0]) + 1
+    cache[:, :, :t] = cache[:, order][:, :, :t].clone()
+    return cache
+
+
 def cast_bf16(src, dst):
     dst.copy_(src.to(BF16))
     return dst
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder"]
 
 
 @contextlib.contextmanager

@@ -15,21 +15,21 @@ from tests._emul import emulated_kernels
 H = 4
 
 
-def _params(eos_boost=0.0):
-    p = orc.xavier_init_(orc.make_params(80, 30, 128, 256, 2, 2, 100, 40, dtype=torch.float64), seed=1)
+def _params(eos_boost=0.0, d=128, dff=256, n_enc=2, n_dec=2):
+    p = orc.xavier_init_(orc.make_params(80, 30, d, dff, n_enc, n_dec, 100, 40, dtype=torch.float64), seed=1)
     p["tgt_word_proj.weight"] = p["tgt_word_proj.weight"] * 12.0        # peaky distributions: robust rankings
     if eos_boost:
         # make EOS competitive late in the sequence: its output row follows the positional encoding of step ~6
-        pe = p["decoder.position_enc.pe"].reshape(-1, 128)
+        pe = p["decoder.position_enc.pe"].reshape(-1, d)
         p["tgt_word_proj.weight"][bo.EOS] = eos_boost * (pe[6] - pe[1])
     return p
 
 
-def _model(p, device):
+def _model(p, device, d=128, dff=256, n_enc=2, n_dec=2):
     import transformer.Models as M
     import transformer.Utils as U
-    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=40, num_enc_layer=2,
-                          num_dec_layer=2, n_heads=H, d_k=32, d_v=32, d_model=128, d_inner_hid=256, dropout=0.1,
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=40, num_enc_layer=n_enc,
+                          num_dec_layer=n_dec, n_heads=H, d_k=d // H, d_v=d // H, d_model=d, d_inner_hid=dff, dropout=0.1,
                           vocab_size=30))
     m = M.Transformer(cfg)
     m.load_state_dict({k: v.float() for k, v in p.items()})
@@ -71,24 +71,29 @@ def test_beam_advance_batch_equals_per_beam_advance():
             assert [a.get_hypothesis(k) for k in range(size)] == [b.get_hypothesis(k) for k in range(size)]
 
 
-def run_decode(device, eos_boost, max_steps):
+def run_decode(device, eos_boost, max_steps, beam=4, shape=None, use_graph=None):
+    """shape = (d_model, d_ff, n_enc, n_dec); BASELINE config 5 is beam 10 on (256, 1024, 6, 6)."""
     from transformer.Decode import Decode
     from transformer.Utils import AttrDict
-    p = _params(eos_boost)
+    shape = shape or (128, 256, 2, 2)
+    p = _params(eos_boost, *shape)
     batch = orc.synthetic_batch(5, 80, 10, 80, 30, seed=2, t_min=30, l_min=5)
     x, in_len = batch["x"], batch["in_len"]
-    dec = Decode(AttrDict(dict(beam_size=4, n_best=2, max_steps=max_steps)), device, model=_model(p, device))
+    dec = Decode(AttrDict(dict(beam_size=beam, n_best=2, max_steps=max_steps, use_graph=use_graph)), device,
+                 model=_model(p, device, *shape))
     hyps, scores = dec.decode_batch((x, in_len))
-    ref_h, ref_s = bo.beam_search(p, x.double(), in_len, H, beam_size=4, n_best=2, max_steps=max_steps)
+    ref_h, ref_s = bo.beam_search(p, x.double(), in_len, H, beam_size=beam, n_best=2, max_steps=max_steps)
+    # bf16 logits of magnitude ~10 carry ~0.03 of absolute noise per step on the 2+2-layer model; a few steps dominate a
+    # score.  The 6+6-layer, d_model 256 model (config 5) is three times as deep: measured 0.16 on its worst hypothesis.
+    tol = 0.12 if shape[2] + shape[3] <= 4 else 0.3
     lengths = set()
     for b in range(x.shape[0]):
         assert len(hyps[b]) == 2 and len(scores[b]) == 2
         for n in range(2):
             got = float(scores[b][n])
             truth = bo.score_hypothesis(p, x[b:b + 1].double(), in_len[b:b + 1], H, hyps[b][n])
-            # bf16 logits of magnitude ~10 carry ~0.03 of absolute noise per step; a few steps dominate a score
-            assert abs(got - truth) <= max(0.12, 5e-2 * abs(truth)), (b, n, got, truth)      # (a)
-        assert float(scores[b][0]) >= float(ref_s[b][0]) - max(0.12, 5e-2 * abs(float(ref_s[b][0])))   # (b)
+            assert abs(got - truth) <= max(tol, 5e-2 * abs(truth)), (b, n, got, truth)      # (a)
+        assert float(scores[b][0]) >= float(ref_s[b][0]) - max(tol, 5e-2 * abs(float(ref_s[b][0])))   # (b)
         assert hyps[b][0] == ref_h[b][0], (b, hyps[b][0], ref_h[b][0])
         lengths.add(len(hyps[b][0]))
     return lengths
