@@ -114,8 +114,8 @@ def test_beam_search_decode_config5_shape_gpu():
     """BASELINE config 5 as stated: beam 10 on the 6+6-layer, d_model 256 model (HIP-graph step, KV cache, device-side
     beams) against the fp64 oracle restatement of Beam.py / Decode.py."""
     from tests import test_decode_cpu as dc
-    assert dc.run_decode("cuda", 0.0, 10, beam=10, shape=(256, 1024, 6, 6)) == {10}
-    lengths = dc.run_decode("cuda", 3.0, 14, beam=10, shape=(256, 1024, 6, 6))
+    assert dc.run_decode("cuda", 0.0, 10, beam=10, shape=(256, 1024, 6, 6), proj_scale=4.0) == {10}
+    lengths = dc.run_decode("cuda", 3.0, 14, beam=10, shape=(256, 1024, 6, 6), proj_scale=4.0)
     assert max(lengths) <= 14
 
 
