@@ -131,6 +131,32 @@ int st_gemm_lnbwd(st_stream_t stream, const void* dY, int lddy, const void* W, i
                   int lddx, float* dgamma, float* dbeta, float* dbias, const unsigned* drop_seed, unsigned drop_salt,
                   int drop_thresh, float drop_scale);
 
+/* ---- row chains for decoder-sized row counts (csrc/st_rowchain.hip) ---------------------------------------------
+ * Everything the decoder does between two attention kernels is row-wise; one launch runs it for blocks of 32 rows:
+ *   PRE   cur = LN(A Wo^T + bo + R) * g0 + be0               (Attention.py:92-94)   out0 / xhat0 / rstd0 as st_gemm_ln
+ *   FFN   H   = dropout1(relu(cur W1^T + b1))                (SubLayers.py:25)      [M, d_ff], saved for the backward
+ *         cur = dropout2(LN(H W2^T + b2 + cur) * g1 + be1)   (SubLayers.py:26-27)   out1 / xhat1 / rstd1
+ *   POST  P   = cur Wp^T + bp, Wp [256 post_blocks, 256]     (Attention.py:74-76 of the NEXT attention)
+ * PRE is present iff R != NULL, FFN iff d_ff > 0, POST iff post_blocks > 0; without PRE the chain input is A.
+ * d_model = 256, d_ff % 256 == 0.  The weights are read from per-wave fragment streams: every GEMM is cut into
+ * 256 x 256 blocks, consumed in the order  Wo | (W1 rows c*256.., W2 columns c*256..) for c = 0.. | Wp rows u*256..;
+ * n_blocks = their number.  st_wfrag_build lays the blocks out (table: 4 x int64 per block on the device - address of
+ * the block's first element in a row-major bf16 matrix, its leading dimension, 16 * (position of the block in its
+ * chain), element offset of the chain in `out` | wave stride (n_blocks * 16 + st_wfrag_depth()) << 40); a chain's
+ * buffer holds 8 * (n_blocks * 16 + st_wfrag_depth()) * 512 bf16.  Rebuild after every weight update.
+ * next_blocks > 0: another chain of that many blocks is stored right behind this one and runs next - the launch warms the
+ * L2 with its streams too (the streams are read once per step, from HBM).
+ * Both dropout sites read the device seed *drop_seed (NULL = off) with their own salt / threshold / scale. */
+int st_wfrag_depth(void);
+int st_wfrag_build(st_stream_t stream, const long long* table, int n_blocks, void* out);
+int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A,
+                 int lda,
+                 const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
+                 float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
+                 void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
+                 int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
+                 int post_blocks, const float* bp, void* P, int ldp);
+
 /* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
  * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).
  * mask (optional bf16 [M,N]): dx is zeroed where mask <= 0 (front-end ReLU,

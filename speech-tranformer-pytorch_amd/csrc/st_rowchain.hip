@@ -1,0 +1,336 @@
+// st_rowchain: chains of row-wise layers for decoder-sized row counts as ONE launch.
+//
+// With ~1,200 target rows (or 320 beam hypotheses in decode) every GEMM of the decoder is a launch of ~20-40 workgroups
+// whose duration is launch ramp + prologue + epilogue, not arithmetic: a GEMM + LayerNorm costs
+// ~7.7 us before its first k-tile.  Between two attention kernels everything the decoder does is row-wise, so one launch
+// can run it all for a block of rows:
+//
+//   PRE   cur = LN(A Wo^T + bo + R) * g0 + be0                 output_linear + residual + layernorm (Attention.py:92-94)
+//   FFN   h   = dropout1(relu(cur W1^T + b1))                  (SubLayers.py:25)
+//         cur = dropout2(LN(h W2^T + b2 + cur) * g1 + be1)     (SubLayers.py:26-27)
+//   POST  P   = cur Wp^T + bp,  Wp [256 nb, 256]               the next attention's q (nb = 1) or q|k|v (nb = 3) projection
+//                                                              (Attention.py:74-76)
+//
+// each part optional: PRE + POST is what follows the decoder's self-attention, PRE + FFN + POST what follows its
+// encoder-decoder attention (POST being the next layer's q|k|v).  A workgroup owns 32 rows for the whole chain; the
+// activations live in LDS; every intermediate the backward pass reads is also written to HBM exactly as the separate
+// kernels write it.  The weights are STREAMED: all GEMMs are cut into 256 x 256 blocks; each of the 8 waves owns 32
+// output columns of every block and reads exactly the weight fragments it multiplies, in the order it multiplies them,
+// from a per-wave "fragment stream" (st_wfrag_build lays the weight blocks out as 1 KB MFMA A-operand fragments in
+// consumption order): one fully coalesced 1 KB load per MFMA, 16 of them in flight per wave, no LDS staging of
+// weights, no barrier inside a block.  d_ff is walked in chunks of 256 hidden columns (W1 block -> LDS -> W2 block
+// accumulates), so the hidden tile never exceeds 16 KB of LDS.  Measured (M = 1206, d_ff 1024): the feed-forward
+// sublayer alone 25.5 us as two launches -> 15.9 us, bound by one CU's 64 B/clk vector-memory path (1 MB of weights
+// per workgroup).
+#include "st_common.cuh"
+
+namespace {
+
+constexpr int RB = 32;       // rows per workgroup: one MFMA row tile
+constexpr int DM = 256;      // d_model = block edge
+constexpr int AS = DM + 8;   // LDS activation row stride in elements (528 B: conflict-free ds_read_b128 over 16 rows)
+constexpr int DEPTH = 16;    // weight fragments in flight per wave (16 KB): exactly one block ahead
+constexpr int NW = 8;        // waves per workgroup
+constexpr int TE = RB * AS;  // elements of one LDS activation tile
+constexpr int TOUCH = 8;     // warm-up lines per thread (covers a 12-block chain and the 2-block one behind it from 4 workgroups per XCD up)
+
+struct ChainArgs {
+  int M;
+  const bf16x8* wfrag;               // this chain's streams: [8 waves][nblocks * 16 + DEPTH fragments][64 lanes]
+  int wave_frags;                    // nblocks * 16 + DEPTH
+  int next_frags;                    // the same of the chain stored right behind this one (0: none): warmed for its launch
+  float eps;
+  const bf16* A; int lda;            // [M, 256]: PRE's GEMM operand (attention context); without PRE the chain input
+  // PRE
+  const bf16* R; int ldr;            // residual [M, 256]
+  const float* bo; const float* g0; const float* be0;
+  bf16* out0; bf16* xhat0; float* rstd0;     // ld 256
+  // FFN
+  int nc;                            // d_ff / 256
+  const float* b1; const float* b2; const float* g1; const float* be1;
+  bf16* H;                           // [M, d_ff] hidden activation as the backward wants it (after ReLU and dropout1)
+  bf16* out1; bf16* xhat1; float* rstd1;     // ld 256
+  DropArgs drop1, drop2;
+  // POST
+  int nb; const float* bp; bf16* P; int ldp;
+};
+
+struct Ctx {
+  int tid, wave, l, hi, r, row0, nvalid;
+  const bf16x8* ws;      // wave-uniform stream cursor: the block to REFILL from (one block ahead of the one being multiplied)
+  bf16x8 ring[DEPTH];
+};
+
+// One 256 x 256 weight block: acc[n = wave*32 + ...][m] (+)= W_block x act^T, refilling the ring with the next block.
+__device__ __forceinline__ void block_mma(Ctx& c, const bf16* act, f32x16& acc) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const bf16x8 xf = frag_nat(act, AS, c.r, ks * 16 + c.hi * 8);
+    acc = mfma32(c.ring[ks], xf, acc);
+    c.ring[ks] = c.ws[ks * 64 + c.l];
+    __builtin_amdgcn_sched_barrier(0);   // keep each refill next to its MFMA: hoisted refills double the live registers
+  }
+  c.ws += 16 * 64;
+}
+
+// [32][256] tile: global (rows past M as zeros) -> LDS
+__device__ __forceinline__ void tile_in(const Ctx& c, const bf16* g, int ld, bf16* t) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    *reinterpret_cast<bf16x8*>(t + rr * AS + cc * 8) = gload8(g + (size_t)(c.row0 + rr) * ld + cc * 8, rr < c.nvalid);
+  }
+}
+// LDS -> global as 512-byte row segments
+__device__ __forceinline__ void tile_out(const Ctx& c, const bf16* t, bf16* g, int ld) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    if (rr < c.nvalid)
+      *reinterpret_cast<bf16x8*>(g + (size_t)(c.row0 + rr) * ld + cc * 8) = *reinterpret_cast<const bf16x8*>(t + rr * AS + cc * 8);
+  }
+}
+
+// acc + bias (+ReLU, dropout) -> bf16 into this wave's 32 columns of an LDS tile
+template <bool RELU, bool DROP>
+__device__ __forceinline__ void epi_store(const Ctx& c, const f32x16& acc, const float* bias, bf16* t, const Drop& d, int gcol0,
+                                          int ncols) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl = c.wave * 32 + 8 * g + 4 * c.hi;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
+    uint32_t bits = 0;
+    if (DROP) bits = d.bits(drop_counter_rc(c.row0 + c.r, gcol0 + jl, ncols));
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[4 * g + e] + bb[e];
+      if (RELU) v = fmaxf(v, 0.f);
+      if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+      o[e] = (bf16)v;
+    }
+    *reinterpret_cast<bf16x4*>(t + c.r * AS + jl) = o;
+  }
+}
+
+// v = acc + bias + res; LayerNorm over the 256 columns held by the 8 waves; xhat -> t_xhat, (dropped) output -> t_out,
+// both then leave for HBM.  Two workgroup barriers inside, one before the copies out: on return t_out is complete.
+template <bool DROP>
+__device__ __forceinline__ void epi_ln(const Ctx& c, f32x16& acc, const float* bias, const bf16* res, const float* gamma,
+                                       const float* beta, float eps, const Drop& d, bf16* t_xhat, bf16* t_out, float (*red)[NW * 32],
+                                       bf16* g_out, bf16* g_xhat, float* g_rstd) {
+  const int j0 = c.wave * 32;
+  float sum = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl = j0 + 8 * g + 4 * c.hi;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
+    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + c.r * AS + jl);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = acc[4 * g + e] + bb[e] + (float)rr[e];
+      acc[4 * g + e] = v;
+      sum += v;
+    }
+  }
+  sum += wave_xor32(sum);
+  if (c.hi == 0) red[0][c.wave * 32 + c.r] = sum;
+  __syncthreads();
+  sum = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) sum += red[0][w * 32 + c.r];
+  const float mean = sum * (1.f / DM);
+  float sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float dv = acc[q] - mean;
+    sq += dv * dv;
+  }
+  sq += wave_xor32(sq);
+  if (c.hi == 0) red[1][c.wave * 32 + c.r] = sq;
+  __syncthreads();
+  sq = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) sq += red[1][w * 32 + c.r];
+  const float rstd = rsqrtf(sq * (1.f / DM) + eps);
+  if (g_rstd && c.wave == 0 && c.hi == 0 && c.r < c.nvalid) g_rstd[c.row0 + c.r] = rstd;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl = j0 + 8 * g + 4 * c.hi;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + jl);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + jl);
+    uint32_t bits = 0;
+    if (DROP) bits = d.bits(drop_counter_rc(c.row0 + c.r, jl, DM));
+    bf16x4 xh, o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float n = (acc[4 * g + e] - mean) * rstd;
+      float v = n * g4[e] + b4[e];
+      if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+      xh[e] = (bf16)n;
+      o[e] = (bf16)v;
+    }
+    *reinterpret_cast<bf16x4*>(t_xhat + c.r * AS + jl) = xh;
+    *reinterpret_cast<bf16x4*>(t_out + c.r * AS + jl) = o;
+  }
+  __syncthreads();
+  if (g_xhat) tile_out(c, t_xhat, g_xhat, DM);
+  tile_out(c, t_out, g_out, DM);
+}
+
+template <bool PRE, bool FFN, bool POST, bool DROP>
+__global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
+  // tiles: A (chain input), R (residual, then the odd hidden chunks), C (cur after PRE), H (even hidden chunks / POST
+  // staging), X (xhat / POST staging), D (cur after FFN)
+  __shared__ __attribute__((aligned(16))) bf16 tiles[6 * TE];
+  __shared__ float red[2][NW * 32];
+  Ctx c;
+  c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
+  c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
+  c.ws = a.wfrag + (size_t)c.wave * a.wave_frags * 64;   // wave-uniform: the loads take an SGPR base + lane offset
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) c.ring[i] = c.ws[i * 64 + c.l];   // the first block goes out before anything else
+  c.ws += DEPTH * 64;
+  // Warm the L2 of this workgroup's XCD with the WHOLE chain's streams - and those of the chain that runs next (they lie
+  // right behind in st_amd.chains' buffer; an attention kernel runs in between): the streams are read once per step, so
+  // a wave's 16 KB in flight would otherwise meet the HBM latency block after block (cold caches, M = 1206: 40.4 us for
+  // the 12-block chain against 22.6 us with the streams cached; 32.8 us with its own lines touched up front).  The
+  // workgroups that share an XCD (dispatch is round-robin over the 8 XCDs) deal the 128-byte lines among their threads;
+  // the values are only consumed at the very end.
+  int touched[TOUCH];
+  {
+    const int nlines = NW * (a.wave_frags + a.next_frags) * 8;     // this chain's streams and the next chain's right behind them
+    const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
+    const char* sb = reinterpret_cast<const char*>(a.wfrag);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) {
+      const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
+      touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* tA = tiles; bf16* tR = tiles + TE; bf16* tC = tiles + 2 * TE; bf16* tH = tiles + 3 * TE; bf16* tX = tiles + 4 * TE;
+  bf16* tD = tiles + 5 * TE;
+  tile_in(c, a.A, a.lda, tA);
+  if (PRE) tile_in(c, a.R, a.ldr, tR);
+  const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
+  __syncthreads();
+
+  const bf16* cur = tA;
+  if (PRE) {
+    f32x16 acc = zero16();
+    block_mma(c, tA, acc);
+    epi_ln<false>(c, acc, a.bo, tR, a.g0, a.be0, a.eps, off, tX, tC, red, a.out0, a.xhat0, a.rstd0);
+    cur = tC;
+  }
+  if (FFN) {
+    const int dff = a.nc * 256;
+    f32x16 acc2 = zero16();
+    for (int ch = 0; ch < a.nc; ++ch) {
+      // chunk ch's tile is rewritten by chunk ch + 2: the barrier of chunk ch + 1 lies in between.  (tR: every wave is past
+      // PRE's reads of it - epi_ln's barriers; tH / tX: free.)
+      bf16* hc = (ch & 1) ? tR : tH;
+      f32x16 acc1 = zero16();
+      block_mma(c, cur, acc1);
+      epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff);
+      __syncthreads();
+      block_mma(c, hc, acc2);
+      tile_out(c, hc, a.H + ch * 256, dff);
+    }
+    epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, tX, tD, red, a.out1, a.xhat1, a.rstd1);
+    cur = tD;
+  }
+  if (POST) {
+    for (int u = 0; u < a.nb; ++u) {
+      // staging tiles alternate; a tile is rewritten two blocks later, one barrier in between (tR / tH: the last hidden
+      // chunks were read before epi_ln's barriers; without FFN they are free after PRE)
+      bf16* st = (u & 1) ? tH : tR;
+      f32x16 acc = zero16();
+      block_mma(c, cur, acc);
+      epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0);
+      __syncthreads();
+      tile_out(c, st, a.P + u * 256, a.ldp);
+    }
+  }
+  int tsum = 0;
+#pragma unroll
+  for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+  if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;      // (never true: keeps the warm-up loads alive)
+}
+
+// Block descriptor table of st_wfrag_build: 4 x int64 per 256 x 256 weight block
+//   [0] address of the block's first element (row n0, column k0 of a row-major bf16 matrix)
+//   [1] leading dimension of that matrix (elements)
+//   [2] destination: fragment index of the block inside a wave's stream (block position * 16)
+//   [3] destination: element offset of the chain's wave-0 stream in the output | (wave stride in fragments) << 40
+// piece (block, wave, ks, lane) = 8 consecutive k of weight row n0 + wave*32 + (lane & 31): the MFMA A operand of that lane.
+__global__ __launch_bounds__(256) void wfrag_build_kernel(const long long* __restrict__ table, bf16* __restrict__ out) {
+  const long long* d = table + (size_t)blockIdx.x * 4;
+  const bf16* src = reinterpret_cast<const bf16*>(d[0]);
+  const long long ld = d[1], frag0 = d[2], base = d[3] & ((1ll << 40) - 1), wstride = d[3] >> 40;
+  const int wave = blockIdx.y;
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out + base) + ((size_t)wave * wstride + frag0) * 64;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int id = p * 256 + threadIdx.x, ks = id >> 6, lane = id & 63;
+    dst[id] = *reinterpret_cast<const bf16x8*>(src + (size_t)(wave * 32 + (lane & 31)) * ld + ks * 16 + (lane >> 5) * 8);
+  }
+}
+
+}  // namespace
+
+extern "C" int st_wfrag_depth(void) { return DEPTH; }
+
+extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_blocks, void* out) {
+  if (n_blocks <= 0) return 0;
+  if (!table || !out) return -1;
+  hipLaunchKernelGGL(wfrag_build_kernel, dim3(n_blocks, NW), dim3(256), 0, stream, table, (bf16*)out);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A, int lda,
+                            const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
+                            float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
+                            void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
+                            int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
+                            int post_blocks, const float* bp, void* P, int ldp) {
+  if (M <= 0) return 0;
+  const bool pre = R != nullptr, ffn = d_ff > 0, post = post_blocks > 0;
+  if (!A || !wfrag || (lda & 7) || (!pre && !ffn && !post)) return -1;
+  if (pre && ((ldr & 7) || !bo || !g0 || !be0 || !out0)) return -2;
+  if (ffn && ((d_ff & 255) || !b1 || !b2 || !g1 || !be1 || !H || !out1)) return -3;
+  if (post && (!bp || !P || (ldp & 7) || ldp < 256 * post_blocks)) return -4;
+  if (n_blocks != (pre ? 1 : 0) + (ffn ? 2 * (d_ff / 256) : 0) + post_blocks) return -5;
+  ChainArgs a;
+  a.M = M; a.wfrag = (const bf16x8*)wfrag; a.wave_frags = n_blocks * 16 + DEPTH; a.eps = eps;
+  a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
+  a.A = (const bf16*)A; a.lda = lda; a.R = (const bf16*)R; a.ldr = ldr; a.bo = bo; a.g0 = g0; a.be0 = be0;
+  a.out0 = (bf16*)out0; a.xhat0 = (bf16*)xhat0; a.rstd0 = rstd0;
+  a.nc = d_ff / 256; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.H = (bf16*)H; a.out1 = (bf16*)out1; a.xhat1 = (bf16*)xhat1;
+  a.rstd1 = rstd1;
+  const bool on1 = ffn && drop_seed && drop1_thresh > 0, on2 = ffn && drop_seed && drop2_thresh > 0;
+  a.drop1.seed = on1 ? drop_seed : nullptr; a.drop1.salt = drop1_salt; a.drop1.thresh = on1 ? drop1_thresh : 0;
+  a.drop1.scale = on1 ? drop1_scale : 1.f;
+  a.drop2.seed = on2 ? drop_seed : nullptr; a.drop2.salt = drop2_salt; a.drop2.thresh = on2 ? drop2_thresh : 0;
+  a.drop2.scale = on2 ? drop2_scale : 1.f;
+  a.nb = post_blocks; a.bp = bp; a.P = (bf16*)P; a.ldp = ldp;
+  const dim3 grid((M + RB - 1) / RB), blk(512);
+  const bool drop = on1 || on2;
+#define ST_CHAIN(PRE_, FFN_, POST_)                                                                            \
+  do {                                                                                                         \
+    if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true>), grid, blk, 0, stream, a);        \
+    else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false>), grid, blk, 0, stream, a);            \
+  } while (0)
+  if (pre && ffn && post) ST_CHAIN(true, true, true);
+  else if (pre && ffn) ST_CHAIN(true, true, false);
+  else if (pre && post) ST_CHAIN(true, false, true);
+  else if (ffn && post) ST_CHAIN(false, true, true);
+  else if (ffn) ST_CHAIN(false, true, false);
+  else if (pre) ST_CHAIN(true, false, false);
+  else ST_CHAIN(false, false, true);
+#undef ST_CHAIN
+  ST_CHECK_LAUNCH();
+  return 0;
+}

@@ -73,6 +73,7 @@ class ParamArena:
                     self.grad_view(p).copy_(p.grad)
                     p.grad = self.grad_view(p)
         self._depth = 0
+        self._derived = []      # objects with .refresh(): layouts derived from the bf16 shadow (st_amd.chains)
         self._grad_ready_cb: Optional[Callable[[int, int], None]] = None
         for mod in root.modules():
             if hasattr(mod, "_st_bind"):
@@ -116,6 +117,8 @@ class ParamArena:
     def refresh(self) -> None:
         """fp32 master -> bf16 shadow (one streaming kernel, ~80 MB at config 2)."""
         native.cast_bf16(self.flat, self.shadow)
+        for d in self._derived:
+            d.refresh()
 
     class _Scope:
         def __init__(self, arena):

@@ -366,9 +366,31 @@ class MhaFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_q, x_kv, anchor, mod, q_rows: Rows, k_rows: Rows, causal: bool, want_attn: bool, drop=None,
-                kv_acc=None, up=None, down=None):
-        """up / down: LnLink to the sublayer that produced x_q / that consumes the output (see LnLink)."""
+                kv_acc=None, up=None, down=None, pre=None):
+        """up / down: LnLink to the sublayer that produced x_q / that consumes the output (see LnLink).
+        pre (chains.SubPre): everything below was already computed by the fused decoder launches - record only."""
         s = mod._st
+        d, H = s.d_model, s.n_head
+        Mq = x_q.shape[0]
+        scale = 1.0 / math.sqrt(d // H)
+        if pre is not None:
+            qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd = (pre.qkv, pre.kvbuf, pre.ctx, pre.ores, pre.lse, pre.out,
+                                                                pre.xhat, pre.rstd)
+        else:
+            qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd = MhaFn.compute(
+                x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, any(ctx.needs_input_grad), scale)
+        ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores)
+        ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
+        ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
+        ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers share one encoder-gradient buffer (or CrossKv's)
+        ctx.up, ctx.down = up, down
+        if down is not None:
+            down.offer(mod, xhat, rstd, s.g_b_o)
+        return out
+
+    @staticmethod
+    def compute(x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, need_bwd, scale):
+        """The forward launches of one attention sublayer -> (qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd)."""
         d, H = s.d_model, s.n_head
         Mq = x_q.shape[0]
         self_attn = x_kv is None
@@ -391,22 +413,14 @@ class MhaFn(torch.autograd.Function):
         # difference partner of dP in dS = P (dP - delta); with O to ~16 bits the two stay consistent
         # (every attention takes it: at config 3's depth the late ENCODER layers' keys are nearly identical across
         # positions too, and their q / k gradients come out 5x off without it - tests/test_fullsize_gpu.py)
-        ores = _empty(Mq, d, x_q) if any(ctx.needs_input_grad) else None      # (grad mode is off inside forward())
+        ores = _empty(Mq, d, x_q) if need_bwd else None      # (grad mode is off inside forward())
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
-        scale = 1.0 / math.sqrt(d // H)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
                     scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
-        ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores)
-        ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
-        ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
-        ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers share one encoder-gradient buffer (or CrossKv's)
-        ctx.up, ctx.down = up, down
-        if down is not None:
-            down.offer(mod, xhat, rstd, s.g_b_o)
-        return out
+        return qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd
 
     @staticmethod
     def backward(ctx, dout):
@@ -478,24 +492,28 @@ class MhaFn(torch.autograd.Function):
                 if acc.seen == acc.n:
                     dx_kv, acc.buf, acc.seen = acc.buf, None, 0
         arena.grads_ready(s.lo, s.hi)
-        return dx_q, dx_kv, None, None, None, None, None, None, None, None, None, None
+        return dx_q, dx_kv, None, None, None, None, None, None, None, None, None, None, None
 
 
 class FfnFn(torch.autograd.Function):
     """out = LN(x + fc2(relu(fc1(x))))   (SubLayers.py:24-28)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mod, drop1=None, drop2=None, up=None, down=None):
+    def forward(ctx, x, anchor, mod, drop1=None, drop2=None, up=None, down=None, pre=None):
         """drop1: dropout after the ReLU (SubLayers.py:25); drop2: on the LayerNorm output (SubLayers.py:27);
-        up / down: LnLink to the sublayer that produced x / that consumes the output."""
+        up / down: LnLink to the sublayer that produced x / that consumes the output;
+        pre (chains.SubPre): the forward values were already computed by a fused launch - record only."""
         s = mod._st
         M, d = x.shape
-        h = _empty(M, s.d_ff, x)
-        linear_fwd(x, s.w1, h, s.b1, relu=True, drop=drop1)
-        out, xhat = _empty(M, d, x), _empty(M, d, x)
-        rstd = torch.empty(M, dtype=F32, device=x.device)
-        nv.gemm_ln(h, s.w2, s.b2, x, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS, drop=drop2,
-                   drop_where=2 if drop2 is not None else 0)
+        if pre is not None:
+            h, out, xhat, rstd = pre.h, pre.out, pre.xhat, pre.rstd
+        else:
+            h = _empty(M, s.d_ff, x)
+            linear_fwd(x, s.w1, h, s.b1, relu=True, drop=drop1)
+            out, xhat = _empty(M, d, x), _empty(M, d, x)
+            rstd = torch.empty(M, dtype=F32, device=x.device)
+            nv.gemm_ln(h, s.w2, s.b2, x, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS, drop=drop2,
+                       drop_where=2 if drop2 is not None else 0)
         ctx.save_for_backward(x, h, xhat, rstd)
         ctx.mod, ctx.drop1, ctx.drop2 = mod, drop1, drop2
         ctx.up, ctx.down = up, down
@@ -521,7 +539,7 @@ class FfnFn(torch.autograd.Function):
         wgrad(dh, x, s.g_w1, gB=s.g_b1)
         dx = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dh, s.w1, ds)
         arena.grads_ready(s.lo, s.hi)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class FrontendFn(torch.autograd.Function):

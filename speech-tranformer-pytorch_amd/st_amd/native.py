@@ -40,6 +40,12 @@ SIGNATURES = {
     "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                    _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                    _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
+    "st_wfrag_depth": [],
+    "st_wfrag_build": [_c_void_p, _c_void_p, _c_int, _c_void_p],
+    "st_row_chain": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float, _c_int,
+                     _c_void_p, _c_void_p, _c_int],
     "st_gemm_lnbwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                       _c_void_p, _c_uint, _c_int, _c_float],
@@ -344,6 +350,76 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
                            *_drop(drop if drop_where in (1, 2) else None), int(drop_where))
     _check(rc, "st_gemm_ln")
     return out
+
+
+_WFRAG_DEPTH = None
+
+
+def wfrag_depth() -> int:
+    """Padding fragments at the end of every wave stream (the chain kernel prefetches this far ahead)."""
+    global _WFRAG_DEPTH
+    if _WFRAG_DEPTH is None:
+        _WFRAG_DEPTH = load().st_wfrag_depth()
+    return _WFRAG_DEPTH
+
+
+def wfrag_build(table, out):
+    """(Re)build weight-fragment streams (csrc/st_rowchain.hip): ``table`` int64 [n_blocks, 4] on the device, one row per
+    256 x 256 weight block: (address of its first element, leading dimension, fragment index inside a wave stream,
+    element offset of the chain in ``out`` | wave stride in fragments << 40)."""
+    if table.dtype != torch.int64 or table.dim() != 2 or table.shape[1] != 4 or not table.is_contiguous() or not table.is_cuda:
+        raise ValueError("wfrag_build: table must be a contiguous int64 [n, 4] device tensor")
+    if out.dtype != BF16 or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError("wfrag_build: out must be a contiguous bf16 device buffer")
+    _tag("wfrag_build", table.shape[0], 0, 0)
+    _check(load().st_wfrag_build(_stream(), table.data_ptr(), table.shape[0], out.data_ptr()), "st_wfrag_build")
+    return out
+
+
+def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
+    """One launch for a chain of row-wise layers over decoder-sized row counts (csrc/st_rowchain.hip).
+    ``chain``: st_amd.chains.Chain (the fragment streams of this chain's weight blocks); A [M, 256] bf16.
+    pre  = (R, bo, gamma, beta, out, xhat, rstd):                 cur = LN(A Wo^T + bo + R)
+    ffn  = (d_ff, b1, b2, gamma, beta, H, out, xhat, rstd, drop1, drop2): cur = drop2(LN(drop1(relu(cur W1^T + b1)) W2^T + b2 + cur))
+    post = (n_blocks_out, bias, P):                               P = cur Wp^T + bias, Wp [256 n_blocks_out, 256]
+    xhat / rstd may be None when no backward follows."""
+    _mat(A, BF16, "A")
+    M, d = A.shape
+    if d != 256:
+        raise ValueError("row_chain: d_model 256 only")
+    wfrag, n_blocks = chain.stream, chain.n_blocks
+    nb = (1 if pre else 0) + (2 * (ffn[0] // 256) if ffn else 0) + (post[0] if post else 0)
+    if nb != n_blocks or wfrag.numel() != 8 * (n_blocks * 16 + wfrag_depth()) * 512 or wfrag.dtype != BF16:
+        raise ValueError("row_chain: the fragment stream does not match the chain")
+    z = (None,) * 11
+    R, bo, g0, be0, out0, xhat0, rstd0 = pre if pre else z[:7]
+    d_ff, b1, b2, g1, be1, H, out1, xhat1, rstd1, drop1, drop2 = ffn if ffn else (0,) + z[:10]
+    pb, bp, P = post if post else (0, None, None)
+    if pre:
+        _mat(R, BF16, "R"), _mat(out0, BF16, "out0"), _vec(bo, F32, d, "bo"), _vec(g0, F32, d, "g0"), _vec(be0, F32, d, "be0")
+        assert out0.stride(0) == d and (xhat0 is None or xhat0.stride(0) == d) and R.shape[0] >= M
+        assert rstd0 is None or (rstd0.dtype == F32 and rstd0.numel() >= M)
+    if ffn:
+        _mat(H, BF16, "H"), _mat(out1, BF16, "out1"), _vec(b1, F32, d_ff, "b1"), _vec(b2, F32, d, "b2")
+        _vec(g1, F32, d, "g1"), _vec(be1, F32, d, "be1")
+        assert H.stride(0) == d_ff and H.shape == (M, d_ff) and out1.stride(0) == d and (xhat1 is None or xhat1.stride(0) == d)
+        assert rstd1 is None or (rstd1.dtype == F32 and rstd1.numel() >= M)
+    if post:
+        _mat(P, BF16, "P"), _vec(bp, F32, 256 * pb, "bp")
+        assert P.shape == (M, 256 * pb)
+    seed = None
+    for dr in (drop1, drop2):
+        if dr is not None and dr.thresh:
+            if seed is not None and seed.data_ptr() != dr.seed.data_ptr():
+                raise ValueError("row_chain: both dropout sites must read the same device seed")
+            seed = dr.seed
+    s1, s2 = _drop(drop1), _drop(drop2)
+    _tag("row_chain", M, n_blocks, d_ff)
+    rc = load().st_row_chain(_stream(), M, wfrag.data_ptr(), n_blocks, int(chain.next_blocks), float(eps), A.data_ptr(), A.stride(0), _p(R),
+                             0 if R is None else R.stride(0), _p(bo), _p(g0), _p(be0), _p(out0), _p(xhat0), _p(rstd0),
+                             int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
+                             s1[1], s1[2], s1[3], s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0))
+    _check(rc, "st_row_chain")
 
 
 def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, drop=None):

@@ -79,13 +79,16 @@ class MultiHeadAttention(nn.Module):
         return rng.site(device, self.dropout.p) if self.training else None
 
     # ---- fast path: bf16 row matrices ----------------------------------------------------------
-    def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal, kv_acc=None, up=None, down=None):
+    def forward_rows(self, x_q, x_kv, q_rows, k_rows, causal, kv_acc=None, up=None, down=None, pre=None):
         """x_q [Mq, d] (and x_kv [Mk, d] for cross-attention, else None) bf16 row matrices.
-        up / down: st_amd.functional.LnLink shared with the sublayer before / after this one (layer stacks only)."""
+        up / down: st_amd.functional.LnLink shared with the sublayer before / after this one (layer stacks only).
+        pre (st_amd.chains.SubPre): the forward values were already computed by fused launches - only record the
+        autograd node."""
         arena = arena_of(self)
         with arena.scope():
+            drop = pre.drop if pre is not None else self._drop(x_q.device)
             return F_.MhaFn.apply(x_q, x_kv, self.linear_q.weight, self, q_rows, k_rows, bool(causal), False,
-                                  self._drop(x_q.device), kv_acc, up, down)
+                                  drop, kv_acc, up, down, pre)
 
     # ---- reference API -------------------------------------------------------------------------
     def forward(self, q, k, v, mask=None):

@@ -44,12 +44,15 @@ class DecoderLayer(nn.Module):
         self.enc_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner_hid, dropout=dropout)
 
-    def forward_rows(self, y, enc, t_rows, in_rows, kv_acc=None, up=None):
-        """-> (output rows, LnLink for the next layer); see EncoderLayer.forward_rows."""
+    def forward_rows(self, y, enc, t_rows, in_rows, kv_acc=None, up=None, pre=None):
+        """-> (output rows, LnLink for the next layer); see EncoderLayer.forward_rows.
+        pre: this layer's (self-attention, encoder-decoder attention, feed-forward) st_amd.chains.SubPre when the
+        forward values come from the fused decoder launches (st_amd.chains.DecoderChains.forward)."""
         l1, l2, l3 = _links(3)
-        s = self.slf_attn.forward_rows(y, None, t_rows, t_rows, True, up=up, down=l1)
-        c = self.enc_attn.forward_rows(s, enc, t_rows, in_rows, False, kv_acc=kv_acc, up=l1, down=l2)
-        return self.pos_ffn.forward_rows(c, up=l2, down=l3), l3
+        pa, pb, pf = pre if pre is not None else (None, None, None)
+        s = self.slf_attn.forward_rows(y, None, t_rows, t_rows, True, up=up, down=l1, pre=pa)
+        c = self.enc_attn.forward_rows(s, enc, t_rows, in_rows, False, kv_acc=kv_acc, up=l1, down=l2, pre=pb)
+        return self.pos_ffn.forward_rows(c, up=l2, down=l3, pre=pf), l3
 
     def forward(self, inputs, enc_output, slf_attn_mask=None, dec_enc_attn_mask=None):
         s, w1 = self.slf_attn(inputs, inputs, inputs, mask=slf_attn_mask)

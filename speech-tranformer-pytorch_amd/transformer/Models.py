@@ -17,6 +17,7 @@ import transformer.Constants as Constants
 from st_amd import functional as F_
 from st_amd import rng
 from st_amd.arena import arena_of, bundle
+from st_amd.chains import DecoderChains
 from transformer.Embedding import PositionalEncoding
 from transformer.Layers import EncoderLayer, DecoderLayer
 
@@ -94,12 +95,27 @@ class Decoder(nn.Module):
         self.tgt_word_emb = nn.Embedding(vocab_size, d_model, Constants.PAD)
         self.layer_stack = nn.ModuleList([
             DecoderLayer(d_model, d_inner_hid, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
+        self.use_row_chains = True      # False: every GEMM of the layer stack is its own launch (A/B runs, tests)
 
     def _st_bind(self, a):
         emb = self.tgt_word_emb.weight
         lo, hi = a.span([emb])
         return bundle(d_model=self.d_model, pad_idx=Constants.PAD, emb_params=[emb], emb_lo=lo, emb_hi=hi,
                       emb=a.master(emb), g_emb=a.grad_view(emb), pe=self.position_enc.pe[0])
+
+    def row_chains(self, arena):
+        """This decoder's row-chain plan (st_amd.chains.DecoderChains) for ``arena``, or None when the layers do not fit the
+        chain kernel.  Built once per arena (its fragment buffer is then refreshed by every ``arena.refresh()``); must
+        first be called outside a HIP-graph capture (Transformer.prepare_layouts does)."""
+        hit = getattr(self, "_st_chains", None)
+        if hit is None or hit[0] is not arena:
+            dc = DecoderChains.plan(list(self.layer_stack), arena) if self.use_row_chains else None
+            if dc is not None:
+                dc.refresh()                     # (the arena's shadow is current: we are inside its scope or about to enter)
+                arena._derived.append(dc)
+            hit = (arena, dc)
+            self._st_chains = hit
+        return hit[1] if self.use_row_chains else None
 
     def forward_rows(self, tokens, tgt_len, enc_rows_mat, in_rows, t_rows=None):
         _check_lengths(tgt_len, min(self.n_max_seq, tokens.shape[1]), "Decoder")
@@ -113,8 +129,19 @@ class Decoder(nn.Module):
             if ckv is not None:
                 # the K/V projections of the encoder output for all layers: one GEMM now (and one in the backward)
                 kv = F_.CrossKvFn.apply(enc_rows_mat, self.layer_stack[0].enc_attn.linear_k.weight, ckv)
+                # decoder-sized row counts: everything between two attention kernels is ONE row-chain launch
+                # (st_amd.chains); the Functions below then only record the autograd nodes over those values
+                dc = self.row_chains(arena) if t_rows.total <= DecoderChains.MAX_ROWS and t_rows.max_len <= 0xffff else None
+                pres = None
+                if dc is not None:
+                    need_bwd = torch.is_grad_enabled() and (y.requires_grad or kv.requires_grad)
+                    with torch.no_grad():
+                        y_out, pres = dc.forward(self.layer_stack, y, kv, t_rows, in_rows, need_bwd)
+                    if not need_bwd:
+                        return y_out, t_rows
                 for l, layer in enumerate(self.layer_stack):
-                    y, link = layer.forward_rows(y, kv, t_rows, in_rows, F_.CrossKvSlot(ckv, l), link)
+                    y, link = layer.forward_rows(y, kv, t_rows, in_rows, F_.CrossKvSlot(ckv, l), link,
+                                                 pre=pres[l] if pres is not None else None)
             else:
                 # one accumulator for the encoder gradient of all layers (only when the encoder output needs one)
                 acc = F_.CrossGradAcc(len(self.layer_stack)) if enc_rows_mat.requires_grad else None
@@ -209,6 +236,7 @@ class Transformer(nn.Module):
         F_.attn_work(in_rows, in_rows, False)     # encoder self-attention
         F_.attn_work(t_rows, t_rows, True)        # decoder self-attention (causal)
         F_.attn_work(t_rows, in_rows, False)      # decoder-encoder attention
+        self.decoder.row_chains(arena_of(self))   # the chain plan's block table (a host->device copy the first time)
         return in_rows, t_rows
 
     def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False,

@@ -37,12 +37,19 @@ class PositionwiseFeedForward(nn.Module):
                       g_w1=a.grad_view(f1.weight), g_b1=a.grad_view(f1.bias), g_w2=a.grad_view(f2.weight),
                       g_b2=a.grad_view(f2.bias), g_gamma=a.grad_view(ln.weight), g_beta=a.grad_view(ln.bias))
 
-    def forward_rows(self, x, up=None, down=None):
-        d1 = rng.site(x.device, self.dropout1.p) if self.training else None      # SubLayers.py:25
-        d2 = rng.site(x.device, self.dropout2.p) if self.training else None      # SubLayers.py:27 (after the LN)
+    def _drops(self, device):
+        """The two dropout sites of one call (None in eval mode / p = 0)."""
+        d1 = rng.site(device, self.dropout1.p) if self.training else None      # SubLayers.py:25
+        d2 = rng.site(device, self.dropout2.p) if self.training else None      # SubLayers.py:27 (after the LN)
+        return d1, d2
+
+    def forward_rows(self, x, up=None, down=None, pre=None):
+        """pre (st_amd.chains.SubPre): the forward values were already computed by a fused launch - only record the
+        autograd node."""
+        d1, d2 = (pre.drop1, pre.drop2) if pre is not None else self._drops(x.device)
         arena = arena_of(self)
         with arena.scope():
-            return F_.FfnFn.apply(x, self.fc1.weight, self, d1, d2, up, down)
+            return F_.FfnFn.apply(x, self.fc1.weight, self, d1, d2, up, down, pre)
 
     def forward(self, inputs):
         shape = inputs.shape

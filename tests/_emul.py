@@ -156,6 +156,44 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
     return out
 
 
+def wfrag_depth():
+    return 16
+
+
+def wfrag_build(table, out):
+    return out        # the emulated chain reads the weight blocks themselves (chains.Chain.blocks)
+
+
+def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
+    """csrc/st_rowchain.hip as a composition of the emulated kernels it replaces (same roundings: every intermediate the
+    separate kernels round to bf16 is rounded here too)."""
+    blocks = list(chain.blocks)
+
+    def take(n):
+        out = [w[n0:n0 + 256, k0:k0 + 256] for w, n0, k0 in blocks[:n]]
+        del blocks[:n]
+        return out
+
+    cur = A
+    if pre:
+        R, bo, g0, be0, out0, xhat0, rstd0 = pre
+        (wo,) = take(1)
+        gemm_ln(A, wo, bo, R[:A.shape[0]], g0, be0, out0, xhat0, rstd0, eps=eps)
+        cur = out0
+    if ffn:
+        d_ff, b1, b2, g1, be1, H, out1, xhat1, rstd1, drop1, drop2 = ffn
+        ws = take(2 * (d_ff // 256))
+        w1 = torch.cat(ws[0::2], 0)
+        w2 = torch.cat(ws[1::2], 1)
+        gemm(cur, w1, H, bias=b1, epi=nv.EPI_BF16_RELU, drop=drop1)
+        gemm_ln(H, w2, b2, cur, g1, be1, out1, xhat1, rstd1, eps=eps, drop=drop2, drop_where=2 if _on(drop2) else 0)
+        cur = out1
+    if post:
+        nb, bp, P = post
+        gemm(cur, torch.cat(take(nb), 0), P, bias=bp)
+    assert not blocks
+
+
 def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, drop=None):
     dy = torch.zeros(dY.shape[0], W.shape[1], dtype=BF16)
     gemm(dY, W, dy, aux=aux, epi=nv.EPI_BF16_ADD if aux is not None else nv.EPI_BF16, y_cmajor=True)
@@ -330,7 +368,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain"]
 
 
 @contextlib.contextmanager

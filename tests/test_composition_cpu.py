@@ -481,3 +481,73 @@ def run_dp_shards_vs_golden(golden_dir, device):
 def test_dp_shards_vs_golden_composition(golden_dir):
     with emulated_kernels():
         run_dp_shards_vs_golden(golden_dir, "cpu")
+
+
+def run_row_chain_step(device):
+    """d_model 256 (the width the row-chain kernel serves): the decoder's layer stack runs as attention kernels + two
+    row chains per layer (st_amd/chains.py); loss, logits and every gradient against the fp64 oracle."""
+    import transformer.Models as M
+    made = []
+    plan = M.DecoderChains.plan
+    M.DecoderChains.plan = staticmethod(lambda layers, arena: made.append(plan(layers, arena)) or made[-1])
+    try:
+        run_wide_step(device, d_model=256, n_head=4, d_ff=512, n_enc=1, n_dec=2)
+    finally:
+        M.DecoderChains.plan = plan
+    assert made and made[0] is not None and len(made[0].f1) == 2, "the decoder did not take the row-chain path"
+
+
+def test_row_chain_step_composition():
+    with emulated_kernels():
+        run_row_chain_step("cpu")
+
+
+def run_row_chains_on_off(device, exact):
+    """The same model and batch with the decoder's row chains on and off (every GEMM its own launch): loss and gradients
+    must agree - bit for bit under the emulation (it composes the same emulated kernels, so this checks the host logic:
+    dropout sites, saved tensors, autograd replay), to rounding on the GPU - in eval mode and in training mode (same
+    seed -> same masks)."""
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import functional as F_, rng
+    from st_amd.arena import arena_of
+    torch.manual_seed(3)
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=20, num_enc_layer=1, num_dec_layer=3,
+                          n_heads=4, d_k=64, d_v=64, d_model=256, d_inner_hid=512, dropout=0.1, vocab_size=30))
+    m = M.Transformer(cfg)
+    U.init_parameters(m)
+    m = m.to(device)
+    rng.seed_tensor(device)
+    batch = orc.synthetic_batch(4, 70, 9, 80, 30, seed=4, t_min=30, l_min=4)
+    x, tok, gt = batch["x"].to(device), batch["tokens"].to(device), batch["gt"].to(device)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+
+    def run(chains_on):
+        m.decoder.use_row_chains = chains_on
+        arena = arena_of(m)
+        arena.zero_grads()
+        rng.manual_seed(5)
+        logits, t_rows = m.forward_packed(x, batch["in_len"], tok, batch["tgt_len"])
+        truth = gt.contiguous().view(-1).index_select(0, t_rows.scatter_index(gt.shape[1]))
+        loss = crit(logits, truth)
+        with F_.deferred_wgrads(True):
+            loss.backward()
+        return loss.item(), logits.detach().clone(), arena.grad.detach().clone()
+
+    try:
+        for training in (False, True):
+            m.train(training)
+            (l1, lg1, g1), (l0, lg0, g0) = run(True), run(False)
+            assert m.decoder._st_chains[1] is not None
+            if exact:
+                assert l1 == l0 and torch.equal(lg1, lg0) and torch.equal(g1, g0), (training, l1, l0)
+            else:
+                assert abs(l1 - l0) <= 2e-4 * abs(l0), (training, l1, l0)
+                assert rel(lg1, lg0) < 5e-3 and rel(g1, g0) < 3e-2, (training, rel(lg1, lg0), rel(g1, g0))
+    finally:
+        m.decoder.use_row_chains = True
+
+
+def test_row_chains_on_off_composition():
+    with emulated_kernels():
+        run_row_chains_on_off("cpu", exact=True)

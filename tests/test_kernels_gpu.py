@@ -630,3 +630,71 @@ def test_gemm_ws_stacked_weights():
     assert torch.equal(out, ref), "stacked gemm_ws differs from the gathered one"
     tiled = nv.gemm(x, W0, torch.empty(M, blocks * rows, dtype=BF16, device="cuda"), bias=b0, stack=(blocks, w_stride, b_stride))
     check(out, tiled, 5e-3, "gemm_ws vs st_gemm_stacked")
+
+
+# ---- row chains (csrc/st_rowchain.hip) -----------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [5, 320, 1206])
+@pytest.mark.parametrize("variant", ["pre+post1", "pre+ffn+post3", "pre+ffn", "ffn", "ffn+post1", "pre+ffn+post3+drop"])
+def test_row_chain_matches_the_separate_kernels(M, variant):
+    """One st_row_chain launch == output_linear + residual + LayerNorm, feed-forward sublayer and the next projection as
+    separate kernels (the emulation composes their emulations): every tensor the backward reads, ragged last row block,
+    strided operand views; with dropout the masks must be the ones st_gemm / st_gemm_ln draw (the backward kernels
+    regenerate them)."""
+    from st_amd import chains
+    d, dff = 256, 1024
+    parts = variant.split("+")
+    has_pre, has_ffn, drop = "pre" in parts, "ffn" in parts, "drop" in parts
+    nb = 3 if "post3" in parts else 1 if "post1" in parts else 0
+    wo, w1, w2 = g(d, d, seed=1, scale=d ** -0.5), g(dff, d, seed=2, scale=d ** -0.5), g(d, dff, seed=3, scale=dff ** -0.5)
+    wp = g(256 * max(nb, 1), d, seed=4, scale=d ** -0.5)
+    bo, b1, b2, bp = g(d, seed=5, dtype=F32), g(dff, seed=6, dtype=F32), g(d, seed=7, dtype=F32), g(256 * max(nb, 1), seed=8, dtype=F32)
+    g0, be0, g1, be1 = g(d, seed=9, dtype=F32) * 0.2 + 1, g(d, seed=10, dtype=F32) * 0.1, g(d, seed=11, dtype=F32) * 0.2 + 1, g(d, seed=12, dtype=F32) * 0.1
+    A, R = g(M, d, seed=13), g(M, d, seed=14)
+    dn1, de1 = _drops(21, 0.1) if drop else (None, None)
+    dn2, de2 = (nv.Drop(dn1.seed, 22, 0.1), em.Drop(de1.seed, 22, 0.1)) if drop else (None, None)   # one device seed, two sites
+
+    def blocks(dev):
+        f = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t)
+        b = []
+        if has_pre:
+            b += chains.blocks_of(f(wo))
+        if has_ffn:
+            b += chains.ffn_blocks(f(w1), f(w2))
+        if nb:
+            b += chains.blocks_of(f(wp))
+        return b
+
+    def run(dev, rc, d1, d2):
+        f = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t)
+        E = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+        o = dict(out0=E(M, d), xhat0=E(M, d), rstd0=E(M, dt=F32), H=E(M, dff), out1=E(M, d), xhat1=E(M, d), rstd1=E(M, dt=F32),
+                 P=E(M, 256 * max(nb, 1)))
+        if dev == "cuda":
+            cs = chains.ChainSet("cuda")
+            cid = cs.add(blocks("cuda"))
+            cs.finalize().rebuild()
+            ch = cs.chain(cid)
+            Aw = torch.zeros(M, d + 64, dtype=BF16, device="cuda")      # strided operand views
+            Aw[:, 32:32 + d] = f(A)
+            Rw = torch.zeros(M + 2, d + 8, dtype=BF16, device="cuda")
+            Rw[:M, :d] = f(R)
+            a_in, r_in = Aw[:, 32:32 + d], Rw[:M, :d]
+        else:
+            ch = chains.Chain(None, len(blocks("cpu")), blocks("cpu"))
+            a_in, r_in = A, R
+        rc(a_in, ch,
+           pre=(r_in, f(bo), f(g0), f(be0), o["out0"], o["xhat0"], o["rstd0"]) if has_pre else None,
+           ffn=(dff, f(b1), f(b2), f(g1), f(be1), o["H"], o["out1"], o["xhat1"], o["rstd1"], d1, d2) if has_ffn else None,
+           post=(nb, f(bp), o["P"]) if nb else None)
+        return o
+
+    got, ref = run("cuda", nv.row_chain, dn1, dn2), run("cpu", em.row_chain, de1, de2)
+    names = (["out0", "xhat0", "rstd0"] if has_pre else []) + (["H", "out1", "xhat1", "rstd1"] if has_ffn else []) + (["P"] if nb else [])
+    for n in names:
+        check(got[n], ref[n], 2e-3 if n.startswith("rstd") else 1e-2, "row_chain %s M=%d: %s" % (variant, M, n))
+    if drop:
+        _zero_pattern_equal(got["H"], ref["H"], "row_chain dropout1")
+        _zero_pattern_equal(got["out1"], ref["out1"], "row_chain dropout2")
+        # and against the kernels the backward pairs with: st_gemm (ReLU + dropout) / st_gemm_ln (drop_where = 2)
+        h = nv.gemm(got["out0"], cu(w1), torch.zeros(M, dff, dtype=BF16, device="cuda"), bias=cu(b1), epi=nv.EPI_BF16_RELU, drop=dn1)
+        _zero_pattern_equal(got["H"], h, "row_chain dropout1 vs st_gemm")

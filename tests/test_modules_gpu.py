@@ -119,6 +119,15 @@ def test_beam_search_decode_config5_shape_gpu():
     assert max(lengths) <= 14
 
 
+def test_row_chain_step_gpu():
+    """Decoder as attention kernels + row chains (d_model 256) against the fp64 oracle."""
+    comp.run_row_chain_step("cuda")
+
+
+def test_row_chains_on_off_gpu():
+    comp.run_row_chains_on_off("cuda", exact=False)
+
+
 def test_config3_layer_shape_step_gpu():
     """d_model 512, 8 heads (BASELINE config 3's layer shape): full step against the fp64 oracle."""
     comp.run_wide_step("cuda")
@@ -282,6 +291,8 @@ def test_fused_backward_paths_match_unfused_paths_full_size():
     x, tokens, in_len, tgt_len, gt = synthetic.make_batch(6, 1000, 50, 80, 4337, seed=5, t_min=300, l_min=20)
     xs, ts, gs = x.cuda(), tokens.cuda(), gt.cuda()
     crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+
+    model.decoder.use_row_chains = False      # (they need CrossKv; their own on / off test is test_row_chains_on_off_gpu)
 
     def run(fused):
         arena = arena_of(model)
