@@ -59,35 +59,56 @@ class Decode(object):
         n, d, S = st.n, dec.d_model, self.max_steps
         dst = dec._st
         x = (dst.emb.index_select(0, st.tokens) + dst.pe.index_select(0, st.step)).to(BF16)   # Models.py:84,87 (repair R3)
-        for l, layer in enumerate(dec.layer_stack):
+        dc = st.chains
+        layers = list(dec.layer_stack)
+
+        def E(cols):
+            return torch.empty(n, cols, dtype=BF16, device=x.device)
+
+        qkv = None
+        for l, layer in enumerate(layers):
             # -- masked self-attention over the cache (the causal mask is implicit: only the past is cached)
             s = layer.slf_attn._st
+            c = layer.enc_attn._st
+            f = layer.pos_ffn._st
             H = s.n_head
             scale = 1.0 / math.sqrt(d // H)
-            qkv = torch.empty(n, 3 * d, dtype=BF16, device=x.device)
-            nv.gemm(x, s.w_qkv, qkv, bias=s.b_qkv)
+            if qkv is None:
+                qkv = E(3 * d)
+                nv.gemm(x, s.w_qkv, qkv, bias=s.b_qkv)
             st.caches[l].index_copy_(1, st.step, qkv[:, d:].unsqueeze(1))
             kv = st.caches[l].view(n * S, 2 * d)
-            ctx = torch.empty(n, d, dtype=BF16, device=x.device)
+            ctx = E(d)
             nv.attn_fwd(qkv[:, :d], kv[:, :d], kv[:, d:], ctx, st.lse, st.q_off, st.q_one, st.c_off, st.c_len, H, 1, False,
                         scale, max_k=S)
-            y = torch.empty(n, d, dtype=BF16, device=x.device)
-            nv.gemm_ln(ctx, s.w_o, s.b_o, x, s.gamma, s.beta, y, None, None, eps=LN_EPS)
+            # -- output_linear + LayerNorm, then the encoder-decoder attention's q projection: separate launches, or ONE
+            #    row chain (csrc/st_rowchain.hip) when the layers fit it
+            y, q = E(d), E(d)
+            if dc is not None:
+                nv.row_chain(ctx, dc.f1[l], pre=(x, s.b_o, s.gamma, s.beta, y, None, None), post=(1, c.b_q, q))
+            else:
+                nv.gemm_ln(ctx, s.w_o, s.b_o, x, s.gamma, s.beta, y, None, None, eps=LN_EPS)
+                nv.gemm(y, c.w_q, q, bias=c.b_q)
             # -- encoder-decoder attention: keys / values projected once per utterance; the beam's hypotheses of one
             #    utterance are consecutive rows = ONE attention problem of `beam` queries (one pass over its keys)
-            s = layer.enc_attn._st
-            q = torch.empty(n, d, dtype=BF16, device=x.device)
-            nv.gemm(y, s.w_q, q, bias=s.b_q)
+            ctx = E(d)
             nv.attn_fwd(q, st.cross[l][:, :d], st.cross[l][:, d:], ctx, st.lse, st.u_off, st.u_len, st.k_off, st.k_len, H,
                         st.beam, False, scale, max_k=st.max_k)
-            z = torch.empty(n, d, dtype=BF16, device=x.device)
-            nv.gemm_ln(ctx, s.w_o, s.b_o, y, s.gamma, s.beta, z, None, None, eps=LN_EPS)
-            # -- position-wise feed-forward
-            s = layer.pos_ffn._st
-            h = torch.empty(n, s.d_ff, dtype=BF16, device=x.device)
-            nv.gemm(z, s.w1, h, bias=s.b1, epi=nv.EPI_BF16_RELU)
-            x = torch.empty(n, d, dtype=BF16, device=x.device)
-            nv.gemm_ln(h, s.w2, s.b2, z, s.gamma, s.beta, x, None, None, eps=LN_EPS)
+            # -- its output_linear + LayerNorm, the position-wise feed-forward, the next layer's q|k|v projection
+            z, h, x_next = E(d), E(f.d_ff), E(d)
+            nxt = layers[l + 1].slf_attn._st if l + 1 < len(layers) else None
+            qkv = E(3 * d) if nxt is not None else None
+            if dc is not None:
+                nv.row_chain(ctx, dc.f2[l], pre=(y, c.b_o, c.gamma, c.beta, z, None, None),
+                             ffn=(f.d_ff, f.b1, f.b2, f.gamma, f.beta, h, x_next, None, None, None, None),
+                             post=(3, nxt.b_qkv, qkv) if nxt is not None else None)
+            else:
+                nv.gemm_ln(ctx, c.w_o, c.b_o, y, c.gamma, c.beta, z, None, None, eps=LN_EPS)
+                nv.gemm(z, f.w1, h, bias=f.b1, epi=nv.EPI_BF16_RELU)
+                nv.gemm_ln(h, f.w2, f.b2, z, f.gamma, f.beta, x_next, None, None, eps=LN_EPS)
+                if nxt is not None:
+                    nv.gemm(x_next, nxt.w_qkv, qkv, bias=nxt.b_qkv)
+            x = x_next
         ms = self.model._st
         logits = torch.empty(n, ms.v_pad, dtype=F32, device=x.device)
         nv.gemm(x, ms.w_vocab, logits, epi=nv.EPI_F32)
@@ -138,6 +159,7 @@ class Decode(object):
                 raise ValueError("Decode: max_steps %d exceeds the decoder's positional-encoding table" % S)
             st = _DecodeState()
             st.B, st.beam, st.n = B, beam, n
+            st.chains = dec.row_chains(arena)          # None: the layers do not fit the row-chain kernel
             st.cross = []
             for layer in dec.layer_stack:                                               # once per utterance
                 s = layer.enc_attn._st
