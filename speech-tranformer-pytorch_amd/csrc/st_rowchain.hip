@@ -26,12 +26,10 @@
 
 namespace {
 
-constexpr int RB = 32;       // rows per workgroup: one MFMA row tile
 constexpr int DM = 256;      // d_model = block edge
 constexpr int AS = DM + 8;   // LDS activation row stride in elements (528 B: conflict-free ds_read_b128 over 16 rows)
 constexpr int DEPTH = 16;    // weight fragments in flight per wave (16 KB): exactly one block ahead
 constexpr int NW = 8;        // waves per workgroup
-constexpr int TE = RB * AS;  // elements of one LDS activation tile
 constexpr int TOUCH = 8;     // warm-up lines per thread (covers a 12-block chain and the 2-block one behind it from 4 workgroups per XCD up)
 
 struct ChainArgs {
@@ -55,36 +53,52 @@ struct ChainArgs {
   int nb; const float* bp; bf16* P; int ldp;
 };
 
-struct Ctx {
+// fragments in flight per wave: with three row tiles a fragment feeds three MFMAs (it is consumed a third as often), and
+// the registers are needed for the accumulators
+template <int MT> struct Ring { static constexpr int D = MT == 1 ? DEPTH : DEPTH / 2; };
+
+template <int MT> struct Ctx {
   int tid, wave, l, hi, r, row0, nvalid;
-  const bf16x8* ws;      // wave-uniform stream cursor: the block to REFILL from (one block ahead of the one being multiplied)
-  bf16x8 ring[DEPTH];
+  const bf16x8* ws;      // wave-uniform stream cursor: the fragment Ring<MT>::D ahead of the next one to be multiplied
+  bf16x8 ring[Ring<MT>::D];
 };
 
-// One 256 x 256 weight block: acc[n = wave*32 + ...][m] (+)= W_block x act^T, refilling the ring with the next block.
-__device__ __forceinline__ void block_mma(Ctx& c, const bf16* act, f32x16& acc) {
+// One 256 x 256 weight block: acc[mt][n = wave*32 + ...][m] (+)= W_block x act^T for the MT row tiles of the workgroup
+// (every weight fragment feeds MT MFMAs), refilling the ring DEPTH fragments ahead.
+template <int MT>
+__device__ __forceinline__ void block_mma(Ctx<MT>& c, const bf16* act, f32x16 (&acc)[MT]) {
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    const bf16x8 xf = frag_nat(act, AS, c.r, ks * 16 + c.hi * 8);
-    acc = mfma32(c.ring[ks], xf, acc);
-    c.ring[ks] = c.ws[ks * 64 + c.l];
-    __builtin_amdgcn_sched_barrier(0);   // keep each refill next to its MFMA: hoisted refills double the live registers
+    bf16x8 xf[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = frag_nat(act, AS, mt * 32 + c.r, ks * 16 + c.hi * 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(c.ring[ks % Ring<MT>::D], xf[mt], acc[mt]);
+    c.ring[ks % Ring<MT>::D] = c.ws[ks * 64 + c.l];
+    __builtin_amdgcn_sched_barrier(0);   // keep each refill next to its MFMAs: hoisted refills double the live registers
   }
   c.ws += 16 * 64;
 }
 
-// [32][256] tile: global (rows past M as zeros) -> LDS
-__device__ __forceinline__ void tile_in(const Ctx& c, const bf16* g, int ld, bf16* t) {
+template <int MT> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT]) {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = zero16();
+}
+
+// [32 MT][256] tile: global (rows past M as zeros) -> LDS
+template <int MT>
+__device__ __forceinline__ void tile_in(const Ctx<MT>& c, const bf16* g, int ld, bf16* t) {
+#pragma unroll
+  for (int p = 0; p < 2 * MT; ++p) {
     const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
     *reinterpret_cast<bf16x8*>(t + rr * AS + cc * 8) = gload8(g + (size_t)(c.row0 + rr) * ld + cc * 8, rr < c.nvalid);
   }
 }
 // LDS -> global as 512-byte row segments
-__device__ __forceinline__ void tile_out(const Ctx& c, const bf16* t, bf16* g, int ld) {
+template <int MT>
+__device__ __forceinline__ void tile_out(const Ctx<MT>& c, const bf16* t, bf16* g, int ld) {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < 2 * MT; ++p) {
     const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
     if (rr < c.nvalid)
       *reinterpret_cast<bf16x8*>(g + (size_t)(c.row0 + rr) * ld + cc * 8) = *reinterpret_cast<const bf16x8*>(t + rr * AS + cc * 8);
@@ -92,113 +106,140 @@ __device__ __forceinline__ void tile_out(const Ctx& c, const bf16* t, bf16* g, i
 }
 
 // acc + bias (+ReLU, dropout) -> bf16 into this wave's 32 columns of an LDS tile
-template <bool RELU, bool DROP>
-__device__ __forceinline__ void epi_store(const Ctx& c, const f32x16& acc, const float* bias, bf16* t, const Drop& d, int gcol0,
-                                          int ncols) {
+template <bool RELU, bool DROP, int MT>
+__device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[MT], const float* bias, bf16* t, const Drop& d,
+                                          int gcol0, int ncols) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl = c.wave * 32 + 8 * g + 4 * c.hi;
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
-    uint32_t bits = 0;
-    if (DROP) bits = d.bits(drop_counter_rc(c.row0 + c.r, gcol0 + jl, ncols));
-    bf16x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = acc[4 * g + e] + bb[e];
-      if (RELU) v = fmaxf(v, 0.f);
-      if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
-      o[e] = (bf16)v;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r;
+      uint32_t bits = 0;
+      if (DROP) bits = d.bits(drop_counter_rc(c.row0 + row, gcol0 + jl, ncols));
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[mt][4 * g + e] + bb[e];
+        if (RELU) v = fmaxf(v, 0.f);
+        if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+        o[e] = (bf16)v;
+      }
+      *reinterpret_cast<bf16x4*>(t + row * AS + jl) = o;
     }
-    *reinterpret_cast<bf16x4*>(t + c.r * AS + jl) = o;
   }
 }
 
 // v = acc + bias + res; LayerNorm over the 256 columns held by the 8 waves; xhat -> t_xhat, (dropped) output -> t_out,
 // both then leave for HBM.  Two workgroup barriers inside, one before the copies out: on return t_out is complete.
-template <bool DROP>
-__device__ __forceinline__ void epi_ln(const Ctx& c, f32x16& acc, const float* bias, const bf16* res, const float* gamma,
-                                       const float* beta, float eps, const Drop& d, bf16* t_xhat, bf16* t_out, float (*red)[NW * 32],
-                                       bf16* g_out, bf16* g_xhat, float* g_rstd) {
+template <bool DROP, int MT>
+__device__ __forceinline__ void epi_ln(const Ctx<MT>& c, f32x16 (&acc)[MT], const float* bias, const bf16* res, const float* gamma,
+                                       const float* beta, float eps, const Drop& d, bf16* t_xhat, bf16* t_out,
+                                       float (*red)[NW * 32 * MT], bf16* g_out, bf16* g_xhat, float* g_rstd) {
   const int j0 = c.wave * 32;
-  float sum = 0.f;
+  float sum[MT], sq[MT], mean[MT], rstd[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) sum[mt] = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl = j0 + 8 * g + 4 * c.hi;
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
-    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + c.r * AS + jl);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float v = acc[4 * g + e] + bb[e] + (float)rr[e];
-      acc[4 * g + e] = v;
-      sum += v;
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + (mt * 32 + c.r) * AS + jl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[mt][4 * g + e] + bb[e] + (float)rr[e];
+        acc[mt][4 * g + e] = v;
+        sum[mt] += v;
+      }
     }
   }
-  sum += wave_xor32(sum);
-  if (c.hi == 0) red[0][c.wave * 32 + c.r] = sum;
-  __syncthreads();
-  sum = 0.f;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) sum += red[0][w * 32 + c.r];
-  const float mean = sum * (1.f / DM);
-  float sq = 0.f;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const float dv = acc[q] - mean;
-    sq += dv * dv;
+  for (int mt = 0; mt < MT; ++mt) {
+    sum[mt] += wave_xor32(sum[mt]);
+    if (c.hi == 0) red[0][(c.wave * MT + mt) * 32 + c.r] = sum[mt];
   }
-  sq += wave_xor32(sq);
-  if (c.hi == 0) red[1][c.wave * 32 + c.r] = sq;
   __syncthreads();
-  sq = 0.f;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) sq += red[1][w * 32 + c.r];
-  const float rstd = rsqrtf(sq * (1.f / DM) + eps);
-  if (g_rstd && c.wave == 0 && c.hi == 0 && c.r < c.nvalid) g_rstd[c.row0 + c.r] = rstd;
+  for (int mt = 0; mt < MT; ++mt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[0][(w * MT + mt) * 32 + c.r];
+    mean[mt] = s * (1.f / DM);
+    sq[mt] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float dv = acc[mt][q] - mean[mt];
+      sq[mt] += dv * dv;
+    }
+    sq[mt] += wave_xor32(sq[mt]);
+    if (c.hi == 0) red[1][(c.wave * MT + mt) * 32 + c.r] = sq[mt];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[1][(w * MT + mt) * 32 + c.r];
+    rstd[mt] = rsqrtf(s * (1.f / DM) + eps);
+    if (g_rstd && c.wave == 0 && c.hi == 0 && mt * 32 + c.r < c.nvalid) g_rstd[c.row0 + mt * 32 + c.r] = rstd[mt];
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl = j0 + 8 * g + 4 * c.hi;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + jl);
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + jl);
-    uint32_t bits = 0;
-    if (DROP) bits = d.bits(drop_counter_rc(c.row0 + c.r, jl, DM));
-    bf16x4 xh, o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float n = (acc[4 * g + e] - mean) * rstd;
-      float v = n * g4[e] + b4[e];
-      if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
-      xh[e] = (bf16)n;
-      o[e] = (bf16)v;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r;
+      uint32_t bits = 0;
+      if (DROP) bits = d.bits(drop_counter_rc(c.row0 + row, jl, DM));
+      bf16x4 xh, o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float n = (acc[mt][4 * g + e] - mean[mt]) * rstd[mt];
+        float v = n * g4[e] + b4[e];
+        if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+        xh[e] = (bf16)n;
+        o[e] = (bf16)v;
+      }
+      *reinterpret_cast<bf16x4*>(t_xhat + row * AS + jl) = xh;
+      *reinterpret_cast<bf16x4*>(t_out + row * AS + jl) = o;
     }
-    *reinterpret_cast<bf16x4*>(t_xhat + c.r * AS + jl) = xh;
-    *reinterpret_cast<bf16x4*>(t_out + c.r * AS + jl) = o;
   }
   __syncthreads();
   if (g_xhat) tile_out(c, t_xhat, g_xhat, DM);
   tile_out(c, t_out, g_out, DM);
 }
 
-template <bool PRE, bool FFN, bool POST, bool DROP>
+// MT = row tiles of 32 per workgroup.  1: decoder-sized row counts (as many workgroups as possible).  3: encoder-sized
+// ones (24,060 rows = 251 workgroups = one round of the 256 CUs; every weight fragment feeds three MFMAs, so a
+// workgroup's MFMA time matches its weight stream; three 50 KB activation tiles fill the LDS).
+template <bool PRE, bool FFN, bool POST, bool DROP, int MT>
 __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
-  // tiles: A (chain input), R (residual, then the odd hidden chunks), C (cur after PRE), H (even hidden chunks / POST
-  // staging), X (xhat / POST staging), D (cur after FFN)
-  __shared__ __attribute__((aligned(16))) bf16 tiles[6 * TE];
-  __shared__ float red[2][NW * 32];
-  Ctx c;
+  constexpr int RB = 32 * MT, TE = RB * AS;
+  // three activation tiles: `cur` (the running activation) and two free ones that serve, in turn, as residual, hidden
+  // chunks, xhat and output staging.  A tile is rewritten only after a workgroup barrier that every wave reaches after its
+  // last read of it (the comments at each site name that barrier).
+  __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
+  __shared__ float red[2][NW * 32 * MT];
+  Ctx<MT> c;
   c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
   c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
   c.ws = a.wfrag + (size_t)c.wave * a.wave_frags * 64;   // wave-uniform: the loads take an SGPR base + lane offset
 #pragma unroll
-  for (int i = 0; i < DEPTH; ++i) c.ring[i] = c.ws[i * 64 + c.l];   // the first block goes out before anything else
-  c.ws += DEPTH * 64;
+  for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];   // the first fragments go out before anything else
+  c.ws += Ring<MT>::D * 64;
   // Warm the L2 of this workgroup's XCD with the WHOLE chain's streams - and those of the chain that runs next (they lie
   // right behind in st_amd.chains' buffer; an attention kernel runs in between): the streams are read once per step, so
   // a wave's 16 KB in flight would otherwise meet the HBM latency block after block (cold caches, M = 1206: 40.4 us for
   // the 12-block chain against 22.6 us with the streams cached; 32.8 us with its own lines touched up front).  The
   // workgroups that share an XCD (dispatch is round-robin over the 8 XCDs) deal the 128-byte lines among their threads;
-  // the values are only consumed at the very end.
+  // the values are only consumed at the very end.  (MT = 3: hundreds of workgroups read the same streams - no warm-up.)
   int touched[TOUCH];
-  {
+  if (MT == 1) {
     const int nlines = NW * (a.wave_frags + a.next_frags) * 8;     // this chain's streams and the next chain's right behind them
     const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
     const char* sb = reinterpret_cast<const char*>(a.wfrag);
@@ -210,53 +251,64 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  bf16* tA = tiles; bf16* tR = tiles + TE; bf16* tC = tiles + 2 * TE; bf16* tH = tiles + 3 * TE; bf16* tX = tiles + 4 * TE;
-  bf16* tD = tiles + 5 * TE;
-  tile_in(c, a.A, a.lda, tA);
-  if (PRE) tile_in(c, a.R, a.ldr, tR);
+  bf16* cur = tiles;             // A
+  bf16* f0 = tiles + TE;         // residual, then the first free tile
+  bf16* f1 = tiles + 2 * TE;
+  tile_in(c, a.A, a.lda, cur);
+  if (PRE) tile_in(c, a.R, a.ldr, f0);
   const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
   __syncthreads();
 
-  const bf16* cur = tA;
   if (PRE) {
-    f32x16 acc = zero16();
-    block_mma(c, tA, acc);
-    epi_ln<false>(c, acc, a.bo, tR, a.g0, a.be0, a.eps, off, tX, tC, red, a.out0, a.xhat0, a.rstd0);
-    cur = tC;
+    f32x16 acc[MT];
+    zero_acc(acc);
+    block_mma(c, cur, acc);
+    // xhat is staged in the A tile (every wave is past its MFMAs on it at epi_ln's first barrier), the output in f1
+    epi_ln<false>(c, acc, a.bo, f0, a.g0, a.be0, a.eps, off, cur, f1, red, a.out0, a.xhat0, a.rstd0);
+    // now: cur = f1; free: f0 (the residual: last read before epi_ln's barriers) and, one barrier later, the A tile (xhat0 is
+    // still being copied out of it)
+    bf16* t = cur; cur = f1; f1 = t;
   }
   if (FFN) {
     const int dff = a.nc * 256;
-    f32x16 acc2 = zero16();
+    f32x16 acc2[MT];
+    zero_acc(acc2);
     for (int ch = 0; ch < a.nc; ++ch) {
-      // chunk ch's tile is rewritten by chunk ch + 2: the barrier of chunk ch + 1 lies in between.  (tR: every wave is past
-      // PRE's reads of it - epi_ln's barriers; tH / tX: free.)
-      bf16* hc = (ch & 1) ? tR : tH;
-      f32x16 acc1 = zero16();
+      // hidden chunks alternate f0, f1; chunk ch's tile is rewritten by chunk ch + 2 with the barrier of chunk ch + 1 in
+      // between; f1's first use (chunk 1) lies behind chunk 0's barrier, which every wave reaches after PRE's copies out
+      bf16* hc = (ch & 1) ? f1 : f0;
+      f32x16 acc1[MT];
+      zero_acc(acc1);
       block_mma(c, cur, acc1);
       epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff);
       __syncthreads();
       block_mma(c, hc, acc2);
       tile_out(c, hc, a.H + ch * 256, dff);
     }
-    epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, tX, tD, red, a.out1, a.xhat1, a.rstd1);
-    cur = tD;
+    // xhat goes to the tile the LAST chunk did not use (last read one chunk earlier), the output replaces cur in place
+    // (its residual reads precede epi_ln's barriers, its MFMA reads too)
+    bf16* tx = (a.nc & 1) ? f1 : f0;
+    epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, tx, cur, red, a.out1, a.xhat1, a.rstd1);
+    if (tx == f0) { f0 = f1; f1 = tx; }      // f0 = the tile free right now, f1 = xhat (still being copied out)
   }
   if (POST) {
     for (int u = 0; u < a.nb; ++u) {
-      // staging tiles alternate; a tile is rewritten two blocks later, one barrier in between (tR / tH: the last hidden
-      // chunks were read before epi_ln's barriers; without FFN they are free after PRE)
-      bf16* st = (u & 1) ? tH : tR;
-      f32x16 acc = zero16();
+      // staging alternates f0, f1: f0 is free (see above), f1 one barrier later; a tile is rewritten two blocks later
+      bf16* st = (u & 1) ? f1 : f0;
+      f32x16 acc[MT];
+      zero_acc(acc);
       block_mma(c, cur, acc);
       epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0);
       __syncthreads();
       tile_out(c, st, a.P + u * 256, a.ldp);
     }
   }
-  int tsum = 0;
+  if (MT == 1) {
+    int tsum = 0;
 #pragma unroll
-  for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
-  if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;      // (never true: keeps the warm-up loads alive)
+    for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+    if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;      // (never true: keeps the warm-up loads alive)
+  }
 }
 
 // Block descriptor table of st_wfrag_build: 4 x int64 per 256 x 256 weight block
@@ -316,12 +368,19 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   a.drop2.seed = on2 ? drop_seed : nullptr; a.drop2.salt = drop2_salt; a.drop2.thresh = on2 ? drop2_thresh : 0;
   a.drop2.scale = on2 ? drop2_scale : 1.f;
   a.nb = post_blocks; a.bp = bp; a.P = (bf16*)P; a.ldp = ldp;
-  const dim3 grid((M + RB - 1) / RB), blk(512);
+  // row tiles per workgroup: 1 while that gives at most one round of workgroups (256 CUs), else 3
+  const int mt = (M + 31) / 32 <= 256 ? 1 : 3;
+  const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
   const bool drop = on1 || on2;
-#define ST_CHAIN(PRE_, FFN_, POST_)                                                                            \
-  do {                                                                                                         \
-    if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true>), grid, blk, 0, stream, a);        \
-    else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false>), grid, blk, 0, stream, a);            \
+#define ST_CHAIN(PRE_, FFN_, POST_)                                                                               \
+  do {                                                                                                            \
+    if (mt == 3) {                                                                                                \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 3>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 3>), grid, blk, 0, stream, a);          \
+    } else {                                                                                                      \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 1>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 1>), grid, blk, 0, stream, a);          \
+    }                                                                                                             \
   } while (0)
   if (pre && ffn && post) ST_CHAIN(true, true, true);
   else if (pre && ffn) ST_CHAIN(true, true, false);

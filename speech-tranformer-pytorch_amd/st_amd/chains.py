@@ -113,10 +113,82 @@ class SubPre:
             setattr(self, k, None)
 
 
+class EncoderChains:
+    """The chains of an encoder's layer stack (Layers.py:16-22, one layer = self-attention -> feed-forward): per layer ONE
+    chain - output_linear + residual + layernorm of the self-attention, the feed-forward sublayer, the NEXT layer's q|k|v
+    projection - so an encoder layer is two launches (attention, chain) instead of five.  At encoder-sized row counts the
+    kernel gives a workgroup 96 rows (24,060 rows = 251 workgroups = one round of the CUs)."""
+
+    def __init__(self, layers, arena):
+        self.arena = arena
+        self.set = ChainSet(arena.device)
+        ids = []
+        n = len(layers)
+        for l, layer in enumerate(layers):
+            sa, ff = layer.slf_attn._st, layer.pos_ffn._st
+            nxt = blocks_of(layers[l + 1].slf_attn._st.w_qkv) if l + 1 < n else []
+            ids.append(self.set.add(blocks_of(sa.w_o) + ffn_blocks(ff.w1, ff.w2) + nxt))
+        self.set.finalize()
+        self.e = [self.set.chain(c, True) for c in ids]
+
+    @staticmethod
+    def plan(layers, arena):
+        if not layers:
+            return None
+        for layer in layers:
+            sa, ff = layer.slf_attn, layer.pos_ffn
+            if any(getattr(m, "_st_arena", None) is not arena for m in (sa, ff)):
+                return None
+            if sa._st.d_model != BLK or ff._st.d_ff % BLK:
+                return None
+        return EncoderChains(layers, arena)
+
+    def refresh(self) -> None:
+        self.set.rebuild()
+
+    def forward(self, layers, x, rows, need_bwd: bool):
+        """The encoder's layer stack on frame rows x [M, 256] (front-end output): per layer self-attention, then the chain.
+        -> (output rows, [(self-attention, feed-forward) SubPre per layer]); nothing here is recorded by autograd."""
+        from .functional import attn_work, linear_fwd
+        M, d = x.shape
+        dev = x.device
+
+        def E(*shape, dt=BF16):
+            return torch.empty(*shape, dtype=dt, device=dev)
+
+        s0 = layers[0].slf_attn._st
+        H = s0.n_head
+        scale = 1.0 / math.sqrt(d // H)
+        work = attn_work(rows, rows, False)[0]
+        qkv = E(M, 3 * d)
+        linear_fwd(x, s0.w_qkv, qkv, s0.b_qkv)
+        pres = []
+        n = len(layers)
+        for l, layer in enumerate(layers):
+            sa, ff = layer.slf_attn, layer.pos_ffn
+            a, f = SubPre(), SubPre()
+            a.qkv, a.drop = qkv, sa._drop(dev)
+            a.ctx, a.lse, a.ores = E(M, d), E(H * M, dt=F32), (E(M, d) if need_bwd else None)
+            nv.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a.ctx, a.lse, rows.off, rows.len, rows.off, rows.len,
+                        H, rows.max_len, False, scale, work=work, drop=a.drop, max_k=rows.max_len, ores=a.ores)
+            a.out, f.out, f.h = E(M, d), E(M, d), E(M, ff._st.d_ff)
+            if need_bwd:
+                a.xhat, a.rstd, f.xhat, f.rstd = E(M, d), E(M, dt=F32), E(M, d), E(M, dt=F32)
+            f.drop1, f.drop2 = ff._drops(dev)
+            nxt = layers[l + 1].slf_attn._st if l + 1 < n else None
+            qkv = E(M, 3 * d) if nxt is not None else None
+            nv.row_chain(a.ctx, self.e[l], pre=(x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
+                         ffn=(ff._st.d_ff, ff._st.b1, ff._st.b2, ff._st.gamma, ff._st.beta, f.h, f.out, f.xhat, f.rstd, f.drop1,
+                              f.drop2),
+                         post=(3, nxt.b_qkv, qkv) if nxt is not None else None)
+            x = f.out
+            pres.append((a, f))
+        return x, pres
+
+
 class DecoderChains:
     """The chains of a decoder's layer stack (see the module docstring); ``None`` from ``plan`` when a layer does not fit
     the kernel (d_model != 256, d_ff not a multiple of 256, parameters outside one arena)."""
-    MAX_ROWS = 4096      # one workgroup per 32 rows, each streaming the whole chain's weights: decoder-sized inputs only
 
     def __init__(self, layers, arena):
         self.arena = arena

@@ -22,13 +22,16 @@ class EncoderLayer(nn.Module):
         self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner_hid, dropout=dropout)
 
-    def forward_rows(self, x, rows, up=None):
+    def forward_rows(self, x, rows, up=None, pre=None):
         """-> (output rows, LnLink the next layer may pass back as ``up``).  The links let each sublayer's backward
         run the previous sublayer's LayerNorm backward inside its last GEMM; they require that nothing but the next
-        sublayer consumes the intermediate tensors, which holds inside the stacks."""
+        sublayer consumes the intermediate tensors, which holds inside the stacks.
+        pre: this layer's (self-attention, feed-forward) st_amd.chains.SubPre when the forward values come from the
+        fused launches (st_amd.chains.EncoderChains.forward)."""
         l1, l2 = _links(2)
-        a = self.slf_attn.forward_rows(x, None, rows, rows, False, up=up, down=l1)
-        return self.pos_ffn.forward_rows(a, up=l1, down=l2), l2
+        pa, pf = pre if pre is not None else (None, None)
+        a = self.slf_attn.forward_rows(x, None, rows, rows, False, up=up, down=l1, pre=pa)
+        return self.pos_ffn.forward_rows(a, up=l1, down=l2, pre=pf), l2
 
     def forward(self, inputs, slf_attn_mask=None):
         a, w = self.slf_attn(inputs, inputs, inputs, mask=slf_attn_mask)

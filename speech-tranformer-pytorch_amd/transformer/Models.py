@@ -17,7 +17,7 @@ import transformer.Constants as Constants
 from st_amd import functional as F_
 from st_amd import rng
 from st_amd.arena import arena_of, bundle
-from st_amd.chains import DecoderChains
+from st_amd.chains import DecoderChains, EncoderChains
 from transformer.Embedding import PositionalEncoding
 from transformer.Layers import EncoderLayer, DecoderLayer
 
@@ -42,6 +42,7 @@ class Encoder(nn.Module):
                                         nn.LayerNorm(d_model, eps=1e-6))
         self.layer_stack = nn.ModuleList([
             EncoderLayer(d_model, d_inner_hid, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
+        self.use_row_chains = True      # False: every GEMM of the layer stack is its own launch (A/B runs, tests)
 
     def _st_bind(self, a):
         lin, ln = self.input_proj[0], self.input_proj[3]
@@ -73,9 +74,31 @@ class Encoder(nn.Module):
             drop = rng.site(xp.device, self.input_proj[2].p) if self.training else None   # Models.py:31: p = 0.5
             e = F_.FrontendFn.apply(xp, self.input_proj[0].weight, self, rows, drop)
             link = None                         # FrontendFn's LayerNorm output is masked/offset: not linked
-            for layer in self.layer_stack:
-                e, link = layer.forward_rows(e, rows, link)
+            # everything between two attention kernels as ONE row-chain launch (st_amd.chains); the Functions below then
+            # only record the autograd nodes over those values
+            ec = self.row_chains(arena)
+            pres = None
+            if ec is not None:
+                need_bwd = torch.is_grad_enabled() and e.requires_grad
+                with torch.no_grad():
+                    e_out, pres = ec.forward(self.layer_stack, e, rows, need_bwd)
+                if not need_bwd:
+                    return e_out, rows
+            for l, layer in enumerate(self.layer_stack):
+                e, link = layer.forward_rows(e, rows, link, pre=pres[l] if pres is not None else None)
         return e, rows
+
+    def row_chains(self, arena):
+        """This encoder's row-chain plan (st_amd.chains.EncoderChains) for ``arena`` or None; see Decoder.row_chains."""
+        hit = getattr(self, "_st_chains", None)
+        if hit is None or hit[0] is not arena:
+            ec = EncoderChains.plan(list(self.layer_stack), arena) if self.use_row_chains else None
+            if ec is not None:
+                ec.refresh()
+                arena._derived.append(ec)
+            hit = (arena, ec)
+            self._st_chains = hit
+        return hit[1] if self.use_row_chains else None
 
     def forward(self, inputs, inputs_length, return_attns=False):
         if return_attns:
@@ -131,7 +154,7 @@ class Decoder(nn.Module):
                 kv = F_.CrossKvFn.apply(enc_rows_mat, self.layer_stack[0].enc_attn.linear_k.weight, ckv)
                 # decoder-sized row counts: everything between two attention kernels is ONE row-chain launch
                 # (st_amd.chains); the Functions below then only record the autograd nodes over those values
-                dc = self.row_chains(arena) if t_rows.total <= DecoderChains.MAX_ROWS and t_rows.max_len <= 0xffff else None
+                dc = self.row_chains(arena)
                 pres = None
                 if dc is not None:
                     need_bwd = torch.is_grad_enabled() and (y.requires_grad or kv.requires_grad)
@@ -236,7 +259,8 @@ class Transformer(nn.Module):
         F_.attn_work(in_rows, in_rows, False)     # encoder self-attention
         F_.attn_work(t_rows, t_rows, True)        # decoder self-attention (causal)
         F_.attn_work(t_rows, in_rows, False)      # decoder-encoder attention
-        self.decoder.row_chains(arena_of(self))   # the chain plan's block table (a host->device copy the first time)
+        self.encoder.row_chains(arena_of(self))   # the chain plans' block tables (a host->device copy the first time)
+        self.decoder.row_chains(arena_of(self))
         return in_rows, t_rows
 
     def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False,

@@ -523,7 +523,7 @@ def run_row_chains_on_off(device, exact):
     crit = torch.nn.CrossEntropyLoss(ignore_index=0)
 
     def run(chains_on):
-        m.decoder.use_row_chains = chains_on
+        m.decoder.use_row_chains = m.encoder.use_row_chains = chains_on
         arena = arena_of(m)
         arena.zero_grads()
         rng.manual_seed(5)
@@ -538,14 +538,18 @@ def run_row_chains_on_off(device, exact):
         for training in (False, True):
             m.train(training)
             (l1, lg1, g1), (l0, lg0, g0) = run(True), run(False)
-            assert m.decoder._st_chains[1] is not None
+            assert m.decoder._st_chains[1] is not None and m.encoder._st_chains[1] is not None
             if exact:
                 assert l1 == l0 and torch.equal(lg1, lg0) and torch.equal(g1, g0), (training, l1, l0)
             else:
-                assert abs(l1 - l0) <= 2e-4 * abs(l0), (training, l1, l0)
-                assert rel(lg1, lg0) < 5e-3 and rel(g1, g0) < 3e-2, (training, rel(lg1, lg0), rel(g1, g0))
+                # two bf16 pipelines with different accumulation orders: rounding flips are amplified layer by layer on
+                # this random-weight model (measured 6e-3 on the logits, 4e-2 on the gradients); each path is held to the
+                # fp64 oracle separately (run_row_chain_step, run_c1_step ...), the kernel to the separate kernels tightly
+                # (tests/test_kernels_gpu.py::test_row_chain_matches_the_separate_kernels)
+                assert abs(l1 - l0) <= 1e-3 * abs(l0), (training, l1, l0)
+                assert rel(lg1, lg0) < 2e-2 and rel(g1, g0) < GRAD_TOL_TENSOR, (training, rel(lg1, lg0), rel(g1, g0))
     finally:
-        m.decoder.use_row_chains = True
+        m.decoder.use_row_chains = m.encoder.use_row_chains = True
 
 
 def test_row_chains_on_off_composition():

@@ -292,7 +292,7 @@ def test_fused_backward_paths_match_unfused_paths_full_size():
     xs, ts, gs = x.cuda(), tokens.cuda(), gt.cuda()
     crit = torch.nn.CrossEntropyLoss(ignore_index=0)
 
-    model.decoder.use_row_chains = False      # (they need CrossKv; their own on / off test is test_row_chains_on_off_gpu)
+    model.decoder.use_row_chains = model.encoder.use_row_chains = False      # (their own on / off test: test_row_chains_on_off_gpu)
 
     def run(fused):
         arena = arena_of(model)

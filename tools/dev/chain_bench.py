@@ -38,7 +38,7 @@ c_ffn = cs.add(chains.ffn_blocks(w1, w2))
 cs.finalize(); cs.rebuild()
 print("rebuild %.1f us for %d blocks" % (timeit(cs.rebuild), cs.table.shape[0]))
 E = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-for M in (320, 1206):
+for M in [int(a) for a in sys.argv[1:]] or (320, 1206):
     ctx, x = rnd(M, d), rnd(M, d)
     # ---- F1: wo + LN, q
     o0, xh0, r0, q0 = E(M, d), E(M, d), E(M, dt=F32), E(M, d)
