@@ -78,8 +78,8 @@ def kernel_report(records):
                     flops *= 2.0                      # dQ and dK/dV bodies in one launch
             elif tag[0] == "ln_bwd":
                 kind = "ln_bwd"
-            elif tag[0] == "row_chain":       # (name, rows, 256 x 256 weight blocks, d_ff)
-                kind, flops = "row_chain", 2.0 * tag[1] * tag[2] * 256 * 256
+            elif tag[0] in ("row_chain", "row_chain_bwd"):       # (name, rows, 256 x 256 weight blocks, d_ff)
+                kind, flops = tag[0], 2.0 * tag[1] * tag[2] * 256 * 256
         a = agg.setdefault(kind, {"ms": 0.0, "launches": 0, "flops": 0.0})
         a["ms"] += ms
         a["launches"] += 1

@@ -157,6 +157,23 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
                  int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
                  int post_blocks, const float* bp, void* P, int ldp);
 
+/* The backward of a row chain in one launch; the chain's stream holds the TRANSPOSED weight blocks (st_wfrag_build table
+ * entry [1] = leading dimension | 1 << 32) in the order HEAD | FFN | TAIL:
+ *   HEAD  (head_blocks > 0)  dy = sum_u dP[:, 256u..] Wp_u + G (G may be NULL);  ds_a = LayerNorm-backward(dropout-backward(dy);
+ *         xhat_a, rstd_a, gamma_a);  dgamma_a / dbeta_a / dbias_a accumulated atomically        (== st_gemm_lnbwd)
+ *   FFN   (d_ff > 0)  dH = (ds W2) masked by H > 0, x mask_scale (== st_gemm ST_EPI_BF16_MASK);  ds_b = LayerNorm-backward(
+ *         dH W1 + ds; xhat_b, rstd_b, gamma_b) and its column sums
+ *   TAIL  (O != NULL)  dctx = ds Wo;  delta[h * M + i] = sum over head h's 64 columns of dctx (O + Ores)   (== ST_EPI_BF16_DELTA)
+ * ds = the running gradient: ds_a after HEAD, ds_b after FFN, the input DS [M, 256] without HEAD.  Heads are 64 columns.
+ * Reference lines: the backward of Attention.py:74-76,92-94 and SubLayers.py:24-28. */
+int st_row_chain_bwd(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, int head_blocks,
+                     const void* dP, int ldp, const void* G, int ldg, const void* xhat_a, const float* rstd_a,
+                     const float* gamma_a, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale,
+                     void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a, const void* DS, int d_ff, const void* H,
+                     float mask_scale, void* dH, const void* xhat_b, const float* rstd_b, const float* gamma_b, void* ds_b,
+                     float* dgamma_b, float* dbeta_b, float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx,
+                     int lddc, float* delta);
+
 /* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
  * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).
  * mask (optional bf16 [M,N]): dx is zeroed where mask <= 0 (front-end ReLU,

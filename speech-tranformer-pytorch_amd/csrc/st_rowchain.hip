@@ -311,22 +311,297 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
   }
 }
 
+// =====================================================================================================================
+// Backward chains: the same row blocks, weight blocks read transposed (st_wfrag_build), in the reverse order of the
+// forward chain:
+//
+//   HEAD  dy = sum_u dP[:, 256u..] Wp_u + G                      the data gradient of the NEXT attention's projection(s)
+//         ds_a = LayerNorm-backward(dropout-backward(dy); xhat_a, rstd_a, gamma_a)      (== st_gemm_lnbwd)
+//         dgamma_a += sum_rows dy xhat,  dbeta_a += sum_rows dy,  dbias_a += sum_rows ds_a
+//   FFN   dH = (ds W2) masked by H > 0, x mask_scale              (== st_gemm EPI_BF16_MASK; SubLayers.py:25-26 backward)
+//         dy = dH W1 + ds;  ds_b = LayerNorm-backward(dy; xhat_b, rstd_b, gamma_b) and its three column sums
+//   TAIL  dctx = ds Wo;  delta[h][i] = sum over head h of dctx (O + Ores)        (== st_gemm EPI_BF16_DELTA)
+//
+// (ds = the running gradient: HEAD's ds_a, else the input DS).  HEAD + TAIL follows the decoder-encoder attention's
+// backward kernel, HEAD + FFN + TAIL the self-attention's (decoder: of the next layer; encoder likewise).
+struct ChainBwdArgs {
+  int M;
+  const bf16x8* wfrag; int wave_frags; int next_frags;
+  // HEAD
+  int nb; const bf16* dP; int ldp; const bf16* G; int ldg;
+  const bf16* xhat_a; const float* rstd_a; const float* gamma_a; DropArgs drop_a;
+  bf16* ds_a; float* dgamma_a; float* dbeta_a; float* dbias_a;
+  const bf16* DS;                    // no HEAD: the chain input [M, 256], ld 256
+  // FFN
+  int nc; const bf16* H; float mask_scale; bf16* dH;
+  const bf16* xhat_b; const float* rstd_b; const float* gamma_b;
+  bf16* ds_b; float* dgamma_b; float* dbeta_b; float* dbias_b;
+  // TAIL
+  const bf16* O; const bf16* Ores; int ldo; bf16* dctx; int lddc; float* delta;
+};
+
+// LayerNorm backward over the 256 columns held by the 8 waves.  acc = the GEMM result; t_aux holds the addend and receives
+// dy (bf16, rounded once as acc + addend, before the dropout mask) in place; t_xhat the saved normalised values; dx goes
+// to t_dx and to HBM; then the three column sums (256 columns x the block's rows, two threads per column) are added
+// atomically.  Barriers: two for the row sums, one before the column pass / copy out; the caller needs one more before
+// t_aux / t_xhat are rewritten.
+template <bool DROP, int MT>
+__device__ __forceinline__ void epi_lnbwd(const Ctx<MT>& c, f32x16 (&acc)[MT], bf16* t_aux, const bf16* t_xhat, bf16* t_dx,
+                                          const float* g_rstd, const float* gamma, const Drop& d, float (*red)[NW * 32 * MT],
+                                          bf16* g_dx, float* dgamma, float* dbeta, float* dbias) {
+  const int j0 = c.wave * 32;
+  float s1[MT], s2[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) s1[mt] = s2[mt] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl = j0 + 8 * g + 4 * c.hi;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + jl);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r, at = row * AS + jl;
+      const bf16x4 xh4 = *reinterpret_cast<const bf16x4*>(t_xhat + at);
+      const bf16x4 ad4 = *reinterpret_cast<const bf16x4*>(t_aux + at);
+      uint32_t bits = 0;
+      if (DROP) bits = d.bits(drop_counter_rc(c.row0 + row, jl, DM));   // the mask the forward drew on this LayerNorm's output
+      bf16x4 dy4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dy4[e] = (bf16)(acc[mt][4 * g + e] + (float)ad4[e]);       // one rounding, as st_gemm_lnbwd
+        float v = (float)dy4[e];
+        if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+        const float gg = v * g4[e];
+        acc[mt][4 * g + e] = gg;                                    // keep g = dy * gamma
+        s1[mt] += gg;
+        s2[mt] += gg * (float)xh4[e];
+      }
+      *reinterpret_cast<bf16x4*>(t_aux + at) = dy4;
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    s1[mt] += wave_xor32(s1[mt]);
+    s2[mt] += wave_xor32(s2[mt]);
+    if (c.hi == 0) {
+      red[0][(c.wave * MT + mt) * 32 + c.r] = s1[mt];
+      red[1][(c.wave * MT + mt) * 32 + c.r] = s2[mt];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      a1 += red[0][(w * MT + mt) * 32 + c.r];
+      a2 += red[1][(w * MT + mt) * 32 + c.r];
+    }
+    const int row = mt * 32 + c.r;
+    const float m1 = a1 * (1.f / DM), m2 = a2 * (1.f / DM), rs = row < c.nvalid ? g_rstd[c.row0 + row] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int jl = j0 + 8 * g + 4 * c.hi, at = row * AS + jl;
+      const bf16x4 xh4 = *reinterpret_cast<const bf16x4*>(t_xhat + at);
+      bf16x4 dx4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dx4[e] = (bf16)(rs * (acc[mt][4 * g + e] - m1 - (float)xh4[e] * m2));
+      *reinterpret_cast<bf16x4*>(t_dx + at) = dx4;
+    }
+  }
+  __syncthreads();
+  tile_out(c, t_dx, g_dx, DM);
+  // column sums: thread = (column, half of the rows)
+  {
+    const int col = c.tid & 255, half = c.tid >> 8, rows = 16 * MT;
+    float cg = 0.f, cb = 0.f, cx = 0.f;
+    for (int i = 0; i < rows; ++i) {
+      const int row = half * rows + i;
+      float v = (float)t_aux[row * AS + col];
+      if (DROP && d.on()) {
+        const uint32_t bits = d.bits(drop_counter_rc(c.row0 + row, col & ~3, DM));
+        v = d.keep(bits, col & 3) ? v * d.scale : 0.f;
+      }
+      cb += v;
+      cg += v * (float)t_xhat[row * AS + col];
+      cx += (float)t_dx[row * AS + col];
+    }
+    if (dgamma) atomicAdd(dgamma + col, cg);
+    if (dbeta) atomicAdd(dbeta + col, cb);
+    if (dbias) atomicAdd(dbias + col, cx);
+  }
+}
+
+template <bool HEAD, bool FFN, bool TAIL, bool DROP, int MT>
+__global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
+  constexpr int RB = 32 * MT, TE = RB * AS;
+  __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
+  __shared__ float red[2][NW * 32 * MT];
+  Ctx<MT> c;
+  c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
+  c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
+  c.ws = a.wfrag + (size_t)c.wave * a.wave_frags * 64;
+#pragma unroll
+  for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
+  c.ws += Ring<MT>::D * 64;
+  int touched[TOUCH];
+  if (MT == 1) {       // warm-up of this and the next chain's streams: see row_chain_kernel
+    const int nlines = NW * (a.wave_frags + a.next_frags) * 8;
+    const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
+    const char* sb = reinterpret_cast<const char*>(a.wfrag);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) {
+      const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
+      touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* t0 = tiles; bf16* t1 = tiles + TE; bf16* t2 = tiles + 2 * TE;
+  const Drop da = make_drop(a.drop_a), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
+  bf16* cur;          // the running gradient ds
+  bf16 *fa, *fb;      // the two other tiles
+
+  if (HEAD) {
+    // t0: the dP blocks one after the other, then ds_a; t1: G -> dy; t2: xhat_a
+    if (a.G) tile_in(c, a.G, a.ldg, t1);
+    else {
+#pragma unroll
+      for (int p = 0; p < 2 * MT; ++p) *reinterpret_cast<bf16x8*>(t1 + ((c.tid + p * 512) >> 5) * AS + ((c.tid + p * 512) & 31) * 8) = zero_bf8();
+    }
+    tile_in(c, a.xhat_a, DM, t2);
+    f32x16 acc[MT];
+    zero_acc(acc);
+    for (int u = 0; u < a.nb; ++u) {
+      if (u) __syncthreads();                    // every wave is past its MFMAs on the previous block of dP
+      tile_in(c, a.dP + u * 256, a.ldp, t0);
+      __syncthreads();
+      block_mma(c, t0, acc);
+    }
+    __syncthreads();                             // t0 is free for ds_a
+    epi_lnbwd<DROP>(c, acc, t1, t2, t0, a.rstd_a, a.gamma_a, da, red, a.ds_a, a.dgamma_a, a.dbeta_a, a.dbias_a);
+    cur = t0; fa = t1; fb = t2;
+    __syncthreads();                             // the column pass has read t1 / t2: free from here
+  } else {
+    tile_in(c, a.DS, DM, t0);
+    cur = t0; fa = t1; fb = t2;
+    __syncthreads();
+  }
+
+  if (FFN) {
+    const int dff = a.nc * 256;
+    f32x16 acc2[MT];
+    zero_acc(acc2);
+    for (int ch = 0; ch < a.nc; ++ch) {
+      bf16* hc = (ch & 1) ? fb : fa;             // rewritten two chunks later, the next chunk's barrier in between
+      // this lane's ReLU / dropout mask values (H > 0), requested before the MFMAs
+      bf16x4 hv[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = min(c.row0 + mt * 32 + c.r, a.M - 1);
+          hv[mt][g] = *reinterpret_cast<const bf16x4*>(a.H + (size_t)row * dff + ch * 256 + c.wave * 32 + 8 * g + 4 * c.hi);
+        }
+      f32x16 acc1[MT];
+      zero_acc(acc1);
+      block_mma(c, cur, acc1);                   // ds x W2[:, chunk]: the hidden gradient before the mask
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bf16 v = (bf16)(acc1[mt][4 * g + e] * a.mask_scale);
+            o[e] = (float)hv[mt][g][e] > 0.f ? v : (bf16)0.f;
+          }
+          *reinterpret_cast<bf16x4*>(hc + (mt * 32 + c.r) * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
+        }
+      __syncthreads();
+      block_mma(c, hc, acc2);                    // dH chunk x W1[chunk, :]
+      tile_out(c, hc, a.dH + ch * 256, dff);
+    }
+    // dy = acc2 + ds (in place over the ds tile), xhat_b into the tile the last chunk did not use, ds_b into the other
+    bf16* tx = (a.nc & 1) ? fb : fa;
+    bf16* td = (a.nc & 1) ? fa : fb;
+    tile_in(c, a.xhat_b, DM, tx);                // (tx: last read one chunk earlier, behind the last chunk's barrier)
+    __syncthreads();                             // xhat_b visible; every wave is past its MFMAs on the last chunk (td)
+    epi_lnbwd<false>(c, acc2, cur, tx, td, a.rstd_b, a.gamma_b, off, red, a.ds_b, a.dgamma_b, a.dbeta_b, a.dbias_b);
+    fa = cur; fb = tx; cur = td;
+    __syncthreads();                             // the column pass has read fa / fb
+  }
+
+  if (TAIL) {
+    // O -> fa, Ores -> fb; dctx is staged in the ds tile once every wave is past its MFMAs on it
+    tile_in(c, a.O, a.ldo, fa);
+    if (a.Ores) tile_in(c, a.Ores, a.ldo, fb);
+    f32x16 acc[MT];
+    zero_acc(acc);
+    block_mma(c, cur, acc);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r;
+      float part = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int at = row * AS + c.wave * 32 + 8 * g + 4 * c.hi;
+        const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(fa + at);
+        bf16x4 r4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        if (a.Ores) r4 = *reinterpret_cast<const bf16x4*>(fb + at);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (bf16)acc[mt][4 * g + e];
+          part += (float)o[e] * ((float)o4[e] + (float)r4[e]);
+        }
+        *reinterpret_cast<bf16x4*>(cur + at) = o;
+      }
+      part += wave_xor32(part);
+      if (c.hi == 0) red[0][(c.wave * MT + mt) * 32 + c.r] = part;     // this wave's 32 columns of the row: half a head
+    }
+    __syncthreads();
+    tile_out(c, cur, a.dctx, a.lddc);
+    // delta[h][row]: heads are 64 columns = two waves
+    for (int i = c.tid; i < 4 * RB; i += 512) {
+      const int h = i / RB, row = i % RB, mt = row >> 5, r = row & 31;
+      if (row < c.nvalid)
+        a.delta[(size_t)h * a.M + c.row0 + row] = red[0][((2 * h) * MT + mt) * 32 + r] + red[0][((2 * h + 1) * MT + mt) * 32 + r];
+    }
+  }
+  if (MT == 1) {
+    int tsum = 0;
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+    if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;
+  }
+}
+
 // Block descriptor table of st_wfrag_build: 4 x int64 per 256 x 256 weight block
 //   [0] address of the block's first element (row n0, column k0 of a row-major bf16 matrix)
-//   [1] leading dimension of that matrix (elements)
+//   [1] leading dimension of that matrix (elements) | transposed << 32: the block is read as its TRANSPOSE (the data
+//       gradient's operand: output index = the weight's column, contraction over its rows)
 //   [2] destination: fragment index of the block inside a wave's stream (block position * 16)
 //   [3] destination: element offset of the chain's wave-0 stream in the output | (wave stride in fragments) << 40
 // piece (block, wave, ks, lane) = 8 consecutive k of weight row n0 + wave*32 + (lane & 31): the MFMA A operand of that lane.
 __global__ __launch_bounds__(256) void wfrag_build_kernel(const long long* __restrict__ table, bf16* __restrict__ out) {
   const long long* d = table + (size_t)blockIdx.x * 4;
   const bf16* src = reinterpret_cast<const bf16*>(d[0]);
-  const long long ld = d[1], frag0 = d[2], base = d[3] & ((1ll << 40) - 1), wstride = d[3] >> 40;
+  const long long ld = d[1] & 0xffffffffll, frag0 = d[2], base = d[3] & ((1ll << 40) - 1), wstride = d[3] >> 40;
+  const bool transposed = (d[1] >> 32) & 1;
   const int wave = blockIdx.y;
   bf16x8* dst = reinterpret_cast<bf16x8*>(out + base) + ((size_t)wave * wstride + frag0) * 64;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int id = p * 256 + threadIdx.x, ks = id >> 6, lane = id & 63;
-    dst[id] = *reinterpret_cast<const bf16x8*>(src + (size_t)(wave * 32 + (lane & 31)) * ld + ks * 16 + (lane >> 5) * 8);
+    const int o = wave * 32 + (lane & 31), c0 = ks * 16 + (lane >> 5) * 8;      // output index, first contraction index
+    if (!transposed) dst[id] = *reinterpret_cast<const bf16x8*>(src + (size_t)o * ld + c0);
+    else {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(c0 + j) * ld + o];      // (coalesced across the lanes' consecutive o)
+      dst[id] = v;
+    }
   }
 }
 
@@ -390,6 +665,58 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   else if (pre) ST_CHAIN(true, false, false);
   else ST_CHAIN(false, false, true);
 #undef ST_CHAIN
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks,
+                                int head_blocks, const void* dP, int ldp, const void* G, int ldg, const void* xhat_a,
+                                const float* rstd_a, const float* gamma_a, const unsigned* drop_seed, unsigned drop_salt,
+                                int drop_thresh, float drop_scale, void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a,
+                                const void* DS, int d_ff, const void* H, float mask_scale, void* dH, const void* xhat_b,
+                                const float* rstd_b, const float* gamma_b, void* ds_b, float* dgamma_b, float* dbeta_b,
+                                float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta) {
+  if (M <= 0) return 0;
+  const bool head = head_blocks > 0, ffn = d_ff > 0, tail = O != nullptr;
+  if (!wfrag || (!head && !ffn && !tail)) return -1;
+  if (head && (!dP || (ldp & 7) || ldp < 256 * head_blocks || (G && (ldg & 7)) || !xhat_a || !rstd_a || !gamma_a || !ds_a)) return -2;
+  if (!head && !DS) return -2;
+  if (ffn && ((d_ff & 255) || !H || !dH || !xhat_b || !rstd_b || !gamma_b || !ds_b)) return -3;
+  if (tail && ((ldo & 7) || !dctx || (lddc & 7) || !delta)) return -4;
+  if (n_blocks != head_blocks + (ffn ? 2 * (d_ff / 256) : 0) + (tail ? 1 : 0)) return -5;
+  ChainBwdArgs a;
+  a.M = M; a.wfrag = (const bf16x8*)wfrag; a.wave_frags = n_blocks * 16 + DEPTH;
+  a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
+  a.nb = head_blocks; a.dP = (const bf16*)dP; a.ldp = ldp; a.G = (const bf16*)G; a.ldg = ldg; a.xhat_a = (const bf16*)xhat_a;
+  a.rstd_a = rstd_a; a.gamma_a = gamma_a;
+  const bool drop = head && drop_seed != nullptr && drop_thresh > 0;
+  a.drop_a.seed = drop ? drop_seed : nullptr; a.drop_a.salt = drop_salt; a.drop_a.thresh = drop ? drop_thresh : 0;
+  a.drop_a.scale = drop ? drop_scale : 1.f;
+  a.ds_a = (bf16*)ds_a; a.dgamma_a = dgamma_a; a.dbeta_a = dbeta_a; a.dbias_a = dbias_a; a.DS = (const bf16*)DS;
+  a.nc = d_ff / 256; a.H = (const bf16*)H; a.mask_scale = mask_scale > 0.f ? mask_scale : 1.f; a.dH = (bf16*)dH;
+  a.xhat_b = (const bf16*)xhat_b; a.rstd_b = rstd_b; a.gamma_b = gamma_b; a.ds_b = (bf16*)ds_b; a.dgamma_b = dgamma_b;
+  a.dbeta_b = dbeta_b; a.dbias_b = dbias_b;
+  a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
+  const int mt = (M + 31) / 32 <= 256 ? 1 : 3;
+  const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
+#define ST_BWD(HEAD_, FFN_, TAIL_)                                                                                     \
+  do {                                                                                                                 \
+    if (mt == 3) {                                                                                                     \
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 3>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 3>), grid, blk, 0, stream, a);          \
+    } else {                                                                                                           \
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 1>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 1>), grid, blk, 0, stream, a);          \
+    }                                                                                                                  \
+  } while (0)
+  if (head && ffn && tail) ST_BWD(true, true, true);
+  else if (head && ffn) ST_BWD(true, true, false);
+  else if (head && tail) ST_BWD(true, false, true);
+  else if (ffn && tail) ST_BWD(false, true, true);
+  else if (ffn) ST_BWD(false, true, false);
+  else if (head) ST_BWD(true, false, false);
+  else ST_BWD(false, false, true);
+#undef ST_BWD
   ST_CHECK_LAUNCH();
   return 0;
 }

@@ -50,6 +50,19 @@ def blocks_of(w: torch.Tensor, order: str = "rows") -> List[Tuple[torch.Tensor, 
     raise ValueError(order)
 
 
+def t_blocks(blocks):
+    """The same blocks read transposed (the data gradient's operand)."""
+    return [(w, n0, k0, True) for w, n0, k0 in blocks]
+
+
+def ffn_blocks_bwd(w1: torch.Tensor, w2: torch.Tensor):
+    """The backward chain's order through the feed-forward weights, all transposed: (W2 columns c*256.., W1 rows c*256..)."""
+    out = []
+    for c in range(0, w1.shape[0], BLK):
+        out += [(w2, 0, c, True), (w1, c, 0, True)]
+    return out
+
+
 def ffn_blocks(w1: torch.Tensor, w2: torch.Tensor) -> List[Tuple[torch.Tensor, int, int]]:
     """W1 [d_ff, 256], W2 [256, d_ff] in the kernel's chunk order: (W1 rows c*256.., W2 columns c*256..) for c = 0.."""
     d_ff = w1.shape[0]
@@ -78,12 +91,14 @@ class ChainSet:
         n = len(blocks)
         wave_frags = n * 16 + self.depth
         base = self._elems
-        for i, (w, n0, k0) in enumerate(blocks):
+        for i, blk in enumerate(blocks):
+            w, n0, k0 = blk[:3]
+            tr = len(blk) > 3 and blk[3]
             if w.dtype != torch.bfloat16 or w.dim() != 2 or w.stride(1) != 1:
                 raise ValueError("ChainSet: weights must be row-major bf16 matrices")
             if n0 + BLK > w.shape[0] or k0 + BLK > w.shape[1] or (w.stride(0) % 8):
                 raise ValueError("ChainSet: block (%d, %d) outside weight %s" % (n0, k0, tuple(w.shape)))
-            self._rows.append([w.data_ptr() + 2 * (n0 * w.stride(0) + k0), w.stride(0), i * 16, base | (wave_frags << 40)])
+            self._rows.append([w.data_ptr() + 2 * (n0 * w.stride(0) + k0), w.stride(0) | (int(tr) << 32), i * 16, base | (wave_frags << 40)])
         self._chains.append((base, n, list(blocks)))     # (keeps the weight tensors alive: the table holds raw addresses)
         self._elems += 8 * wave_frags * 512
         return len(self._chains) - 1
@@ -106,11 +121,106 @@ class ChainSet:
 class SubPre:
     """What a sublayer's autograd Function (functional.MhaFn / FfnFn) takes INSTEAD of launching its forward kernels:
     the tensors those kernels would have produced, and the dropout sites that were used."""
-    __slots__ = ("qkv", "kvbuf", "ctx", "ores", "lse", "h", "out", "xhat", "rstd", "drop", "drop1", "drop2")
+    __slots__ = ("qkv", "kvbuf", "ctx", "ores", "lse", "h", "out", "xhat", "rstd", "drop", "drop1", "drop2", "bwd", "key")
 
     def __init__(self):
         for k in self.__slots__:
             setattr(self, k, None)
+
+
+class ChainBackward:
+    """One backward pass over a layer stack whose forward ran as row chains: the sublayers' autograd Functions
+    (functional.MhaFn / FfnFn) ask it for the pieces of their backward that lie between two attention-backward kernels,
+    and it runs those as ONE st_row_chain_bwd launch per gap:
+
+      * ``input_grad(key, dproj, ds)`` - called where an attention's backward would compute its input gradient
+        (dproj W + ds, pushed through the LayerNorm backward of the sublayer in front): launches the backward chain of
+        everything in front of it down to the previous attention (LayerNorm backward, feed-forward backward, the
+        previous attention's d(context) + delta) and returns the normalised gradient that flows on;
+      * ``stored(key)`` - what such a launch already produced for the sublayer ``key`` (its normalised output gradient
+        ds, the hidden gradient, d(context), delta ...), so that its Function only adds its weight gradients;
+      * ``ffn_tail(l, ds)`` - the same for the LAST feed-forward of the stack, whose output gradient arrives from outside.
+
+    Weight gradients stay with the Functions (they are deferred into the grouped launch)."""
+
+    def __init__(self, owner, layers, pres):
+        self.owner, self.layers, self.pres = owner, layers, pres
+        self.done = {}
+
+    def stored(self, key):
+        return self.done.pop(key, None)
+
+    def _empty(self, like, cols=None, dt=BF16, rows=None):
+        return torch.empty(like.shape[0] if rows is None else rows, *(() if cols is None else (cols,)), dtype=dt, device=like.device)
+
+    def _ffn_tail_chain(self, chain, l, ds_f, head, attn_key, attn_pre, attn_mod):
+        """[HEAD +] feed-forward backward of layer l + d(context) / delta of the attention in front of it."""
+        f = self.pres[l][-1]
+        ff = self.layers[l].pos_ffn
+        fs, as_ = ff._st, attn_mod._st
+        arena = ff._st_arena
+        arena.attach_grads(fs.params, fs.lo, fs.hi)
+        arena.attach_grads(as_.params, as_.lo, as_.hi)
+        M = f.out.shape[0]
+        dH, ds_b, dctx = self._empty(f.out, fs.d_ff), self._empty(f.out, BLK), self._empty(f.out, BLK)
+        delta = torch.empty(as_.n_head * M, dtype=F32, device=f.out.device)
+        scale = f.drop1.scale if f.drop1 is not None and f.drop1.thresh else 1.0
+        nv.row_chain_bwd(chain, M, head=head, ds_in=None if head else ds_f,
+                         ffn=(fs.d_ff, f.h, scale, dH, attn_pre.xhat, attn_pre.rstd, as_.gamma, ds_b, as_.g_gamma, as_.g_beta,
+                              as_.g_b_o),
+                         tail=(attn_pre.ctx, attn_pre.ores, dctx, delta))
+        self.done[("ffn", l)] = dict(ds=ds_f, dh=dH, dx=ds_b)
+        self.done[(attn_key, l)] = dict(ds=ds_b, dctx=dctx, delta=delta)
+
+    def _ffn_head(self, l, dqkv, ds_s):
+        f = self.pres[l][-1]
+        fs = self.layers[l].pos_ffn._st
+        ds_f = self._empty(f.out, BLK)
+        return ds_f, (3, dqkv, ds_s, f.xhat, f.rstd, fs.gamma, f.drop2, ds_f, fs.g_gamma, fs.g_beta, fs.g_b2)
+
+
+class EncoderBackward(ChainBackward):
+    def input_grad(self, key, dproj, ds):
+        kind, l = key
+        if kind != "self" or l == 0:
+            return None
+        ds_f, head = self._ffn_head(l - 1, dproj, ds)
+        self._ffn_tail_chain(self.owner.bwd[l - 1], l - 1, ds_f, head, "self", self.pres[l - 1][0], self.layers[l - 1].slf_attn)
+        return ds_f
+
+    def ffn_tail(self, l, ds):
+        self._ffn_tail_chain(self.owner.bwd[l], l, ds, None, "self", self.pres[l][0], self.layers[l].slf_attn)
+        return self.stored(("ffn", l))
+
+
+class DecoderBackward(ChainBackward):
+    def input_grad(self, key, dproj, ds):
+        kind, l = key
+        if kind == "self":
+            if l == 0:
+                return None
+            ds_f, head = self._ffn_head(l - 1, dproj, ds)
+            self._ffn_tail_chain(self.owner.bwd2[l - 1], l - 1, ds_f, head, "cross", self.pres[l - 1][1],
+                                 self.layers[l - 1].enc_attn)
+            return ds_f
+        # after the encoder-decoder attention's backward kernel: LayerNorm backward of the self-attention sublayer and its
+        # d(context) / delta
+        a = self.pres[l][0]
+        sa = self.layers[l].slf_attn._st
+        arena = self.layers[l].slf_attn._st_arena
+        arena.attach_grads(sa.params, sa.lo, sa.hi)
+        M = a.out.shape[0]
+        ds_s, dctx = self._empty(a.out, BLK), self._empty(a.out, BLK)
+        delta = torch.empty(sa.n_head * M, dtype=F32, device=a.out.device)
+        nv.row_chain_bwd(self.owner.bwd1[l], M,
+                         head=(1, dproj, ds, a.xhat, a.rstd, sa.gamma, None, ds_s, sa.g_gamma, sa.g_beta, sa.g_b_o),
+                         tail=(a.ctx, a.ores, dctx, delta))
+        self.done[("self", l)] = dict(ds=ds_s, dctx=dctx, delta=delta)
+        return ds_s
+
+    def ffn_tail(self, l, ds):
+        self._ffn_tail_chain(self.owner.bwd2[l], l, ds, None, "cross", self.pres[l][1], self.layers[l].enc_attn)
+        return self.stored(("ffn", l))
 
 
 class EncoderChains:
@@ -130,6 +240,17 @@ class EncoderChains:
             ids.append(self.set.add(blocks_of(sa.w_o) + ffn_blocks(ff.w1, ff.w2) + nxt))
         self.set.finalize()
         self.e = [self.set.chain(c, True) for c in ids]
+        # backward chains, stored in running order (last layer first): [next layer's q|k|v projection] + feed-forward +
+        # output_linear, all read transposed
+        self.bset = ChainSet(arena.device)
+        ids = {}
+        for l in range(n - 1, -1, -1):
+            sa, ff = layers[l].slf_attn._st, layers[l].pos_ffn._st
+            head = t_blocks(blocks_of(layers[l + 1].slf_attn._st.w_qkv)) if l + 1 < n else []
+            ids[l] = self.bset.add(head + ffn_blocks_bwd(ff.w1, ff.w2) + t_blocks(blocks_of(sa.w_o)))
+        self.bset.finalize()
+        self.bwd = [self.bset.chain(ids[l], True) for l in range(n)]
+        self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
 
     @staticmethod
     def plan(layers, arena):
@@ -145,6 +266,7 @@ class EncoderChains:
 
     def refresh(self) -> None:
         self.set.rebuild()
+        self.bset.rebuild()
 
     def forward(self, layers, x, rows, need_bwd: bool):
         """The encoder's layer stack on frame rows x [M, 256] (front-end output): per layer self-attention, then the chain.
@@ -183,6 +305,11 @@ class EncoderChains:
                          post=(3, nxt.b_qkv, qkv) if nxt is not None else None)
             x = f.out
             pres.append((a, f))
+        if need_bwd and self.use_bwd:
+            cb = EncoderBackward(self, list(layers), pres)
+            for l, (a, f) in enumerate(pres):
+                a.bwd = f.bwd = cb
+                a.key, f.key = ("self", l), ("ffn", l)
         return x, pres
 
 
@@ -203,6 +330,19 @@ class DecoderChains:
         self.set.finalize()
         self.f1 = [self.set.chain(c, True) for c in f1]      # stored in running order: F1(0), F2(0), F1(1), ...
         self.f2 = [self.set.chain(c, True) for c in f2]
+        # backward chains in running order (last layer first): B2(l) = [q|k|v projection of layer l + 1] + feed-forward +
+        # the encoder-decoder attention's output_linear; B1(l) = its q projection + the self-attention's output_linear
+        self.bset = ChainSet(arena.device)
+        b1, b2 = {}, {}
+        for l in range(n - 1, -1, -1):
+            sa, ca, ff = layers[l].slf_attn._st, layers[l].enc_attn._st, layers[l].pos_ffn._st
+            head = t_blocks(blocks_of(layers[l + 1].slf_attn._st.w_qkv)) if l + 1 < n else []
+            b2[l] = self.bset.add(head + ffn_blocks_bwd(ff.w1, ff.w2) + t_blocks(blocks_of(ca.w_o)))
+            b1[l] = self.bset.add(t_blocks(blocks_of(ca.w_q)) + t_blocks(blocks_of(sa.w_o)))
+        self.bset.finalize()
+        self.bwd2 = [self.bset.chain(b2[l], True) for l in range(n)]
+        self.bwd1 = [self.bset.chain(b1[l], True) for l in range(n)]
+        self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
 
     @staticmethod
     def plan(layers, arena):
@@ -218,6 +358,7 @@ class DecoderChains:
 
     def refresh(self) -> None:
         self.set.rebuild()
+        self.bset.rebuild()
 
     def forward(self, layers, x, kv, t_rows, in_rows, need_bwd: bool):
         """The decoder's layer stack on target rows x [M, 256] (embedding + positional encoding), kv = CrossKv's buffer
@@ -272,4 +413,9 @@ class DecoderChains:
                          post=(3, nxt.b_qkv, qkv) if nxt is not None else None)
             x = f.out
             pres.append((a, b, f))
+        if need_bwd and self.use_bwd:
+            cb = DecoderBackward(self, list(layers), pres)
+            for l, (a, b, f) in enumerate(pres):
+                a.bwd = b.bwd = f.bwd = cb
+                a.key, b.key, f.key = ("self", l), ("cross", l), ("ffn", l)
         return x, pres

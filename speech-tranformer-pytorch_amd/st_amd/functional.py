@@ -384,6 +384,7 @@ class MhaFn(torch.autograd.Function):
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
         ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers share one encoder-gradient buffer (or CrossKv's)
         ctx.up, ctx.down = up, down
+        ctx.chain = (pre.bwd, pre.key) if pre is not None and pre.bwd is not None else None   # chains.ChainBackward
         if down is not None:
             down.offer(mod, xhat, rstd, s.g_b_o)
         return out
@@ -431,16 +432,26 @@ class MhaFn(torch.autograd.Function):
         Mq = x_q.shape[0]
         dout = dout.contiguous()
         arena.attach_grads(s.params, s.lo, s.hi)
-        ds = ctx.down.claim(dout) if ctx.down is not None else None
-        if ds is None:
-            ds = _empty(Mq, d, x_q)
-            nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b_o)
+        # row-chain stacks: a backward chain launched by the sublayer behind this one already produced this sublayer's
+        # LayerNorm backward, d(context) and delta (chains.ChainBackward)
+        got = ctx.chain[0].stored(ctx.chain[1]) if ctx.chain is not None else None
+        if got is not None:
+            ds, dctx, delta = got["ds"], got["dctx"], got["delta"]
+            if dout.data_ptr() != ds.data_ptr():
+                raise RuntimeError("MhaFn.backward: the gradient reaching this sublayer is not the one its backward chain "
+                                   "produced (its output has more than one consumer?)")
+        else:
+            ds = ctx.down.claim(dout) if ctx.down is not None else None
+            if ds is None:
+                ds = _empty(Mq, d, x_q)
+                nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b_o)
         wgrad(ds, attn_ctx, s.g_w_o)
-        dctx = _empty(Mq, d, x_q)
-        delta = torch.empty(H * Mq, dtype=F32, device=x_q.device)
-        # d(context) and, in the same launch, delta = rowsum(d(context) * context) per head: the two attention
-        # backward kernels then depend on nothing but finished buffers and run as ONE launch
-        nv.gemm(ds, s.w_o, dctx, epi=nv.EPI_BF16_DELTA, aux=attn_ctx, y_cmajor=True, delta=delta, head_dim=d // H, aux2=ores)
+        if got is None:
+            dctx = _empty(Mq, d, x_q)
+            delta = torch.empty(H * Mq, dtype=F32, device=x_q.device)
+            # d(context) and, in the same launch, delta = rowsum(d(context) * context) per head: the two attention
+            # backward kernels then depend on nothing but finished buffers and run as ONE launch
+            nv.gemm(ds, s.w_o, dctx, epi=nv.EPI_BF16_DELTA, aux=attn_ctx, y_cmajor=True, delta=delta, head_dim=d // H, aux2=ores)
         if x_kv is None:
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             # key rows past k_len (padded layout only) get no gradient: they must read as zeros
@@ -463,12 +474,16 @@ class MhaFn(torch.autograd.Function):
         nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
                     q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop)
         dx_kv = None
+        # row-chain stacks: everything down to the previous attention's backward kernel is one launch
+        dx_q = ctx.chain[0].input_grad(ctx.chain[1], dqkv, ds) if ctx.chain is not None and ctx.needs_input_grad[0] else None
         if x_kv is None:
             wgrad(dqkv, x_q, s.g_w_qkv, gB=s.g_b_qkv)
-            dx_q = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dqkv, s.w_qkv, ds)
+            if dx_q is None:
+                dx_q = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dqkv, s.w_qkv, ds)
         else:
             wgrad(dqkv, x_q, s.g_w_q, gB=s.g_b_q)
-            dx_q = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dqkv, s.w_q, ds)
+            if dx_q is None:
+                dx_q = _input_grad(ctx.up if ctx.needs_input_grad[0] else None, dqkv, s.w_q, ds)
             acc = ctx.kv_acc
             if slot is not None:
                 # weight and input gradients of all layers' K/V projections: CrossKvFn.backward, from the whole dkv
@@ -517,6 +532,7 @@ class FfnFn(torch.autograd.Function):
         ctx.save_for_backward(x, h, xhat, rstd)
         ctx.mod, ctx.drop1, ctx.drop2 = mod, drop1, drop2
         ctx.up, ctx.down = up, down
+        ctx.chain = (pre.bwd, pre.key) if pre is not None and pre.bwd is not None else None   # chains.ChainBackward
         if down is not None:
             down.offer(mod, xhat, rstd, s.g_b2, drop2)
         return out
@@ -529,10 +545,21 @@ class FfnFn(torch.autograd.Function):
         M, d = x.shape
         dout = dout.contiguous()
         arena.attach_grads(s.params, s.lo, s.hi)
-        ds = ctx.down.claim(dout) if ctx.down is not None else None
+        got = ctx.chain[0].stored(ctx.chain[1]) if ctx.chain is not None else None
+        if got is not None and dout.data_ptr() != got["ds"].data_ptr():
+            raise RuntimeError("FfnFn.backward: the gradient reaching this sublayer is not the one its backward chain "
+                               "produced (its output has more than one consumer?)")
+        ds = got["ds"] if got is not None else (ctx.down.claim(dout) if ctx.down is not None else None)
         if ds is None:
             ds = _empty(M, d, x)
             nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b2, drop=ctx.drop2)
+        if got is None and ctx.chain is not None and ctx.needs_input_grad[0]:
+            got = ctx.chain[0].ffn_tail(ctx.chain[1][1], ds)      # the last feed-forward of a row-chain stack
+        if got is not None:
+            wgrad(ds, h, s.g_w2)
+            wgrad(got["dh"], x, s.g_w1, gB=s.g_b1)
+            arena.grads_ready(s.lo, s.hi)
+            return got["dx"], None, None, None, None, None, None, None
         wgrad(ds, h, s.g_w2)
         dh = _empty(M, s.d_ff, x)
         dgrad(ds, s.w2, dh, epi=nv.EPI_BF16_MASK, aux=h, drop=ctx.drop1)   # h is the dropped activation: 0 where dropped

@@ -46,6 +46,10 @@ SIGNATURES = {
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float, _c_int,
                      _c_void_p, _c_void_p, _c_int],
+    "st_row_chain_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                         _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                         _c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p],
     "st_gemm_lnbwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                       _c_void_p, _c_uint, _c_int, _c_float],
@@ -420,6 +424,49 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
                              int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
                              s1[1], s1[2], s1[3], s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0))
     _check(rc, "st_row_chain")
+
+
+def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
+    """One launch for the backward of a row chain (csrc/st_rowchain.hip; ``chain`` holds the TRANSPOSED weight blocks in
+    the order HEAD | FFN | TAIL).
+    head = (n_blocks, dP, G, xhat, rstd, gamma, drop, ds_out, dgamma, dbeta, dbias):
+           dy = dP Wp + G;  ds_out = LayerNorm-backward(dropout-backward(dy)); column sums accumulated atomically
+    ds_in: without head, the running gradient [M, 256] the chain starts from
+    ffn  = (d_ff, H, mask_scale, dH, xhat, rstd, gamma, ds_out, dgamma, dbeta, dbias):
+           dH = (ds W2) masked by H > 0, scaled;  ds_out = LayerNorm-backward(dH W1 + ds)
+    tail = (O, Ores, dctx, delta): dctx = ds Wo, delta[h][i] = sum over head h (64 columns) of dctx (O + Ores)"""
+    z = (None,) * 11
+    nb, dP, G, xa, ra, ga, drop, dsa, dga, dba, dbia = head if head else (0,) + z[:10]
+    d_ff, H, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn if ffn else (0, None, 1.0) + z[:8]
+    O, Ores, dctx, delta = tail if tail else z[:4]
+    n_blocks = nb + (2 * (d_ff // 256) if ffn else 0) + (1 if tail else 0)
+    if n_blocks != chain.n_blocks or chain.stream.numel() != 8 * (n_blocks * 16 + wfrag_depth()) * 512:
+        raise ValueError("row_chain_bwd: the fragment stream does not match the chain")
+    for t, cols, name in ((dP, 256 * nb, "dP"), (G, 256, "G"), (xa, 256, "xhat_a"), (dsa, 256, "ds_a"), (ds_in, 256, "ds_in"),
+                          (H, d_ff, "H"), (dH, d_ff, "dH"), (xb, 256, "xhat_b"), (dsb, 256, "ds_b"), (O, 256, "O"),
+                          (Ores, 256, "Ores"), (dctx, 256, "dctx")):
+        if t is not None:
+            _mat(t, BF16, name)
+            if t.shape[0] < M or t.shape[1] != cols:
+                raise ValueError("row_chain_bwd: %s has shape %s, expected [>= %d, %d]" % (name, tuple(t.shape), M, cols))
+    for t, name in ((xa, "xhat_a"), (dsa, "ds_a"), (ds_in, "ds_in"), (xb, "xhat_b"), (dsb, "ds_b")):
+        assert t is None or t.stride(0) == 256, name
+    assert (H is None or H.stride(0) == d_ff) and (dH is None or dH.stride(0) == d_ff)
+    assert O is None or Ores is None or Ores.stride(0) == O.stride(0)
+    for v, n, name in ((ra, M, "rstd_a"), (ga, 256, "gamma_a"), (dga, 256, "dgamma_a"), (dba, 256, "dbeta_a"), (dbia, 256, "dbias_a"),
+                       (rb, M, "rstd_b"), (gb, 256, "gamma_b"), (dgb, 256, "dgamma_b"), (dbb, 256, "dbeta_b"), (dbib, 256, "dbias_b"),
+                       (delta, 4 * M, "delta")):
+        _vec(v, F32, n, name)
+    if head is None and ds_in is None:
+        raise ValueError("row_chain_bwd: without head the chain needs ds_in")
+    sd = _drop(drop)
+    _tag("row_chain_bwd", M, n_blocks, d_ff)
+    rc = load().st_row_chain_bwd(
+        _stream(), M, chain.stream.data_ptr(), n_blocks, int(chain.next_blocks), int(nb), _p(dP), 0 if dP is None else dP.stride(0),
+        _p(G), 0 if G is None else G.stride(0), _p(xa), _p(ra), _p(ga), sd[0], sd[1], sd[2], sd[3], _p(dsa), _p(dga), _p(dba),
+        _p(dbia), _p(ds_in), int(d_ff), _p(H), float(msc), _p(dH), _p(xb), _p(rb), _p(gb), _p(dsb), _p(dgb), _p(dbb), _p(dbib),
+        _p(O), _p(Ores), 0 if O is None else O.stride(0), _p(dctx), 0 if dctx is None else dctx.stride(0), _p(delta))
+    _check(rc, "st_row_chain_bwd")
 
 
 def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, drop=None):

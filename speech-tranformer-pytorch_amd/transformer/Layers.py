@@ -8,9 +8,10 @@ from transformer.Attention import MultiHeadAttention
 from transformer.SubLayers import PositionwiseFeedForward
 
 
-def _links(n):
-    """LnLinks only when a backward pass will follow."""
-    on = torch.is_grad_enabled()
+def _links(n, pre=None):
+    """LnLinks only when a backward pass will follow - and not when the stack's backward runs as row chains
+    (st_amd.chains.ChainBackward does the LayerNorm-backward hand-over itself)."""
+    on = torch.is_grad_enabled() and not (pre is not None and pre[0].bwd is not None)
     return [LnLink() if on else None for _ in range(n)]
 
 
@@ -28,7 +29,7 @@ class EncoderLayer(nn.Module):
         sublayer consumes the intermediate tensors, which holds inside the stacks.
         pre: this layer's (self-attention, feed-forward) st_amd.chains.SubPre when the forward values come from the
         fused launches (st_amd.chains.EncoderChains.forward)."""
-        l1, l2 = _links(2)
+        l1, l2 = _links(2, pre)
         pa, pf = pre if pre is not None else (None, None)
         a = self.slf_attn.forward_rows(x, None, rows, rows, False, up=up, down=l1, pre=pa)
         return self.pos_ffn.forward_rows(a, up=l1, down=l2, pre=pf), l2
@@ -51,7 +52,7 @@ class DecoderLayer(nn.Module):
         """-> (output rows, LnLink for the next layer); see EncoderLayer.forward_rows.
         pre: this layer's (self-attention, encoder-decoder attention, feed-forward) st_amd.chains.SubPre when the
         forward values come from the fused decoder launches (st_amd.chains.DecoderChains.forward)."""
-        l1, l2, l3 = _links(3)
+        l1, l2, l3 = _links(3, pre)
         pa, pb, pf = pre if pre is not None else (None, None, None)
         s = self.slf_attn.forward_rows(y, None, t_rows, t_rows, True, up=up, down=l1, pre=pa)
         c = self.enc_attn.forward_rows(s, enc, t_rows, in_rows, False, kv_acc=kv_acc, up=l1, down=l2, pre=pb)

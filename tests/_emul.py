@@ -194,6 +194,43 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
     assert not blocks
 
 
+def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
+    """csrc/st_rowchain.hip's backward chain as a composition of the emulated kernels it replaces."""
+    blocks = list(chain.blocks)
+
+    def take(n):
+        out = [w[n0:n0 + 256, k0:k0 + 256] for w, n0, k0, tr in blocks[:n]]
+        assert all(b[3] for b in blocks[:n]), "backward chains read transposed blocks"
+        del blocks[:n]
+        return out
+
+    ds = ds_in[:M] if ds_in is not None else None
+    if head:
+        nb, dP, G, xa, ra, ga, drop, dsa, dga, dba, dbia = head
+        wp = torch.cat(take(nb), 0)                          # [256 nb (contraction), 256]
+        gemm_lnbwd(dP[:M], wp, None if G is None else G[:M], xa, ra[:M], ga, dsa[:M], dga, dba, dbia, drop=drop)
+        ds = dsa[:M]
+    if ffn:
+        d_ff, H, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn
+        ws = take(2 * (d_ff // 256))
+        w2 = torch.cat(ws[0::2], 1)                          # [256 (contraction), d_ff]
+        w1 = torch.cat(ws[1::2], 0)                          # [d_ff (contraction), 256]
+        acc = ds.float() @ w2.float()
+        dH[:M] = ((acc * msc).to(BF16).float() * (H[:M].float() > 0)).to(BF16)
+        gemm_lnbwd(dH[:M], w1, ds, xb, rb[:M], gb, dsb[:M], dgb, dbb, dbib)
+        ds = dsb[:M]
+    if tail:
+        O, Ores, dctx, delta = tail
+        (wo,) = take(1)
+        dl = torch.zeros(4 * M, dtype=torch.float32)
+        out = torch.zeros(M, 256, dtype=BF16)
+        gemm(ds, wo, out, epi=nv.EPI_BF16_DELTA, aux=O[:M], aux2=None if Ores is None else Ores[:M], y_cmajor=True, delta=dl,
+             head_dim=64)
+        dctx[:M] = out
+        delta.view(4, -1)[:, :M] = dl.view(4, M)
+    assert not blocks
+
+
 def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, drop=None):
     dy = torch.zeros(dY.shape[0], W.shape[1], dtype=BF16)
     gemm(dY, W, dy, aux=aux, epi=nv.EPI_BF16_ADD if aux is not None else nv.EPI_BF16, y_cmajor=True)
@@ -368,7 +405,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd"]
 
 
 @contextlib.contextmanager

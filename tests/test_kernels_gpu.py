@@ -698,3 +698,61 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
         # and against the kernels the backward pairs with: st_gemm (ReLU + dropout) / st_gemm_ln (drop_where = 2)
         h = nv.gemm(got["out0"], cu(w1), torch.zeros(M, dff, dtype=BF16, device="cuda"), bias=cu(b1), epi=nv.EPI_BF16_RELU, drop=dn1)
         _zero_pattern_equal(got["H"], h, "row_chain dropout1 vs st_gemm")
+
+
+@pytest.mark.parametrize("M", [5, 320, 1206, 9000])
+@pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail"])
+def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
+    """One st_row_chain_bwd launch == st_gemm_lnbwd, st_gemm (mask epilogue), st_gemm_lnbwd and st_gemm (delta epilogue) as
+    separate kernels (the emulation composes their emulations): every gradient tensor, the atomically accumulated
+    LayerNorm / bias gradients, delta; ragged last row block; both row-tile geometries (M = 9000: 96-row workgroups)."""
+    from st_amd import chains
+    d, dff = 256, 1024
+    parts = variant.split("+")
+    nb = 3 if "head3" in parts else 1 if "head1" in parts else 0
+    has_ffn, has_tail, drop = "ffn" in parts, "tail" in parts, "drop" in parts
+    wp, w1, w2, wo = g(256 * max(nb, 1), d, seed=1, scale=d ** -0.5), g(dff, d, seed=2, scale=d ** -0.5), \
+        g(d, dff, seed=3, scale=dff ** -0.5), g(d, d, seed=4, scale=d ** -0.5)
+    dP, G, DS = g(M, 256 * max(nb, 1), seed=5, scale=0.3), g(M, d, seed=6, scale=0.3), g(M, d, seed=7, scale=0.3)
+    xa, xb = g(M, d, seed=8), g(M, d, seed=9)
+    ra, rb = g(M, seed=10, dtype=F32).abs() + 0.5, g(M, seed=11, dtype=F32).abs() + 0.5
+    ga, gb = g(d, seed=12, dtype=F32) * 0.2 + 1, g(d, seed=13, dtype=F32) * 0.2 + 1
+    H = torch.relu(g(M, dff, seed=14))
+    O, Ores = g(M, d, seed=15), g(M, d, seed=16, scale=2.0 ** -9)
+    dn, de = _drops(31, 0.1) if drop else (None, None)
+
+    def blocks(f):
+        b = []
+        if nb:
+            b += chains.t_blocks(chains.blocks_of(f(wp)))
+        if has_ffn:
+            b += chains.ffn_blocks_bwd(f(w1), f(w2))
+        if has_tail:
+            b += chains.t_blocks(chains.blocks_of(f(wo)))
+        return b
+
+    def run(dev, fn, dr):
+        f = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t)
+        Z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+        o = dict(ds_a=Z(M, d), dga=Z(d, dt=F32) + 1, dba=Z(d, dt=F32) + 2, dbia=Z(d, dt=F32) + 3, dH=Z(M, dff), ds_b=Z(M, d),
+                 dgb=Z(d, dt=F32) - 1, dbb=Z(d, dt=F32) - 2, dbib=Z(d, dt=F32) - 3, dctx=Z(M, d), delta=Z(4 * M, dt=F32))
+        if dev == "cuda":
+            cs = chains.ChainSet("cuda")
+            cid = cs.add(blocks(f))
+            cs.finalize().rebuild()
+            ch = cs.chain(cid)
+        else:
+            ch = chains.Chain(None, len(blocks(f)), blocks(f))
+        fn(ch, M,
+           head=(nb, f(dP), f(G), f(xa), f(ra), f(ga), dr, o["ds_a"], o["dga"], o["dba"], o["dbia"]) if nb else None,
+           ds_in=None if nb else f(DS),
+           ffn=(dff, f(H), 1.0 / 0.9 if drop else 1.0, o["dH"], f(xb), f(rb), f(gb), o["ds_b"], o["dgb"], o["dbb"], o["dbib"]) if has_ffn else None,
+           tail=(f(O), f(Ores), o["dctx"], o["delta"]) if has_tail else None)
+        return o
+
+    got, ref = run("cuda", nv.row_chain_bwd, dn), run("cpu", em.row_chain_bwd, de)
+    names = (["ds_a", "dga", "dba", "dbia"] if nb else []) + (["dH", "ds_b", "dgb", "dbb", "dbib"] if has_ffn else []) + \
+        (["dctx", "delta"] if has_tail else [])
+    for n in names:
+        tol = 1e-2 if got[n].dtype == BF16 else 5e-3
+        check(got[n], ref[n], tol, "row_chain_bwd %s M=%d: %s" % (variant, M, n))

@@ -301,7 +301,7 @@ def test_fused_backward_paths_match_unfused_paths_full_size():
         saved = (F_.CrossKv.plan, L._links)
         if not fused:
             F_.CrossKv.plan = staticmethod(lambda mods: None)
-            L._links = lambda n: [None] * n
+            L._links = lambda n, pre=None: [None] * n
         try:
             logits, t_rows = model.forward_packed(xs, in_len, ts, tgt_len)
             truth = gs.contiguous().view(-1).index_select(0, t_rows.scatter_index(gs.shape[1]))
