@@ -141,14 +141,15 @@ int st_gemm_lnbwd(st_stream_t stream, const void* dY, int lddy, const void* W, i
  * d_model = 256, d_ff % 256 == 0.  The weights are read from per-wave fragment streams: every GEMM is cut into
  * 256 x 256 blocks, consumed in the order  Wo | (W1 rows c*256.., W2 columns c*256..) for c = 0.. | Wp rows u*256..;
  * n_blocks = their number.  st_wfrag_build lays the blocks out (table: 4 x int64 per block on the device - address of
- * the block's first element in a row-major bf16 matrix, its leading dimension, 16 * (position of the block in its
- * chain), element offset of the chain in `out` | wave stride (n_blocks * 16 + st_wfrag_depth()) << 40); a chain's
- * buffer holds 8 * (n_blocks * 16 + st_wfrag_depth()) * 512 bf16.  Rebuild after every weight update.
+ * the block's first element in a row-major bf16 matrix, its leading dimension (| 1 << 32: read the block transposed),
+ * 16 * (position of the block in its chain) | wave stride (n_blocks * 16 + st_wfrag_depth()) << 32, address of the
+ * chain's buffer); a chain's buffer holds 8 * (n_blocks * 16 + st_wfrag_depth()) * 512 bf16.  One table may fill any
+ * number of chains.  Rebuild after every weight update.
  * next_blocks > 0: another chain of that many blocks is stored right behind this one and runs next - the launch warms the
  * L2 with its streams too (the streams are read once per step, from HBM).
  * Both dropout sites read the device seed *drop_seed (NULL = off) with their own salt / threshold / scale. */
 int st_wfrag_depth(void);
-int st_wfrag_build(st_stream_t stream, const long long* table, int n_blocks, void* out);
+int st_wfrag_build(st_stream_t stream, const long long* table, int n_blocks);
 int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A,
                  int lda,
                  const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,

@@ -601,16 +601,17 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
 //   [0] address of the block's first element (row n0, column k0 of a row-major bf16 matrix)
 //   [1] leading dimension of that matrix (elements) | transposed << 32: the block is read as its TRANSPOSE (the data
 //       gradient's operand: output index = the weight's column, contraction over its rows)
-//   [2] destination: fragment index of the block inside a wave's stream (block position * 16)
-//   [3] destination: element offset of the chain's wave-0 stream in the output | (wave stride in fragments) << 40
+//   [2] destination: fragment index of the block inside a wave's stream (block position * 16) | (wave stride in
+//       fragments) << 32
+//   [3] destination: ADDRESS of the chain's wave-0 stream (so one table - one launch - can fill several buffers)
 // piece (block, wave, ks, lane) = 8 consecutive k of weight row n0 + wave*32 + (lane & 31): the MFMA A operand of that lane.
-__global__ __launch_bounds__(256) void wfrag_build_kernel(const long long* __restrict__ table, bf16* __restrict__ out) {
+__global__ __launch_bounds__(256) void wfrag_build_kernel(const long long* __restrict__ table) {
   const long long* d = table + (size_t)blockIdx.x * 4;
   const bf16* src = reinterpret_cast<const bf16*>(d[0]);
-  const long long ld = d[1] & 0xffffffffll, frag0 = d[2], base = d[3] & ((1ll << 40) - 1), wstride = d[3] >> 40;
+  const long long ld = d[1] & 0xffffffffll, frag0 = d[2] & 0xffffffffll, wstride = d[2] >> 32;
   const bool transposed = (d[1] >> 32) & 1;
   const int wave = blockIdx.y;
-  bf16x8* dst = reinterpret_cast<bf16x8*>(out + base) + ((size_t)wave * wstride + frag0) * 64;
+  bf16x8* dst = reinterpret_cast<bf16x8*>(d[3]) + ((size_t)wave * wstride + frag0) * 64;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int id = p * 256 + threadIdx.x, ks = id >> 6, lane = id & 63;
@@ -629,10 +630,10 @@ __global__ __launch_bounds__(256) void wfrag_build_kernel(const long long* __res
 
 extern "C" int st_wfrag_depth(void) { return DEPTH; }
 
-extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_blocks, void* out) {
+extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_blocks) {
   if (n_blocks <= 0) return 0;
-  if (!table || !out) return -1;
-  hipLaunchKernelGGL(wfrag_build_kernel, dim3(n_blocks, NW), dim3(256), 0, stream, table, (bf16*)out);
+  if (!table) return -1;
+  hipLaunchKernelGGL(wfrag_build_kernel, dim3(n_blocks, NW), dim3(256), 0, stream, table);
   ST_CHECK_LAUNCH();
   return 0;
 }

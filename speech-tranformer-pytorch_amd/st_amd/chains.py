@@ -98,24 +98,55 @@ class ChainSet:
                 raise ValueError("ChainSet: weights must be row-major bf16 matrices")
             if n0 + BLK > w.shape[0] or k0 + BLK > w.shape[1] or (w.stride(0) % 8):
                 raise ValueError("ChainSet: block (%d, %d) outside weight %s" % (n0, k0, tuple(w.shape)))
-            self._rows.append([w.data_ptr() + 2 * (n0 * w.stride(0) + k0), w.stride(0) | (int(tr) << 32), i * 16, base | (wave_frags << 40)])
+            self._rows.append([w.data_ptr() + 2 * (n0 * w.stride(0) + k0), w.stride(0) | (int(tr) << 32), (i * 16) | (wave_frags << 32),
+                               2 * base])      # [3]: byte offset of the chain for now; finalize() adds the buffer's address
         self._chains.append((base, n, list(blocks)))     # (keeps the weight tensors alive: the table holds raw addresses)
         self._elems += 8 * wave_frags * 512
         return len(self._chains) - 1
 
     def finalize(self) -> "ChainSet":
-        self.table = torch.tensor(self._rows, dtype=torch.int64).to(self.device)
         self.buf = torch.zeros(self._elems, dtype=torch.bfloat16, device=self.device)
+        rows = torch.tensor(self._rows, dtype=torch.int64)
+        rows[:, 3] += self.buf.data_ptr()
+        self.table = rows.to(self.device)
         return self
 
     def rebuild(self) -> None:
-        nv.wfrag_build(self.table, self.buf)
+        nv.wfrag_build(self.table)
+
 
     def chain(self, cid: int, runs_before_next: bool = False) -> Chain:
         """runs_before_next: chain cid + 1 (stored right behind) is the next chain to run after this one."""
         base, n, blocks = self._chains[cid]
         nxt = self._chains[cid + 1][1] if runs_before_next and cid + 1 < len(self._chains) else 0
         return Chain(self.buf[base:base + 8 * (n * 16 + self.depth) * 512], n, blocks, nxt)
+
+
+class ChainHub:
+    """All ChainSets of one parameter arena, rebuilt with ONE launch after every ``arena.refresh()`` (the tables hold
+    absolute addresses, so they concatenate)."""
+
+    def __init__(self):
+        self.sets: List[ChainSet] = []
+        self.table = None
+
+    @staticmethod
+    def of(arena) -> "ChainHub":
+        for d in arena._derived:
+            if isinstance(d, ChainHub):
+                return d
+        hub = ChainHub()
+        arena._derived.append(hub)
+        return hub
+
+    def add(self, *sets: ChainSet) -> None:
+        self.sets += list(sets)
+        self.table = torch.cat([s.table for s in self.sets], 0).contiguous()
+        nv.wfrag_build(torch.cat([s.table for s in sets], 0).contiguous())      # the new ones, from the current shadow
+
+    def refresh(self) -> None:
+        if self.table is not None:
+            nv.wfrag_build(self.table)
 
 
 class SubPre:
@@ -251,6 +282,7 @@ class EncoderChains:
         self.bset.finalize()
         self.bwd = [self.bset.chain(ids[l], True) for l in range(n)]
         self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
+        ChainHub.of(arena).add(self.set, self.bset)
 
     @staticmethod
     def plan(layers, arena):
@@ -263,10 +295,6 @@ class EncoderChains:
             if sa._st.d_model != BLK or ff._st.d_ff % BLK:
                 return None
         return EncoderChains(layers, arena)
-
-    def refresh(self) -> None:
-        self.set.rebuild()
-        self.bset.rebuild()
 
     def forward(self, layers, x, rows, need_bwd: bool):
         """The encoder's layer stack on frame rows x [M, 256] (front-end output): per layer self-attention, then the chain.
@@ -343,6 +371,7 @@ class DecoderChains:
         self.bwd2 = [self.bset.chain(b2[l], True) for l in range(n)]
         self.bwd1 = [self.bset.chain(b1[l], True) for l in range(n)]
         self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
+        ChainHub.of(arena).add(self.set, self.bset)
 
     @staticmethod
     def plan(layers, arena):
@@ -355,10 +384,6 @@ class DecoderChains:
             if sa._st.d_model != BLK or ff._st.d_ff % BLK:
                 return None
         return DecoderChains(layers, arena)
-
-    def refresh(self) -> None:
-        self.set.rebuild()
-        self.bset.rebuild()
 
     def forward(self, layers, x, kv, t_rows, in_rows, need_bwd: bool):
         """The decoder's layer stack on target rows x [M, 256] (embedding + positional encoding), kv = CrossKv's buffer

@@ -41,7 +41,7 @@ SIGNATURES = {
                    _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                    _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
     "st_wfrag_depth": [],
-    "st_wfrag_build": [_c_void_p, _c_void_p, _c_int, _c_void_p],
+    "st_wfrag_build": [_c_void_p, _c_void_p, _c_int],
     "st_row_chain": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float, _c_int,
@@ -367,17 +367,14 @@ def wfrag_depth() -> int:
     return _WFRAG_DEPTH
 
 
-def wfrag_build(table, out):
+def wfrag_build(table):
     """(Re)build weight-fragment streams (csrc/st_rowchain.hip): ``table`` int64 [n_blocks, 4] on the device, one row per
-    256 x 256 weight block: (address of its first element, leading dimension, fragment index inside a wave stream,
-    element offset of the chain in ``out`` | wave stride in fragments << 40)."""
+    256 x 256 weight block: (address of its first element, leading dimension | transposed << 32, fragment index inside a
+    wave stream | wave stride in fragments << 32, address of the chain's buffer) - see st_amd/chains.py."""
     if table.dtype != torch.int64 or table.dim() != 2 or table.shape[1] != 4 or not table.is_contiguous() or not table.is_cuda:
         raise ValueError("wfrag_build: table must be a contiguous int64 [n, 4] device tensor")
-    if out.dtype != BF16 or not out.is_contiguous() or not out.is_cuda:
-        raise ValueError("wfrag_build: out must be a contiguous bf16 device buffer")
     _tag("wfrag_build", table.shape[0], 0, 0)
-    _check(load().st_wfrag_build(_stream(), table.data_ptr(), table.shape[0], out.data_ptr()), "st_wfrag_build")
-    return out
+    _check(load().st_wfrag_build(_stream(), table.data_ptr(), table.shape[0]), "st_wfrag_build")
 
 
 def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):

@@ -93,9 +93,6 @@ class Encoder(nn.Module):
         hit = getattr(self, "_st_chains", None)
         if hit is None or hit[0] is not arena:
             ec = EncoderChains.plan(list(self.layer_stack), arena) if self.use_row_chains else None
-            if ec is not None:
-                ec.refresh()
-                arena._derived.append(ec)
             hit = (arena, ec)
             self._st_chains = hit
         return hit[1] if self.use_row_chains else None
@@ -128,14 +125,12 @@ class Decoder(nn.Module):
 
     def row_chains(self, arena):
         """This decoder's row-chain plan (st_amd.chains.DecoderChains) for ``arena``, or None when the layers do not fit the
-        chain kernel.  Built once per arena (its fragment buffer is then refreshed by every ``arena.refresh()``); must
-        first be called outside a HIP-graph capture (Transformer.prepare_layouts does)."""
+        chain kernel.  Built once per arena (its fragment buffers join the arena's ChainHub: filled now from the current
+        bf16 shadow, then by every ``arena.refresh()``); must first be called outside a HIP-graph capture
+        (Transformer.prepare_layouts does)."""
         hit = getattr(self, "_st_chains", None)
         if hit is None or hit[0] is not arena:
             dc = DecoderChains.plan(list(self.layer_stack), arena) if self.use_row_chains else None
-            if dc is not None:
-                dc.refresh()                     # (the arena's shadow is current: we are inside its scope or about to enter)
-                arena._derived.append(dc)
             hit = (arena, dc)
             self._st_chains = hit
         return hit[1] if self.use_row_chains else None

@@ -160,8 +160,8 @@ def wfrag_depth():
     return 16
 
 
-def wfrag_build(table, out):
-    return out        # the emulated chain reads the weight blocks themselves (chains.Chain.blocks)
+def wfrag_build(table):
+    return None       # the emulated chain reads the weight blocks themselves (chains.Chain.blocks)
 
 
 def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
