@@ -151,3 +151,33 @@ if "misc" in which:
         x, o = rnd(m, n), torch.zeros(n, dtype=F32, device=dev)
         us = timeit(lambda: nv.colsum(x, o))
         report("colsum [%d,%d]" % (m, n), us, 0, 2.0 * m * n)
+
+if "chain" in which:
+    # row chains (csrc/st_rowchain.hip): the encoder layer's chain at 24,060 rows and the decoder's at 1,206, forward and
+    # backward, next to the separate kernels they replace (tools/dev/chain_bench.py has the element-wise comparison)
+    from st_amd import chains
+    d_, dff = 256, 1024
+    wo, wqkv, w1, w2 = rnd(d_, d_) * 0.1, rnd(3 * d_, d_) * 0.1, rnd(dff, d_) * 0.1, rnd(d_, dff) * 0.1
+    vec = lambda n: torch.randn(n, device=dev) * 0.1
+    bo, bqkv, b1, b2, g0, be0, g1, be1 = vec(d_), vec(3 * d_), vec(dff), vec(d_), vec(d_) + 1, vec(d_), vec(d_) + 1, vec(d_)
+    cs = chains.ChainSet(dev)
+    cf = cs.add(chains.blocks_of(wo) + chains.ffn_blocks(w1, w2) + chains.blocks_of(wqkv))
+    cb = cs.add(chains.t_blocks(chains.blocks_of(wqkv)) + chains.ffn_blocks_bwd(w1, w2) + chains.t_blocks(chains.blocks_of(wo)))
+    cs.finalize().rebuild()
+    chf, chb = cs.chain(cf), cs.chain(cb)
+    E = lambda *s, dtype=BF16: torch.empty(*s, dtype=dtype, device=dev)
+    for rows in (M, Md):
+        ctx, x = rnd(rows, d_), rnd(rows, d_)
+        c_, xc, rc, h_, y_, xy, ry, p_ = E(rows, d_), E(rows, d_), E(rows, dtype=F32), E(rows, dff), E(rows, d_), E(rows, d_), E(rows, dtype=F32), E(rows, 3 * d_)
+        us = timeit(lambda: nv.row_chain(ctx, chf, pre=(x, bo, g0, be0, c_, xc, rc), ffn=(dff, b1, b2, g1, be1, h_, y_, xy, ry, None, None),
+                                         post=(3, bqkv, p_)))
+        fl = 2.0 * rows * 12 * 256 * 256
+        report("row_chain fwd  wo+LN, FFN, qkv [%d]" % rows, us, fl, 2.0 * rows * (2 * d_ + 4 * d_ + dff + 3 * d_))
+        dqkv, dss, Hm, O_, Or = rnd(rows, 3 * d_), rnd(rows, d_), torch.relu(rnd(rows, dff)), rnd(rows, d_), rnd(rows, d_) * 0.004
+        ra, rb = torch.rand(rows, device=dev) + 0.5, torch.rand(rows, device=dev) + 0.5
+        dsa, dH, dsb, dctx, delta = E(rows, d_), E(rows, dff), E(rows, d_), E(rows, d_), E(4 * rows, dtype=F32)
+        acc = [torch.zeros(d_, device=dev) for _ in range(6)]
+        us = timeit(lambda: nv.row_chain_bwd(chb, rows, head=(3, dqkv, dss, xc, ra, g0, None, dsa, acc[0], acc[1], acc[2]),
+                                             ffn=(dff, Hm, 1.0, dH, xy, rb, g1, dsb, acc[3], acc[4], acc[5]), tail=(O_, Or, dctx, delta)))
+        report("row_chain bwd  qkv^T+LNbwd, FFN^T+LNbwd, wo^T+delta [%d]" % rows, us, fl,
+               2.0 * rows * (3 * d_ + 2 * d_ + dff + d_ + 2 * d_ + d_ + dff + d_ + d_))

@@ -3,15 +3,15 @@
 # per-kernel micro-benchmark; no other trace domains).  Run through gpurun; summary -> gpurun_out/pmc_issue_mix.txt
 export TMPDIR=/tmp
 cd /root/repo
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d gpurun_out/pmc2 -o p -- python tools/bench_kernels.py gemm attn > gpurun_out/pmc2.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA --kernel-trace -d gpurun_out/pmc3 -o p -- python tools/bench_kernels.py gemm attn > gpurun_out/pmc3.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/pmc2 -o p -- python tools/bench_kernels.py gemm attn chain > gpurun_out/pmc2.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA --kernel-trace -d /tmp/pmc3 -o p -- python tools/bench_kernels.py gemm attn chain > gpurun_out/pmc3.log 2>&1
 python - <<'PY' > gpurun_out/pmc_issue_mix.txt
 import sqlite3
 rows = {}
-for db in ("gpurun_out/pmc2/p_results.db", "gpurun_out/pmc3/p_results.db"):
+for db in ("/tmp/pmc2/p_results.db", "/tmp/pmc3/p_results.db"):
     c = sqlite3.connect(db)
     q = ("select kernel_name, grid_size, counter_name, avg(value), avg(duration) from counters_collection "
-         "where kernel_name like '%gemm_sym_kernel%' or kernel_name like '%attn_%kernel%' or kernel_name like '%gemm_ln%' or kernel_name like '%wgrad_group%' "
+         "where kernel_name like '%gemm_sym_kernel%' or kernel_name like '%attn_%kernel%' or kernel_name like '%gemm_ln%' or kernel_name like '%wgrad_group%' or kernel_name like '%row_chain%' "
          "group by kernel_name, grid_size, counter_name")
     for name, grid, cn, val, dur in c.execute(q):
         rows.setdefault((name, grid), {})[cn] = val
