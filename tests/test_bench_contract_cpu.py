@@ -3,6 +3,7 @@ real `python bench.py` run printed on the MI355X): every field the driver reads 
 import glob
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -19,7 +20,7 @@ def test_committed_bench_line_follows_the_contract():
     assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     # value = frames of the timed steps / wall time, consistent with ms_per_step
-    frames = int(d["config"]["workload"].split("(")[1].split(" valid frames")[0])
+    frames = int(re.search(r"\((\d+) valid frames", d["config"]["workload"]).group(1))
     assert abs(d["value"] - frames * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
