@@ -160,7 +160,7 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
 
 /* The backward of a row chain in one launch; the chain's stream holds the TRANSPOSED weight blocks (st_wfrag_build table
  * entry [1] = leading dimension | 1 << 32) in the order HEAD | FFN | TAIL:
- *   HEAD  (head_blocks > 0)  dy = sum_u dP[:, 256u..] Wp_u + G (G may be NULL);  ds_a = LayerNorm-backward(dropout-backward(dy);
+ *   HEAD  (xhat_a != NULL)  dy = sum_u dP[:, 256u..] Wp_u + G (G may be NULL; head_blocks may be 0: dy = G);  ds_a = LayerNorm-backward(dropout-backward(dy);
  *         xhat_a, rstd_a, gamma_a);  dgamma_a / dbeta_a / dbias_a accumulated atomically        (== st_gemm_lnbwd)
  *   FFN   (d_ff > 0)  dH = (ds W2) masked by H > 0, x mask_scale (== st_gemm ST_EPI_BF16_MASK);  ds_b = LayerNorm-backward(
  *         dH W1 + ds; xhat_b, rstd_b, gamma_b) and its column sums

@@ -698,9 +698,14 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
                                 const float* rstd_b, const float* gamma_b, void* ds_b, float* dgamma_b, float* dbeta_b,
                                 float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta) {
   if (M <= 0) return 0;
-  const bool head = head_blocks > 0, ffn = d_ff > 0, tail = O != nullptr;
-  if (!wfrag || (!head && !ffn && !tail)) return -1;
-  if (head && (!dP || (ldp & 7) || ldp < 256 * head_blocks || (G && (ldg & 7)) || !xhat_a || !rstd_a || !gamma_a || !ds_a)) return -2;
+  // HEAD is present iff xhat_a is given; with head_blocks == 0 it is the bare LayerNorm backward of G (the gradient that
+  // reaches the LAST sublayer of a stack from outside)
+  const bool head = xhat_a != nullptr, ffn = d_ff > 0, tail = O != nullptr;
+  if (!wfrag || head_blocks < 0 || (!head && !ffn && !tail)) return -1;
+  if (head && ((head_blocks > 0 && (!dP || (ldp & 7) || ldp < 256 * head_blocks)) || (head_blocks == 0 && !G) || (G && (ldg & 7)) ||
+               !rstd_a || !gamma_a || !ds_a))
+    return -2;
+  if (!head && head_blocks > 0) return -2;
   if (!head && !DS) return -2;
   if (ffn && ((d_ff & 255) || !H || !dH || !xhat_b || !rstd_b || !gamma_b || !ds_b)) return -3;
   if (tail && ((ldo & 7) || !dctx || (lddc & 7) || !delta)) return -4;

@@ -170,7 +170,8 @@ class ChainBackward:
         previous attention's d(context) + delta) and returns the normalised gradient that flows on;
       * ``stored(key)`` - what such a launch already produced for the sublayer ``key`` (its normalised output gradient
         ds, the hidden gradient, d(context), delta ...), so that its Function only adds its weight gradients;
-      * ``ffn_tail(l, ds)`` - the same for the LAST feed-forward of the stack, whose output gradient arrives from outside.
+      * ``ffn_tail(l, dout)`` - the same for the LAST feed-forward of the stack, whose output gradient arrives from outside
+        (its LayerNorm backward is the head of that chain).
 
     Weight gradients stay with the Functions (they are deferred into the grouped launch)."""
 
@@ -204,10 +205,13 @@ class ChainBackward:
         self.done[(attn_key, l)] = dict(ds=ds_b, dctx=dctx, delta=delta)
 
     def _ffn_head(self, l, dqkv, ds_s):
+        """The LayerNorm backward of feed-forward l's output: of dqkv W_qkv + ds_s (the next layer's self-attention), or
+        - dqkv None - of the raw gradient ds_s that reaches the last layer from outside the stack."""
         f = self.pres[l][-1]
         fs = self.layers[l].pos_ffn._st
         ds_f = self._empty(f.out, BLK)
-        return ds_f, (3, dqkv, ds_s, f.xhat, f.rstd, fs.gamma, f.drop2, ds_f, fs.g_gamma, fs.g_beta, fs.g_b2)
+        return ds_f, (3 if dqkv is not None else 0, dqkv, ds_s, f.xhat, f.rstd, fs.gamma, f.drop2, ds_f, fs.g_gamma, fs.g_beta,
+                      fs.g_b2)
 
 
 class EncoderBackward(ChainBackward):
@@ -219,8 +223,10 @@ class EncoderBackward(ChainBackward):
         self._ffn_tail_chain(self.owner.bwd[l - 1], l - 1, ds_f, head, "self", self.pres[l - 1][0], self.layers[l - 1].slf_attn)
         return ds_f
 
-    def ffn_tail(self, l, ds):
-        self._ffn_tail_chain(self.owner.bwd[l], l, ds, None, "self", self.pres[l][0], self.layers[l].slf_attn)
+    def ffn_tail(self, l, dout):
+        """dout: the raw gradient of the stack's output (its LayerNorm backward is the chain's head)."""
+        ds_f, head = self._ffn_head(l, None, dout)
+        self._ffn_tail_chain(self.owner.bwd[l], l, ds_f, head, "self", self.pres[l][0], self.layers[l].slf_attn)
         return self.stored(("ffn", l))
 
 
@@ -249,8 +255,9 @@ class DecoderBackward(ChainBackward):
         self.done[("self", l)] = dict(ds=ds_s, dctx=dctx, delta=delta)
         return ds_s
 
-    def ffn_tail(self, l, ds):
-        self._ffn_tail_chain(self.owner.bwd2[l], l, ds, None, "cross", self.pres[l][1], self.layers[l].enc_attn)
+    def ffn_tail(self, l, dout):
+        ds_f, head = self._ffn_head(l, None, dout)
+        self._ffn_tail_chain(self.owner.bwd2[l], l, ds_f, head, "cross", self.pres[l][1], self.layers[l].enc_attn)
         return self.stored(("ffn", l))
 
 

@@ -549,12 +549,14 @@ class FfnFn(torch.autograd.Function):
         if got is not None and dout.data_ptr() != got["ds"].data_ptr():
             raise RuntimeError("FfnFn.backward: the gradient reaching this sublayer is not the one its backward chain "
                                "produced (its output has more than one consumer?)")
+        if got is None and ctx.chain is not None and ctx.needs_input_grad[0]:
+            # the last feed-forward of a row-chain stack: its LayerNorm backward, hidden gradient and input gradient are one
+            # chain launch (with the d(context) / delta of the attention in front)
+            got = ctx.chain[0].ffn_tail(ctx.chain[1][1], dout)
         ds = got["ds"] if got is not None else (ctx.down.claim(dout) if ctx.down is not None else None)
         if ds is None:
             ds = _empty(M, d, x)
             nv.ln_bwd(dout, xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b2, drop=ctx.drop2)
-        if got is None and ctx.chain is not None and ctx.needs_input_grad[0]:
-            got = ctx.chain[0].ffn_tail(ctx.chain[1][1], ds)      # the last feed-forward of a row-chain stack
         if got is not None:
             wgrad(ds, h, s.g_w2)
             wgrad(got["dh"], x, s.g_w1, gB=s.g_b1)

@@ -428,6 +428,7 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     the order HEAD | FFN | TAIL).
     head = (n_blocks, dP, G, xhat, rstd, gamma, drop, ds_out, dgamma, dbeta, dbias):
            dy = dP Wp + G;  ds_out = LayerNorm-backward(dropout-backward(dy)); column sums accumulated atomically
+           (n_blocks = 0, dP = None: dy = G - the bare LayerNorm backward of a gradient arriving from outside the stack)
     ds_in: without head, the running gradient [M, 256] the chain starts from
     ffn  = (d_ff, H, mask_scale, dH, xhat, rstd, gamma, ds_out, dgamma, dbeta, dbias):
            dH = (ds W2) masked by H > 0, scaled;  ds_out = LayerNorm-backward(dH W1 + ds)

@@ -207,8 +207,11 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     ds = ds_in[:M] if ds_in is not None else None
     if head:
         nb, dP, G, xa, ra, ga, drop, dsa, dga, dba, dbia = head
-        wp = torch.cat(take(nb), 0)                          # [256 nb (contraction), 256]
-        gemm_lnbwd(dP[:M], wp, None if G is None else G[:M], xa, ra[:M], ga, dsa[:M], dga, dba, dbia, drop=drop)
+        if nb:
+            wp = torch.cat(take(nb), 0)                          # [256 nb (contraction), 256]
+            gemm_lnbwd(dP[:M], wp, None if G is None else G[:M], xa, ra[:M], ga, dsa[:M], dga, dba, dbia, drop=drop)
+        else:
+            ln_bwd(G[:M], xa[:M], ra[:M], ga, dsa[:M], dga, dba, dbia, drop=drop)
         ds = dsa[:M]
     if ffn:
         d_ff, H, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn

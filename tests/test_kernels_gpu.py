@@ -701,7 +701,8 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
 
 
 @pytest.mark.parametrize("M", [5, 320, 1206, 9000])
-@pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail"])
+@pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail",
+                                     "head0+ffn+tail+drop"])
 def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
     """One st_row_chain_bwd launch == st_gemm_lnbwd, st_gemm (mask epilogue), st_gemm_lnbwd and st_gemm (delta epilogue) as
     separate kernels (the emulation composes their emulations): every gradient tensor, the atomically accumulated
@@ -710,6 +711,7 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
     d, dff = 256, 1024
     parts = variant.split("+")
     nb = 3 if "head3" in parts else 1 if "head1" in parts else 0
+    has_head = nb > 0 or "head0" in parts          # head0: the bare LayerNorm backward of G (no GEMM in front)
     has_ffn, has_tail, drop = "ffn" in parts, "tail" in parts, "drop" in parts
     wp, w1, w2, wo = g(256 * max(nb, 1), d, seed=1, scale=d ** -0.5), g(dff, d, seed=2, scale=d ** -0.5), \
         g(d, dff, seed=3, scale=dff ** -0.5), g(d, d, seed=4, scale=d ** -0.5)
@@ -744,14 +746,14 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
         else:
             ch = chains.Chain(None, len(blocks(f)), blocks(f))
         fn(ch, M,
-           head=(nb, f(dP), f(G), f(xa), f(ra), f(ga), dr, o["ds_a"], o["dga"], o["dba"], o["dbia"]) if nb else None,
-           ds_in=None if nb else f(DS),
+           head=(nb, f(dP) if nb else None, f(G), f(xa), f(ra), f(ga), dr, o["ds_a"], o["dga"], o["dba"], o["dbia"]) if has_head else None,
+           ds_in=None if has_head else f(DS),
            ffn=(dff, f(H), 1.0 / 0.9 if drop else 1.0, o["dH"], f(xb), f(rb), f(gb), o["ds_b"], o["dgb"], o["dbb"], o["dbib"]) if has_ffn else None,
            tail=(f(O), f(Ores), o["dctx"], o["delta"]) if has_tail else None)
         return o
 
     got, ref = run("cuda", nv.row_chain_bwd, dn), run("cpu", em.row_chain_bwd, de)
-    names = (["ds_a", "dga", "dba", "dbia"] if nb else []) + (["dH", "ds_b", "dgb", "dbb", "dbib"] if has_ffn else []) + \
+    names = (["ds_a", "dga", "dba", "dbia"] if has_head else []) + (["dH", "ds_b", "dgb", "dbb", "dbib"] if has_ffn else []) + \
         (["dctx", "delta"] if has_tail else [])
     for n in names:
         tol = 1e-2 if got[n].dtype == BF16 else 5e-3
