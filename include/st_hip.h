@@ -244,6 +244,17 @@ int st_embed_pe_fwd(st_stream_t stream, const long long* tok, int B, int L, cons
 int st_embed_bwd(st_stream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
                  const int* off, const int* len, int pad_idx, float* demb, int V);
 
+/* Beam.advance (Beam.py:43-74) for all B utterances in one launch, from the raw vocabulary logits f32 [B * beam, ldl] (V
+   valid columns): log-softmax per hypothesis (Decode.py:102), the `beam` best of score + log-probability over beam x V
+   (best first; Beam.py:53-57), back-pointer = flat / V, token = flat % V (Beam.py:63-66), done once the best hypothesis emits
+   `eos` (Beam.py:70-72; a done utterance is frozen: identity back-pointers, scores / tokens unchanged).  Device state,
+   updated in place: scores f32 [B, beam], tokens i64 [B * beam], done u8 [B], lengths i64 [B], the trellis hist_scores f32 /
+   back i64 / toks i64 [S, B, beam] at row *step (device scalar), order i64 [B * beam] = the cache rows the hypotheses
+   inherit (input of st_cache_reorder).  beam <= 16. */
+int st_beam_advance(st_stream_t stream, const float* logits, int ldl, int V, int beam, int B, const long long* step, int eos,
+                    float* scores, long long* tokens, unsigned char* done, long long* lengths, float* hist_scores,
+                    long long* back, long long* toks, long long* order);
+
 /* Beam-search decode (transformer/Decode.py with a KV cache): cache bf16 [L][n][S][W]; for every layer, position
    t <= *step (device scalar) and utterance (beam consecutive hypothesis rows), row u*beam+s <- row order[u*beam+s]
    (device int64 [n], a row of the same utterance: Beam.py:65 back-pointers), in place. */

@@ -457,6 +457,182 @@ __global__ __launch_bounds__(256) void cache_reorder_kernel(bf16* cache, const l
   }
 }
 
+// Beam.advance (Beam.py:43-74) for every utterance at once: one workgroup per utterance.
+//   word_lk[j][v] = logits[j][v] - logsumexp(logits[j][:V])           (the `prob_projection` log-softmax, Decode.py:102)
+//   the `beam` best of scores[j] + word_lk[j][v] over the beam x V candidates, best first (Beam.py:53-57, ties: lowest
+//   flat index), origin = flat / V, token = flat % V (Beam.py:63-66); an utterance whose best hypothesis just emitted EOS
+//   is done (Beam.py:70-72) and frozen from then on: scores / tokens keep their values, its back-pointers are the identity.
+// State (all device memory, updated in place): scores f32 [B][beam]; tokens i64 [B*beam]; done u8 [B]; lengths i64 [B];
+// the trellis hist_scores f32 / back i64 / toks i64 [S][B][beam] at row *step; order i64 [B*beam] (the cache rows the
+// hypotheses inherit, for st_cache_reorder).
+// candidate (x, xi) precedes (y, yi) in the result order: larger value first, lower flat index on ties
+__device__ __forceinline__ bool beam_before(float x, int xi, float y, int yi) { return x > y || (x == y && xi < yi); }
+
+// The KLOC best candidates of this thread that come strictly AFTER (lim, limi) in the result order (lim = +inf: all),
+// best first.  A thread's candidates are flat = j * V + v, v = tid, tid + 512, ...  (a short compare chain per candidate:
+// the 64 lanes of a wave insert at different times, so a deep per-thread list would be paid by every candidate)
+template <int KLOC, bool FIRST>
+__device__ __forceinline__ void beam_local_best(const float* lg, int ldl, int V, int beam, const float* scores_b, const float* s_lse,
+                                                int tid, float lim, int limi, float (&val)[KLOC], int (&idx)[KLOC]) {
+#pragma unroll
+  for (int i = 0; i < KLOC; ++i) { val[i] = -INFINITY; idx[i] = 0x7fffffff; }
+  // (unit = one batch of 12 loads of one row; the next unit's loads are issued before this one's compare chains)
+  const int nbatch = (V + 512 * 12 - 1) / (512 * 12), units = beam * nbatch;
+  float nx[12];
+#pragma unroll
+  for (int u = 0; u < 12; ++u) nx[u] = (u * 512 + tid < V) ? lg[u * 512 + tid] : -INFINITY;
+  for (int un = 0; un < units; ++un) {
+    const int j = un / nbatch, v0 = (un % nbatch) * 512 * 12;
+    const float base = scores_b[j] - s_lse[j];
+    {
+      float xs[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) xs[u] = nx[u];
+      if (un + 1 < units) {
+        const int j2 = (un + 1) / nbatch, w0 = ((un + 1) % nbatch) * 512 * 12;
+        const float* row2 = lg + (size_t)j2 * ldl;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) nx[u] = (w0 + u * 512 + tid < V) ? row2[w0 + u * 512 + tid] : -INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        float x = base + xs[u];
+        int xi = j * V + v0 + u * 512 + tid;
+        const bool in_range = (v0 + u * 512 + tid < V) && (FIRST || beam_before(lim, limi, x, xi));
+        if (in_range && beam_before(x, xi, val[KLOC - 1], idx[KLOC - 1])) {
+#pragma unroll
+          for (int i = 0; i < KLOC; ++i) {
+            const bool better = beam_before(x, xi, val[i], idx[i]);
+            const float tv = better ? val[i] : x;
+            const int ti = better ? idx[i] : xi;
+            val[i] = better ? x : val[i];
+            idx[i] = better ? xi : idx[i];
+            x = tv; xi = ti;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void beam_advance_kernel(const float* __restrict__ logits, int ldl, int V, int beam, int B,
+                                                           const long long* __restrict__ step_p, int eos, float* scores,
+                                                           long long* tokens, unsigned char* done, long long* lengths,
+                                                           float* hist_scores, long long* back, long long* toks,
+                                                           long long* order) {
+  constexpr int KLOC = 2, KMAX = 16;
+  __shared__ float s_lse[KMAX], s_sc[KMAX];
+  __shared__ float s_wv[2][8];
+  __shared__ int s_wi[2][8], s_wt[2][8];
+  __shared__ float s_best[KMAX];
+  __shared__ int s_bidx[KMAX];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const long long step = *step_p;
+  const float* lg = logits + (size_t)b * beam * ldl;
+  if (tid < beam) s_sc[tid] = scores[b * beam + tid];
+  // ---- log-sum-exp of every hypothesis row: half-wave g takes row g (beam <= 16), one pass with a running (max, sum);
+  //      loads issued in batches of 16 (32 workgroups cannot hide a dependent global load per element)
+  {
+    const int g = tid >> 5, l32 = tid & 31;
+    float mx = -INFINITY, sm = 0.f;
+    if (g < beam) {
+      const float* row = lg + (size_t)g * ldl;
+      for (int v0 = 0; v0 < V; v0 += 32 * 16) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = (v0 + u * 32 + l32 < V) ? row[v0 + u * 32 + l32] : -INFINITY;
+        float bm = x[0];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) bm = fmaxf(bm, x[u]);
+        const float mn = fmaxf(mx, bm);
+        if (mn > -INFINITY) {
+          float bs = 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) bs += __expf(x[u] - mn);
+          sm = sm * __expf(mx - mn) + bs;
+          mx = mn;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 16; o; o >>= 1) {
+      const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(sm, o, 64);
+      const float mn = fmaxf(mx, om);
+      if (mn > -INFINITY) sm = sm * __expf(mx - mn) + os * __expf(om - mn);
+      mx = mn;
+    }
+    if (g < beam && l32 == 0) s_lse[g] = mx + __logf(sm);
+  }
+  __syncthreads();
+  float val[KLOC];
+  int idx[KLOC];
+  beam_local_best<KLOC, true>(lg, ldl, V, beam, s_sc, s_lse, tid, INFINITY, -1, val, idx);
+  // ---- merge: `beam` rounds of a workgroup-wide arg-max over the threads' current heads; a thread whose KLOC candidates are
+  //      all taken (it holds more than KLOC of the winners: rare) refills from the ones after its last
+  int head = 0;
+  for (int rnd = 0; rnd < beam; ++rnd) {
+    float x = -INFINITY;
+    int xi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < KLOC; ++i)
+      if (head == i) { x = val[i]; xi = idx[i]; }
+    int xt = tid;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+      const float ov = __shfl_xor(x, o, 64);
+      const int oi = __shfl_xor(xi, o, 64), ot = __shfl_xor(xt, o, 64);
+      if (beam_before(ov, oi, x, xi)) { x = ov; xi = oi; xt = ot; }
+    }
+    const int pp = rnd & 1;       // ping-pong exchange buffers: one barrier per round
+    if (lane == 0) { s_wv[pp][wave] = x; s_wi[pp][wave] = xi; s_wt[pp][wave] = xt; }
+    __syncthreads();
+    float bx = s_wv[pp][0];
+    int bi = s_wi[pp][0], bt = s_wt[pp][0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w)
+      if (beam_before(s_wv[pp][w], s_wi[pp][w], bx, bi)) { bx = s_wv[pp][w]; bi = s_wi[pp][w]; bt = s_wt[pp][w]; }
+    if (tid == 0) { s_best[rnd] = bx; s_bidx[rnd] = bi; }
+    if (tid == bt && ++head == KLOC) {
+      beam_local_best<KLOC, false>(lg, ldl, V, beam, s_sc, s_lse, tid, bx, bi, val, idx);
+      head = 0;
+    }
+  }
+  __syncthreads();
+  // ---- the state update (one thread per beam slot)
+  if (tid < beam) {
+    const int s = tid;
+    const bool live = !done[b];
+    const size_t at = ((size_t)step * B + b) * beam + s;
+    const int flat = s_bidx[s];
+    const long long origin = live ? flat / V : s, token = flat % V;
+    hist_scores[at] = s_sc[s];
+    back[at] = origin;
+    toks[at] = token;
+    order[b * beam + s] = origin + (long long)b * beam;
+    if (live) {
+      scores[b * beam + s] = s_best[s];
+      tokens[b * beam + s] = token;
+      if (s == 0) {
+        lengths[b] += 1;
+        if (token == eos) done[b] = 1;
+      }
+    }
+  }
+}
+
+extern "C" int st_beam_advance(hipStream_t stream, const float* logits, int ldl, int V, int beam, int B, const long long* step,
+                               int eos, float* scores, long long* tokens, unsigned char* done, long long* lengths,
+                               float* hist_scores, long long* back, long long* toks, long long* order) {
+  if (B <= 0) return 0;
+  if (beam <= 0 || beam > 16 || V <= 0 || ldl < V || !logits || !step || !scores || !tokens || !done || !lengths || !hist_scores ||
+      !back || !toks || !order)
+    return -1;
+  hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(512), 0, stream, logits, ldl, V, beam, B, step, eos, scores, tokens, done,
+                     lengths, hist_scores, back, toks, order);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int st_cache_reorder(hipStream_t stream, void* cache, const long long* order, const long long* step, int L,
                                 int n, int S, int W, int beam) {
   if (L <= 0 || n <= 0 || S <= 0) return 0;

@@ -74,6 +74,8 @@ SIGNATURES = {
     "st_embed_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                      _c_void_p, _c_int],
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
+    "st_beam_advance": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "st_cache_reorder": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int],
     "st_adam_clip": [_c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_float, _c_float, _c_float, _c_float],
@@ -650,6 +652,28 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     _check(load().st_embed_bwd(_stream(), tok.data_ptr(), B, L, dy.data_ptr(), dy.stride(0), D, off.data_ptr(),
                                length.data_ptr(), int(pad_idx), demb.data_ptr(), demb.shape[0]), "st_embed_bwd")
     return demb
+
+
+def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order):
+    """Beam.advance for all utterances in one launch (see st_beam_advance): logits f32 [B * beam, >= V]; the state tensors
+    are updated in place (scores f32 [B, beam], tokens i64 [B * beam], done bool [B], lengths i64 [B], hist_scores f32 /
+    back i64 / toks i64 [S, B, beam] at row ``step`` (i64 [1], device)); order i64 [B * beam] receives the cache rows."""
+    B = scores.shape[0]
+    if not (logits.is_cuda and logits.dtype == F32 and logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == B * beam):
+        raise ValueError("beam_advance: logits must be an fp32 [B * beam, >= V] row matrix on the GPU")
+    for t, dt, n, name in ((scores, F32, B * beam, "scores"), (tokens, I64, B * beam, "tokens"), (lengths, I64, B, "lengths"),
+                           (order, I64, B * beam, "order"), (step, I64, 1, "step")):
+        _vec(t, dt, n, name)
+    if done.dtype != torch.bool or not done.is_contiguous() or done.numel() != B or not done.is_cuda:
+        raise ValueError("beam_advance: done must be a contiguous bool [B] tensor on the GPU")
+    S = hist_scores.shape[0]
+    for t, dt, name in ((hist_scores, F32, "hist_scores"), (back, I64, "back"), (toks, I64, "toks")):
+        if tuple(t.shape) != (S, B, beam) or t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("beam_advance: %s must be a contiguous [S, B, beam] tensor" % name)
+    _tag("beam_advance", B, beam, V)
+    _check(load().st_beam_advance(_stream(), logits.data_ptr(), logits.stride(0), int(V), int(beam), B, step.data_ptr(), int(eos),
+                                  scores.data_ptr(), tokens.data_ptr(), done.data_ptr(), lengths.data_ptr(),
+                                  hist_scores.data_ptr(), back.data_ptr(), toks.data_ptr(), order.data_ptr()), "st_beam_advance")
 
 
 def cache_reorder(cache, order, step, beam):

@@ -52,7 +52,7 @@ class Decode(object):
     # ---- one decoder step for all n = B * beam hypotheses; everything that changes from step to step is DEVICE state ---
     @torch.no_grad()
     def _step(self, st):
-        """-> log-probabilities [n, V] fp32 of the next token; writes the step's self-attention K|V into the caches.
+        """-> vocabulary logits [n, v_pad] fp32 of the next token; writes the step's self-attention K|V into the caches.
         ``st`` (a _DecodeState) holds: tokens [n] int64, step [1] int64, c_len [n] int32 (= step + 1), caches
         [L, n, S, 2d], the per-utterance encoder keys / values ``cross[l]`` and the attention layouts."""
         dec = self.model.decoder
@@ -112,32 +112,19 @@ class Decode(object):
         ms = self.model._st
         logits = torch.empty(n, ms.v_pad, dtype=F32, device=x.device)
         nv.gemm(x, ms.w_vocab, logits, epi=nv.EPI_F32)
-        return torch.log_softmax(logits[:, :self.model.vocab_size], dim=-1)         # the undefined `prob_projection`
+        return logits           # the log-softmax (the undefined `prob_projection`) is taken by st_beam_advance
 
     @torch.no_grad()
-    def _advance(self, st, word_lk):
-        """Beam.advance (Beam.py:43-74) for every utterance at once, on the device: top-k over beam x vocab of
-        score + log-probability, back-pointer = index // vocab, token = index % vocab, an utterance is finished once
-        the top of its beam emits EOS - after which its state is frozen (the reference removes it from the batch,
-        Decode.py:112-165; here it keeps its rows and is ignored).  Step 0 expands slot 0 only (Beam.py:48-51): the
-        other slots start at -inf.  Then the caches follow the back-pointers and the step counters advance."""
-        B, beam, V = st.B, st.beam, word_lk.shape[-1]
-        table = (word_lk.view(B, beam, V) + st.scores.unsqueeze(2)).view(B, beam * V)
-        best_scores, best_flat = table.topk(beam, 1, True, True)
-        origin = best_flat // V
-        token = best_flat - origin * V
-        live = ~st.done                                                     # utterances that advance in this step
-        lv = live.unsqueeze(1)
-        st.hist_scores.index_copy_(0, st.step, st.scores.unsqueeze(0))
-        st.scores.copy_(torch.where(lv, best_scores, st.scores))
-        origin = torch.where(lv, origin, st.slot_ids)
-        st.back.index_copy_(0, st.step, origin.unsqueeze(0))
-        st.toks.index_copy_(0, st.step, token.unsqueeze(0))
-        st.tokens.copy_(torch.where(lv, token, st.tokens.view(B, beam)).view(-1))
-        st.lengths.add_(live.to(st.lengths.dtype))
-        st.done.logical_or_(live & (token[:, 0] == Constants.EOS))
-        order = (origin + st.row0).view(-1)
-        nv.cache_reorder(st.caches, order, st.step, beam)
+    def _advance(self, st, logits):
+        """Beam.advance (Beam.py:43-74) for every utterance at once, on the device, as ONE launch (``st_beam_advance``):
+        log-softmax of the logits, top-k over beam x vocab of score + log-probability, back-pointer = index // vocab,
+        token = index % vocab; an utterance is finished once the top of its beam emits EOS - after which its state is
+        frozen (the reference removes it from the batch, Decode.py:112-165; here it keeps its rows and is ignored).
+        Step 0 expands slot 0 only (Beam.py:48-51): the other slots start at -inf.  Then the caches follow the
+        back-pointers and the step counters advance."""
+        nv.beam_advance(logits, self.model.vocab_size, st.beam, st.step, Constants.EOS, st.scores, st.tokens, st.done,
+                        st.lengths, st.hist_scores, st.back, st.toks, st.order)
+        nv.cache_reorder(st.caches, st.order, st.step, st.beam)
         st.step.add_(1)
         st.c_len.add_(1)
 
@@ -184,8 +171,7 @@ class Decode(object):
             st.hist_scores = torch.zeros(S, B, beam, dtype=F32, device=dev)
             st.back = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
             st.toks = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
-            st.slot_ids = torch.arange(beam, device=dev).unsqueeze(0).expand(B, beam).contiguous()
-            st.row0 = (torch.arange(B, device=dev) * beam).unsqueeze(1)
+            st.order = torch.zeros(n, dtype=torch.long, device=dev)
 
             def one_step():
                 self._advance(st, self._step(st))

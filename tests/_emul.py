@@ -396,6 +396,28 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     return demb
 
 
+def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order):
+    """Beam.advance for all utterances with torch ops (the formulation transformer/Decode.py used before st_beam_advance)."""
+    B = scores.shape[0]
+    word_lk = torch.log_softmax(logits[:, :V].float(), dim=-1)
+    table = (word_lk.view(B, beam, V) + scores.unsqueeze(2)).view(B, beam * V)
+    best_scores, best_flat = table.topk(beam, 1, True, True)
+    origin = best_flat // V
+    token = best_flat - origin * V
+    live = ~done
+    lv = live.unsqueeze(1)
+    hist_scores.index_copy_(0, step, scores.unsqueeze(0))
+    scores.copy_(torch.where(lv, best_scores, scores))
+    slot_ids = torch.arange(beam).unsqueeze(0).expand(B, beam)
+    origin = torch.where(lv, origin, slot_ids)
+    back.index_copy_(0, step, origin.unsqueeze(0))
+    toks.index_copy_(0, step, token.unsqueeze(0))
+    tokens.copy_(torch.where(lv, token, tokens.view(B, beam)).view(-1))
+    lengths.add_(live.to(lengths.dtype))
+    done.logical_or_(live & (token[:, 0] == eos))
+    order.copy_((origin + (torch.arange(B) * beam).unsqueeze(1)).view(-1))
+
+
 def cache_reorder(cache, order, step, beam):
     t = int(step.reshape(-1)[0]) + 1
     cache[:, :, :t] = cache[:, order][:, :, :t].clone()
@@ -408,7 +430,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "beam_advance"]
 
 
 @contextlib.contextmanager
@@ -432,4 +454,4 @@ def emulated_kernels():
             setattr(nv, n, f)
         nv.Drop = saved_drop
         st_optim.ScheduledOptim._allow_cpu_arena = saved_cpu_arena
-        st_arena.ParamArena._require_gpu = saved_req
+        st_arena.ParamArena._require_gpu = staticmethod(saved_req)

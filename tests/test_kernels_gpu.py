@@ -758,3 +758,36 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
     for n in names:
         tol = 1e-2 if got[n].dtype == BF16 else 5e-3
         check(got[n], ref[n], tol, "row_chain_bwd %s M=%d: %s" % (variant, M, n))
+
+
+@pytest.mark.parametrize("B,beam,V", [(5, 4, 30), (32, 10, 4337), (3, 16, 1000)])
+def test_beam_advance_matches_torch_formulation(B, beam, V):
+    """st_beam_advance (log-softmax + top-k over beam x V + Beam.py's bookkeeping, one launch) against the torch
+    formulation (tests/_emul.py) over several steps, with finished utterances (frozen), -inf slots (step 0) and EOS."""
+    gen = torch.Generator().manual_seed(7)
+    S, eos, ld = 6, 2, (V + 7) // 8 * 8
+
+    def state(dev):
+        sc = torch.full((B, beam), float("-inf"))
+        sc[:, 0] = 0.0
+        return dict(scores=sc.to(dev), tokens=torch.ones(B * beam, dtype=torch.long, device=dev), done=torch.zeros(B, dtype=torch.bool, device=dev),
+                    lengths=torch.zeros(B, dtype=torch.long, device=dev), hist=torch.zeros(S, B, beam, device=dev),
+                    back=torch.zeros(S, B, beam, dtype=torch.long, device=dev), toks=torch.zeros(S, B, beam, dtype=torch.long, device=dev),
+                    order=torch.zeros(B * beam, dtype=torch.long, device=dev), step=torch.zeros(1, dtype=torch.long, device=dev))
+
+    a, b = state("cuda"), state("cpu")
+    for t in range(S):
+        logits = torch.randn(B * beam, ld, generator=gen) * 4
+        if t >= 2:
+            logits[0, eos] += 30.0          # utterance 0 finishes: its best hypothesis emits EOS
+        for st, fn, dev in ((a, nv.beam_advance, "cuda"), (b, em.beam_advance, "cpu")):
+            fn(logits.to(dev), V, beam, st["step"], eos, st["scores"], st["tokens"], st["done"], st["lengths"], st["hist"],
+               st["back"], st["toks"], st["order"])
+            st["step"] += 1
+        assert torch.equal(a["done"].cpu(), b["done"]) and torch.equal(a["lengths"].cpu(), b["lengths"]), t
+        live = ~b["done"] | (b["lengths"] == t + 1)        # rows of utterances that advanced in this step
+        assert torch.equal(a["back"].cpu()[t], b["back"][t]) and torch.equal(a["order"].cpu(), b["order"]), t
+        assert torch.equal(a["toks"].cpu()[t][live], b["toks"][t][live]) and torch.equal(a["tokens"].cpu(), b["tokens"]), t
+        assert torch.allclose(a["scores"].cpu(), b["scores"], atol=2e-5, rtol=1e-6) and \
+            torch.allclose(a["hist"].cpu()[t], b["hist"][t], atol=2e-5, rtol=1e-6), t
+    assert bool(b["done"][0]) and not bool(b["done"][1:].all())
