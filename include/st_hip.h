@@ -271,6 +271,17 @@ int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);
 int st_adam_clip(st_stream_t stream, long long n, float* p, float* g, float* m, float* v, const float* lr,
                  const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps);
 
+/* Cross-entropy over ragged logits rows (train.py:40,120: nn.CrossEntropyLoss(ignore_index = 0), mean over the
+ * non-ignored tokens).  logits f32 [R, ldl] (V valid columns; padding columns holding -1e30 may be counted as valid),
+ * target i64 [R].  st_ce_fwd: lse[r] = logsumexp(logits[r, :V]) (f32 [R], kept for the backward); row_loss[r] (f32 [R],
+ * scratch) = lse[r] - logits[r, target[r]] on the non-ignored rows; sums[0] = their sum, sums[1] = their number
+ * (loss = sums[0] / sums[1]).  st_ce_bwd: dlogits (bf16 [R, ldd], ldd % 8 == 0, columns >= V zero) = (softmax - onehot) * *grad_out /
+ * sums[1] on the non-ignored rows, 0 elsewhere - the operand of the vocabulary projection's backward GEMMs. */
+int st_ce_fwd(st_stream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
+              float* lse, float* row_loss, float* sums);
+int st_ce_bwd(st_stream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
+              const float* lse, const float* sums, const float* grad_out, void* dlogits, int ldd);
+
 /* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
 int st_probe_tr16(st_stream_t stream, const void* in, void* out);
 int st_probe_mfma(st_stream_t stream, const void* A, const void* Bt, float* D);

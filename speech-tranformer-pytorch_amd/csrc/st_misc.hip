@@ -642,6 +642,113 @@ extern "C" int st_cache_reorder(hipStream_t stream, void* cache, const long long
   return 0;
 }
 
+// ---- cross-entropy over ragged logits rows (train.py:40,120: nn.CrossEntropyLoss(ignore_index = 0), mean over the
+//      non-ignored tokens).  One workgroup per row.
+// forward: lse[r] = logsumexp(logits[r, :V]); row_loss[r] = lse[r] - logits[r, target[r]] (0 for target == ignore); a second,
+// one-workgroup kernel sums them (1,200 workgroups adding to ONE address serialise in the L2: 43 us measured that way).
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ldl, int V, const long long* __restrict__ target,
+                                                     int ignore, float* __restrict__ lse, float* __restrict__ row_loss) {
+  __shared__ float red[4];
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* row = logits + (size_t)r * ldl;
+  float mx = -INFINITY, sm = 0.f;
+  for (int v0 = 0; v0 < V; v0 += 256 * 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = (v0 + u * 256 + tid < V) ? row[v0 + u * 256 + tid] : -INFINITY;
+    float bm = x[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) bm = fmaxf(bm, x[u]);
+    const float mn = fmaxf(mx, bm);
+    if (mn > -INFINITY) {
+      float bs = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bs += __expf(x[u] - mn);
+      sm = sm * __expf(mx - mn) + bs;
+      mx = mn;
+    }
+  }
+  float wm = mx;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+  if (lane == 0) red[wave] = wm;
+  __syncthreads();
+  const float gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = (mx > -INFINITY) ? sm * __expf(mx - gm) : 0.f;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  __syncthreads();
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const float l = gm + __logf(red[0] + red[1] + red[2] + red[3]);
+    lse[r] = l;
+    const long long t = target[r];
+    if (t != ignore && (t < 0 || t >= V)) __builtin_trap();
+    row_loss[r] = t != ignore ? l - row[t] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void ce_sum_kernel(const float* __restrict__ row_loss, const long long* __restrict__ target, int ignore,
+                                                     int R, float* __restrict__ sums) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float a = 0.f, n = 0.f;
+  for (int r = tid; r < R; r += 256) {
+    a += row_loss[r];
+    n += target[r] != ignore ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o, 64); n += __shfl_xor(n, o, 64); }
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = n; }
+  __syncthreads();
+  if (tid == 0) {
+    sums[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    sums[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+// backward: dlogits[r][v] = (exp(logits[r][v] - lse[r]) - [v == target[r]]) * go / count for target[r] != ignore, else 0 (bf16)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ldl, int V, const long long* __restrict__ target,
+                                                     int ignore, const float* __restrict__ lse, const float* __restrict__ sums,
+                                                     const float* __restrict__ go, bf16* __restrict__ dl, int ldd) {
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (size_t)r * ldl;
+  bf16* out = dl + (size_t)r * ldd;
+  const long long t = target[r];
+  const float scale = (t != ignore && sums[1] > 0.f) ? *go / sums[1] : 0.f;
+  const float l = lse[r];
+  for (int v = tid * 8; v < ldd; v += 256 * 8) {      // ldd % 8 == 0; columns >= V get zeros
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = v + e;
+      float g = 0.f;
+      if (c < V && scale != 0.f) g = (__expf(row[c] - l) - (c == t ? 1.f : 0.f)) * scale;
+      o[e] = (bf16)g;
+    }
+    *reinterpret_cast<bf16x8*>(out + v) = o;
+  }
+}
+
+extern "C" int st_ce_fwd(hipStream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
+                         float* lse, float* row_loss, float* sums) {
+  if (R <= 0) return 0;
+  if (!logits || !target || !lse || !row_loss || !sums || V <= 0 || ldl < V) return -1;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, target, ignore_index, lse, row_loss);
+  hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, stream, row_loss, target, ignore_index, R, sums);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_ce_bwd(hipStream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
+                         const float* lse, const float* sums, const float* grad_out, void* dlogits, int ldd) {
+  if (R <= 0) return 0;
+  if (!logits || !target || !lse || !sums || !grad_out || !dlogits || V <= 0 || ldl < V || ldd < V || (ldd & 7)) return -1;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, target, ignore_index, lse, sums, grad_out,
+                     (bf16*)dlogits, ldd);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int st_cast_bf16(hipStream_t stream, const float* src, void* dst, long long n) {
   if (n <= 0) return 0;
   if (n & 7) return -1;

@@ -653,12 +653,75 @@ class VocabFn(torch.autograd.Function):
         mod = ctx.mod
         s, arena = mod._st, mod._st_arena
         arena.attach_grads(s.vocab_params, s.vocab_lo, s.vocab_hi)
-        dl = dlogits.to(BF16)
+        dl = dlogits if dlogits.dtype == BF16 else dlogits.to(BF16)      # (CeFn hands over bf16 directly)
         wgrad(dl, x, s.g_w_vocab)
         dx = _empty(x.shape[0], x.shape[1], x)
         dgrad(dl, s.w_vocab, dx)
         arena.grads_ready(s.vocab_lo, s.vocab_hi)
         return dx, None, None, None
+
+
+class VocabCeFn(torch.autograd.Function):
+    """loss = CrossEntropy(dec W_vocab^T, target) (Models.py:151 + train.py:40,120) as ONE autograd node: the bf16 logits
+    gradient st_ce_bwd writes goes straight into the vocabulary projection's two backward GEMMs (as separate nodes autograd
+    would cast it to the logits' fp32 and VocabFn back to bf16: two more passes over [rows, V])."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, mod, target, ignore_index):
+        s = mod._st
+        R = x.shape[0]
+        logits = torch.empty(R, s.v_pad, dtype=F32, device=x.device)
+        nv.gemm(x, s.w_vocab, logits, epi=nv.EPI_F32, bias=s.pad_bias)      # padding columns at -1e30: probability 0
+        lse = torch.empty(R, dtype=F32, device=x.device)
+        sums = torch.empty(2, dtype=F32, device=x.device)
+        nv.ce_fwd(logits, target, ignore_index, lse, sums)
+        ctx.save_for_backward(x, logits, target, lse, sums)
+        ctx.mod, ctx.ignore_index = mod, ignore_index
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, go):
+        x, logits, target, lse, sums = ctx.saved_tensors
+        mod = ctx.mod
+        s, arena = mod._st, mod._st_arena
+        arena.attach_grads(s.vocab_params, s.vocab_lo, s.vocab_hi)
+        dl = torch.empty(logits.shape, dtype=BF16, device=logits.device)
+        nv.ce_bwd(logits, target, ctx.ignore_index, lse, sums, go.reshape(1).float(), dl)
+        wgrad(dl, x, s.g_w_vocab)
+        dx = _empty(x.shape[0], x.shape[1], x)
+        dgrad(dl, s.w_vocab, dx)
+        arena.grads_ready(s.vocab_lo, s.vocab_hi)
+        return dx, None, None, None, None
+
+
+class CeFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index) (train.py:40,120: mean over the non-ignored tokens) over ragged fp32 logits rows as
+    two launches: forward = per-row log-sum-exp + the loss sum and token count, backward = (softmax - onehot) * grad / count
+    written straight in bf16 - the operand VocabFn.backward feeds to its two GEMMs (PyTorch runs log-softmax, nll-loss,
+    their two backwards and a cast: five passes over the [rows, V] logits)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        R = logits.shape[0]
+        lse = torch.empty(R, dtype=F32, device=logits.device)
+        sums = torch.empty(2, dtype=F32, device=logits.device)
+        nv.ce_fwd(logits, target, ignore_index, lse, sums)
+        ctx.save_for_backward(logits, target, lse, sums)
+        ctx.ignore_index = ignore_index
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, go):
+        logits, target, lse, sums = ctx.saved_tensors
+        dl = torch.empty(logits.shape, dtype=BF16, device=logits.device)
+        nv.ce_bwd(logits, target, ctx.ignore_index, lse, sums, go.reshape(1).float(), dl)
+        return dl, None, None
+
+
+def cross_entropy_rows(logits, target, ignore_index=0):
+    """Mean cross-entropy of fp32 logits rows [R, V] (contiguous; padding columns at -1e30 are fine) against int64 targets,
+    rows with ``ignore_index`` excluded (nn.CrossEntropyLoss(ignore_index=0), train.py:120)."""
+    return CeFn.apply(logits, target.contiguous(), ignore_index)
 
 
 class PackFn(torch.autograd.Function):

@@ -76,6 +76,9 @@ SIGNATURES = {
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
     "st_beam_advance": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "st_ce_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "st_ce_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                  _c_int],
     "st_cache_reorder": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int],
     "st_adam_clip": [_c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_float, _c_float, _c_float, _c_float],
@@ -686,6 +689,33 @@ def cache_reorder(cache, order, step, beam):
     _check(load().st_cache_reorder(_stream(), cache.data_ptr(), order.data_ptr(), step.data_ptr(), L, n, S, W, int(beam)),
            "st_cache_reorder")
     return cache
+
+
+def ce_fwd(logits, target, ignore_index, lse, sums, V=None):
+    """lse[r] = logsumexp(logits[r, :V]); sums = (sum of the non-ignored rows' losses, their count) - see st_ce_fwd."""
+    if not (logits.is_cuda and logits.dtype == F32 and logits.dim() == 2 and logits.stride(1) == 1):
+        raise ValueError("ce_fwd: logits must be an fp32 row matrix on the GPU")
+    R = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    _vec(target, I64, R, "target"), _vec(lse, F32, R, "lse"), _vec(sums, F32, 2, "sums")
+    row_loss = torch.empty(R, dtype=F32, device=logits.device)       # scratch: summed by the call's second launch
+    _tag("ce_fwd", R, V, 0)
+    _check(load().st_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), int(ignore_index),
+                            lse.data_ptr(), row_loss.data_ptr(), sums.data_ptr()), "st_ce_fwd")
+
+
+def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None):
+    """dlogits (bf16, same shape as logits) = d(mean loss) / d(logits) * grad_out - see st_ce_bwd."""
+    R = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    _mat(dlogits, BF16, "dlogits")
+    if dlogits.shape[0] != R or dlogits.shape[1] < V or dlogits.stride(0) % 8 or dlogits.shape[1] != dlogits.stride(0):
+        raise ValueError("ce_bwd: dlogits must be a contiguous bf16 [R, >= V] matrix with a row length that is a multiple of 8")
+    _vec(grad_out, F32, 1, "grad_out")
+    _tag("ce_bwd", R, V, 0)
+    _check(load().st_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), int(ignore_index),
+                            lse.data_ptr(), sums.data_ptr(), grad_out.data_ptr(), dlogits.data_ptr(), dlogits.stride(0)),
+           "st_ce_bwd")
 
 
 def cast_bf16(src, dst):

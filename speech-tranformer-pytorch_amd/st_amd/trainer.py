@@ -70,9 +70,9 @@ class TrainStep:
             # loss over the valid tokens only: the kernels' ragged logits rows against the matching ground-truth
             # entries.  Identical to train.py:40 on the padded [B, L, V] tensor: its padded positions carry
             # ground truth 0 = ignore_index, and the mean is over non-ignored tokens either way.
-            logits, t_rows = self.model.forward_packed(inputs, input_lengths, targets, target_lengths, padded_logits=True)
-            truth = ground_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ground_truth.shape[1]))
-            loss = self.crit(logits, truth)
+            # (projection + cross-entropy as one autograd node: functional.VocabCeFn)
+            loss, t_rows = self.model.forward_packed(inputs, input_lengths, targets, target_lengths, ce_truth=ground_truth,
+                                                     ignore_index=self.crit.ignore_index)
         else:
             logits, _ = self.model(inputs, input_lengths, targets, target_lengths)
             loss = self.crit(logits.contiguous().view(-1, self.vocab_size), ground_truth.contiguous().view(-1))
@@ -89,10 +89,9 @@ class TrainStep:
         flushed).  Leaves (encoder output, its gradient) in ``self._cut`` for :meth:`_encoder_backward`."""
         self.optimizer.zero_grad()
         rng.advance()
-        logits, t_rows, enc, enc_leaf = self.model.forward_packed(inputs, input_lengths, targets, target_lengths,
-                                                                  cut_encoder=True, padded_logits=True)
-        truth = ground_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ground_truth.shape[1]))
-        loss = self.crit(logits, truth)
+        loss, t_rows, enc, enc_leaf = self.model.forward_packed(inputs, input_lengths, targets, target_lengths,
+                                                                cut_encoder=True, ce_truth=ground_truth,
+                                                                ignore_index=self.crit.ignore_index)
         with deferred_wgrads(True):
             loss.backward()
         self._cut = (enc, enc_leaf.grad)

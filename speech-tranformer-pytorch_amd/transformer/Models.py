@@ -259,7 +259,7 @@ class Transformer(nn.Module):
         return in_rows, t_rows
 
     def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False,
-                       padded_logits=False):
+                       padded_logits=False, ce_truth=None, ignore_index=0):
         """The same computation with the logits left in the ragged layout the kernels produce:
         -> (logits [sum(targets_pos), V] fp32 (a column slice of a [*, v_pad] buffer), Rows of the target side).
         ``Rows.scatter_index(L)`` maps row r to its position b*L + t in the padded layout; trainer.TrainStep uses
@@ -276,8 +276,14 @@ class Transformer(nn.Module):
             dec, _ = self.decoder.forward_rows(targets, targets_pos, enc_in, in_rows, t_rows)
             # padded_logits: return the whole [*, v_pad] buffer with the padding columns at -1e30 (a cross-entropy over it
             # equals the one over the vocabulary, and neither the column slice nor its gradient is ever copied)
-            logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self, padded_logits)   # [sum(tgt_len), v_pad]
-        if not padded_logits:
+            if ce_truth is not None:
+                # ce_truth [B, L] int64 (the padded ground truth of train.py:40): the first return value is the token-mean
+                # cross-entropy (train.py:40,120) instead of the logits - projection + loss as one autograd node
+                truth = ce_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ce_truth.shape[1]))
+                logits = F_.VocabCeFn.apply(dec, self.tgt_word_proj.weight, self, truth, ignore_index)
+            else:
+                logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self, padded_logits)   # [sum(tgt_len), v_pad]
+        if not padded_logits and ce_truth is None:
             logits = logits[:, :self.vocab_size]
         if cut_encoder:
             return logits, t_rows, enc, enc_in

@@ -791,3 +791,28 @@ def test_beam_advance_matches_torch_formulation(B, beam, V):
         assert torch.allclose(a["scores"].cpu(), b["scores"], atol=2e-5, rtol=1e-6) and \
             torch.allclose(a["hist"].cpu()[t], b["hist"][t], atol=2e-5, rtol=1e-6), t
     assert bool(b["done"][0]) and not bool(b["done"][1:].all())
+
+
+@pytest.mark.parametrize("R,V", [(7, 30), (1206, 4337)])
+def test_cross_entropy_rows_matches_torch(R, V):
+    """st_ce_fwd / st_ce_bwd (functional.cross_entropy_rows) == nn.CrossEntropyLoss(ignore_index=0) on fp32 logits rows whose
+    padding columns hold -1e30 (what VocabFn hands the loss): value and gradient (bf16), ignored rows, a scaled upstream
+    gradient."""
+    from st_amd.functional import cross_entropy_rows
+    vp = (V + 7) // 8 * 8
+    gen = torch.Generator().manual_seed(3)
+    logits = torch.full((R, vp), -1e30)
+    logits[:, :V] = torch.randn(R, V, generator=gen) * 3
+    target = torch.randint(1, V, (R,), generator=gen)
+    target[::5] = 0                                        # ignored rows
+    ref_in = logits[:, :V].clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(ignore_index=0)(ref_in, target)
+    (ref * 0.7).backward()
+    x = logits.cuda().requires_grad_(True)
+    loss = cross_entropy_rows(x, target.cuda(), 0)
+    (loss * 0.7).backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    if vp > V:      # (autograd casts the bf16 gradient to the leaf's fp32; functional.VocabCeFn consumes it as bf16)
+        assert float(x.grad[:, V:].abs().max()) == 0.0
+    check(x.grad[:, :V], ref_in.grad, 6e-3, "cross-entropy gradient")
+    assert float(x.grad[::5].abs().max()) == 0.0
