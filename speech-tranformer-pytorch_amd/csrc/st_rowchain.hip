@@ -237,15 +237,18 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
   // a wave's 16 KB in flight would otherwise meet the HBM latency block after block (cold caches, M = 1206: 40.4 us for
   // the 12-block chain against 22.6 us with the streams cached; 32.8 us with its own lines touched up front).  The
   // workgroups that share an XCD (dispatch is round-robin over the 8 XCDs) deal the 128-byte lines among their threads;
-  // the values are only consumed at the very end.  (MT = 3: hundreds of workgroups read the same streams - no warm-up.)
-  int touched[TOUCH];
-  if (MT == 1) {
-    const int nlines = NW * (a.wave_frags + a.next_frags) * 8;     // this chain's streams and the next chain's right behind them
+  // the values are only consumed at the very end.  MT = 3 (hundreds of workgroups, ~31 per XCD, all starting at the same
+  // fragment): one line per thread covers the chain's own streams - without it every workgroup of an XCD waits for the
+  // same HBM fetches block after block (the stream runs at the latency-bound rate of a single requester).
+  constexpr int NTOUCH = MT == 1 ? TOUCH : 1;
+  int touched[NTOUCH];
+  {
+    const int nlines = NW * (a.wave_frags + (MT == 1 ? a.next_frags : 0)) * 8;
     const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
     const char* sb = reinterpret_cast<const char*>(a.wfrag);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < TOUCH; ++t) {
+    for (int t = 0; t < NTOUCH; ++t) {
       const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
       touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
     }
@@ -303,10 +306,10 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
       tile_out(c, st, a.P + u * 256, a.ldp);
     }
   }
-  if (MT == 1) {
+  {
     int tsum = 0;
 #pragma unroll
-    for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+    for (int t = 0; t < NTOUCH; ++t) tsum ^= touched[t];
     if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;      // (never true: keeps the warm-up loads alive)
   }
 }
@@ -463,14 +466,15 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
 #pragma unroll
   for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
   c.ws += Ring<MT>::D * 64;
-  int touched[TOUCH];
-  if (MT == 1) {       // warm-up of this and the next chain's streams: see row_chain_kernel
-    const int nlines = NW * (a.wave_frags + a.next_frags) * 8;
+  constexpr int NTOUCH = MT == 1 ? TOUCH : 1;
+  int touched[NTOUCH];
+  {       // warm-up of this (and, at decoder size, the next) chain's streams: see row_chain_kernel
+    const int nlines = NW * (a.wave_frags + (MT == 1 ? a.next_frags : 0)) * 8;
     const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
     const char* sb = reinterpret_cast<const char*>(a.wfrag);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < TOUCH; ++t) {
+    for (int t = 0; t < NTOUCH; ++t) {
       const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
       touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
     }
@@ -589,10 +593,10 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
         a.delta[(size_t)h * a.M + c.row0 + row] = red[0][((2 * h) * MT + mt) * 32 + r] + red[0][((2 * h + 1) * MT + mt) * 32 + r];
     }
   }
-  if (MT == 1) {
+  {
     int tsum = 0;
 #pragma unroll
-    for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+    for (int t = 0; t < NTOUCH; ++t) tsum ^= touched[t];
     if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;
   }
 }
