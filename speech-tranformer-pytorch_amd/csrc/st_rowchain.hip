@@ -94,6 +94,24 @@ __device__ __forceinline__ void tile_in(const Ctx<MT>& c, const bf16* g, int ld,
     *reinterpret_cast<bf16x8*>(t + rr * AS + cc * 8) = gload8(g + (size_t)(c.row0 + rr) * ld + cc * 8, rr < c.nvalid);
   }
 }
+// the same in two halves, so that the loads fly under a block of MFMAs: global -> registers now, registers -> LDS later
+template <int MT> struct TileRegs { bf16x8 v[2 * MT]; };
+template <int MT>
+__device__ __forceinline__ void tile_load(const Ctx<MT>& c, const bf16* g, int ld, TileRegs<MT>& t) {
+#pragma unroll
+  for (int p = 0; p < 2 * MT; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    t.v[p] = gload8(g + (size_t)(c.row0 + rr) * ld + cc * 8, rr < c.nvalid);
+  }
+}
+template <int MT>
+__device__ __forceinline__ void tile_store(const Ctx<MT>& c, const TileRegs<MT>& t, bf16* lds) {
+#pragma unroll
+  for (int p = 0; p < 2 * MT; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    *reinterpret_cast<bf16x8*>(lds + rr * AS + cc * 8) = t.v[p];
+  }
+}
 // LDS -> global as 512-byte row segments
 template <int MT>
 __device__ __forceinline__ void tile_out(const Ctx<MT>& c, const bf16* t, bf16* g, int ld) {
@@ -495,13 +513,17 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
     tile_in(c, a.xhat_a, DM, t2);
     f32x16 acc[MT];
     zero_acc(acc);
+    // (block u + 1 of dP is requested before the MFMAs on block u and stored after them: its latency is hidden)
+    TileRegs<MT> nxt;
+    if (a.nb > 0) tile_load(c, a.dP, a.ldp, nxt);
     for (int u = 0; u < a.nb; ++u) {
-      if (u) __syncthreads();                    // every wave is past its MFMAs on the previous block of dP
-      tile_in(c, a.dP + u * 256, a.ldp, t0);
+      tile_store(c, nxt, t0);
       __syncthreads();
+      if (u + 1 < a.nb) tile_load(c, a.dP + (u + 1) * 256, a.ldp, nxt);
       block_mma(c, t0, acc);
+      __syncthreads();                           // every wave is past its MFMAs on this block of dP: t0 may be rewritten
     }
-    __syncthreads();                             // t0 is free for ds_a
+    if (a.nb == 0) __syncthreads();              // (bare LayerNorm backward: the G / xhat tiles must be visible)
     epi_lnbwd<DROP>(c, acc, t1, t2, t0, a.rstd_a, a.gamma_a, da, red, a.ds_a, a.dgamma_a, a.dbeta_a, a.dbias_a);
     cur = t0; fa = t1; fb = t2;
     __syncthreads();                             // the column pass has read t1 / t2: free from here
@@ -556,12 +578,16 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
   }
 
   if (TAIL) {
-    // O -> fa, Ores -> fb; dctx is staged in the ds tile once every wave is past its MFMAs on it
-    tile_in(c, a.O, a.ldo, fa);
-    if (a.Ores) tile_in(c, a.Ores, a.ldo, fb);
+    // O -> fa, Ores -> fb (requested before the MFMAs, stored after them); dctx is staged in the ds tile once every wave is
+    // past its MFMAs on it
+    TileRegs<MT> ro, rr_;
+    tile_load(c, a.O, a.ldo, ro);
+    if (a.Ores) tile_load(c, a.Ores, a.ldo, rr_);
     f32x16 acc[MT];
     zero_acc(acc);
     block_mma(c, cur, acc);
+    tile_store(c, ro, fa);
+    if (a.Ores) tile_store(c, rr_, fb);
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
