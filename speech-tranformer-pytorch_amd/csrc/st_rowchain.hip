@@ -232,7 +232,8 @@ __device__ __forceinline__ void epi_ln(const Ctx<MT>& c, f32x16 (&acc)[MT], cons
   tile_out(c, t_out, g_out, DM);
 }
 
-// MT = row tiles of 32 per workgroup.  1: decoder-sized row counts (as many workgroups as possible).  3: encoder-sized
+// MT = row tiles of 32 per workgroup.  1: decoder-sized row counts (as many workgroups as possible).  2: in between (a
+// strong-scaling shard of the batch).  3: encoder-sized
 // ones (24,060 rows = 251 workgroups = one round of the 256 CUs; every weight fragment feeds three MFMAs, so a
 // workgroup's MFMA time matches its weight stream; three 50 KB activation tiles fill the LDS).
 template <bool PRE, bool FFN, bool POST, bool DROP, int MT>
@@ -694,8 +695,8 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   a.drop2.seed = on2 ? drop_seed : nullptr; a.drop2.salt = drop2_salt; a.drop2.thresh = on2 ? drop2_thresh : 0;
   a.drop2.scale = on2 ? drop2_scale : 1.f;
   a.nb = post_blocks; a.bp = bp; a.P = (bf16*)P; a.ldp = ldp;
-  // row tiles per workgroup: 1 while that gives at most one round of workgroups (256 CUs), else 3
-  const int mt = (M + 31) / 32 <= 256 ? 1 : 3;
+  // row tiles per workgroup: the smallest of 1, 2, 3 that gives at most one round of workgroups (256 CUs)
+  const int mt = (M + 31) / 32 <= 256 ? 1 : (M + 63) / 64 <= 256 ? 2 : 3;
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
   const bool drop = on1 || on2;
 #define ST_CHAIN(PRE_, FFN_, POST_)                                                                               \
@@ -703,6 +704,9 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
     if (mt == 3) {                                                                                                \
       if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 3>), grid, blk, 0, stream, a);      \
       else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 3>), grid, blk, 0, stream, a);          \
+    } else if (mt == 2) {                                                                                         \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 2>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 2>), grid, blk, 0, stream, a);          \
     } else {                                                                                                      \
       if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 1>), grid, blk, 0, stream, a);      \
       else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 1>), grid, blk, 0, stream, a);          \
@@ -753,13 +757,16 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   a.xhat_b = (const bf16*)xhat_b; a.rstd_b = rstd_b; a.gamma_b = gamma_b; a.ds_b = (bf16*)ds_b; a.dgamma_b = dgamma_b;
   a.dbeta_b = dbeta_b; a.dbias_b = dbias_b;
   a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
-  const int mt = (M + 31) / 32 <= 256 ? 1 : 3;
+  const int mt = (M + 31) / 32 <= 256 ? 1 : (M + 63) / 64 <= 256 ? 2 : 3;
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
 #define ST_BWD(HEAD_, FFN_, TAIL_)                                                                                     \
   do {                                                                                                                 \
     if (mt == 3) {                                                                                                     \
       if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 3>), grid, blk, 0, stream, a);      \
       else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 3>), grid, blk, 0, stream, a);          \
+    } else if (mt == 2) {                                                                                              \
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 2>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 2>), grid, blk, 0, stream, a);          \
     } else {                                                                                                           \
       if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 1>), grid, blk, 0, stream, a);      \
       else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 1>), grid, blk, 0, stream, a);          \
