@@ -244,6 +244,13 @@ int st_embed_pe_fwd(st_stream_t stream, const long long* tok, int B, int L, cons
 int st_embed_bwd(st_stream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
                  const int* off, const int* len, int pad_idx, float* demb, int V);
 
+/* Decode-shaped self-attention of one beam-search step (Decode.py:96-98 with a KV cache): one query per hypothesis.
+   qkv bf16 [n, ldq] = this step's q | k | v (3 * H * 64 columns); cache bf16 [n][S][2 * H * 64] of ONE layer; appends k | v
+   at position *step (device scalar) and writes ctx [n, ldc] = softmax(q K^T * scale) V over positions 0 .. *step.
+   d_k = 64, S <= 128. */
+int st_decode_self_attn(st_stream_t stream, const void* qkv, int ldq, void* cache, const long long* step, void* ctx, int ldc,
+                        int n, int S, int H, int d_k, float scale);
+
 /* Beam.advance (Beam.py:43-74) for all B utterances in one launch, from the raw vocabulary logits f32 [B * beam, ldl] (V
    valid columns): log-softmax per hypothesis (Decode.py:102), the `beam` best of score + log-probability over beam x V
    (best first; Beam.py:53-57), back-pointer = flat / V, token = flat % V (Beam.py:63-66), done once the best hypothesis emits

@@ -476,13 +476,17 @@ __device__ __forceinline__ void beam_local_best(const float* lg, int ldl, int V,
                                                 int tid, float lim, int limi, float (&val)[KLOC], int (&idx)[KLOC]) {
 #pragma unroll
   for (int i = 0; i < KLOC; ++i) { val[i] = -INFINITY; idx[i] = 0x7fffffff; }
-  // (unit = one batch of 12 loads of one row; the next unit's loads are issued before this one's compare chains)
+  // (unit = one batch of 12 loads of one row; the next unit's loads are issued before this one's compare chains).  Row j's
+  // columns are dealt to the threads rotated by 53 j: the best next tokens of the hypotheses of one beam tend to be the SAME
+  // tokens, and with one column -> one thread for all rows a single thread would own most of the winners (measured on the
+  // benchmark model: five refill scans per step, 114 us instead of 50)
   const int nbatch = (V + 512 * 12 - 1) / (512 * 12), units = beam * nbatch;
   float nx[12];
 #pragma unroll
   for (int u = 0; u < 12; ++u) nx[u] = (u * 512 + tid < V) ? lg[u * 512 + tid] : -INFINITY;
   for (int un = 0; un < units; ++un) {
     const int j = un / nbatch, v0 = (un % nbatch) * 512 * 12;
+    const int vs = (tid + j * 53) & 511;
     const float base = scores_b[j] - s_lse[j];
     {
       float xs[12];
@@ -490,15 +494,16 @@ __device__ __forceinline__ void beam_local_best(const float* lg, int ldl, int V,
       for (int u = 0; u < 12; ++u) xs[u] = nx[u];
       if (un + 1 < units) {
         const int j2 = (un + 1) / nbatch, w0 = ((un + 1) % nbatch) * 512 * 12;
+        const int vs2 = (tid + j2 * 53) & 511;
         const float* row2 = lg + (size_t)j2 * ldl;
 #pragma unroll
-        for (int u = 0; u < 12; ++u) nx[u] = (w0 + u * 512 + tid < V) ? row2[w0 + u * 512 + tid] : -INFINITY;
+        for (int u = 0; u < 12; ++u) nx[u] = (w0 + u * 512 + vs2 < V) ? row2[w0 + u * 512 + vs2] : -INFINITY;
       }
 #pragma unroll
       for (int u = 0; u < 12; ++u) {
         float x = base + xs[u];
-        int xi = j * V + v0 + u * 512 + tid;
-        const bool in_range = (v0 + u * 512 + tid < V) && (FIRST || beam_before(lim, limi, x, xi));
+        int xi = j * V + v0 + u * 512 + vs;
+        const bool in_range = (v0 + u * 512 + vs < V) && (FIRST || beam_before(lim, limi, x, xi));
         if (in_range && beam_before(x, xi, val[KLOC - 1], idx[KLOC - 1])) {
 #pragma unroll
           for (int i = 0; i < KLOC; ++i) {
@@ -618,6 +623,89 @@ __global__ __launch_bounds__(512) void beam_advance_kernel(const float* __restri
       }
     }
   }
+}
+
+// Decode-shaped self-attention (Decode.py:96-98 with a KV cache): one wave per (hypothesis, head), ONE query each.
+// Appends the step's K | V (columns [d, 3d) of qkv) to cache [n][S][2d] at position t = *step and attends over positions
+// 0 .. t: scores on the VALU (lane = key, 64 keys per pass), softmax by wave reductions, P V with lane = value column.
+// d_k = 64.  Replaces cache.index_copy_ + st_attn_fwd (whose 128-query tile holds one query per hypothesis here).
+__global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16* __restrict__ qkv, int ldq, bf16* cache, const long long* __restrict__ step_p,
+                                                               bf16* __restrict__ ctx, int ldc, int n, int S, int H, float scale) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave, i = item / H, h = item % H;
+  if (i >= n) return;
+  const int d = H * 64, t = (int)*step_p;
+  const bf16* row = qkv + (size_t)i * ldq;
+  bf16* cbase = cache + (size_t)i * S * 2 * d;
+  // the step's K | V into the cache (lanes 0-7: K, 8-15: V; 16 bytes each)
+  if (l < 16) {
+    const int part = l >> 3, c = (l & 7) * 8;
+    *reinterpret_cast<bf16x8*>(cbase + (size_t)t * 2 * d + part * d + h * 64 + c) =
+        *reinterpret_cast<const bf16x8*>(row + d + part * d + h * 64 + c);
+  }
+  // q (64 values) in registers of every lane (same address for all lanes: one broadcast load per 16 bytes)
+  float q[64];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + h * 64 + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e] * scale;
+  }
+  // scores: lane = key (keys l and l + 64); the newest key is read from qkv (its cache line was written by other lanes)
+  float sc[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int k = l + 64 * p;
+    float acc = -INFINITY;
+    if (k <= t) {
+      const bf16* kr = (k == t) ? row + d + h * 64 : cbase + (size_t)k * 2 * d + h * 64;
+      acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(kr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], (float)v[e], acc);
+      }
+    }
+    sc[p] = acc;
+  }
+  float mx = fmaxf(sc[0], sc[1]);
+#pragma unroll
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float pr[2] = {sc[0] > -INFINITY ? __expf(sc[0] - mx) : 0.f, sc[1] > -INFINITY ? __expf(sc[1] - mx) : 0.f};
+  float sm = pr[0] + pr[1];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) sm += __shfl_xor(sm, o, 64);
+  const float inv = 1.f / sm;
+  // context: lane = value column; p[k] broadcast from lane k.  Loads in batches of 16 keys (a load per iteration would be
+  // a chain of L2 latencies: there is one wave per SIMD-slot here and nothing to hide behind)
+  float out = 0.f;
+  for (int k0 = 0; k0 <= t; k0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = min(k0 + u, t);
+      const bf16* vr = (k == t) ? row + 2 * d + h * 64 : cbase + (size_t)k * 2 * d + d + h * 64;
+      v[u] = (float)vr[l];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = k0 + u;
+      const float p = k <= t ? __shfl(k < 64 ? pr[0] : pr[1], k & 63, 64) : 0.f;
+      out = fmaf(p, v[u], out);
+    }
+  }
+  ctx[(size_t)i * ldc + h * 64 + l] = (bf16)(out * inv);
+}
+
+extern "C" int st_decode_self_attn(hipStream_t stream, const void* qkv, int ldq, void* cache, const long long* step, void* ctx,
+                                   int ldc, int n, int S, int H, int d_k, float scale) {
+  if (n <= 0) return 0;
+  if (d_k != 64 || H <= 0 || S <= 0 || S > 128 || (ldq & 7) || !qkv || !cache || !step || !ctx) return -1;
+  hipLaunchKernelGGL(decode_self_attn_kernel, dim3((n * H + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, ldq, (bf16*)cache, step,
+                     (bf16*)ctx, ldc, n, S, H, scale);
+  ST_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int st_beam_advance(hipStream_t stream, const float* logits, int ldl, int V, int beam, int B, const long long* step,

@@ -74,6 +74,8 @@ SIGNATURES = {
     "st_embed_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                      _c_void_p, _c_int],
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
+    "st_decode_self_attn": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                            _c_float],
     "st_beam_advance": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "st_ce_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
@@ -655,6 +657,23 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     _check(load().st_embed_bwd(_stream(), tok.data_ptr(), B, L, dy.data_ptr(), dy.stride(0), D, off.data_ptr(),
                                length.data_ptr(), int(pad_idx), demb.data_ptr(), demb.shape[0]), "st_embed_bwd")
     return demb
+
+
+def decode_self_attn(qkv, cache, step, ctx, n_head, scale):
+    """One beam-search step's self-attention (one query per hypothesis): appends this step's k | v (columns [d, 3d) of qkv
+    [n, 3d]) to ``cache`` [n, S, 2d] (one layer, contiguous) at position ``step`` (i64 [1], device) and writes the context
+    [n, d] over positions 0 .. step.  d / n_head = 64, S <= 128."""
+    _mat(qkv, BF16, "qkv"), _mat(ctx, BF16, "ctx")
+    n, S, w = cache.shape
+    d = w // 2
+    if not (cache.is_cuda and cache.dtype == BF16 and cache.is_contiguous()) or qkv.shape != (n, 3 * d) or ctx.shape != (n, d):
+        raise ValueError("decode_self_attn: qkv [n, 3d], cache [n, S, 2d] (contiguous bf16), ctx [n, d]")
+    if d % n_head or d // n_head != 64 or S > 128:
+        raise ValueError("decode_self_attn: head width 64 and at most 128 cached positions")
+    _vec(step, I64, 1, "step")
+    _tag("decode_self_attn", n, n_head, S)
+    _check(load().st_decode_self_attn(_stream(), qkv.data_ptr(), qkv.stride(0), cache.data_ptr(), step.data_ptr(), ctx.data_ptr(),
+                                      ctx.stride(0), n, S, int(n_head), d // n_head, float(scale)), "st_decode_self_attn")
 
 
 def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order):

@@ -76,11 +76,15 @@ class Decode(object):
             if qkv is None:
                 qkv = E(3 * d)
                 nv.gemm(x, s.w_qkv, qkv, bias=s.b_qkv)
-            st.caches[l].index_copy_(1, st.step, qkv[:, d:].unsqueeze(1))
-            kv = st.caches[l].view(n * S, 2 * d)
             ctx = E(d)
-            nv.attn_fwd(qkv[:, :d], kv[:, :d], kv[:, d:], ctx, st.lse, st.q_off, st.q_one, st.c_off, st.c_len, H, 1, False,
-                        scale, max_k=S)
+            if d // H == 64 and S <= 128:
+                # decode-shaped kernel: one wave per (hypothesis, head); it also appends this step's K | V to the cache
+                nv.decode_self_attn(qkv, st.caches[l], st.step, ctx, H, scale)
+            else:
+                st.caches[l].index_copy_(1, st.step, qkv[:, d:].unsqueeze(1))
+                kv = st.caches[l].view(n * S, 2 * d)
+                nv.attn_fwd(qkv[:, :d], kv[:, :d], kv[:, d:], ctx, st.lse, st.q_off, st.q_one, st.c_off, st.c_len, H, 1, False,
+                            scale, max_k=S)
             # -- output_linear + LayerNorm, then the encoder-decoder attention's q projection: separate launches, or ONE
             #    row chain (csrc/st_rowchain.hip) when the layers fit it
             y, q = E(d), E(d)

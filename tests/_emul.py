@@ -396,6 +396,19 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     return demb
 
 
+def decode_self_attn(qkv, cache, step, ctx, n_head, scale):
+    n, S, w = cache.shape
+    d = w // 2
+    t = int(step)
+    cache[:, t] = qkv[:, d:]
+    k = cache[:, :t + 1, :d].float().view(n, t + 1, n_head, d // n_head)
+    v = cache[:, :t + 1, d:].float().view(n, t + 1, n_head, d // n_head)
+    q = qkv[:, :d].float().view(n, 1, n_head, d // n_head)
+    sc = (q * k).sum(-1) * scale                         # [n, t + 1, H]
+    p = torch.softmax(sc, dim=1).unsqueeze(-1)
+    ctx.copy_((p * v).sum(1).reshape(n, d).to(BF16))
+
+
 def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order):
     """Beam.advance for all utterances with torch ops (the formulation transformer/Decode.py used before st_beam_advance)."""
     B = scores.shape[0]
@@ -449,7 +462,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "beam_advance", "ce_fwd", "ce_bwd"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "beam_advance", "ce_fwd", "ce_bwd", "decode_self_attn"]
 
 
 @contextlib.contextmanager

@@ -816,3 +816,20 @@ def test_cross_entropy_rows_matches_torch(R, V):
         assert float(x.grad[:, V:].abs().max()) == 0.0
     check(x.grad[:, :V], ref_in.grad, 6e-3, "cross-entropy gradient")
     assert float(x.grad[::5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("t", [0, 1, 37, 63, 64, 99])
+def test_decode_self_attention_matches_reference(t):
+    """st_decode_self_attn (one query per hypothesis over the KV cache, appending this step's K | V) == the fp32 softmax
+    attention over cache positions 0 .. t, for positions inside and beyond the first 64-key pass."""
+    n, H, d, S = 37, 4, 256, 100
+    qkv = g(n, 3 * d, seed=1)
+    cache = g(n, S, 2 * d, seed=2)
+    step = torch.tensor([t], dtype=torch.long)
+    cg, ce = cache.clone().cuda(), cache.clone()
+    out_g, out_e = torch.zeros(n, d, dtype=BF16, device="cuda"), torch.zeros(n, d, dtype=BF16)
+    nv.decode_self_attn(cu(qkv), cg, step.cuda(), out_g, H, 0.125)
+    em.decode_self_attn(qkv, ce, step, out_e, H, 0.125)
+    check(out_g, out_e, 1e-2, "decode self-attention t=%d" % t)
+    assert torch.equal(cg.cpu()[:, t], qkv[:, d:]) and torch.equal(cg.cpu()[:, t + 1:], cache[:, t + 1:]) and \
+        torch.equal(cg.cpu()[:, :t], cache[:, :t])
