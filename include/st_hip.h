@@ -244,6 +244,11 @@ int st_embed_pe_fwd(st_stream_t stream, const long long* tok, int B, int L, cons
 int st_embed_bwd(st_stream_t stream, const long long* tok, int B, int L, const void* dy, int ld, int D,
                  const int* off, const int* len, int pad_idx, float* demb, int V);
 
+/* One beam-search step's decoder input (Models.py:84,87): out bf16 [n, D] = emb[tokens[i]] + pe[*step] (emb f32 [V, D],
+   pe f32 [>= *step + 1, D], *step a device scalar); ids outside [0, V) trap. */
+int st_embed_step(st_stream_t stream, const long long* tokens, const float* emb, int V, const float* pe, const long long* step,
+                  void* out, int n, int D);
+
 /* Decode-shaped self-attention of one beam-search step (Decode.py:96-98 with a KV cache): one query per hypothesis.
    qkv bf16 [n, ldq] = this step's q | k | v (3 * H * 64 columns); cache bf16 [n][S][2 * H * 64] of ONE layer; appends k | v
    at position *step (device scalar) and writes ctx [n, ldc] = softmax(q K^T * scale) V over positions 0 .. *step.

@@ -625,6 +625,32 @@ __global__ __launch_bounds__(512) void beam_advance_kernel(const float* __restri
   }
 }
 
+// One beam-search step's decoder input: out[i] = bf16(emb[tokens[i]] + pe[*step])   (Models.py:84,87 with repair R3)
+__global__ __launch_bounds__(256) void embed_step_kernel(const long long* __restrict__ tokens, const float* __restrict__ emb, int V,
+                                                         const float* __restrict__ pe, const long long* __restrict__ step_p,
+                                                         bf16* __restrict__ out, int n, int D) {
+  const int per_row = D / 4, id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= n * per_row) return;
+  const int i = id / per_row, c = (id % per_row) * 4;
+  const long long t = tokens[i];
+  if (t < 0 || t >= V) __builtin_trap();
+  const f32x4 e = *reinterpret_cast<const f32x4*>(emb + (size_t)t * D + c);
+  const f32x4 p = *reinterpret_cast<const f32x4*>(pe + (size_t)*step_p * D + c);
+  bf16x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (bf16)(e[k] + p[k]);
+  *reinterpret_cast<bf16x4*>(out + (size_t)i * D + c) = o;
+}
+
+extern "C" int st_embed_step(hipStream_t stream, const long long* tokens, const float* emb, int V, const float* pe, const long long* step,
+                             void* out, int n, int D) {
+  if (n <= 0) return 0;
+  if (!tokens || !emb || !pe || !step || !out || (D & 3)) return -1;
+  hipLaunchKernelGGL(embed_step_kernel, dim3((n * (D / 4) + 255) / 256), dim3(256), 0, stream, tokens, emb, V, pe, step, (bf16*)out, n, D);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
 // Decode-shaped self-attention (Decode.py:96-98 with a KV cache): one wave per (hypothesis, head), ONE query each.
 // Appends the step's K | V (columns [d, 3d) of qkv) to cache [n][S][2d] at position t = *step and attends over positions
 // 0 .. t: scores on the VALU (lane = key, 64 keys per pass), softmax by wave reductions, P V with lane = value column.

@@ -74,6 +74,7 @@ SIGNATURES = {
     "st_embed_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                      _c_void_p, _c_int],
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
+    "st_embed_step": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int],
     "st_decode_self_attn": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                             _c_float],
     "st_beam_advance": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
@@ -657,6 +658,18 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     _check(load().st_embed_bwd(_stream(), tok.data_ptr(), B, L, dy.data_ptr(), dy.stride(0), D, off.data_ptr(),
                                length.data_ptr(), int(pad_idx), demb.data_ptr(), demb.shape[0]), "st_embed_bwd")
     return demb
+
+
+def embed_step(tokens, emb, pe, step, out):
+    """out bf16 [n, D] = emb[tokens] + pe[step] (step: i64 [1] on the device) - one beam-search step's decoder input."""
+    n, D = out.shape
+    _mat(out, BF16, "out"), _vec(tokens, I64, n, "tokens"), _vec(step, I64, 1, "step")
+    if not (emb.is_cuda and emb.dtype == F32 and emb.dim() == 2 and emb.is_contiguous() and emb.shape[1] == D and
+            pe.is_cuda and pe.dtype == F32 and pe.dim() == 2 and pe.is_contiguous() and pe.shape[1] == D and out.stride(0) == D):
+        raise ValueError("embed_step: emb [V, D] / pe [S, D] contiguous fp32, out contiguous [n, D]")
+    _check(load().st_embed_step(_stream(), tokens.data_ptr(), emb.data_ptr(), emb.shape[0], pe.data_ptr(), step.data_ptr(),
+                                out.data_ptr(), n, D), "st_embed_step")
+    return out
 
 
 def decode_self_attn(qkv, cache, step, ctx, n_head, scale):

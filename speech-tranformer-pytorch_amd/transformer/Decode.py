@@ -58,7 +58,7 @@ class Decode(object):
         dec = self.model.decoder
         n, d, S = st.n, dec.d_model, self.max_steps
         dst = dec._st
-        x = (dst.emb.index_select(0, st.tokens) + dst.pe.index_select(0, st.step)).to(BF16)   # Models.py:84,87 (repair R3)
+        x = nv.embed_step(st.tokens, dst.emb, dst.pe, st.step, torch.empty(n, d, dtype=BF16, device=st.tokens.device))  # Models.py:84,87
         dc = st.chains
         layers = list(dec.layer_stack)
 
@@ -130,7 +130,8 @@ class Decode(object):
                         st.lengths, st.hist_scores, st.back, st.toks, st.order)
         nv.cache_reorder(st.caches, st.order, st.step, st.beam)
         st.step.add_(1)
-        st.c_len.add_(1)
+        if st.need_c_len:          # (only the fall-back self-attention path reads the cache length vector)
+            st.c_len.add_(1)
 
     @torch.no_grad()
     def decode_batch(self, src_batch):
@@ -151,6 +152,7 @@ class Decode(object):
             st = _DecodeState()
             st.B, st.beam, st.n = B, beam, n
             st.chains = dec.row_chains(arena)          # None: the layers do not fit the row-chain kernel
+            st.need_c_len = not (dec.d_model // dec.layer_stack[0].slf_attn.n_head == 64 and self.max_steps <= 128)
             st.cross = []
             for layer in dec.layer_stack:                                               # once per utterance
                 s = layer.enc_attn._st

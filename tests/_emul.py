@@ -396,6 +396,11 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     return demb
 
 
+def embed_step(tokens, emb, pe, step, out):
+    out.copy_((emb.index_select(0, tokens) + pe.index_select(0, step)).to(BF16))
+    return out
+
+
 def decode_self_attn(qkv, cache, step, ctx, n_head, scale):
     n, S, w = cache.shape
     d = w // 2
@@ -462,7 +467,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "beam_advance", "ce_fwd", "ce_bwd", "decode_self_attn"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "beam_advance", "ce_fwd", "ce_bwd", "decode_self_attn", "embed_step"]
 
 
 @contextlib.contextmanager
