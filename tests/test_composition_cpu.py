@@ -555,3 +555,14 @@ def run_row_chains_on_off(device, exact):
 def test_row_chains_on_off_composition():
     with emulated_kernels():
         run_row_chains_on_off("cpu", exact=True)
+
+
+def run_row_chain_step_narrow_heads(device):
+    """d_model 256 with 8 heads (d_k 32): the forward runs as row chains, the backward falls back to the per-GEMM path with the
+    LayerNorm hand-over links (the backward chains' delta epilogue is written for 64-wide heads) - against the fp64 oracle."""
+    run_wide_step(device, d_model=256, n_head=8, d_ff=512, n_enc=1, n_dec=2)
+
+
+def test_row_chain_step_narrow_heads_composition():
+    with emulated_kernels():
+        run_row_chain_step_narrow_heads("cpu")

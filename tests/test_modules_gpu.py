@@ -124,6 +124,10 @@ def test_row_chain_step_gpu():
     comp.run_row_chain_step("cuda")
 
 
+def test_row_chain_step_narrow_heads_gpu():
+    comp.run_row_chain_step_narrow_heads("cuda")
+
+
 def test_row_chains_on_off_gpu():
     comp.run_row_chains_on_off("cuda", exact=False)
 
