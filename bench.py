@@ -259,11 +259,16 @@ def main():
             ts.append(time.perf_counter() - t)
         return sorted(ts)[len(ts) // 2] * 1e3
     ms_median = synced_median(max(args.steps, 5))
-    eager_ms = None
+    eager_ms = eager_ms_synced = None
     if not args.no_graph:
         step.use_graph = False
         run(2)
-        eager_ms = synced_median(max(args.steps // 2, 5))
+        eager_ms_synced = synced_median(max(args.steps // 2, 5))
+        torch.cuda.synchronize()                      # free-running (how a training loop calls it): the host launches ahead
+        t_e = time.perf_counter()
+        run(max(args.steps // 2, 5))
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t_e) / max(args.steps // 2, 5) * 1e3
         step.use_graph = True
     exposed_ms = None
     if reducer is not None and reducer.active:
@@ -405,6 +410,35 @@ def main():
                           "EOS), KV cache, device-side beams, one HIP-graph replay per step; includes the encoder pass"
                           % (BATCH, len(hyps[0][0]))}
 
+    # ---- a loader whose batches never repeat a length signature (N = 1 only, outside the timed region): six different seeded
+    # batches cycled through (a) TrainStep(bucket=(T_max, L_max)) - ONE captured step on padded layouts with device-resident
+    # lengths - and (b) the eager packed step (every kernel launched from Python, new ragged layouts per batch)
+    loader_proof = None
+    if world == 1 and not args.no_graph and not args.no_decode:
+        try:
+            bs = []
+            for sd in range(6):
+                bx, bt, bil, btl, bgt = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"], seed=100 + sd,
+                                                             t_min=T_MIN, l_min=L_MIN)
+                bs.append((bx.cuda(), bil, bt.cuda(), btl, bgt.cuda()))
+            res = {}
+            for name, kw in (("bucket_graph_ms_per_step", dict(use_graph=True, graph_warmup=1, bucket=(T_MAX, L_MAX))),
+                             ("eager_ms_per_step", dict(use_graph=False))):
+                st_l = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, **kw)
+                for k in range(6):
+                    st_l(*bs[k])
+                torch.cuda.synchronize()
+                t_l = time.perf_counter()
+                for k in range(18):
+                    st_l(*bs[k % 6])
+                torch.cuda.synchronize()
+                res[name] = round((time.perf_counter() - t_l) / 18 * 1e3, 3)
+            res["note"] = ("six batches with different lengths, cycled: one graph over B x T_max = %d padded rows vs eager launches "
+                           "over the ~%d packed rows" % (BATCH * T_MAX, int(in_len.sum())))
+            loader_proof = res
+        except Exception as e:  # noqa: BLE001 - the headline line must still be printed
+            loader_proof = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- N > 1, default (weak) mode: also time the SPECIFIED partition - the global B = 32 batch of BASELINE config 2
     # split contiguously over the ranks (4 utterances per GPU at N = 8, SURVEY 8e / north star) - in the same run
     strong = None
@@ -440,6 +474,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "ms_per_step_median_synced": round(ms_median, 3),
             "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
+            "eager_ms_per_step_synced": None if eager_ms_synced is None else round(eager_ms_synced, 3),
             "allreduce_exposed_ms": exposed_ms,
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: 6+6L d256 h4 dff1024 V4337, 80-d fbank, %s, "
@@ -461,6 +496,8 @@ def main():
             out["train_mode"] = train_mode
         if decode is not None:
             out["decode"] = decode
+        if loader_proof is not None:
+            out["loader_proof"] = loader_proof
 
     # ---- CPU baseline: the oracle restatement on this box's host cores (rank 0, N = 1 only) -------
     # Runs in a child process with a hard timeout so that a slow / oversubscribed host can never

@@ -313,6 +313,9 @@ class EncoderChains:
         def E(*shape, dt=BF16):
             return torch.empty(*shape, dtype=dt, device=dev)
 
+        def EZ(m, n, layout):      # attention outputs: rows past a length are never written - zeros on padded layouts
+            return (torch.empty if layout.dense else torch.zeros)(m, n, dtype=BF16, device=dev)
+
         s0 = layers[0].slf_attn._st
         H = s0.n_head
         scale = 1.0 / math.sqrt(d // H)
@@ -325,7 +328,7 @@ class EncoderChains:
             sa, ff = layer.slf_attn, layer.pos_ffn
             a, f = SubPre(), SubPre()
             a.qkv, a.drop = qkv, sa._drop(dev)
-            a.ctx, a.lse, a.ores = E(M, d), E(H * M, dt=F32), (E(M, d) if need_bwd else None)
+            a.ctx, a.lse, a.ores = EZ(M, d, rows), E(H * M, dt=F32), (EZ(M, d, rows) if need_bwd else None)
             nv.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a.ctx, a.lse, rows.off, rows.len, rows.off, rows.len,
                         H, rows.max_len, False, scale, work=work, drop=a.drop, max_k=rows.max_len, ores=a.ores)
             a.out, f.out, f.h = E(M, d), E(M, d), E(M, ff._st.d_ff)
@@ -404,6 +407,9 @@ class DecoderChains:
         def E(*shape, dt=BF16):
             return torch.empty(*shape, dtype=dt, device=dev)
 
+        def EZ(m, n, layout):      # attention outputs: rows past a length are never written - zeros on padded layouts
+            return (torch.empty if layout.dense else torch.zeros)(m, n, dtype=BF16, device=dev)
+
         s0 = layers[0].slf_attn._st
         H = s0.n_head
         scale = 1.0 / math.sqrt(d // H)
@@ -417,7 +423,7 @@ class DecoderChains:
             a, b, f = SubPre(), SubPre(), SubPre()
             # ---- causal self-attention (Attention.py:82-90)
             a.qkv, a.drop = qkv, sa._drop(dev)
-            a.ctx, a.lse, a.ores = E(M, d), E(H * M, dt=F32), (E(M, d) if need_bwd else None)
+            a.ctx, a.lse, a.ores = EZ(M, d, t_rows), E(H * M, dt=F32), (EZ(M, d, t_rows) if need_bwd else None)
             nv.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a.ctx, a.lse, t_rows.off, t_rows.len, t_rows.off, t_rows.len,
                         H, t_rows.max_len, True, scale, work=work_self, drop=a.drop, max_k=t_rows.max_len, ores=a.ores)
             # ---- F1: its output_linear + residual + LayerNorm, the next attention's q
@@ -429,7 +435,7 @@ class DecoderChains:
                          post=(1, ca._st.b_q, b.qkv))
             # ---- encoder-decoder attention over this layer's column block of kv
             b.kvbuf, b.drop = kv[:, l * 2 * d:(l + 1) * 2 * d], ca._drop(dev)
-            b.ctx, b.lse, b.ores = E(M, d), E(H * M, dt=F32), (E(M, d) if need_bwd else None)
+            b.ctx, b.lse, b.ores = EZ(M, d, t_rows), E(H * M, dt=F32), (EZ(M, d, t_rows) if need_bwd else None)
             nv.attn_fwd(b.qkv, b.kvbuf[:, :d], b.kvbuf[:, d:], b.ctx, b.lse, t_rows.off, t_rows.len, in_rows.off, in_rows.len,
                         H, t_rows.max_len, False, scale, work=work_cross, drop=b.drop, max_k=in_rows.max_len, ores=b.ores)
             # ---- F2: its output_linear + residual + LayerNorm, the feed-forward sublayer, the next layer's q|k|v

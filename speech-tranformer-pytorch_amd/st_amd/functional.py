@@ -91,8 +91,39 @@ class Rows:
             ln = host.to(device=device, dtype=I32)
         return Rows(off, ln, T, B * T, host, dense=lengths is None)
 
+    @staticmethod
+    def bucket(B: int, T: int, device) -> "Rows":
+        """Padded layout whose LENGTHS live only on the device (``set_lengths`` refreshes them in place): the layout of a
+        captured step that serves every batch of a (B, T) bucket - nothing the kernels are launched with depends on the
+        lengths (grids and work lists cover all B x T rows; the kernels skip what lies past a length)."""
+        off = torch.arange(B, dtype=I32, device=device) * T
+        r = Rows(off, torch.full((B,), T, dtype=I32, device=device), T, B * T, None, dense=False)
+        r.pos        # the position table exists before the capture; set_lengths rewrites it in place
+        return r
+
+    def set_lengths(self, lengths: torch.Tensor) -> None:
+        """(bucket layout) new utterance lengths, 1 <= len <= T: device vector and position table rewritten in place."""
+        if self.lens_host is not None or self.dense:
+            raise RuntimeError("Rows.set_lengths: only for Rows.bucket layouts")
+        if int(lengths.min()) < 1 or int(lengths.max()) > self.max_len or lengths.numel() != self.B:
+            raise ValueError("Rows.set_lengths: lengths must lie in [1, %d] for %d utterances" % (self.max_len, self.B))
+        self.len.copy_(lengths.to(dtype=I32), non_blocking=True)
+        self._pos.zero_()
+        nv.row_index(self.off, self.len, self.max_len, self._pos)
+
+    @property
+    def is_bucket(self) -> bool:
+        return self.lens_host is None and not self.dense
+
     def scatter_index(self, L: int) -> torch.Tensor:
         """Row b*L + t of a padded [B, L, *] tensor for every packed row (int64, on device)."""
+        if self.is_bucket:
+            if L != self.max_len:
+                raise ValueError("Rows.scatter_index: a bucket layout of %d rows per utterance cannot index a [B, %d] tensor"
+                                 % (self.max_len, L))
+            if self._scatter is None:
+                self._scatter = (("scatter", L), torch.arange(self.total, device=self.off.device))
+            return self._scatter[1]
         key = ("scatter", L)
         cache = getattr(self, "_scatter", None)
         if cache is None or cache[0] != key:
@@ -409,12 +440,14 @@ class MhaFn(torch.autograd.Function):
                 kvbuf = _empty(x_kv.shape[0], 2 * d, x_q)
                 nv.gemm(x_kv, s.w_kv, kvbuf, bias=s.b_kv)
             Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
-        attn_ctx = _empty(Mq, d, x_q)
+        # (rows past a length are never written by the attention kernel: on padded layouts they must still hold finite
+        # values - they are operands of the weight-gradient GEMMs, multiplied by exact zeros)
+        attn_ctx = _empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)
         # what rounding the context to bf16 drops (kept only when a backward follows): delta = rowsum(dO * O) is a
         # difference partner of dP in dS = P (dP - delta); with O to ~16 bits the two stay consistent
         # (every attention takes it: at config 3's depth the late ENCODER layers' keys are nearly identical across
         # positions too, and their q / k gradients come out 5x off without it - tests/test_fullsize_gpu.py)
-        ores = _empty(Mq, d, x_q) if need_bwd else None      # (grad mode is off inside forward())
+        ores = (_empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)) if need_bwd else None
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
                     scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
@@ -459,7 +492,8 @@ class MhaFn(torch.autograd.Function):
             dQ, dK, dV = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
         else:
             Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
-            dqkv = _empty(Mq, d, x_q)
+            # (query rows past a length - padded layouts - get no gradient from the kernel: they must read as zeros)
+            dqkv = _empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)
             slot = ctx.kv_acc if isinstance(ctx.kv_acc, CrossKvSlot) else None
             if slot is not None:
                 st = slot.state
@@ -616,7 +650,7 @@ class EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, mod, tokens, rows: Rows):
         s = mod._st
-        out = torch.empty(rows.total, s.d_model, dtype=BF16, device=tokens.device)
+        out = (torch.empty if rows.dense else torch.zeros)(rows.total, s.d_model, dtype=BF16, device=tokens.device)
         nv.embed_pe_fwd(tokens, s.emb, s.pe, rows.off, rows.len, out)
         ctx.mod, ctx.rows = mod, rows
         ctx.save_for_backward(tokens)

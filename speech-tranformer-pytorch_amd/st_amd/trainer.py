@@ -49,13 +49,19 @@ def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
 class TrainStep:
     def __init__(self, model: nn.Module, optimizer, vocab_size: int, max_grad_norm: float,
                  reducer: Optional[GradReducer] = None, use_graph: bool = False, graph_warmup: int = 2,
-                 max_graphs: int = 8):
+                 max_graphs: int = 8, bucket=None):
         self.model, self.optimizer = model, optimizer
         self.vocab_size, self.max_grad_norm = vocab_size, max_grad_norm
         self.crit = nn.CrossEntropyLoss(ignore_index=0)          # train.py:120
         self.reducer = reducer
         self.global_step = 0
         self.use_graph, self.graph_warmup, self.max_graphs = use_graph, graph_warmup, max_graphs
+        # bucket = (T_cap, L_cap): ONE captured step serves every batch of B utterances with at most T_cap frames and L_cap
+        # target tokens - the batch is staged into static padded buffers, the lengths live on the device (Rows.bucket), so
+        # a loader whose batches never repeat a length signature still replays a graph.  Costs the padding rows
+        # (B * T_cap instead of sum(len) rows through the row-wise kernels): for length-bucketed loaders.
+        self.bucket = None if bucket is None else (int(bucket[0]), int(bucket[1]))
+        self._buckets = {}
         self._graphs = collections.OrderedDict()      # signature -> captured step (LRU)
         self._seen = collections.OrderedDict()        # signature -> eager sightings before the capture
         self._g_fb = self._g_enc = self._g_opt = None
@@ -63,10 +69,13 @@ class TrainStep:
         self._cut = None
 
     # ---- the two halves of a step -------------------------------------------------------------
-    def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, captured=False):
+    def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, captured=False, layouts=None):
         self.optimizer.zero_grad()
         rng.advance()                          # next step's dropout masks (an in-place device add: capturable)
-        if hasattr(self.model, "forward_packed"):
+        if layouts is not None:
+            loss, _ = self.model.forward_packed(inputs, input_lengths, targets, target_lengths, ce_truth=ground_truth,
+                                                ignore_index=self.crit.ignore_index, layouts=layouts)
+        elif hasattr(self.model, "forward_packed"):
             # loss over the valid tokens only: the kernels' ragged logits rows against the matching ground-truth
             # entries.  Identical to train.py:40 on the padded [B, L, V] tensor: its padded positions carry
             # ground truth 0 = ignore_index, and the mean is over non-ignored tokens either way.
@@ -84,14 +93,14 @@ class TrainStep:
         return loss.detach()
 
     # ---- data-parallel graph mode: the backward in two captures -----------------------------------
-    def _forward_decoder_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth):
+    def _forward_decoder_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, layouts=None):
         """zero_grad, forward, loss, and the backward down to the encoder output (weight gradients of the decoder
         flushed).  Leaves (encoder output, its gradient) in ``self._cut`` for :meth:`_encoder_backward`."""
         self.optimizer.zero_grad()
         rng.advance()
         loss, t_rows, enc, enc_leaf = self.model.forward_packed(inputs, input_lengths, targets, target_lengths,
                                                                 cut_encoder=True, ce_truth=ground_truth,
-                                                                ignore_index=self.crit.ignore_index)
+                                                                ignore_index=self.crit.ignore_index, layouts=layouts)
         with deferred_wgrads(True):
             loss.backward()
         self._cut = (enc, enc_leaf.grad)
@@ -121,8 +130,8 @@ class TrainStep:
         self.optimizer.step_captured()
         return grad_norm
 
-    def _eager(self, batch):
-        loss = self._forward_backward(*batch)
+    def _eager(self, batch, layouts=None):
+        loss = self._forward_backward(*batch, layouts=layouts)
         if self.reducer is not None:
             self.reducer.synchronize()
         self.optimizer.update_learning_rate(self.global_step)
@@ -133,6 +142,8 @@ class TrainStep:
         self.global_step += 1
         t_max, l_max = int(input_lengths.max()), int(target_lengths.max())     # host ints when lengths are CPU tensors
         batch = (inputs[:, :t_max], input_lengths, targets[:, :l_max], target_lengths, ground_truth[:, :l_max])
+        if self.bucket is not None:
+            return self._bucket_call(*batch)
         if not self.use_graph:
             return self._eager(batch)
 
@@ -152,6 +163,50 @@ class TrainStep:
             while len(self._graphs) > self.max_graphs:
                 self._graphs.popitem(last=False)         # least recently used: its graphs, pool and pinned layouts go
         self._graphs.move_to_end(sig)
+        return self._replay(cap)
+
+    def _bucket_call(self, inputs, input_lengths, targets, target_lengths, ground_truth):
+        """Bucket mode: stage the batch into the bucket's static buffers, refresh the device-resident lengths, replay."""
+        T_cap, L_cap = self.bucket
+        B, T, Fd = inputs.shape
+        L = targets.shape[1]
+        if T > T_cap or L > L_cap or ground_truth.shape[1] > L_cap:
+            raise ValueError("TrainStep(bucket=%r): batch of %d frames / %d tokens does not fit" % (self.bucket, T, L))
+        key = (B, Fd, inputs.dtype, str(inputs.device))
+        st = self._buckets.get(key)
+        if st is None:
+            from .functional import Rows
+            dev = inputs.device
+            st = _Bucket()
+            st.x = torch.zeros(B, T_cap, Fd, dtype=inputs.dtype, device=dev)
+            st.tok = torch.zeros(B, L_cap, dtype=targets.dtype, device=dev)
+            st.gt = torch.zeros(B, L_cap, dtype=ground_truth.dtype, device=dev)
+            st.layouts = (Rows.bucket(B, T_cap, dev), Rows.bucket(B, L_cap, dev))
+            if hasattr(self.model, "prepare_layouts"):          # chain plans, work lists: before any capture
+                from .functional import attn_work
+                self.model.prepare_layouts(torch.full((B,), T_cap), torch.full((B,), L_cap), L_cap, dev)
+                ir, tr = st.layouts
+                attn_work(ir, ir, False), attn_work(tr, tr, True), attn_work(tr, ir, False)
+                tr.scatter_index(L_cap)
+            self._buckets[key] = st
+        st.x[:, :T].copy_(inputs, non_blocking=True)
+        st.tok.zero_()
+        st.tok[:, :L].copy_(targets, non_blocking=True)
+        st.gt.zero_()                                            # padding positions: ground truth 0 = ignore_index
+        st.gt[:, :ground_truth.shape[1]].copy_(ground_truth, non_blocking=True)
+        st.layouts[0].set_lengths(input_lengths)
+        st.layouts[1].set_lengths(target_lengths)
+        batch = (st.x, input_lengths, st.tok, target_lengths, st.gt)
+        if not self.use_graph:
+            return self._eager(batch, layouts=st.layouts)
+        if st.cap is None:
+            st.seen += 1
+            if st.seen <= self.graph_warmup:
+                return self._eager(batch, layouts=st.layouts)
+            st.cap = self._capture(batch, layouts=st.layouts)
+        return self._replay(st.cap)
+
+    def _replay(self, cap):
         self._g_fb, self._g_enc, self._g_opt, self._dec_lo = cap.g_fb, cap.g_enc, cap.g_opt, cap.dec_lo     # (introspection / tests)
         self.optimizer.update_learning_rate(self.global_step)
         cap.g_fb.replay()
@@ -165,7 +220,7 @@ class TrainStep:
             cap.g_opt.replay()
         return cap.loss, cap.gnorm
 
-    def _capture(self, batch):
+    def _capture(self, batch, layouts=None):
         if hasattr(self.optimizer, "_flat_state") and getattr(self.optimizer, "arena", None) is not None:
             self.optimizer._flat_state()      # Adam's lazily created state must exist BEFORE the capture (a captured
                                               # zero-fill would reset it on every replay)
@@ -174,7 +229,9 @@ class TrainStep:
         # the captured kernels read the ragged layouts (offsets, lengths, positions, attention work lists, scatter
         # index) by ADDRESS: pin the layout objects of this batch for as long as its graphs live (the layout cache may
         # be flushed by other shapes meanwhile)
-        if hasattr(self.model, "prepare_layouts"):
+        if layouts is not None:
+            cap.keep = layouts
+        elif hasattr(self.model, "prepare_layouts"):
             cap.keep = self.model.prepare_layouts(batch[1], batch[3], batch[2].shape[1], batch[0].device)
         pool = torch.cuda.graph_pool_handle()           # one pool per signature: replays of different signatures interleave freely
         cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -189,22 +246,31 @@ class TrainStep:
         if split:
             cap.g_enc, cap.dec_lo = torch.cuda.CUDAGraph(), self._decoder_grad_start()
             with torch.cuda.graph(cap.g_fb, pool=pool, **mode):
-                cap.loss = self._forward_decoder_backward(*batch)
+                cap.loss = self._forward_decoder_backward(*batch, layouts=layouts)
             with torch.cuda.graph(cap.g_enc, pool=pool, **mode):
                 self._encoder_backward()
         elif self.reducer is not None and self.reducer.active:
             with torch.cuda.graph(cap.g_fb, pool=pool, **mode):
-                cap.loss = self._forward_backward(*batch, captured=True)
+                cap.loss = self._forward_backward(*batch, captured=True, layouts=layouts)
         else:                                           # nothing happens between backward and the update: ONE graph
             cap.g_opt = None
             with torch.cuda.graph(cap.g_fb, pool=pool, **mode):
-                cap.loss = self._forward_backward(*batch, captured=True)
+                cap.loss = self._forward_backward(*batch, captured=True, layouts=layouts)
                 cap.gnorm = self._clip_and_update()
             return cap
         with torch.cuda.graph(cap.g_opt, pool=pool, **mode):
             cap.gnorm = self._clip_and_update()
         # capture only records; the step that triggered it is executed by the replay that follows
         return cap
+
+
+class _Bucket:
+    """Bucket mode: static staging buffers, device-length layouts and the captured step of one (B, feature) shape."""
+    __slots__ = ("x", "tok", "gt", "layouts", "cap", "seen")
+
+    def __init__(self):
+        self.x = self.tok = self.gt = self.layouts = self.cap = None
+        self.seen = 0
 
 
 class _Captured:

@@ -259,7 +259,7 @@ class Transformer(nn.Module):
         return in_rows, t_rows
 
     def forward_packed(self, inputs, inputs_pos, targets, targets_pos, want_enc=False, cut_encoder=False,
-                       padded_logits=False, ce_truth=None, ignore_index=0):
+                       padded_logits=False, ce_truth=None, ignore_index=0, layouts=None):
         """The same computation with the logits left in the ragged layout the kernels produce:
         -> (logits [sum(targets_pos), V] fp32 (a column slice of a [*, v_pad] buffer), Rows of the target side).
         ``Rows.scatter_index(L)`` maps row r to its position b*L + t in the padded layout; trainer.TrainStep uses
@@ -267,7 +267,10 @@ class Transformer(nn.Module):
         if self.return_attns:
             raise NotImplementedError("HIP path: attention maps are not materialised (config.return_attns must be falsy)")
         arena = arena_of(self)
-        in_rows, t_rows = self.prepare_layouts(inputs_pos, targets_pos, targets.shape[1], inputs.device)
+        # layouts = (input Rows, target Rows): given by the caller (trainer.TrainStep's bucket mode: padded layouts whose
+        # lengths live on the device), else the packed layouts of this batch
+        in_rows, t_rows = layouts if layouts is not None else \
+            self.prepare_layouts(inputs_pos, targets_pos, targets.shape[1], inputs.device)
         with arena.scope():
             enc, _ = self.encoder.forward_rows(inputs, inputs_pos, in_rows)
             # cut_encoder: the decoder runs on a detached leaf, so that the backward can be taken in two calls -

@@ -566,3 +566,47 @@ def run_row_chain_step_narrow_heads(device):
 def test_row_chain_step_narrow_heads_composition():
     with emulated_kernels():
         run_row_chain_step_narrow_heads("cpu")
+
+
+def run_bucket_mode(device, use_graph):
+    """TrainStep(bucket=(T_cap, L_cap)): ONE captured step (padded layouts, lengths on the device) must serve batches whose
+    lengths never repeat - six seeded batches through it against the eager packed step on a twin model: loss, clip norm
+    and the weights after every update."""
+    import copy
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd.trainer import TrainStep
+    from transformer.Optim import ScheduledOptim
+    torch.manual_seed(5)
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=96, max_target_length=12, num_enc_layer=2, num_dec_layer=2,
+                          n_heads=4, d_k=64, d_v=64, d_model=256, d_inner_hid=512, dropout=0.0, vocab_size=30))
+    ma = M.Transformer(cfg)
+    U.init_parameters(ma)
+    mb = copy.deepcopy(ma)
+    ma, mb = ma.eval().to(device), mb.eval().to(device)
+    oa = ScheduledOptim(ma, 256, U.AttrDict(n_warmup_steps=50))
+    ob = ScheduledOptim(mb, 256, U.AttrDict(n_warmup_steps=50))
+    T_cap, L_cap = 96, 12
+    sa = TrainStep(ma, oa, 30, 5.0, use_graph=use_graph, graph_warmup=1, bucket=(T_cap, L_cap))
+    sb = TrainStep(mb, ob, 30, 5.0, use_graph=False)
+    for i in range(6):
+        b = orc.synthetic_batch(4, T_cap, L_cap, 80, 30, seed=20 + i, t_min=40, l_min=4)
+        T, L = int(b["in_len"].max()), int(b["tgt_len"].max())
+        x, tok, gt = b["x"][:, :T].to(device), b["tokens"][:, :L].to(device), b["gt"][:, :L].to(device)
+        la, ga = sa(x, b["in_len"], tok, b["tgt_len"], gt)
+        lb, gb = sb(x, b["in_len"], tok, b["tgt_len"], gt)
+        la, ga, lb, gb = float(la), float(ga), float(lb), float(gb)
+        assert abs(la - lb) <= 2e-3 * abs(lb), (i, la, lb)
+        assert abs(ga - gb) <= 3e-2 * abs(gb), (i, ga, gb)
+        for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
+            assert torch.isfinite(p).all(), (i, n)
+        da = torch.cat([p.detach().reshape(-1) for p in ma.parameters()]).double()
+        db = torch.cat([p.detach().reshape(-1) for p in mb.parameters()]).double()
+        assert float((da - db).norm() / db.norm()) < 2e-3, (i, float((da - db).norm() / db.norm()))
+    if use_graph:
+        assert len(sa._buckets) == 1 and next(iter(sa._buckets.values())).cap is not None
+
+
+def test_bucket_mode_composition():
+    with emulated_kernels():
+        run_bucket_mode("cpu", use_graph=False)

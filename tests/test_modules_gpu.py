@@ -124,6 +124,14 @@ def test_row_chain_step_gpu():
     comp.run_row_chain_step("cuda")
 
 
+def test_bucket_mode_one_capture_serves_changing_lengths_gpu():
+    comp.run_bucket_mode("cuda", use_graph=True)
+
+
+def test_bucket_mode_eager_gpu():
+    comp.run_bucket_mode("cuda", use_graph=False)
+
+
 def test_row_chain_step_narrow_heads_gpu():
     comp.run_row_chain_step_narrow_heads("cuda")
 
