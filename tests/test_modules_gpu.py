@@ -248,14 +248,14 @@ def test_split_backward_graphs_with_reducer_match_single_graph():
                             vocab_size=30))
         inputs, targets, in_len, tgt_len, truth = synthetic.make_batch(4, 160, 20, 80, 30, seed=1, t_min=60, l_min=6)
         results = []
-        for with_reducer in (False, True):
+        for with_reducer, bucket in ((False, None), (True, None), (True, (160, 20))):    # (last: + the loader-proof capture)
             torch.manual_seed(0)
             model = Transformer(cfg).cuda()
             init_parameters(model)
             model.eval()
             opt = ScheduledOptim(model, 128, AttrDict(n_warmup_steps=4000))
             red = dp.GradReducer(arena_of(model), bucket_bytes=64 << 10, force=True) if with_reducer else None
-            step = TrainStep(model, opt, 30, 5.0, reducer=red, use_graph=True, graph_warmup=1)
+            step = TrainStep(model, opt, 30, 5.0, reducer=red, use_graph=True, graph_warmup=1, bucket=bucket)
             x, t, gt = inputs.cuda(), targets.cuda(), truth.cuda()
             out = []
             for _ in range(4):
@@ -265,7 +265,7 @@ def test_split_backward_graphs_with_reducer_match_single_graph():
                 assert step._g_enc is not None and 0 < step._dec_lo < arena_of(model).total
                 assert len(red.buckets) > 4
             results.append(([l for l, _ in out], [g for _, g in out], arena_of(model).flat.detach().float().cpu().clone()))
-        (l0, g0, p0), (l1, g1, p1) = results
+        (l0, g0, p0), (l1, g1, p1), (l2, g2, p2) = results
         # Step 1 starts from identical weights: the two paths (one graph with grouped weight gradients and the stacked
         # K/V GEMM | eager hooks, then split graphs around the all-reduce) differ by kernel-composition rounding only
         # (measured 4e-4 on the gradient).  Later steps see weights that differ in the sign of a few Adam updates and
@@ -278,6 +278,9 @@ def test_split_backward_graphs_with_reducer_match_single_graph():
         for a, b in zip(g0, g1):
             assert abs(a - b) <= 1e-2 * abs(a), (g0, g1)
         assert float((p0 - p1).norm() / p0.norm()) < 5e-3
+        # the same split capture over the bucket's padded layouts (device-resident lengths)
+        assert abs(l0[0] - l2[0]) <= 1e-3 * abs(l0[0]) and abs(g0[0] - g2[0]) <= 1e-2 * g0[0], (l0, l2, g0, g2)
+        assert float((p0 - p2).norm() / p0.norm()) < 5e-3
     finally:
         dist.destroy_process_group()
 

@@ -23,4 +23,4 @@ print("eager host-only (no final sync) %.3f ms/step" % ((time.perf_counter() - t
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): step(xs, il, ts, tl, gs)
 torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:5000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
