@@ -63,7 +63,7 @@ def kernel_report(records):
                 _, xt, yt, M, N, K, epi = tag
                 kind = {(0, 0): "gemm_fwd", (0, 1): "gemm_dgrad", (1, 1): "gemm_wgrad"}[(xt, yt)]
                 flops = 2.0 * M * N * K
-            elif tag[0] == "wgrad_group":      # several weight gradients in one launch; tag = (name, n, flops)
+            elif tag[0] in ("wgrad_group", "wgrad_wide"):      # several weight gradients in one launch; tag = (name, n, flops)
                 kind, flops = "gemm_wgrad", float(tag[2])
             elif tag[0] in ("gemm_ln", "gemm_lnbwd"):
                 kind, flops = tag[0], 2.0 * tag[1] * tag[2] * tag[3]

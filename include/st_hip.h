@@ -106,6 +106,13 @@ int st_wgrad_group(st_stream_t stream, int n, const void* const* X, const int* l
                    const int* lddy, float* const* dW, const int* lddw, float* const* db, const int* tokens,
                    const int* K_in, const int* N_out, const int* splits);
 
+/* The same contract for ENCODER-sized token counts (st_wgrad.hip): 256 x 256 output tiles, one 8-wave workgroup per
+ * CU.  splits[q] cuts problem q's token axis; the caller picks it so that the launch has about one workgroup per CU:
+ * sum_q ceil(K_in/256) * ceil(N_out/256) * splits[q] ~ 256 (st_amd/functional.py: flush_deferred_wgrads). */
+int st_wgrad_wide(st_stream_t stream, int n, const void* const* X, const int* ldx, const void* const* dY,
+                  const int* lddy, float* const* dW, const int* lddw, float* const* db, const int* tokens,
+                  const int* K_in, const int* N_out, const int* splits);
+
 /* out = LayerNorm(act(X W^T + bias) + res) * gamma + beta (+ pe[pos[row]]),
  * N = d_model in {128, 256, 512}.  Replaces output_linear + residual +
  * layernorm (Attention.py:92-94), fc2 + residual + layernorm

@@ -143,21 +143,26 @@ template <int KG> struct SmemSize {
   static constexpr int E = KG * 4 * TILE_E > XCH_E ? KG * 4 * TILE_E : XCH_E;
 };
 
-// One output tile (of one split) of one problem; `bid` is the workgroup's index within that problem's grid.
-template <bool XT, bool YT, int EPI, int KG, bool DROP = false>
-__device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem_all) {
-  const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0, tid = threadIdx.x & 255;
-  bf16* smem = smem_all + grp * 4 * TILE_E;
-  // XCD-local tile walk: workgroup b runs on XCD b % 8 (own L2).  forward / dgrad: an XCD owns X row-tiles
-  // i = x, x+8, ... and its consecutive workgroups take the tiles_j tiles that share one row-tile (the panel
-  // crosses the fabric once); weight gradients: an XCD owns splits s = x, x+8, ... and walks their (i, j) tiles.
+// XCD-local tile walk of a single-problem launch: workgroup b runs on XCD b % 8 (own L2).  forward / dgrad: an XCD owns
+// X row-tiles i = x, x+8, ... and its consecutive workgroups take the tiles_j tiles that share one row-tile (the panel
+// crosses the fabric once); weight gradients: an XCD owns splits s = x, x+8, ... and walks their (i, j) tiles.
+// -> false: this workgroup lies in the padding of the grid.
+__device__ __forceinline__ bool xcd_walk(const GemmArgs& a, int bid, int& ts, int& ti, int& tj) {
   const int xcd = bid & 7, q = bid >> 3;
   const int minor = a.splits > 1 ? a.tiles_i * a.tiles_j : a.tiles_j;
   const int major = xcd + 8 * (q / minor), mi = q % minor;
-  if (major >= (a.splits > 1 ? a.splits : a.tiles_i)) return;
-  int ts = 0, ti, tj;
+  if (major >= (a.splits > 1 ? a.splits : a.tiles_i)) return false;
+  ts = 0;
   if (a.splits > 1) { ts = major; ti = mi % a.tiles_i; tj = mi / a.tiles_i; }
   else { ti = major; tj = mi; }
+  return true;
+}
+
+// Output tile (ti, tj) over token split ts of one problem.
+template <bool XT, bool YT, int EPI, int KG, bool DROP = false>
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, int ts, int ti, int tj, bf16* smem_all) {
+  const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0, tid = threadIdx.x & 255;
+  bf16* smem = smem_all + grp * 4 * TILE_E;
   const int i0 = ti * 128, j0 = tj * 128;
   int c_begin = ts * a.c_per_split, c_end = min(a.Kc, c_begin + a.c_per_split);
   int nk = (c_end - c_begin + BK - 1) / BK;
@@ -427,7 +432,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int bid, bf16* smem
 template <bool XT, bool YT, int EPI, int KG, bool DROP = false>
 __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ST_GEMM_OCC) void gemm_sym_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 smem_all[SmemSize<KG>::E];
-  gemm_body<XT, YT, EPI, KG, DROP>(a, blockIdx.x, smem_all);
+  int ts, ti, tj;
+  if (!xcd_walk(a, blockIdx.x, ts, ti, tj)) return;
+  gemm_body<XT, YT, EPI, KG, DROP>(a, ts, ti, tj, smem_all);
 }
 
 // Several weight-gradient problems in ONE launch (the decoder's are ~20 workgroups each and pure latency when
@@ -456,7 +463,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_group_kernel(GroupArgs g) {
   a.c_per_split = p.c_per_split; a.tiles_i = p.tiles_i; a.tiles_j = p.tiles_j; a.splits = p.splits;
   a.head_dim = 0; a.yseg_shift = 31; a.yseg_extra = 0; a.bias_extra = 0;
   a.drop.seed = nullptr; a.drop.salt = 0; a.drop.thresh = 0; a.drop.scale = 1.f;
-  gemm_body<true, true, EPI_F32_ATOMIC_T, 1>(a, (int)blockIdx.x - g.first[pi], smem_all);
+  // compact walk (no XCD padding): these are decoder-sized problems of 4 .. 70 tiles whose operands fit every L2 - the
+  // XCD-local walk of the single-problem launch would put a problem with two row tiles and one split on XCDs 0 and 1 only
+  const int local = (int)blockIdx.x - g.first[pi], tiles = p.tiles_i * p.tiles_j;
+  gemm_body<true, true, EPI_F32_ATOMIC_T, 1>(a, local / tiles, (local % tiles) % p.tiles_i, (local % tiles) / p.tiles_i, smem_all);
 }
 
 template <bool XT, bool YT>
@@ -511,7 +521,8 @@ extern "C" int st_wgrad_group(hipStream_t stream, int n, const void* const* X, c
       if (ldx[q] < ((K_in[q] + 7) & ~7) || lddy[q] < ((N_out[q] + 7) & ~7)) return -3;
       GemmArgs a;
       a.M = K_in[q]; a.N = N_out[q]; a.Kc = tokens[q];
-      const int grid = plan_splits(a, splits[q] < 1 ? 1 : splits[q]);
+      plan_splits(a, splits[q] < 1 ? 1 : splits[q]);
+      const int grid = a.splits * a.tiles_i * a.tiles_j;
       GroupProblem& p = g.p[g.n];
       p.X = (const bf16*)X[q]; p.ldx = ldx[q]; p.Y = (const bf16*)dY[q]; p.ldy = lddy[q]; p.D = dW[q]; p.ldd = lddw[q];
       p.bias = db ? db[q] : nullptr; p.M = a.M; p.N = a.N; p.Kc = a.Kc; p.c_per_split = a.c_per_split;

@@ -15,7 +15,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB = os.path.join(LIBDIR, "libst_hip.so")
 STAMP = LIB + ".srchash"
-SOURCES = ["st_gemm_sym.hip", "st_gemm_ws.hip", "st_gemm_ln.hip", "st_gemm_lnbwd.hip", "st_rowchain.hip", "st_attn.hip",
+SOURCES = ["st_gemm_sym.hip", "st_wgrad.hip", "st_gemm_ws.hip", "st_gemm_ln.hip", "st_gemm_lnbwd.hip", "st_rowchain.hip", "st_attn.hip",
            "st_misc.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-shared",
          "-Wno-unused-result"]

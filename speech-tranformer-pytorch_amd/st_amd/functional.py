@@ -196,6 +196,7 @@ class _Deferred:
     HIP graph.  The operand tensors stay referenced by the list until the launch is enqueued."""
     active = False
     pending = []
+    WIDE_ROWS = 8192          # token counts from here up take st_wgrad_wide
     ROWS_PER_SPLIT = 3072     # ~48 k-steps per workgroup; measured on config 2 (24060 rows): 8 splits beat 4, 12 and 16
 
     @staticmethod
@@ -207,10 +208,30 @@ class _Deferred:
         return s
 
 
-def flush_deferred_wgrads():
+def _wide_plan(problems, cus: int = 256):
+    """Token splits for the 256 x 256-tile launch (st_wgrad_wide): as many as keep the launch within one workgroup per
+    CU - every output tile then takes that many rounds of fp32 atomics (3 on config 2: 72 tiles) - and at least 256
+    tokens per workgroup."""
+    tiles = sum(-(-p[0].shape[1] // 256) * -(-p[5] // 256) for p in problems)
+    rows = min(p[0].shape[0] for p in problems)
+    sp = max(1, min(cus // max(tiles, 1), rows // 256))
+    return [p[:4] + (sp, p[5]) for p in problems]
+
+
+def flush_deferred_wgrads(final: bool = True):
+    """Encoder-sized problems go to the wide-tile kernel, decoder-sized ones to the 128 x 128 grouped launch.
+    final=False (the end of the decoder's backward): the encoder-sized problems collected so far - the decoder's
+    encoder-decoder key/value projections - stay pending and join the encoder's launch, which then has one workgroup
+    per CU at 3 token splits (config 2: 73 + 12 tiles); on their own they are 12 tiles at 21 splits."""
     if _Deferred.pending:
-        nv.wgrad_group(_Deferred.pending)
-        _Deferred.pending.clear()
+        wide = [p for p in _Deferred.pending if p[0].shape[0] >= _Deferred.WIDE_ROWS]
+        rest = [p for p in _Deferred.pending if p[0].shape[0] < _Deferred.WIDE_ROWS]
+        if rest:
+            nv.wgrad_group(rest)
+        if wide and final:
+            nv.wgrad_group(_wide_plan(wide), wide=True)
+            wide = []
+        _Deferred.pending[:] = wide
 
 
 class deferred_wgrads:
@@ -663,7 +684,7 @@ class EmbedFn(torch.autograd.Function):
         s, arena = mod._st, mod._st_arena
         arena.attach_grads(s.emb_params, s.emb_lo, s.emb_hi)
         nv.embed_bwd(tokens, dout.contiguous(), ctx.rows.off, ctx.rows.len, s.pad_idx, s.g_emb)
-        flush_deferred_wgrads()      # the decoder's backward ends here: its deferred weight gradients go out as one launch
+        flush_deferred_wgrads(final=False)      # the decoder's backward ends here: its deferred weight gradients go out as one launch
         arena.grads_ready(s.emb_lo, s.emb_hi)
         return None, None, None, None
 

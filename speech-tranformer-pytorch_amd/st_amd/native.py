@@ -37,6 +37,8 @@ SIGNATURES = {
                    _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_int, _c_long, _c_long],
     "st_wgrad_group": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                        _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "st_wgrad_wide": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                      _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "st_gemm_ln": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
                    _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
                    _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
@@ -309,10 +311,11 @@ def ws_ok(M, N, K):
     return K == 256 and N % 256 == 0 and M >= 12288
 
 
-def wgrad_group(problems):
+def wgrad_group(problems, wide=False):
     """One launch for several weight gradients.  problems: iterable of (X [tokens, K_in] bf16, dY [tokens, N_out]
     bf16, gW f32 [>= N_out, K_in], gB f32 [N_out] or None, splits, N_out) - the argument tuple of
-    ``functional.wgrad``; each is gW[n][k] += sum_m dY[m][n] X[m][k] (and gB[n] += sum_m dY[m][n])."""
+    ``functional.wgrad``; each is gW[n][k] += sum_m dY[m][n] X[m][k] (and gB[n] += sum_m dY[m][n]).
+    wide: the 256 x 256-tile kernel for encoder-sized token counts (st_wgrad_wide) instead of the 128 x 128 one."""
     problems = list(problems)
     n = len(problems)
     if n == 0:
@@ -328,9 +331,10 @@ def wgrad_group(problems):
         X[q], dY[q], dW[q], dB[q] = x.data_ptr(), dy.data_ptr(), gw.data_ptr(), _p(gb)
         ldx[q], lddy[q], lddw[q] = x.stride(0), dy.stride(0), gw.stride(0)
         tokens[q], k_in[q], n_out[q], splits[q] = x.shape[0], x.shape[1], rows, sp
-    _tag("wgrad_group", n, sum(2.0 * pr[0].shape[0] * pr[0].shape[1] * pr[5] for pr in problems))
-    rc = load().st_wgrad_group(_stream(), n, X, ldx, dY, lddy, dW, lddw, dB, tokens, k_in, n_out, splits)
-    _check(rc, "st_wgrad_group")
+    name = "st_wgrad_wide" if wide else "st_wgrad_group"
+    _tag(name[3:], n, sum(2.0 * pr[0].shape[0] * pr[0].shape[1] * pr[5] for pr in problems))
+    rc = getattr(load(), name)(_stream(), n, X, ldx, dY, lddy, dW, lddw, dB, tokens, k_in, n_out, splits)
+    _check(rc, name)
 
 
 def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False, pe=None, pos=None, pre=None,

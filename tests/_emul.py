@@ -122,7 +122,7 @@ def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps):
     p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-float(lr) / bc1)
 
 
-def wgrad_group(problems):
+def wgrad_group(problems, wide=False):
     for x, dy, gw, gb, sp, rows in problems:
         gemm(x, dy, gw, bias=gb, epi=nv.EPI_F32_ATOMIC_T, x_cmajor=True, y_cmajor=True, splits=sp, n=rows)
 

@@ -447,6 +447,27 @@ def test_wgrad_group_matches_individual_launches():
             check(gb, rb, 1e-5, "wgrad_group db problem %d" % q)
 
 
+def test_wgrad_wide_matches_fp32():
+    """st_wgrad_wide (256 x 256 tiles, encoder-sized token counts): dW += dY^T X and db += colsum(dY) against fp32 matmuls
+    of the same bf16 operands - shapes with partial tiles on every axis, 1 .. 7 token splits (also more splits than
+    k-tiles), with / without a bias gradient, more than one launch's worth of problems, accumulation on top of existing
+    gradients."""
+    shapes = [(9000, 768, 256, 3, True), (8200, 256, 256, 7, True), (8300, 1024, 256, 2, True),
+              (8192, 256, 1024, 1, False), (333, 296, 200, 3, True), (50, 520, 256, 5, False),
+              (1000, 264, 72, 4, True)] * 7      # 49 > WIDE_MAX
+    probs, ref = [], []
+    for q, (m, n, k, sp, with_b) in enumerate(shapes):
+        dy, x = g(m, n, seed=10 + q), g(m, k, seed=60 + q)
+        init, b0 = g(n, k, seed=5, dtype=F32), g(1, n, seed=6, dtype=F32).view(-1)
+        probs.append((cu(x), cu(dy), cu(init.clone()), cu(b0.clone()) if with_b else None, sp, n))
+        ref.append((init + dy.float().t() @ x.float(), b0 + dy.float().sum(0)))
+    nv.wgrad_group(probs, wide=True)
+    for q, ((_, _, gw, gb, _, _), (rw, rb)) in enumerate(zip(probs, ref)):
+        check(gw, rw, 2e-5, "wgrad_wide dW problem %d" % q)
+        if gb is not None:
+            check(gb, rb, 2e-5, "wgrad_wide db problem %d" % q)
+
+
 def test_feat_stack_kernel():
     """st_feat_stack (CMVN + frame stacking + subsampling + ragged pack) against the oracle restatement of Dataset.py."""
     from tests import test_features_cpu as tf

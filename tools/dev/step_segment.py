@@ -2,8 +2,14 @@
 consecutive fused-Adam launches in the middle of the timed loop).  usage: step_segment.py <results.db> [adam_index]"""
 import collections, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
-rows = c.execute("select name, start, end from kernels order by start").fetchall()
-adam = [i for i, r in enumerate(rows) if "FusedOptimizerTensorListMeta" in r[0]]
+tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+if "kernels" in tabs:
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+else:       # rocprofv3 >= 7: dispatch + symbol tables
+    kd = [t for t in tabs if "kernel_dispatch" in t][0]
+    ks = [t for t in tabs if "info_kernel_symbol" in t][0]
+    rows = c.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start" % (kd, ks)).fetchall()
+adam = [i for i, r in enumerate(rows) if "FusedOptimizerTensorListMeta" in r[0] or "adam_clip_kernel" in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) // 2
 seg = rows[adam[k] + 1:adam[k + 1] + 1]
 span = (seg[-1][2] - seg[0][1]) / 1e3

@@ -11,7 +11,7 @@ rows = {}
 for db in ("/tmp/pmc2/p_results.db", "/tmp/pmc3/p_results.db"):
     c = sqlite3.connect(db)
     q = ("select kernel_name, grid_size, counter_name, avg(value), avg(duration) from counters_collection "
-         "where kernel_name like '%gemm_sym_kernel%' or kernel_name like '%attn_%kernel%' or kernel_name like '%gemm_ln%' or kernel_name like '%wgrad_group%' or kernel_name like '%row_chain%' "
+         "where kernel_name like '%gemm_sym_kernel%' or kernel_name like '%attn_%kernel%' or kernel_name like '%gemm_ln%' or kernel_name like '%wgrad_group%' or kernel_name like '%wgrad_wide%' or kernel_name like '%row_chain%' "
          "group by kernel_name, grid_size, counter_name")
     for name, grid, cn, val, dur in c.execute(q):
         rows.setdefault((name, grid), {})[cn] = val
