@@ -58,3 +58,49 @@ def test_dropout_hash_statistics():
         kq = em.keep_qk(d, 3, 300, 500)
         assert abs(kq.float().mean().item() - want) < 6e-3
         assert abs((kq == em.keep_qk(d, 4, 300, 500)).float().mean().item() - (want * want + (1 - want) ** 2)) < 8e-3
+
+
+def test_deferred_weight_gradients_split_wide_and_grouped_launches():
+    """Host logic of the deferred weight gradients (st_amd.functional): decoder-sized problems leave with the flush at the
+    end of the decoder's backward, encoder-sized ones stay pending until the final flush and go out as ONE wide-tile
+    launch whose token splits keep it within one workgroup per CU; the results equal the direct launches."""
+    from st_amd import functional as F_
+    from st_amd import native as nv
+    from tests import _emul as em
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g).bfloat16()
+    big, small = F_._Deferred.WIDE_ROWS + 100, 300
+    shapes = [(small, 256, 256), (big, 256, 512), (small, 256, 768), (big, 256, 1024), (big, 1024, 256), (big, 80, 256)]
+    calls = []
+    with em.emulated_kernels():
+        orig = nv.wgrad_group
+
+        def spy(problems, wide=False):
+            problems = list(problems)
+            calls.append((wide, [(p[0].shape[0], p[0].shape[1], p[5], p[4]) for p in problems]))
+            return orig(problems, wide=wide)
+
+        nv.wgrad_group = spy
+        try:
+            outs, refs = [], []
+            with F_.deferred_wgrads(True):
+                for i, (m, k, n) in enumerate(shapes):
+                    x, dy = rnd(m, k), rnd(m, n)
+                    gw, gb = torch.zeros(n, k), torch.zeros(n)
+                    F_.wgrad(dy, x, gw, gB=gb)
+                    outs.append((gw, gb))
+                    refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+                    if i == 2:
+                        F_.flush_deferred_wgrads(final=False)       # what EmbedFn.backward does
+                        assert [c[0] for c in calls] == [False] and len(calls[0][1]) == 2
+                        assert len(F_._Deferred.pending) == 1       # the encoder-sized one waits
+            assert not F_._Deferred.pending
+        finally:
+            nv.wgrad_group = orig
+    assert [c[0] for c in calls] == [False, True]
+    wide = calls[1][1]
+    assert sorted(p[0] for p in wide) == [big] * 4
+    tiles = sum(-(-k // 256) * -(-n // 256) for _, k, n, _ in wide)
+    assert len({p[3] for p in wide}) == 1 and 1 <= wide[0][3] and tiles * wide[0][3] <= 256 < tiles * (wide[0][3] + 1)
+    for (gw, gb), (rw, rb) in zip(outs, refs):
+        assert torch.allclose(gw, rw, rtol=1e-3, atol=1e-2) and torch.allclose(gb, rb, rtol=1e-3, atol=1e-2)
