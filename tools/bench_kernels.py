@@ -103,23 +103,10 @@ if "gemm" in which:
             fl += 2.0 * M * n * k
     us = timeit(lambda: nv.wgrad_group(probs), n=5)
     report("wgrad_group encoder (24 problems)", us, fl, 0.0)
-    # the decoder's weight gradients (config 2: 1206 target rows): 37 problems in one grouped launch
-    for dsp in (1, 2):
-        dprobs, dfl = [], 0.0
-        for (n, k, cnt) in ((256, 256, 18), (768, 256, 6), (1024, 256, 6), (256, 1024, 6), (4344, 256, 1)):
-            for _ in range(cnt):
-                dprobs.append((rnd(Md, k), rnd(Md, n), torch.zeros(n, k, dtype=F32, device=dev), torch.zeros(n, dtype=F32, device=dev), dsp, n))
-                dfl += 2.0 * Md * n * k
-        us = timeit(lambda: nv.wgrad_group(dprobs), n=5)
-        report("wgrad_group decoder (37 problems) splits=%d" % dsp, us, dfl, 0.0)
-        us = timeit(lambda: nv.wgrad_group(dprobs[:18]), n=5)
-        report("wgrad_group decoder (18 x 256x256) splits=%d" % dsp, us, dfl, 0.0)
-        us = timeit(lambda: nv.wgrad_group(dprobs[-1:]), n=5)
-        report("wgrad_group decoder (vocab only) splits=%d" % dsp, us, dfl, 0.0)
-    for sp in (1, 2, 3, 4, 5, 7):
-        wide = [p[:4] + (sp, p[5]) for p in probs]
-        us = timeit(lambda: nv.wgrad_group(wide, wide=True), n=5)
-        report("wgrad_wide  encoder (24 problems) splits=%d" % sp, us, fl, 0.0)
+    from st_amd.functional import _wide_plan
+    wide = _wide_plan(probs)
+    us = timeit(lambda: nv.wgrad_group(wide, wide=True), n=5)
+    report("wgrad_wide  encoder (24 problems, %d token splits)" % wide[0][4], us, fl, 0.0)
 
 if "attn" in which:
     def offs(lens):
