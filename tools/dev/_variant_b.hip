@@ -283,10 +283,7 @@ __device__ __forceinline__ void keep16(const Drop& dr, int bh, int fixed, int va
 // and the two partial softmax states are merged through LDS at the end - half the serial tile chain per workgroup.
 // One workgroup per CU for KS = 2 (its 128-key register stages + the two-term P need > 256 registers: 44 spilled at two
 // per CU; the decoder-encoder attention is <= one workgroup per CU anyway): 21.4 -> 18.6 us, same box.
-// PS: P enters the P V product as two bf16 terms (AttnArgs::psplit).  A template parameter, not a run-time branch: the two
-// paths keep the O accumulators in different registers, and the compiler reconciled them with 64 v_mov_b64 per 64-key
-// tile in the single-term path (a quarter of that loop's VALU instructions).
-template <int DK, bool DROP, int KS, bool PS>
+template <int DK, bool DROP, int KS>
 __global__ __launch_bounds__(256, KS > 1 ? 1 : 2) void attn_fwd_kernel(AttnArgs a) {
   using G = TileGeo<DK, TILE * KS>;
   constexpr int NT = DK / 16;   // k-steps of the QK^T contraction
@@ -402,7 +399,7 @@ __global__ __launch_bounds__(256, KS > 1 ? 1 : 2) void attn_fwd_kernel(AttnArgs 
       for (int hf = 0; hf < 2; ++hf) {
         const bf16x8 pf = pack_acc8(s[kb], 8 * hf);
         const int base = kb * 32 + 16 * hf + 4 * hi;
-        if (PS) {
+        if (a.psplit) {   // (workgroup-uniform)
           bf16x8 pl;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pl[j] = (bf16)(s[kb][8 * hf + j] - (float)pf[j]);
@@ -790,10 +787,8 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
 #define ST_FWD(DKK, DR) \
-  do { if (ks2 && a.psplit) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2, true>), grid, block, 0, stream, a); \
-       else if (ks2) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2, false>), grid, block, 0, stream, a); \
-       else if (a.psplit) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 1, true>), grid, block, 0, stream, a); \
-       else hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 1, false>), grid, block, 0, stream, a); } while (0)
+  do { if (ks2) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a); \
+       else hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a); } while (0)
   if (d_k == 64 && !drop) ST_FWD(64, false);
   else if (d_k == 64) ST_FWD(64, true);
   else if (!drop) ST_FWD(32, false);
