@@ -161,9 +161,15 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
                  int lda,
                  const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
                  float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
-                 void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
+                 unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed,
+                 unsigned drop1_salt,
                  int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
                  int post_blocks, const float* bp, void* P, int ldp);
+
+/* relu_bits (st_row_chain: optional output, st_row_chain_bwd: input): which hidden values of the feed-forward sublayer are
+ * > 0 after ReLU and dropout (the mask of SubLayers.py:25's backward), one bit per value in a layout private to the two
+ * kernels; st_row_chain_mask_words(M, d_ff) 64-bit words.  The backward chain reads these instead of H. */
+int st_row_chain_mask_words(int M, int d_ff);
 
 /* The backward of a row chain in one launch; the chain's stream holds the TRANSPOSED weight blocks (st_wfrag_build table
  * entry [1] = leading dimension | 1 << 32) in the order HEAD | FFN | TAIL:
@@ -177,8 +183,8 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
 int st_row_chain_bwd(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, int head_blocks,
                      const void* dP, int ldp, const void* G, int ldg, const void* xhat_a, const float* rstd_a,
                      const float* gamma_a, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale,
-                     void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a, const void* DS, int d_ff, const void* H,
-                     float mask_scale, void* dH, const void* xhat_b, const float* rstd_b, const float* gamma_b, void* ds_b,
+                     void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a, const void* DS, int d_ff,
+                     const unsigned long long* relu_bits, float mask_scale, void* dH, const void* xhat_b, const float* rstd_b, const float* gamma_b, void* ds_b,
                      float* dgamma_b, float* dbeta_b, float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx,
                      int lddc, float* delta);
 

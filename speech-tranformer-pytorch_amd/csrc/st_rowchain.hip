@@ -46,7 +46,11 @@ struct ChainArgs {
   // FFN
   int nc;                            // d_ff / 256
   const float* b1; const float* b2; const float* g1; const float* be1;
-  bf16* H;                           // [M, d_ff] hidden activation as the backward wants it (after ReLU and dropout1)
+  bf16* H;                           // [M, d_ff] hidden activation (after ReLU and dropout1): the weight gradient's operand
+  unsigned long long* relu_bits;     // optional: which hidden values are > 0, for st_row_chain_bwd - one word per lane, chunk
+                                     // and workgroup in the accumulator layout both kernels share (bit 16 mt + 4 g + e), so the
+                                     // backward chain reads 8 bytes per lane and chunk instead of H (49 MB per encoder layer,
+                                     // as 8-byte pieces scattered over 32 rows per load instruction)
   bf16* out1; bf16* xhat1; float* rstd1;     // ld 256
   DropArgs drop1, drop2;
   // POST
@@ -124,9 +128,11 @@ __device__ __forceinline__ void tile_out(const Ctx<MT>& c, const bf16* t, bf16* 
 }
 
 // acc + bias (+ReLU, dropout) -> bf16 into this wave's 32 columns of an LDS tile
+// bits (optional): this wave's 64 words of ChainArgs::relu_bits for the block
 template <bool RELU, bool DROP, int MT>
 __device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[MT], const float* bias, bf16* t, const Drop& d,
-                                          int gcol0, int ncols) {
+                                          int gcol0, int ncols, unsigned long long* bits = nullptr) {
+  uint32_t pos_lo = 0, pos_hi = 0;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl = c.wave * 32 + 8 * g + 4 * c.hi;
@@ -134,19 +140,25 @@ __device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 32 + c.r;
-      uint32_t bits = 0;
-      if (DROP) bits = d.bits(drop_counter_rc(c.row0 + row, gcol0 + jl, ncols));
+      uint32_t db = 0;
+      if (DROP) db = d.bits(drop_counter_rc(c.row0 + row, gcol0 + jl, ncols));
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = acc[mt][4 * g + e] + bb[e];
         if (RELU) v = fmaxf(v, 0.f);
-        if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+        if (DROP && d.on()) v = d.keep(db, e) ? v * d.scale : 0.f;
         o[e] = (bf16)v;
+        if (RELU) {
+          const int b = mt * 16 + 4 * g + e;
+          if (b < 32) pos_lo |= ((float)o[e] > 0.f ? 1u : 0u) << b;
+          else pos_hi |= ((float)o[e] > 0.f ? 1u : 0u) << (b - 32);
+        }
       }
       *reinterpret_cast<bf16x4*>(t + row * AS + jl) = o;
     }
   }
+  if (RELU && bits != nullptr) bits[c.l] = ((unsigned long long)pos_hi << 32) | pos_lo;
 }
 
 // v = acc + bias + res; LayerNorm over the 256 columns held by the 8 waves; xhat -> t_xhat, (dropped) output -> t_out,
@@ -302,7 +314,8 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
       f32x16 acc1[MT];
       zero_acc(acc1);
       block_mma(c, cur, acc1);
-      epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff);
+      epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff,
+                            a.relu_bits ? a.relu_bits + ((size_t)(blockIdx.x * a.nc + ch) * NW + c.wave) * 64 : nullptr);
       __syncthreads();
       block_mma(c, hc, acc2);
       tile_out(c, hc, a.H + ch * 256, dff);
@@ -355,7 +368,7 @@ struct ChainBwdArgs {
   bf16* ds_a; float* dgamma_a; float* dbeta_a; float* dbias_a;
   const bf16* DS;                    // no HEAD: the chain input [M, 256], ld 256
   // FFN
-  int nc; const bf16* H; float mask_scale; bf16* dH;
+  int nc; const unsigned long long* relu_bits; float mask_scale; bf16* dH;
   const bf16* xhat_b; const float* rstd_b; const float* gamma_b;
   bf16* ds_b; float* dgamma_b; float* dbeta_b; float* dbias_b;
   // TAIL
@@ -540,15 +553,8 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
     zero_acc(acc2);
     for (int ch = 0; ch < a.nc; ++ch) {
       bf16* hc = (ch & 1) ? fb : fa;             // rewritten two chunks later, the next chunk's barrier in between
-      // this lane's ReLU / dropout mask values (H > 0), requested before the MFMAs
-      bf16x4 hv[MT][4];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = min(c.row0 + mt * 32 + c.r, a.M - 1);
-          hv[mt][g] = *reinterpret_cast<const bf16x4*>(a.H + (size_t)row * dff + ch * 256 + c.wave * 32 + 8 * g + 4 * c.hi);
-        }
+      // this lane's ReLU / dropout mask bits of the chunk (st_row_chain wrote them), requested before the MFMAs
+      const unsigned long long relu = a.relu_bits[((size_t)(blockIdx.x * a.nc + ch) * NW + c.wave) * 64 + c.l];
       f32x16 acc1[MT];
       zero_acc(acc1);
       block_mma(c, cur, acc1);                   // ds x W2[:, chunk]: the hidden gradient before the mask
@@ -560,7 +566,9 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bf16 v = (bf16)(acc1[mt][4 * g + e] * a.mask_scale);
-            o[e] = (float)hv[mt][g][e] > 0.f ? v : (bf16)0.f;
+            const int b = mt * 16 + 4 * g + e;
+            const bool on = b < 32 ? (((uint32_t)relu >> b) & 1u) : (((uint32_t)(relu >> 32) >> (b - 32)) & 1u);
+            o[e] = on ? v : (bf16)0.f;
           }
           *reinterpret_cast<bf16x4*>(hc + (mt * 32 + c.r) * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
         }
@@ -669,10 +677,22 @@ extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_
   return 0;
 }
 
+namespace {
+// row tiles per workgroup: the smallest of 1, 2, 3 that gives at most one round of workgroups (256 CUs)
+int row_tiles(int M) { return (M + 31) / 32 <= 256 ? 1 : (M + 63) / 64 <= 256 ? 2 : 3; }
+}  // namespace
+
+// 64-bit words of the relu_bits buffer st_row_chain writes and st_row_chain_bwd reads for M rows and this d_ff
+extern "C" int st_row_chain_mask_words(int M, int d_ff) {
+  if (M <= 0 || d_ff <= 0) return 0;
+  const int mt = row_tiles(M);
+  return ((M + 32 * mt - 1) / (32 * mt)) * (d_ff / 256) * NW * 64;
+}
+
 extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A, int lda,
                             const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
                             float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
-                            void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
+                            unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
                             int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
                             int post_blocks, const float* bp, void* P, int ldp) {
   if (M <= 0) return 0;
@@ -687,7 +707,7 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
   a.A = (const bf16*)A; a.lda = lda; a.R = (const bf16*)R; a.ldr = ldr; a.bo = bo; a.g0 = g0; a.be0 = be0;
   a.out0 = (bf16*)out0; a.xhat0 = (bf16*)xhat0; a.rstd0 = rstd0;
-  a.nc = d_ff / 256; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.H = (bf16*)H; a.out1 = (bf16*)out1; a.xhat1 = (bf16*)xhat1;
+  a.nc = d_ff / 256; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.H = (bf16*)H; a.relu_bits = relu_bits; a.out1 = (bf16*)out1; a.xhat1 = (bf16*)xhat1;
   a.rstd1 = rstd1;
   const bool on1 = ffn && drop_seed && drop1_thresh > 0, on2 = ffn && drop_seed && drop2_thresh > 0;
   a.drop1.seed = on1 ? drop_seed : nullptr; a.drop1.salt = drop1_salt; a.drop1.thresh = on1 ? drop1_thresh : 0;
@@ -695,8 +715,7 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   a.drop2.seed = on2 ? drop_seed : nullptr; a.drop2.salt = drop2_salt; a.drop2.thresh = on2 ? drop2_thresh : 0;
   a.drop2.scale = on2 ? drop2_scale : 1.f;
   a.nb = post_blocks; a.bp = bp; a.P = (bf16*)P; a.ldp = ldp;
-  // row tiles per workgroup: the smallest of 1, 2, 3 that gives at most one round of workgroups (256 CUs)
-  const int mt = (M + 31) / 32 <= 256 ? 1 : (M + 63) / 64 <= 256 ? 2 : 3;
+  const int mt = row_tiles(M);
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
   const bool drop = on1 || on2;
 #define ST_CHAIN(PRE_, FFN_, POST_)                                                                               \
@@ -728,7 +747,8 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
                                 int head_blocks, const void* dP, int ldp, const void* G, int ldg, const void* xhat_a,
                                 const float* rstd_a, const float* gamma_a, const unsigned* drop_seed, unsigned drop_salt,
                                 int drop_thresh, float drop_scale, void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a,
-                                const void* DS, int d_ff, const void* H, float mask_scale, void* dH, const void* xhat_b,
+                                const void* DS, int d_ff, const unsigned long long* relu_bits, float mask_scale, void* dH,
+                                const void* xhat_b,
                                 const float* rstd_b, const float* gamma_b, void* ds_b, float* dgamma_b, float* dbeta_b,
                                 float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta) {
   if (M <= 0) return 0;
@@ -741,7 +761,7 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
     return -2;
   if (!head && head_blocks > 0) return -2;
   if (!head && !DS) return -2;
-  if (ffn && ((d_ff & 255) || !H || !dH || !xhat_b || !rstd_b || !gamma_b || !ds_b)) return -3;
+  if (ffn && ((d_ff & 255) || !relu_bits || !dH || !xhat_b || !rstd_b || !gamma_b || !ds_b)) return -3;
   if (tail && ((ldo & 7) || !dctx || (lddc & 7) || !delta)) return -4;
   if (n_blocks != head_blocks + (ffn ? 2 * (d_ff / 256) : 0) + (tail ? 1 : 0)) return -5;
   ChainBwdArgs a;
@@ -753,11 +773,11 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   a.drop_a.seed = drop ? drop_seed : nullptr; a.drop_a.salt = drop_salt; a.drop_a.thresh = drop ? drop_thresh : 0;
   a.drop_a.scale = drop ? drop_scale : 1.f;
   a.ds_a = (bf16*)ds_a; a.dgamma_a = dgamma_a; a.dbeta_a = dbeta_a; a.dbias_a = dbias_a; a.DS = (const bf16*)DS;
-  a.nc = d_ff / 256; a.H = (const bf16*)H; a.mask_scale = mask_scale > 0.f ? mask_scale : 1.f; a.dH = (bf16*)dH;
+  a.nc = d_ff / 256; a.relu_bits = relu_bits; a.mask_scale = mask_scale > 0.f ? mask_scale : 1.f; a.dH = (bf16*)dH;
   a.xhat_b = (const bf16*)xhat_b; a.rstd_b = rstd_b; a.gamma_b = gamma_b; a.ds_b = (bf16*)ds_b; a.dgamma_b = dgamma_b;
   a.dbeta_b = dbeta_b; a.dbias_b = dbias_b;
   a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
-  const int mt = (M + 31) / 32 <= 256 ? 1 : (M + 63) / 64 <= 256 ? 2 : 3;
+  const int mt = row_tiles(M);
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
 #define ST_BWD(HEAD_, FFN_, TAIL_)                                                                                     \
   do {                                                                                                                 \

@@ -152,7 +152,7 @@ class ChainHub:
 class SubPre:
     """What a sublayer's autograd Function (functional.MhaFn / FfnFn) takes INSTEAD of launching its forward kernels:
     the tensors those kernels would have produced, and the dropout sites that were used."""
-    __slots__ = ("qkv", "kvbuf", "ctx", "ores", "lse", "h", "out", "xhat", "rstd", "drop", "drop1", "drop2", "bwd", "key")
+    __slots__ = ("qkv", "kvbuf", "ctx", "ores", "lse", "h", "bits", "out", "xhat", "rstd", "drop", "drop1", "drop2", "bwd", "key")
 
     def __init__(self):
         for k in self.__slots__:
@@ -198,7 +198,7 @@ class ChainBackward:
         delta = torch.empty(as_.n_head * M, dtype=F32, device=f.out.device)
         scale = f.drop1.scale if f.drop1 is not None and f.drop1.thresh else 1.0
         nv.row_chain_bwd(chain, M, head=head, ds_in=None if head else ds_f,
-                         ffn=(fs.d_ff, f.h, scale, dH, attn_pre.xhat, attn_pre.rstd, as_.gamma, ds_b, as_.g_gamma, as_.g_beta,
+                         ffn=(fs.d_ff, f.bits, scale, dH, attn_pre.xhat, attn_pre.rstd, as_.gamma, ds_b, as_.g_gamma, as_.g_beta,
                               as_.g_b_o),
                          tail=(attn_pre.ctx, attn_pre.ores, dctx, delta))
         self.done[("ffn", l)] = dict(ds=ds_f, dh=dH, dx=ds_b)
@@ -335,11 +335,13 @@ class EncoderChains:
             if need_bwd:
                 a.xhat, a.rstd, f.xhat, f.rstd = E(M, d), E(M, dt=F32), E(M, d), E(M, dt=F32)
             f.drop1, f.drop2 = ff._drops(dev)
+            if need_bwd and self.use_bwd:       # the backward chain masks with these bits instead of reading f.h
+                f.bits = torch.empty(nv.chain_mask_words(M, ff._st.d_ff), dtype=torch.int64, device=dev)
             nxt = layers[l + 1].slf_attn._st if l + 1 < n else None
             qkv = E(M, 3 * d) if nxt is not None else None
             nv.row_chain(a.ctx, self.e[l], pre=(x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
                          ffn=(ff._st.d_ff, ff._st.b1, ff._st.b2, ff._st.gamma, ff._st.beta, f.h, f.out, f.xhat, f.rstd, f.drop1,
-                              f.drop2),
+                              f.drop2, f.bits),
                          post=(3, nxt.b_qkv, qkv) if nxt is not None else None)
             x = f.out
             pres.append((a, f))
@@ -443,11 +445,13 @@ class DecoderChains:
             if need_bwd:
                 b.xhat, b.rstd, f.xhat, f.rstd = E(M, d), E(M, dt=F32), E(M, d), E(M, dt=F32)
             f.drop1, f.drop2 = ff._drops(dev)
+            if need_bwd and self.use_bwd:
+                f.bits = torch.empty(nv.chain_mask_words(M, ff._st.d_ff), dtype=torch.int64, device=dev)
             nxt = layers[l + 1].slf_attn._st if l + 1 < n else None
             qkv = E(M, 3 * d) if nxt is not None else None
             nv.row_chain(b.ctx, self.f2[l], pre=(a.out, ca._st.b_o, ca._st.gamma, ca._st.beta, b.out, b.xhat, b.rstd),
                          ffn=(ff._st.d_ff, ff._st.b1, ff._st.b2, ff._st.gamma, ff._st.beta, f.h, f.out, f.xhat, f.rstd, f.drop1,
-                              f.drop2),
+                              f.drop2, f.bits),
                          post=(3, nxt.b_qkv, qkv) if nxt is not None else None)
             x = f.out
             pres.append((a, b, f))

@@ -46,8 +46,9 @@ SIGNATURES = {
     "st_wfrag_build": [_c_void_p, _c_void_p, _c_int],
     "st_row_chain": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float, _c_int,
-                     _c_void_p, _c_void_p, _c_int],
+                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
+                     _c_int, _c_void_p, _c_void_p, _c_int],
+    "st_row_chain_mask_words": [_c_int, _c_int],
     "st_row_chain_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                          _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
@@ -393,7 +394,8 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
     """One launch for a chain of row-wise layers over decoder-sized row counts (csrc/st_rowchain.hip).
     ``chain``: st_amd.chains.Chain (the fragment streams of this chain's weight blocks); A [M, 256] bf16.
     pre  = (R, bo, gamma, beta, out, xhat, rstd):                 cur = LN(A Wo^T + bo + R)
-    ffn  = (d_ff, b1, b2, gamma, beta, H, out, xhat, rstd, drop1, drop2): cur = drop2(LN(drop1(relu(cur W1^T + b1)) W2^T + b2 + cur))
+    ffn  = (d_ff, b1, b2, gamma, beta, H, out, xhat, rstd, drop1, drop2[, relu_bits]): cur = drop2(LN(drop1(relu(cur W1^T + b1)) W2^T + b2 + cur));
+           relu_bits (int64 [chain_mask_words(M, d_ff)]) receives the H > 0 mask row_chain_bwd reads
     post = (n_blocks_out, bias, P):                               P = cur Wp^T + bias, Wp [256 n_blocks_out, 256]
     xhat / rstd may be None when no backward follows."""
     _mat(A, BF16, "A")
@@ -406,6 +408,9 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
         raise ValueError("row_chain: the fragment stream does not match the chain")
     z = (None,) * 11
     R, bo, g0, be0, out0, xhat0, rstd0 = pre if pre else z[:7]
+    relu_bits = None
+    if ffn and len(ffn) == 12:        # (.., relu_bits): int64 [chain_mask_words(M, d_ff)] for row_chain_bwd
+        relu_bits, ffn = ffn[11], ffn[:11]
     d_ff, b1, b2, g1, be1, H, out1, xhat1, rstd1, drop1, drop2 = ffn if ffn else (0,) + z[:10]
     pb, bp, P = post if post else (0, None, None)
     if pre:
@@ -417,6 +422,7 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
         _vec(g1, F32, d, "g1"), _vec(be1, F32, d, "be1")
         assert H.stride(0) == d_ff and H.shape == (M, d_ff) and out1.stride(0) == d and (xhat1 is None or xhat1.stride(0) == d)
         assert rstd1 is None or (rstd1.dtype == F32 and rstd1.numel() >= M)
+        assert relu_bits is None or (relu_bits.dtype == torch.int64 and relu_bits.is_contiguous() and relu_bits.numel() >= chain_mask_words(M, d_ff))
     if post:
         _mat(P, BF16, "P"), _vec(bp, F32, 256 * pb, "bp")
         assert P.shape == (M, 256 * pb)
@@ -430,9 +436,33 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
     _tag("row_chain", M, n_blocks, d_ff)
     rc = load().st_row_chain(_stream(), M, wfrag.data_ptr(), n_blocks, int(chain.next_blocks), float(eps), A.data_ptr(), A.stride(0), _p(R),
                              0 if R is None else R.stride(0), _p(bo), _p(g0), _p(be0), _p(out0), _p(xhat0), _p(rstd0),
-                             int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
+                             int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(relu_bits), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
                              s1[1], s1[2], s1[3], s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0))
     _check(rc, "st_row_chain")
+
+
+def chain_mask_words(M: int, d_ff: int) -> int:
+    """int64 words of the ReLU-mask buffer a feed-forward row chain over M rows writes (row_chain) and reads (row_chain_bwd)."""
+    return int(load().st_row_chain_mask_words(int(M), int(d_ff)))
+
+
+def relu_bits_from(H):
+    """The relu_bits buffer of a hidden activation H [M, d_ff] that did NOT come out of row_chain (a separate forward, a
+    test): word ((workgroup * d_ff/256 + chunk) * 8 + wave) * 64 + lane, bit 16 mt + 4 g + e  <->  row
+    workgroup * 32 MT + 32 mt + (lane & 31), column 256 chunk + 32 wave + 8 g + 4 (lane >> 5) + e - the accumulator layout
+    of csrc/st_rowchain.hip (MT row tiles per workgroup as st_row_chain picks them for M)."""
+    M, d_ff = H.shape
+    words = chain_mask_words(M, d_ff)
+    nc = d_ff // 256
+    n_wg = words // (nc * 512)
+    mt_n = -(-M // (32 * n_wg))                       # rows per workgroup / 32
+    rows = n_wg * 32 * mt_n
+    pos = torch.zeros(rows, d_ff, dtype=torch.int64, device=H.device)
+    pos[:M] = (H.float() > 0).to(torch.int64)
+    # [wg, mt, r, ch, wave, g, hi, e] -> [wg, ch, wave, hi, r, mt, g, e]
+    v = pos.view(n_wg, mt_n, 32, nc, 8, 4, 2, 4).permute(0, 3, 4, 6, 2, 1, 5, 7).reshape(n_wg * nc * 8 * 64, mt_n * 16)
+    shifts = torch.arange(mt_n * 16, device=H.device, dtype=torch.int64)
+    return (v << shifts).sum(1).contiguous()
 
 
 def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
@@ -442,18 +472,18 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
            dy = dP Wp + G;  ds_out = LayerNorm-backward(dropout-backward(dy)); column sums accumulated atomically
            (n_blocks = 0, dP = None: dy = G - the bare LayerNorm backward of a gradient arriving from outside the stack)
     ds_in: without head, the running gradient [M, 256] the chain starts from
-    ffn  = (d_ff, H, mask_scale, dH, xhat, rstd, gamma, ds_out, dgamma, dbeta, dbias):
-           dH = (ds W2) masked by H > 0, scaled;  ds_out = LayerNorm-backward(dH W1 + ds)
+    ffn  = (d_ff, relu_bits, mask_scale, dH, xhat, rstd, gamma, ds_out, dgamma, dbeta, dbias):
+           dH = (ds W2) masked by H > 0 (the bits the forward chain wrote), scaled;  ds_out = LayerNorm-backward(dH W1 + ds)
     tail = (O, Ores, dctx, delta): dctx = ds Wo, delta[h][i] = sum over head h (64 columns) of dctx (O + Ores)"""
     z = (None,) * 11
     nb, dP, G, xa, ra, ga, drop, dsa, dga, dba, dbia = head if head else (0,) + z[:10]
-    d_ff, H, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn if ffn else (0, None, 1.0) + z[:8]
+    d_ff, bits, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn if ffn else (0, None, 1.0) + z[:8]
     O, Ores, dctx, delta = tail if tail else z[:4]
     n_blocks = nb + (2 * (d_ff // 256) if ffn else 0) + (1 if tail else 0)
     if n_blocks != chain.n_blocks or chain.stream.numel() != 8 * (n_blocks * 16 + wfrag_depth()) * 512:
         raise ValueError("row_chain_bwd: the fragment stream does not match the chain")
     for t, cols, name in ((dP, 256 * nb, "dP"), (G, 256, "G"), (xa, 256, "xhat_a"), (dsa, 256, "ds_a"), (ds_in, 256, "ds_in"),
-                          (H, d_ff, "H"), (dH, d_ff, "dH"), (xb, 256, "xhat_b"), (dsb, 256, "ds_b"), (O, 256, "O"),
+                          (dH, d_ff, "dH"), (xb, 256, "xhat_b"), (dsb, 256, "ds_b"), (O, 256, "O"),
                           (Ores, 256, "Ores"), (dctx, 256, "dctx")):
         if t is not None:
             _mat(t, BF16, name)
@@ -461,7 +491,9 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
                 raise ValueError("row_chain_bwd: %s has shape %s, expected [>= %d, %d]" % (name, tuple(t.shape), M, cols))
     for t, name in ((xa, "xhat_a"), (dsa, "ds_a"), (ds_in, "ds_in"), (xb, "xhat_b"), (dsb, "ds_b")):
         assert t is None or t.stride(0) == 256, name
-    assert (H is None or H.stride(0) == d_ff) and (dH is None or dH.stride(0) == d_ff)
+    assert dH is None or dH.stride(0) == d_ff
+    if ffn and (bits is None or bits.dtype != torch.int64 or not bits.is_contiguous() or bits.numel() < chain_mask_words(M, d_ff)):
+        raise ValueError("row_chain_bwd: relu_bits must be the int64 buffer the forward chain wrote (chain_mask_words(M, d_ff) words)")
     assert O is None or Ores is None or Ores.stride(0) == O.stride(0)
     for v, n, name in ((ra, M, "rstd_a"), (ga, 256, "gamma_a"), (dga, 256, "dgamma_a"), (dba, 256, "dbeta_a"), (dbia, 256, "dbias_a"),
                        (rb, M, "rstd_b"), (gb, 256, "gamma_b"), (dgb, 256, "dgamma_b"), (dbb, 256, "dbeta_b"), (dbib, 256, "dbias_b"),
@@ -474,7 +506,7 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     rc = load().st_row_chain_bwd(
         _stream(), M, chain.stream.data_ptr(), n_blocks, int(chain.next_blocks), int(nb), _p(dP), 0 if dP is None else dP.stride(0),
         _p(G), 0 if G is None else G.stride(0), _p(xa), _p(ra), _p(ga), sd[0], sd[1], sd[2], sd[3], _p(dsa), _p(dga), _p(dba),
-        _p(dbia), _p(ds_in), int(d_ff), _p(H), float(msc), _p(dH), _p(xb), _p(rb), _p(gb), _p(dsb), _p(dgb), _p(dbb), _p(dbib),
+        _p(dbia), _p(ds_in), int(d_ff), _p(bits), float(msc), _p(dH), _p(xb), _p(rb), _p(gb), _p(dsb), _p(dgb), _p(dbb), _p(dbib),
         _p(O), _p(Ores), 0 if O is None else O.stride(0), _p(dctx), 0 if dctx is None else dctx.stride(0), _p(delta))
     _check(rc, "st_row_chain_bwd")
 

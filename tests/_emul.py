@@ -164,6 +164,32 @@ def wfrag_build(table):
     return None       # the emulated chain reads the weight blocks themselves (chains.Chain.blocks)
 
 
+def chain_mask_words(M, d_ff):
+    """The real kernels' buffer size (include/st_hip.h: st_row_chain_mask_words); the emulation packs one bit per hidden
+    value row-major into its first M * d_ff / 64 words."""
+    mt = 1 if (M + 31) // 32 <= 256 else 2 if (M + 63) // 64 <= 256 else 3
+    return ((M + 32 * mt - 1) // (32 * mt)) * (d_ff // 256) * 8 * 64
+
+
+def _pack_bits(mask, out):
+    import numpy as np
+    w = np.packbits(mask.cpu().numpy().astype(np.uint8).reshape(-1), bitorder="little")
+    w = np.concatenate([w, np.zeros((-len(w)) % 8, dtype=np.uint8)]).view(np.int64)
+    out[:len(w)] = torch.from_numpy(w.copy())
+
+
+def _unpack_bits(words, M, d_ff):
+    import numpy as np
+    b = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")[:M * d_ff]
+    return torch.from_numpy(b.astype(np.bool_)).view(M, d_ff)
+
+
+def relu_bits_from(H):
+    out = torch.zeros(chain_mask_words(*H.shape), dtype=torch.int64)
+    _pack_bits(H.float() > 0, out)
+    return out
+
+
 def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
     """csrc/st_rowchain.hip as a composition of the emulated kernels it replaces (same roundings: every intermediate the
     separate kernels round to bf16 is rounded here too)."""
@@ -181,11 +207,14 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
         gemm_ln(A, wo, bo, R[:A.shape[0]], g0, be0, out0, xhat0, rstd0, eps=eps)
         cur = out0
     if ffn:
-        d_ff, b1, b2, g1, be1, H, out1, xhat1, rstd1, drop1, drop2 = ffn
+        relu_bits = ffn[11] if len(ffn) == 12 else None
+        d_ff, b1, b2, g1, be1, H, out1, xhat1, rstd1, drop1, drop2 = ffn[:11]
         ws = take(2 * (d_ff // 256))
         w1 = torch.cat(ws[0::2], 0)
         w2 = torch.cat(ws[1::2], 1)
         gemm(cur, w1, H, bias=b1, epi=nv.EPI_BF16_RELU, drop=drop1)
+        if relu_bits is not None:
+            _pack_bits(H[:A.shape[0]].float() > 0, relu_bits)
         gemm_ln(H, w2, b2, cur, g1, be1, out1, xhat1, rstd1, eps=eps, drop=drop2, drop_where=2 if _on(drop2) else 0)
         cur = out1
     if post:
@@ -214,12 +243,12 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
             ln_bwd(G[:M], xa[:M], ra[:M], ga, dsa[:M], dga, dba, dbia, drop=drop)
         ds = dsa[:M]
     if ffn:
-        d_ff, H, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn
+        d_ff, relu_bits, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn
         ws = take(2 * (d_ff // 256))
         w2 = torch.cat(ws[0::2], 1)                          # [256 (contraction), d_ff]
         w1 = torch.cat(ws[1::2], 0)                          # [d_ff (contraction), 256]
         acc = ds.float() @ w2.float()
-        dH[:M] = ((acc * msc).to(BF16).float() * (H[:M].float() > 0)).to(BF16)
+        dH[:M] = ((acc * msc).to(BF16).float() * _unpack_bits(relu_bits, M, d_ff)).to(BF16)
         gemm_lnbwd(dH[:M], w1, ds, xb, rb[:M], gb, dsb[:M], dgb, dbb, dbib)
         ds = dsb[:M]
     if tail:
@@ -467,7 +496,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "beam_advance", "ce_fwd", "ce_bwd", "decode_self_attn", "embed_step"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "decode_self_attn", "embed_step"]
 
 
 @contextlib.contextmanager

@@ -703,9 +703,11 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
         else:
             ch = chains.Chain(None, len(blocks("cpu")), blocks("cpu"))
             a_in, r_in = A, R
+        if has_ffn and dev == "cuda":
+            o["bits"] = torch.zeros(nv.chain_mask_words(M, dff), dtype=torch.int64, device=dev)
         rc(a_in, ch,
            pre=(r_in, f(bo), f(g0), f(be0), o["out0"], o["xhat0"], o["rstd0"]) if has_pre else None,
-           ffn=(dff, f(b1), f(b2), f(g1), f(be1), o["H"], o["out1"], o["xhat1"], o["rstd1"], d1, d2) if has_ffn else None,
+           ffn=(dff, f(b1), f(b2), f(g1), f(be1), o["H"], o["out1"], o["xhat1"], o["rstd1"], d1, d2, o.get("bits")) if has_ffn else None,
            post=(nb, f(bp), o["P"]) if nb else None)
         return o
 
@@ -713,6 +715,14 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
     names = (["out0", "xhat0", "rstd0"] if has_pre else []) + (["H", "out1", "xhat1", "rstd1"] if has_ffn else []) + (["P"] if nb else [])
     for n in names:
         check(got[n], ref[n], 2e-3 if n.startswith("rstd") else 1e-2, "row_chain %s M=%d: %s" % (variant, M, n))
+    if has_ffn:      # the ReLU-mask bits the backward chain will read == the bits of the H the same launch wrote
+        want = nv.relu_bits_from(got["H"])
+        diff = got["bits"] ^ want
+        nc, n_wg = dff // 256, want.numel() // (dff // 256 * 512)
+        mt = -(-M // (32 * n_wg))
+        sh = torch.arange(mt * 16, device="cuda", dtype=torch.int64)
+        bad = ((diff.unsqueeze(1) >> sh) & 1).view(n_wg, nc, 8, 2, 32, mt, 4, 4).permute(0, 5, 4, 1, 2, 6, 3, 7).reshape(n_wg * mt * 32, dff)
+        assert int(bad[:M].sum()) == 0, "row_chain %s M=%d: relu_bits differ from H > 0 inside the valid rows" % (variant, M)
     if drop:
         _zero_pattern_equal(got["H"], ref["H"], "row_chain dropout1")
         _zero_pattern_equal(got["out1"], ref["out1"], "row_chain dropout2")
@@ -769,7 +779,8 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
         fn(ch, M,
            head=(nb, f(dP) if nb else None, f(G), f(xa), f(ra), f(ga), dr, o["ds_a"], o["dga"], o["dba"], o["dbia"]) if has_head else None,
            ds_in=None if has_head else f(DS),
-           ffn=(dff, f(H), 1.0 / 0.9 if drop else 1.0, o["dH"], f(xb), f(rb), f(gb), o["ds_b"], o["dgb"], o["dbb"], o["dbib"]) if has_ffn else None,
+           ffn=(dff, (nv if dev == "cuda" else em).relu_bits_from(f(H)), 1.0 / 0.9 if drop else 1.0, o["dH"], f(xb), f(rb), f(gb),
+                o["ds_b"], o["dgb"], o["dbb"], o["dbib"]) if has_ffn else None,
            tail=(f(O), f(Ores), o["dctx"], o["delta"]) if has_tail else None)
         return o
 
