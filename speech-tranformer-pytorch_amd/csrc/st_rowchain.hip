@@ -23,6 +23,7 @@
 // sublayer alone 25.5 us as two launches -> 15.9 us, bound by one CU's 64 B/clk vector-memory path (1 MB of weights
 // per workgroup).
 #include "st_common.cuh"
+#include <type_traits>
 
 namespace {
 
@@ -288,8 +289,13 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
   bf16* cur = tiles;             // A
   bf16* f0 = tiles + TE;         // residual, then the first free tile
   bf16* f1 = tiles + 2 * TE;
-  tile_in(c, a.A, a.lda, cur);
-  if (PRE) tile_in(c, a.R, a.ldr, f0);
+  {   // A and the residual are requested together (one global round trip), then stored
+    TileRegs<MT> ra, rr;
+    tile_load(c, a.A, a.lda, ra);
+    if (PRE) tile_load(c, a.R, a.ldr, rr);
+    tile_store(c, ra, cur);
+    if (PRE) tile_store(c, rr, f0);
+  }
   const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
   __syncthreads();
 
@@ -519,17 +525,23 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
 
   if (HEAD) {
     // t0: the dP blocks one after the other, then ds_a; t1: G -> dy; t2: xhat_a
-    if (a.G) tile_in(c, a.G, a.ldg, t1);
-    else {
-#pragma unroll
-      for (int p = 0; p < 2 * MT; ++p) *reinterpret_cast<bf16x8*>(t1 + ((c.tid + p * 512) >> 5) * AS + ((c.tid + p * 512) & 31) * 8) = zero_bf8();
-    }
-    tile_in(c, a.xhat_a, DM, t2);
-    f32x16 acc[MT];
-    zero_acc(acc);
+    // G, xhat_a and the first dP block are requested together (one global round trip, not three), then stored
     // (block u + 1 of dP is requested before the MFMAs on block u and stored after them: its latency is hidden)
     TileRegs<MT> nxt;
-    if (a.nb > 0) tile_load(c, a.dP, a.ldp, nxt);
+    {
+      TileRegs<MT> rg, rx;
+      if (a.G) tile_load(c, a.G, a.ldg, rg);
+      tile_load(c, a.xhat_a, DM, rx);
+      if (a.nb > 0) tile_load(c, a.dP, a.ldp, nxt);
+      if (a.G) tile_store(c, rg, t1);
+      else {
+#pragma unroll
+        for (int p = 0; p < 2 * MT; ++p) *reinterpret_cast<bf16x8*>(t1 + ((c.tid + p * 512) >> 5) * AS + ((c.tid + p * 512) & 31) * 8) = zero_bf8();
+      }
+      tile_store(c, rx, t2);
+    }
+    f32x16 acc[MT];
+    zero_acc(acc);
     for (int u = 0; u < a.nb; ++u) {
       tile_store(c, nxt, t0);
       __syncthreads();
@@ -551,7 +563,10 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
     const int dff = a.nc * 256;
     f32x16 acc2[MT];
     zero_acc(acc2);
-    for (int ch = 0; ch < a.nc; ++ch) {
+    TileRegs<MT> xr;                             // xhat_b on its way to LDS (live in the last chunk only)
+    // one hidden chunk; LAST: xhat_b is requested under the chunk's second block of MFMAs (the last chunk is peeled off the
+    // loop so that its 8 MT registers are not live through the whole loop)
+    auto chunk = [&](int ch, auto last) {
       bf16* hc = (ch & 1) ? fb : fa;             // rewritten two chunks later, the next chunk's barrier in between
       // this lane's ReLU / dropout mask bits of the chunk (st_row_chain wrote them), requested before the MFMAs
       const unsigned long long relu = a.relu_bits[((size_t)(blockIdx.x * a.nc + ch) * NW + c.wave) * 64 + c.l];
@@ -573,13 +588,16 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
           *reinterpret_cast<bf16x4*>(hc + (mt * 32 + c.r) * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
         }
       __syncthreads();
+      if (decltype(last)::value) tile_load(c, a.xhat_b, DM, xr);
       block_mma(c, hc, acc2);                    // dH chunk x W1[chunk, :]
       tile_out(c, hc, a.dH + ch * 256, dff);
-    }
+    };
+    for (int ch = 0; ch + 1 < a.nc; ++ch) chunk(ch, std::false_type{});
+    chunk(a.nc - 1, std::true_type{});
     // dy = acc2 + ds (in place over the ds tile), xhat_b into the tile the last chunk did not use, ds_b into the other
     bf16* tx = (a.nc & 1) ? fb : fa;
     bf16* td = (a.nc & 1) ? fa : fb;
-    tile_in(c, a.xhat_b, DM, tx);                // (tx: last read one chunk earlier, behind the last chunk's barrier)
+    tile_store(c, xr, tx);                       // (tx: last read one chunk earlier, behind the last chunk's barrier)
     __syncthreads();                             // xhat_b visible; every wave is past its MFMAs on the last chunk (td)
     epi_lnbwd<false>(c, acc2, cur, tx, td, a.rstd_b, a.gamma_b, off, red, a.ds_b, a.dgamma_b, a.dbeta_b, a.dbias_b);
     fa = cur; fb = tx; cur = td;

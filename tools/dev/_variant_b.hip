@@ -1,859 +1,805 @@
-// Fused masked scaled-dot-product attention, forward and backward (gfx950).
+// st_rowchain: chains of row-wise layers for decoder-sized row counts as ONE launch.
 //
-// Replaces the score / mask / softmax / context chain of MultiHeadAttention.forward
-// (reference transformer/Attention.py:82-90): S = QK^T / sqrt(d_k), key-padding and
-// causal masking, softmax over keys, context = P V - without ever materialising the
-// [B, h, Lq, Lk] tensors.  The dense masks of transformer/Utils.py:41-70 are replaced
-// by per-utterance lengths: key j of utterance b is masked iff j >= k_len[b]
-// (padding_info_mask) or, when `causal`, j > i (feature_info_mask).
+// With ~1,200 target rows (or 320 beam hypotheses in decode) every GEMM of the decoder is a launch of ~20-40 workgroups
+// whose duration is launch ramp + prologue + epilogue, not arithmetic: a GEMM + LayerNorm costs
+// ~7.7 us before its first k-tile.  Between two attention kernels everything the decoder does is row-wise, so one launch
+// can run it all for a block of rows:
 //
-// Layout: activations are row matrices [rows, ld] (bf16); utterance b owns rows
-// off[b] .. off[b] + len[b] - 1 (packed or padded, the kernel does not care); head h
-// is the column slice [h*DK, (h+1)*DK).  Q, K, V may live in one fused [rows, 3d]
-// projection buffer - each has its own base pointer and leading dimension.
+//   PRE   cur = LN(A Wo^T + bo + R) * g0 + be0                 output_linear + residual + layernorm (Attention.py:92-94)
+//   FFN   h   = dropout1(relu(cur W1^T + b1))                  (SubLayers.py:25)
+//         cur = dropout2(LN(h W2^T + b2 + cur) * g1 + be1)     (SubLayers.py:26-27)
+//   POST  P   = cur Wp^T + bp,  Wp [256 nb, 256]               the next attention's q (nb = 1) or q|k|v (nb = 3) projection
+//                                                              (Attention.py:74-76)
 //
-// All three kernels keep the "row statistics" index on the LANE: scores are computed
-// transposed (S^T = K Q^T, lane = query) in the forward and dQ kernels and as
-// S = Q K^T (lane = key) in the dK/dV kernel, so softmax max/sum, LSE and delta are
-// lane-local and the second MFMA of every pair consumes the first one's accumulator
-// registers directly (pack_acc8) - no P / dS round trip through LDS.
-//
-// Work decomposition: one workgroup (4 waves x 32 rows) per (utterance, head, 128-row tile).  The host
-// passes a WORK LIST of (utterance, tile) pairs sorted by decreasing cost (number of streamed tiles), so the
-// hardware dispatcher - which hands out workgroups in blockIdx order as CUs free up - does longest-first
-// list scheduling over the ragged batch; without a list the kernels enumerate utterance-major.
-//
-// Memory pipeline (same scheme as st_gemm_sym.hip; measured: the kernels are instruction-issue bound, and
-// LDS-DMA tops out at ~10 B/clk/CU): every thread carries 16-byte chunks of the streamed 64-row tiles
-// global -> registers (two tiles in flight) -> padded LDS double buffer, with byte offsets fixed for the whole
-// kernel - the steady-state loop has no address arithmetic, no guards and one barrier per tile.  Rows past
-// the end of a sequence are CLAMPED onto its last row (finite data); the mask path zeroes their weight.
+// each part optional: PRE + POST is what follows the decoder's self-attention, PRE + FFN + POST what follows its
+// encoder-decoder attention (POST being the next layer's q|k|v).  A workgroup owns 32 rows for the whole chain; the
+// activations live in LDS; every intermediate the backward pass reads is also written to HBM exactly as the separate
+// kernels write it.  The weights are STREAMED: all GEMMs are cut into 256 x 256 blocks; each of the 8 waves owns 32
+// output columns of every block and reads exactly the weight fragments it multiplies, in the order it multiplies them,
+// from a per-wave "fragment stream" (st_wfrag_build lays the weight blocks out as 1 KB MFMA A-operand fragments in
+// consumption order): one fully coalesced 1 KB load per MFMA, 16 of them in flight per wave, no LDS staging of
+// weights, no barrier inside a block.  d_ff is walked in chunks of 256 hidden columns (W1 block -> LDS -> W2 block
+// accumulates), so the hidden tile never exceeds 16 KB of LDS.  Measured (M = 1206, d_ff 1024): the feed-forward
+// sublayer alone 25.5 us as two launches -> 15.9 us, bound by one CU's 64 B/clk vector-memory path (1 MB of weights
+// per workgroup).
 #include "st_common.cuh"
 
 namespace {
 
-constexpr int TILE = 64;      // rows (keys or queries) per streamed tile
-constexpr int WG_ROWS = 128;  // rows owned by a workgroup (4 waves x 32)
+constexpr int DM = 256;      // d_model = block edge
+constexpr int AS = DM + 8;   // LDS activation row stride in elements (528 B: conflict-free ds_read_b128 over 16 rows)
+constexpr int DEPTH = 16;    // weight fragments in flight per wave (16 KB): exactly one block ahead
+constexpr int NW = 8;        // waves per workgroup
+constexpr int TOUCH = 8;     // warm-up lines per thread (covers a 12-block chain and the 2-block one behind it from 4 workgroups per XCD up)
 
-struct AttnArgs {
-  const bf16* Q; int ldq;
-  const bf16* K; int ldk;
-  const bf16* V; int ldv;
-  bf16* O; int ldo;               // forward: output; backward: forward output (for delta)
-  bf16* Ores;                     // forward, optional: bf16(O_fp32 - bf16(O_fp32)), same layout as O - with it the
-                                  // backward's delta = rowsum(dO * (O + Ores)) sees O to ~16 mantissa bits
-  const bf16* dO; int lddo;
-  bf16* dQ; int lddq;
-  bf16* dK; int lddk;
-  bf16* dV; int lddv;
-  float* lse;                     // [H][q_rows_total], log2 domain: m + log2(l)
-  float* delta;                   // [H][q_rows_total]
-  const int* q_off; const int* q_len;
-  const int* k_off; const int* k_len;
-  const int* work;                // (b << 16) | tile, sorted by decreasing cost; or null
-  int tiles_max;                  // without a work list: tiles per utterance enumerated
-  int H;
-  int q_rows_total;
-  int causal;
-  int psplit;                     // forward: P enters the P V product as two bf16 terms (hi + lo): the context, and with it
-                                  // the backward's delta = rowsum(dO * O), is then consistent with the fp32 P the backward
-                                  // recomputes - sum_k dS(q, k) = 0 to ~2^-16 instead of ~2^-9 (matters where the keys
-                                  // are nearly identical and dQ / dK are differences of almost equal terms); small-Lq only
-  float scale;                    // 1/sqrt(d_k)
-  DropArgs drop;                  // attention-probability dropout (Attention.py:89), training mode only
+struct ChainArgs {
+  int M;
+  const bf16x8* wfrag;               // this chain's streams: [8 waves][nblocks * 16 + DEPTH fragments][64 lanes]
+  int wave_frags;                    // nblocks * 16 + DEPTH
+  int next_frags;                    // the same of the chain stored right behind this one (0: none): warmed for its launch
+  float eps;
+  const bf16* A; int lda;            // [M, 256]: PRE's GEMM operand (attention context); without PRE the chain input
+  // PRE
+  const bf16* R; int ldr;            // residual [M, 256]
+  const float* bo; const float* g0; const float* be0;
+  bf16* out0; bf16* xhat0; float* rstd0;     // ld 256
+  // FFN
+  int nc;                            // d_ff / 256
+  const float* b1; const float* b2; const float* g1; const float* be1;
+  bf16* H;                           // [M, d_ff] hidden activation (after ReLU and dropout1): the weight gradient's operand
+  unsigned long long* relu_bits;     // optional: which hidden values are > 0, for st_row_chain_bwd - one word per lane, chunk
+                                     // and workgroup in the accumulator layout both kernels share (bit 16 mt + 4 g + e), so the
+                                     // backward chain reads 8 bytes per lane and chunk instead of H (49 MB per encoder layer,
+                                     // as 8-byte pieces scattered over 32 rows per load instruction)
+  bf16* out1; bf16* xhat1; float* rstd1;     // ld 256
+  DropArgs drop1, drop2;
+  // POST
+  int nb; const float* bp; bf16* P; int ldp;
 };
 
-// blockIdx.x -> (utterance, head, tile)
-__device__ __forceinline__ void decode_item(const AttnArgs& a, int bid, int& b, int& h, int& tile) {
-  const int idx = bid / a.H;
-  h = bid % a.H;
-  if (a.work) {
-    const int w = a.work[idx];
-    b = w >> 16;
-    tile = w & 0xffff;
-  } else {
-    b = idx / a.tiles_max;
-    tile = idx % a.tiles_max;
+// fragments in flight per wave: with three row tiles a fragment feeds three MFMAs (it is consumed a third as often), and
+// the registers are needed for the accumulators
+template <int MT> struct Ring { static constexpr int D = MT == 1 ? DEPTH : DEPTH / 2; };
+
+template <int MT> struct Ctx {
+  int tid, wave, l, hi, r, row0, nvalid;
+  const bf16x8* ws;      // wave-uniform stream cursor: the fragment Ring<MT>::D ahead of the next one to be multiplied
+  bf16x8 ring[Ring<MT>::D];
+};
+
+// One 256 x 256 weight block: acc[mt][n = wave*32 + ...][m] (+)= W_block x act^T for the MT row tiles of the workgroup
+// (every weight fragment feeds MT MFMAs), refilling the ring DEPTH fragments ahead.
+template <int MT>
+__device__ __forceinline__ void block_mma(Ctx<MT>& c, const bf16* act, f32x16 (&acc)[MT]) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    bf16x8 xf[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = frag_nat(act, AS, mt * 32 + c.r, ks * 16 + c.hi * 8);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(c.ring[ks % Ring<MT>::D], xf[mt], acc[mt]);
+    c.ring[ks % Ring<MT>::D] = c.ws[ks * 64 + c.l];
+    __builtin_amdgcn_sched_barrier(0);   // keep each refill next to its MFMAs: hoisted refills double the live registers
+  }
+  c.ws += 16 * 64;
+}
+
+template <int MT> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = zero16();
+}
+
+// [32 MT][256] tile: global (rows past M as zeros) -> LDS
+template <int MT>
+__device__ __forceinline__ void tile_in(const Ctx<MT>& c, const bf16* g, int ld, bf16* t) {
+#pragma unroll
+  for (int p = 0; p < 2 * MT; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    *reinterpret_cast<bf16x8*>(t + rr * AS + cc * 8) = gload8(g + (size_t)(c.row0 + rr) * ld + cc * 8, rr < c.nvalid);
+  }
+}
+// the same in two halves, so that the loads fly under a block of MFMAs: global -> registers now, registers -> LDS later
+template <int MT> struct TileRegs { bf16x8 v[2 * MT]; };
+template <int MT>
+__device__ __forceinline__ void tile_load(const Ctx<MT>& c, const bf16* g, int ld, TileRegs<MT>& t) {
+#pragma unroll
+  for (int p = 0; p < 2 * MT; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    t.v[p] = gload8(g + (size_t)(c.row0 + rr) * ld + cc * 8, rr < c.nvalid);
+  }
+}
+template <int MT>
+__device__ __forceinline__ void tile_store(const Ctx<MT>& c, const TileRegs<MT>& t, bf16* lds) {
+#pragma unroll
+  for (int p = 0; p < 2 * MT; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    *reinterpret_cast<bf16x8*>(lds + rr * AS + cc * 8) = t.v[p];
+  }
+}
+// LDS -> global as 512-byte row segments
+template <int MT>
+__device__ __forceinline__ void tile_out(const Ctx<MT>& c, const bf16* t, bf16* g, int ld) {
+#pragma unroll
+  for (int p = 0; p < 2 * MT; ++p) {
+    const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
+    if (rr < c.nvalid)
+      *reinterpret_cast<bf16x8*>(g + (size_t)(c.row0 + rr) * ld + cc * 8) = *reinterpret_cast<const bf16x8*>(t + rr * AS + cc * 8);
   }
 }
 
-// ---- streamed [64 x DK] tiles ----------------------------------------------------------------------
-// LDS image: natural rows, stride DK + 8 elements (144 B / 80 B): ds_read_b128 row fragments over 16 rows
-// and the 4-row groups of ds_read_b64_tr_b16 are both bank-conflict free (DK = 64).
-template <int DK, int ROWS = TILE> struct TileGeo {
-  static constexpr int STR = DK + 8, E = ROWS * STR, CPR = DK / 8, CH = ROWS * CPR / 256;   // CH chunks per thread
-};
-
-template <int DK, int ROWS = TILE>
-struct Stage {
-  using G = TileGeo<DK, ROWS>;
-  bf16x8 v[G::CH];
-  // chunk id = tid + p*256 -> tile row id / CPR, 16-byte chunk id % CPR
-  static __device__ __forceinline__ void offsets(uint32_t (&off)[G::CH], int ld) {
+// acc + bias (+ReLU, dropout) -> bf16 into this wave's 32 columns of an LDS tile
+// bits (optional): this wave's 64 words of ChainArgs::relu_bits for the block
+template <bool RELU, bool DROP, int MT>
+__device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[MT], const float* bias, bf16* t, const Drop& d,
+                                          int gcol0, int ncols, unsigned long long* bits = nullptr) {
+  uint32_t pos_lo = 0, pos_hi = 0;
 #pragma unroll
-    for (int p = 0; p < G::CH; ++p) {
-      const int id = threadIdx.x + p * 256;
-      off[p] = ((uint32_t)(id / G::CPR) * (uint32_t)ld + (id % G::CPR) * 8) * 2u;
+  for (int g = 0; g < 4; ++g) {
+    const int jl = c.wave * 32 + 8 * g + 4 * c.hi;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r;
+      uint32_t db = 0;
+      if (DROP) db = d.bits(drop_counter_rc(c.row0 + row, gcol0 + jl, ncols));
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[mt][4 * g + e] + bb[e];
+        if (RELU) v = fmaxf(v, 0.f);
+        if (DROP && d.on()) v = d.keep(db, e) ? v * d.scale : 0.f;
+        o[e] = (bf16)v;
+        if (RELU) {
+          const int b = mt * 16 + 4 * g + e;
+          if (b < 32) pos_lo |= ((float)o[e] > 0.f ? 1u : 0u) << b;
+          else pos_hi |= ((float)o[e] > 0.f ? 1u : 0u) << (b - 32);
+        }
+      }
+      *reinterpret_cast<bf16x4*>(t + row * AS + jl) = o;
     }
   }
-  // rows r0 .. r0+ROWS-1 of the utterance's column slice `base`; rows >= nvalid read row nvalid-1
-  __device__ __forceinline__ void load(const uint32_t (&off)[G::CH], const bf16* __restrict__ base, int ld, int r0,
-                                       int nvalid) {
-    if (r0 + ROWS <= nvalid) {
-      const char* tb = reinterpret_cast<const char*>(base + (size_t)r0 * ld);
+  if (RELU && bits != nullptr) bits[c.l] = ((unsigned long long)pos_hi << 32) | pos_lo;
+}
+
+// v = acc + bias + res; LayerNorm over the 256 columns held by the 8 waves; xhat -> t_xhat, (dropped) output -> t_out,
+// both then leave for HBM.  Two workgroup barriers inside, one before the copies out: on return t_out is complete.
+template <bool DROP, int MT>
+__device__ __forceinline__ void epi_ln(const Ctx<MT>& c, f32x16 (&acc)[MT], const float* bias, const bf16* res, const float* gamma,
+                                       const float* beta, float eps, const Drop& d, bf16* t_xhat, bf16* t_out,
+                                       float (*red)[NW * 32 * MT], bf16* g_out, bf16* g_xhat, float* g_rstd) {
+  const int j0 = c.wave * 32;
+  float sum[MT], sq[MT], mean[MT], rstd[MT];
 #pragma unroll
-      for (int p = 0; p < G::CH; ++p) v[p] = *reinterpret_cast<const bf16x8*>(tb + off[p]);
-    } else {
+  for (int mt = 0; mt < MT; ++mt) sum[mt] = 0.f;
 #pragma unroll
-      for (int p = 0; p < G::CH; ++p) {
-        const int id = threadIdx.x + p * 256;
-        const int row = min(r0 + id / G::CPR, nvalid - 1);
-        v[p] = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + (id % G::CPR) * 8);
+  for (int g = 0; g < 4; ++g) {
+    const int jl = j0 + 8 * g + 4 * c.hi;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + (mt * 32 + c.r) * AS + jl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[mt][4 * g + e] + bb[e] + (float)rr[e];
+        acc[mt][4 * g + e] = v;
+        sum[mt] += v;
       }
     }
   }
-  __device__ __forceinline__ void store(bf16* tile) const {
 #pragma unroll
-    for (int p = 0; p < G::CH; ++p) {
-      const int id = threadIdx.x + p * 256;
-      *reinterpret_cast<bf16x8*>(tile + (id / G::CPR) * G::STR + (id % G::CPR) * 8) = v[p];
-    }
+  for (int mt = 0; mt < MT; ++mt) {
+    sum[mt] += wave_xor32(sum[mt]);
+    if (c.hi == 0) red[0][(c.wave * MT + mt) * 32 + c.r] = sum[mt];
   }
-};
-
-// Row fragment: elements t16*16 + hi*8 .. +7 of tile row R (A or B operand, contraction along DK).
-template <int DK>
-__device__ __forceinline__ bf16x8 rd_nat(const bf16* tile, int R, int t16) {
-  const int hi = (threadIdx.x & 63) >> 5;
-  return frag_nat(tile, TileGeo<DK>::STR, R, t16 * 16 + hi * 8);
-}
-// Transposing fragment: for column d0 + (lane & 31), the 8 tile rows base+0..3 and base+8..11
-// (base already includes 4*hi) - the contraction runs over the tile's ROWS.
-template <int DK>
-__device__ __forceinline__ bf16x8 rd_tr(const bf16* tile, int d0, int base) {
-  return frag_tr(tile, TileGeo<DK>::STR, d0, base, base + 8);
-}
-
-// The software pipeline shared by the three kernels.  load(set, tile) fills register set `set`,
-// store(set) writes it to LDS buffer `set`, compute(buf, tile) consumes LDS buffer `buf`.
-// Steady state has no conditionals, so the compiler's s_waitcnt vmcnt() stays counted: the loads of
-// tile it+2 remain in flight across the LDS store of tile it+1.
-template <typename L, typename S, typename C>
-__device__ __forceinline__ void stream_tiles(int ntiles, L load, S store, C compute) {
-  if (ntiles <= 0) return;   // (workgroup-uniform) nothing visible: the accumulators stay zero
-  load(0, 0);
-  if (ntiles > 1) load(1, 1);
-  store(0);
   __syncthreads();
-  int it = 0;
-  for (; it + 3 < ntiles; it += 2) {
-    load(0, it + 2);
-    compute(0, it);
-    store(1);
-    __syncthreads();
-    load(1, it + 3);
-    compute(1, it + 1);
-    store(0);
-    __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[0][(w * MT + mt) * 32 + c.r];
+    mean[mt] = s * (1.f / DM);
+    sq[mt] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float dv = acc[mt][q] - mean[mt];
+      sq[mt] += dv * dv;
+    }
+    sq[mt] += wave_xor32(sq[mt]);
+    if (c.hi == 0) red[1][(c.wave * MT + mt) * 32 + c.r] = sq[mt];
   }
-  // tail: 1..3 tiles left; tile `it` is in LDS buffer 0, tile it+1 (if any) in register set 1
-  if (it + 2 < ntiles) load(0, it + 2);
-  compute(0, it);
-  if (it + 1 < ntiles) {
-    store(1);
-    __syncthreads();
-    compute(1, it + 1);
-    if (it + 2 < ntiles) {
-      store(0);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[1][(w * MT + mt) * 32 + c.r];
+    rstd[mt] = rsqrtf(s * (1.f / DM) + eps);
+    if (g_rstd && c.wave == 0 && c.hi == 0 && mt * 32 + c.r < c.nvalid) g_rstd[c.row0 + mt * 32 + c.r] = rstd[mt];
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int jl = j0 + 8 * g + 4 * c.hi;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + jl);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + jl);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r;
+      uint32_t bits = 0;
+      if (DROP) bits = d.bits(drop_counter_rc(c.row0 + row, jl, DM));
+      bf16x4 xh, o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float n = (acc[mt][4 * g + e] - mean[mt]) * rstd[mt];
+        float v = n * g4[e] + b4[e];
+        if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+        xh[e] = (bf16)n;
+        o[e] = (bf16)v;
+      }
+      *reinterpret_cast<bf16x4*>(t_xhat + row * AS + jl) = xh;
+      *reinterpret_cast<bf16x4*>(t_out + row * AS + jl) = o;
+    }
+  }
+  __syncthreads();
+  if (g_xhat) tile_out(c, t_xhat, g_xhat, DM);
+  tile_out(c, t_out, g_out, DM);
+}
+
+// MT = row tiles of 32 per workgroup.  1: decoder-sized row counts (as many workgroups as possible).  2: in between (a
+// strong-scaling shard of the batch).  3: encoder-sized
+// ones (24,060 rows = 251 workgroups = one round of the 256 CUs; every weight fragment feeds three MFMAs, so a
+// workgroup's MFMA time matches its weight stream; three 50 KB activation tiles fill the LDS).
+template <bool PRE, bool FFN, bool POST, bool DROP, int MT>
+__global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
+  constexpr int RB = 32 * MT, TE = RB * AS;
+  // three activation tiles: `cur` (the running activation) and two free ones that serve, in turn, as residual, hidden
+  // chunks, xhat and output staging.  A tile is rewritten only after a workgroup barrier that every wave reaches after its
+  // last read of it (the comments at each site name that barrier).
+  __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
+  __shared__ float red[2][NW * 32 * MT];
+  Ctx<MT> c;
+  c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
+  c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
+  c.ws = a.wfrag + (size_t)c.wave * a.wave_frags * 64;   // wave-uniform: the loads take an SGPR base + lane offset
+#pragma unroll
+  for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];   // the first fragments go out before anything else
+  c.ws += Ring<MT>::D * 64;
+  // Warm the L2 of this workgroup's XCD with the WHOLE chain's streams - and those of the chain that runs next (they lie
+  // right behind in st_amd.chains' buffer; an attention kernel runs in between): the streams are read once per step, so
+  // a wave's 16 KB in flight would otherwise meet the HBM latency block after block (cold caches, M = 1206: 40.4 us for
+  // the 12-block chain against 22.6 us with the streams cached; 32.8 us with its own lines touched up front).  The
+  // workgroups that share an XCD (dispatch is round-robin over the 8 XCDs) deal the 128-byte lines among their threads;
+  // the values are only consumed at the very end.  MT = 3 (hundreds of workgroups, ~31 per XCD, all starting at the same
+  // fragment): one line per thread covers the chain's own streams - without it every workgroup of an XCD waits for the
+  // same HBM fetches block after block (the stream runs at the latency-bound rate of a single requester).
+  constexpr int NTOUCH = MT == 1 ? TOUCH : 1;
+  int touched[NTOUCH];
+  {
+    const int nlines = NW * (a.wave_frags + (MT == 1 ? a.next_frags : 0)) * 8;
+    const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
+    const char* sb = reinterpret_cast<const char*>(a.wfrag);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NTOUCH; ++t) {
+      const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
+      touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* cur = tiles;             // A
+  bf16* f0 = tiles + TE;         // residual, then the first free tile
+  bf16* f1 = tiles + 2 * TE;
+  tile_in(c, a.A, a.lda, cur);
+  if (PRE) tile_in(c, a.R, a.ldr, f0);
+  const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
+  __syncthreads();
+
+  if (PRE) {
+    f32x16 acc[MT];
+    zero_acc(acc);
+    block_mma(c, cur, acc);
+    // xhat is staged in the A tile (every wave is past its MFMAs on it at epi_ln's first barrier), the output in f1
+    epi_ln<false>(c, acc, a.bo, f0, a.g0, a.be0, a.eps, off, cur, f1, red, a.out0, a.xhat0, a.rstd0);
+    // now: cur = f1; free: f0 (the residual: last read before epi_ln's barriers) and, one barrier later, the A tile (xhat0 is
+    // still being copied out of it)
+    bf16* t = cur; cur = f1; f1 = t;
+  }
+  if (FFN) {
+    const int dff = a.nc * 256;
+    f32x16 acc2[MT];
+    zero_acc(acc2);
+    for (int ch = 0; ch < a.nc; ++ch) {
+      // hidden chunks alternate f0, f1; chunk ch's tile is rewritten by chunk ch + 2 with the barrier of chunk ch + 1 in
+      // between; f1's first use (chunk 1) lies behind chunk 0's barrier, which every wave reaches after PRE's copies out
+      bf16* hc = (ch & 1) ? f1 : f0;
+      f32x16 acc1[MT];
+      zero_acc(acc1);
+      block_mma(c, cur, acc1);
+      epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff,
+                            a.relu_bits ? a.relu_bits + ((size_t)(blockIdx.x * a.nc + ch) * NW + c.wave) * 64 : nullptr);
       __syncthreads();
-      compute(0, it + 2);
+      block_mma(c, hc, acc2);
+      tile_out(c, hc, a.H + ch * 256, dff);
+    }
+    // xhat goes to the tile the LAST chunk did not use (last read one chunk earlier), the output replaces cur in place
+    // (its residual reads precede epi_ln's barriers, its MFMA reads too)
+    bf16* tx = (a.nc & 1) ? f1 : f0;
+    epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, tx, cur, red, a.out1, a.xhat1, a.rstd1);
+    if (tx == f0) { f0 = f1; f1 = tx; }      // f0 = the tile free right now, f1 = xhat (still being copied out)
+  }
+  if (POST) {
+    for (int u = 0; u < a.nb; ++u) {
+      // staging alternates f0, f1: f0 is free (see above), f1 one barrier later; a tile is rewritten two blocks later
+      bf16* st = (u & 1) ? f1 : f0;
+      f32x16 acc[MT];
+      zero_acc(acc);
+      block_mma(c, cur, acc);
+      epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0);
+      __syncthreads();
+      tile_out(c, st, a.P + u * 256, a.ldp);
     }
   }
-  __syncthreads();   // the epilogue reuses the tile buffers
+  {
+    int tsum = 0;
+#pragma unroll
+    for (int t = 0; t < NTOUCH; ++t) tsum ^= touched[t];
+    if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;      // (never true: keeps the warm-up loads alive)
+  }
 }
 
-// Store a transposed accumulator tile (lane = row, registers = DK columns) as coalesced rows:
-// through a wave-private [32][DK] LDS patch so HBM sees whole DK*2-byte row segments instead of
-// 64 scattered 8-byte writes per instruction.  `patch` is this wave's private 32*DK elements.
-template <int DK, bool RESID = false>
-__device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float mul, bf16* gbase, int ld, int row0,
-                                           int nvalid_rows) {
-  constexpr int ND = DK / 32, CPR = DK / 8;
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+// =====================================================================================================================
+// Backward chains: the same row blocks, weight blocks read transposed (st_wfrag_build), in the reverse order of the
+// forward chain:
+//
+//   HEAD  dy = sum_u dP[:, 256u..] Wp_u + G                      the data gradient of the NEXT attention's projection(s)
+//         ds_a = LayerNorm-backward(dropout-backward(dy); xhat_a, rstd_a, gamma_a)      (== st_gemm_lnbwd)
+//         dgamma_a += sum_rows dy xhat,  dbeta_a += sum_rows dy,  dbias_a += sum_rows ds_a
+//   FFN   dH = (ds W2) masked by H > 0, x mask_scale              (== st_gemm EPI_BF16_MASK; SubLayers.py:25-26 backward)
+//         dy = dH W1 + ds;  ds_b = LayerNorm-backward(dy; xhat_b, rstd_b, gamma_b) and its three column sums
+//   TAIL  dctx = ds Wo;  delta[h][i] = sum over head h of dctx (O + Ores)        (== st_gemm EPI_BF16_DELTA)
+//
+// (ds = the running gradient: HEAD's ds_a, else the input DS).  HEAD + TAIL follows the decoder-encoder attention's
+// backward kernel, HEAD + FFN + TAIL the self-attention's (decoder: of the next layer; encoder likewise).
+struct ChainBwdArgs {
+  int M;
+  const bf16x8* wfrag; int wave_frags; int next_frags;
+  // HEAD
+  int nb; const bf16* dP; int ldp; const bf16* G; int ldg;
+  const bf16* xhat_a; const float* rstd_a; const float* gamma_a; DropArgs drop_a;
+  bf16* ds_a; float* dgamma_a; float* dbeta_a; float* dbias_a;
+  const bf16* DS;                    // no HEAD: the chain input [M, 256], ld 256
+  // FFN
+  int nc; const unsigned long long* relu_bits; float mask_scale; bf16* dH;
+  const bf16* xhat_b; const float* rstd_b; const float* gamma_b;
+  bf16* ds_b; float* dgamma_b; float* dbeta_b; float* dbias_b;
+  // TAIL
+  const bf16* O; const bf16* Ores; int ldo; bf16* dctx; int lddc; float* delta;
+};
+
+// LayerNorm backward over the 256 columns held by the 8 waves.  acc = the GEMM result; t_aux holds the addend and receives
+// dy (bf16, rounded once as acc + addend, before the dropout mask) in place; t_xhat the saved normalised values; dx goes
+// to t_dx and to HBM; then the three column sums (256 columns x the block's rows, two threads per column) are added
+// atomically.  Barriers: two for the row sums, one before the column pass / copy out; the caller needs one more before
+// t_aux / t_xhat are rewritten.
+template <bool DROP, int MT>
+__device__ __forceinline__ void epi_lnbwd(const Ctx<MT>& c, f32x16 (&acc)[MT], bf16* t_aux, const bf16* t_xhat, bf16* t_dx,
+                                          const float* g_rstd, const float* gamma, const Drop& d, float (*red)[NW * 32 * MT],
+                                          bf16* g_dx, float* dgamma, float* dbeta, float* dbias) {
+  const int j0 = c.wave * 32;
+  float s1[MT], s2[MT];
 #pragma unroll
-  for (int d = 0; d < ND; ++d)
+  for (int mt = 0; mt < MT; ++mt) s1[mt] = s2[mt] = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 v;
+  for (int g = 0; g < 4; ++g) {
+    const int jl = j0 + 8 * g + 4 * c.hi;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + jl);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r, at = row * AS + jl;
+      const bf16x4 xh4 = *reinterpret_cast<const bf16x4*>(t_xhat + at);
+      const bf16x4 ad4 = *reinterpret_cast<const bf16x4*>(t_aux + at);
+      uint32_t bits = 0;
+      if (DROP) bits = d.bits(drop_counter_rc(c.row0 + row, jl, DM));   // the mask the forward drew on this LayerNorm's output
+      bf16x4 dy4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float x = acc[d][4 * g + e] * mul;
-        v[e] = RESID ? (bf16)(x - (float)(bf16)x) : (bf16)x;      // RESID: what the bf16 rounding of x dropped
+        dy4[e] = (bf16)(acc[mt][4 * g + e] + (float)ad4[e]);       // one rounding, as st_gemm_lnbwd
+        float v = (float)dy4[e];
+        if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
+        const float gg = v * g4[e];
+        acc[mt][4 * g + e] = gg;                                    // keep g = dy * gamma
+        s1[mt] += gg;
+        s2[mt] += gg * (float)xh4[e];
       }
-      const int col = d * 32 + 8 * g + 4 * hi;
-      *reinterpret_cast<bf16x4*>(patch + r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7)) = v;
+      *reinterpret_cast<bf16x4*>(t_aux + at) = dy4;
     }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < 32 * CPR / 64; ++p) {
-    const int id = p * 64 + l, rr = id / CPR, c = id % CPR;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rr * DK + ((c ^ (rr & (CPR - 1))) << 3));
-    if (rr < nvalid_rows) *reinterpret_cast<bf16x8*>(gbase + (size_t)(row0 + rr) * ld + c * 8) = v;
   }
-}
-
-// The same for a value AND what its bf16 rounding dropped (O, Ores), in ONE pass: both images are written to two
-// patches, one LDS wait, both are read back and stored - half the dependent LDS round trips of two store_rows calls
-// (the attention epilogue is a latency tail: every wave of the workgroup is in it at the same time).
-template <int DK>
-__device__ __forceinline__ void store_rows_pair(bf16* patch_hi, bf16* patch_lo, const f32x16* acc, float mul, bf16* g_hi,
-                                                bf16* g_lo, int ld, int row0, int nvalid_rows) {
-  constexpr int ND = DK / 32, CPR = DK / 8;
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
 #pragma unroll
-  for (int d = 0; d < ND; ++d)
+  for (int mt = 0; mt < MT; ++mt) {
+    s1[mt] += wave_xor32(s1[mt]);
+    s2[mt] += wave_xor32(s2[mt]);
+    if (c.hi == 0) {
+      red[0][(c.wave * MT + mt) * 32 + c.r] = s1[mt];
+      red[1][(c.wave * MT + mt) * 32 + c.r] = s2[mt];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      a1 += red[0][(w * MT + mt) * 32 + c.r];
+      a2 += red[1][(w * MT + mt) * 32 + c.r];
+    }
+    const int row = mt * 32 + c.r;
+    const float m1 = a1 * (1.f / DM), m2 = a2 * (1.f / DM), rs = row < c.nvalid ? g_rstd[c.row0 + row] : 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 vh, vl;
+      const int jl = j0 + 8 * g + 4 * c.hi, at = row * AS + jl;
+      const bf16x4 xh4 = *reinterpret_cast<const bf16x4*>(t_xhat + at);
+      bf16x4 dx4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = acc[d][4 * g + e] * mul;
-        vh[e] = (bf16)x;
-        vl[e] = (bf16)(x - (float)vh[e]);
-      }
-      const int col = d * 32 + 8 * g + 4 * hi;
-      const int at = r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7);
-      *reinterpret_cast<bf16x4*>(patch_hi + at) = vh;
-      *reinterpret_cast<bf16x4*>(patch_lo + at) = vl;
+      for (int e = 0; e < 4; ++e) dx4[e] = (bf16)(rs * (acc[mt][4 * g + e] - m1 - (float)xh4[e] * m2));
+      *reinterpret_cast<bf16x4*>(t_dx + at) = dx4;
     }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < 32 * CPR / 64; ++p) {
-    const int id = p * 64 + l, rr = id / CPR, c = id % CPR;
-    const int at = rr * DK + ((c ^ (rr & (CPR - 1))) << 3);
-    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(patch_hi + at);
-    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(patch_lo + at);
-    if (rr < nvalid_rows) {
-      *reinterpret_cast<bf16x8*>(g_hi + (size_t)(row0 + rr) * ld + c * 8) = vh;
-      *reinterpret_cast<bf16x8*>(g_lo + (size_t)(row0 + rr) * ld + c * 8) = vl;
+  }
+  __syncthreads();
+  tile_out(c, t_dx, g_dx, DM);
+  // column sums: thread = (column, half of the rows); the upper half hands its sums over through LDS (red is free: the row
+  // sums were consumed before the barrier above), so a workgroup issues ONE atomic per column and quantity - the adds of
+  // all workgroups to one address serialise in the L2 (measured at 251 workgroups: 17 us of a 94 us launch with two)
+  {
+    const int col = c.tid & 255, half = c.tid >> 8, rows = 16 * MT;
+    float cg = 0.f, cb = 0.f, cx = 0.f;
+    for (int i = 0; i < rows; ++i) {
+      const int row = half * rows + i;
+      float v = (float)t_aux[row * AS + col];
+      if (DROP && d.on()) {
+        const uint32_t bits = d.bits(drop_counter_rc(c.row0 + row, col & ~3, DM));
+        v = d.keep(bits, col & 3) ? v * d.scale : 0.f;
+      }
+      cb += v;
+      cg += v * (float)t_xhat[row * AS + col];
+      cx += (float)t_dx[row * AS + col];
+    }
+    float* xch = &red[0][0];          // 2 * NW * 32 * MT >= 768 floats for MT >= 2; MT = 1: 512 -> two rounds
+    if (MT >= 2) {
+      if (half) { xch[col] = cg; xch[256 + col] = cb; xch[512 + col] = cx; }
+      __syncthreads();
+      if (!half) {
+        if (dgamma) atomicAdd(dgamma + col, cg + xch[col]);
+        if (dbeta) atomicAdd(dbeta + col, cb + xch[256 + col]);
+        if (dbias) atomicAdd(dbias + col, cx + xch[512 + col]);
+      }
+    } else {
+      if (half) { xch[col] = cg; xch[256 + col] = cb; }
+      __syncthreads();
+      if (!half) {
+        if (dgamma) atomicAdd(dgamma + col, cg + xch[col]);
+        if (dbeta) atomicAdd(dbeta + col, cb + xch[256 + col]);
+      }
+      __syncthreads();
+      if (half) xch[col] = cx;
+      __syncthreads();
+      if (!half && dbias) atomicAdd(dbias + col, cx + xch[col]);
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Forward.  Each wave owns 32 query rows (lane & 31); key / value tiles are streamed.
-// ---------------------------------------------------------------------------------------------
-// Keep decisions of one lane's 16 accumulator registers: register r <-> pair (fixed, var0 + acc_row(r, hi)).
-// FIXED_IS_Q: the lane's own index is the query (forward / dQ: registers run over keys), else it is the key.
-template <bool FIXED_IS_Q>
-__device__ __forceinline__ void keep16(const Drop& dr, int bh, int fixed, int var0, int hi, bool (&keep)[16]) {
-  // Lanes l and l ^ 1 hold neighbouring fixed indices (2f, 2f + 1: tile origins are even) and therefore need the SAME
-  // eight hashes (a 2 x 2 block serves both).  Each computes four - the even lane register groups g = 0, 1, the odd
-  // lane g = 2, 3 - and fetches the other four from its neighbour with a DPP move (the hash costs two quarter-rate
-  // v_mul_lo_u32; this halves what dropout adds to the VALU-bound softmax).
-  const int par = threadIdx.x & 1, fx = fixed & 1;
-  uint32_t own[4], nb[4];
+template <bool HEAD, bool FFN, bool TAIL, bool DROP, int MT>
+__global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
+  constexpr int RB = 32 * MT, TE = RB * AS;
+  __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
+  __shared__ float red[2][NW * 32 * MT];
+  Ctx<MT> c;
+  c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
+  c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
+  c.ws = a.wfrag + (size_t)c.wave * a.wave_frags * 64;
 #pragma unroll
-  for (int gi = 0; gi < 2; ++gi)
+  for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
+  c.ws += Ring<MT>::D * 64;
+  constexpr int NTOUCH = MT == 1 ? TOUCH : 1;
+  int touched[NTOUCH];
+  {       // warm-up of this (and, at decoder size, the next) chain's streams: see row_chain_kernel
+    const int nlines = NW * (a.wave_frags + (MT == 1 ? a.next_frags : 0)) * 8;
+    const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
+    const char* sb = reinterpret_cast<const char*>(a.wfrag);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int v = var0 + 8 * (2 * par + gi) + 4 * hi + 2 * hb;
-      own[gi * 2 + hb] = FIXED_IS_Q ? dr.bits(drop_counter_qk(bh, fixed, v)) : dr.bits(drop_counter_qk(bh, v, fixed));
+    for (int t = 0; t < NTOUCH; ++t) {
+      const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
+      touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* t0 = tiles; bf16* t1 = tiles + TE; bf16* t2 = tiles + 2 * TE;
+  const Drop da = make_drop(a.drop_a), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
+  bf16* cur;          // the running gradient ds
+  bf16 *fa, *fb;      // the two other tiles
+
+  if (HEAD) {
+    // t0: the dP blocks one after the other, then ds_a; t1: G -> dy; t2: xhat_a
+    if (a.G) tile_in(c, a.G, a.ldg, t1);
+    else {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) nb[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)own[j], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = (g & 1) * 2 + hb;
-      uint32_t bits = ((g >> 1) == par) ? own[j] : nb[j];
-      // byte of (q, k) inside its block = 2 * (q & 1) + (k & 1); this lane's two elements differ in the variable index
-      bits >>= FIXED_IS_Q ? 16 * fx : 8 * fx;
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-        keep[4 * g + 2 * hb + e] = (int)((bits >> (FIXED_IS_Q ? 8 * e : 16 * e)) & 0xffu) >= dr.thresh;
+      for (int p = 0; p < 2 * MT; ++p) *reinterpret_cast<bf16x8*>(t1 + ((c.tid + p * 512) >> 5) * AS + ((c.tid + p * 512) & 31) * 8) = zero_bf8();
     }
-}
-
-// KS = 2 ("few queries, many keys": the decoder-encoder attention, <= 64 queries against ~1000 keys): the workgroup
-// owns 64 query rows and streams 128-key stages; waves 0,1 take the first 64 keys of a stage, waves 2,3 the second
-// and the two partial softmax states are merged through LDS at the end - half the serial tile chain per workgroup.
-// One workgroup per CU for KS = 2 (its 128-key register stages + the two-term P need > 256 registers: 44 spilled at two
-// per CU; the decoder-encoder attention is <= one workgroup per CU anyway): 21.4 -> 18.6 us, same box.
-template <int DK, bool DROP, int KS>
-__global__ __launch_bounds__(256, KS > 1 ? 1 : 2) void attn_fwd_kernel(AttnArgs a) {
-  using G = TileGeo<DK, TILE * KS>;
-  constexpr int NT = DK / 16;   // k-steps of the QK^T contraction
-  constexpr int ND = DK / 32;   // 32-wide output column tiles
-  constexpr int ROWS = TILE * KS, QROWS = WG_ROWS / KS;
-  __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];   // 2 buffers x (K tile, V tile)
-
-  int b, h, tile;
-  decode_item(a, blockIdx.x, b, h, tile);
-  const int lq = a.q_len[b], lk = a.k_len[b];
-  const int q0 = tile * QROWS;
-  if (q0 >= lq) return;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
-  const int qw = KS > 1 ? (wave & 1) : wave, kp = KS > 1 ? (wave >> 1) : 0;   // query block, key half
-  const int q = q0 + qw * 32 + (l & 31);
-  const bool q_ok = q < lq;
-  const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
-  const float c2 = a.scale * 1.4426950408889634f;  // scores -> log2 domain
-  const Drop dr = make_drop(a.drop);
-  const int bh = b * a.H + h;
-
-  const int k_hi = a.causal ? min(lk, q0 + QROWS) : lk;   // keys this workgroup can see
-  const int ntiles = (k_hi + ROWS - 1) / ROWS;
-  const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;
-  const bf16* vbase = a.V + (size_t)a.k_off[b] * a.ldv + h * DK;
-
-  bf16x8 qf[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8);
-
-  uint32_t offk[G::CH], offv[G::CH];
-  Stage<DK, ROWS>::offsets(offk, a.ldk);
-  Stage<DK, ROWS>::offsets(offv, a.ldv);
-  Stage<DK, ROWS> sk[2], sv[2];
-
-  f32x16 o[ND];
-#pragma unroll
-  for (int d = 0; d < ND; ++d) o[d] = zero16();
-  float m = -INFINITY, lsum = 0.f;
-
-  auto load = [&](int set, int it) {
-    sk[set].load(offk, kbase, a.ldk, it * ROWS, lk);
-    sv[set].load(offv, vbase, a.ldv, it * ROWS, lk);
-  };
-  auto store = [&](int set) {
-    sk[set].store(smem + set * 2 * G::E);
-    sv[set].store(smem + set * 2 * G::E + G::E);
-  };
-  auto compute = [&](int buf, int it) {
-    const bf16* ks = smem + buf * 2 * G::E + kp * TILE * G::STR;   // this wave's 64 keys of the stage
-    const bf16* vs = ks + G::E;
-    const int kt = it * ROWS + kp * TILE;
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      s[kb] = zero16();
-#pragma unroll
-      for (int t = 0; t < NT; ++t) s[kb] = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s[kb]);
+    tile_in(c, a.xhat_a, DM, t2);
+    f32x16 acc[MT];
+    zero_acc(acc);
+    // (block u + 1 of dP is requested before the MFMAs on block u and stored after them: its latency is hidden)
+    TileRegs<MT> nxt;
+    if (a.nb > 0) tile_load(c, a.dP, a.ldp, nxt);
+    for (int u = 0; u < a.nb; ++u) {
+      tile_store(c, nxt, t0);
+      __syncthreads();
+      if (u + 1 < a.nb) tile_load(c, a.dP + (u + 1) * 256, a.ldp, nxt);
+      block_mma(c, t0, acc);
+      __syncthreads();                           // every wave is past its MFMAs on this block of dP: t0 may be rewritten
     }
-    // masks only on tiles that cross a sequence end or the diagonal (wave-uniform test)
-    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + qw * 32);
-    if (!full) {
+    if (a.nb == 0) __syncthreads();              // (bare LayerNorm backward: the G / xhat tiles must be visible)
+    epi_lnbwd<DROP>(c, acc, t1, t2, t0, a.rstd_a, a.gamma_a, da, red, a.ds_a, a.dgamma_a, a.dbeta_a, a.dbias_a);
+    cur = t0; fa = t1; fb = t2;
+    __syncthreads();                             // the column pass has read t1 / t2: free from here
+  } else {
+    tile_in(c, a.DS, DM, t0);
+    cur = t0; fa = t1; fb = t2;
+    __syncthreads();
+  }
+
+  if (FFN) {
+    const int dff = a.nc * 256;
+    f32x16 acc2[MT];
+    zero_acc(acc2);
+    for (int ch = 0; ch < a.nc; ++ch) {
+      bf16* hc = (ch & 1) ? fb : fa;             // rewritten two chunks later, the next chunk's barrier in between
+      // this lane's ReLU / dropout mask bits of the chunk (st_row_chain wrote them), requested before the MFMAs
+      const unsigned long long relu = a.relu_bits[((size_t)(blockIdx.x * a.nc + ch) * NW + c.wave) * 64 + c.l];
+      f32x16 acc1[MT];
+      zero_acc(acc1);
+      block_mma(c, cur, acc1);                   // ds x W2[:, chunk]: the hidden gradient before the mask
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt + kb * 32 + acc_row(r, hi);
-          if (key >= lk || (a.causal && key > q)) s[kb][r] = -INFINITY;
-        }
-    }
-    float mx = -INFINITY;
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, wave_xor32(mx));
-    // log2 domain; m_new is finite from the first tile on (key 0 is visible to every query)
-    const float m_new = fmaxf(m, mx * c2);
-    if (__any(m_new != m)) {   // the running maximum settles after a few tiles: skip the rescale then
-      const float m_fin = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m - m_fin);
-      lsum *= alpha;
-#pragma unroll
-      for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-      m = m_new;
-    }
-    const float m_use = (m == -INFINITY) ? 0.f : m;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c2, -m_use));
-        s[kb][r] = p;
-        psum += p;
-      }
-    lsum += psum;
-    if (DROP) {   // dropped probabilities leave the normaliser untouched; the 1/(1-p) scale is folded into `inv`
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        bool keep[16];
-        keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = keep[r] ? s[kb][r] : 0.f;
-      }
-    }
-    // O^T += V^T P^T : A operand = V^T (transposing LDS read), B operand = P^T (own registers)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack_acc8(s[kb], 8 * hf);
-        const int base = kb * 32 + 16 * hf + 4 * hi;
-        if (a.psplit) {   // (workgroup-uniform)
-          bf16x8 pl;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pl[j] = (bf16)(s[kb][8 * hf + j] - (float)pf[j]);
-#pragma unroll
-          for (int d = 0; d < ND; ++d) {
-            const bf16x8 vf = rd_tr<DK>(vs, d * 32, base);
-            o[d] = mfma32(vf, pf, o[d]);
-            o[d] = mfma32(vf, pl, o[d]);
+          for (int e = 0; e < 4; ++e) {
+            const bf16 v = (bf16)(acc1[mt][4 * g + e] * a.mask_scale);
+            const int b = mt * 16 + 4 * g + e;
+            const bool on = b < 32 ? (((uint32_t)relu >> b) & 1u) : (((uint32_t)(relu >> 32) >> (b - 32)) & 1u);
+            o[e] = on ? v : (bf16)0.f;
           }
-        } else {
-#pragma unroll
-          for (int d = 0; d < ND; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
+          *reinterpret_cast<bf16x4*>(hc + (mt * 32 + c.r) * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
         }
-      }
-  };
-  stream_tiles(ntiles, load, store, compute);
-
-  float ltot = lsum + wave_xor32(lsum);
-  if (KS > 1) {   // merge the two key halves: (m, l, O) of waves 2,3 -> LDS -> waves 0,1
-    float* xch = reinterpret_cast<float*>(smem + 2 * 32 * DK) + qw * (2 + ND * 16) * 64 + l;   // behind the 2 store patches
-    if (kp == 1) {
-      xch[0] = m;
-      xch[64] = ltot;
-#pragma unroll
-      for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(2 + d * 16 + r) * 64] = o[d][r];
+      __syncthreads();
+      block_mma(c, hc, acc2);                    // dH chunk x W1[chunk, :]
+      tile_out(c, hc, a.dH + ch * 256, dff);
     }
+    // dy = acc2 + ds (in place over the ds tile), xhat_b into the tile the last chunk did not use, ds_b into the other
+    bf16* tx = (a.nc & 1) ? fb : fa;
+    bf16* td = (a.nc & 1) ? fa : fb;
+    tile_in(c, a.xhat_b, DM, tx);                // (tx: last read one chunk earlier, behind the last chunk's barrier)
+    __syncthreads();                             // xhat_b visible; every wave is past its MFMAs on the last chunk (td)
+    epi_lnbwd<false>(c, acc2, cur, tx, td, a.rstd_b, a.gamma_b, off, red, a.ds_b, a.dgamma_b, a.dbeta_b, a.dbias_b);
+    fa = cur; fb = tx; cur = td;
+    __syncthreads();                             // the column pass has read fa / fb
+  }
+
+  if (TAIL) {
+    // O -> fa, Ores -> fb (requested before the MFMAs, stored after them); dctx is staged in the ds tile once every wave is
+    // past its MFMAs on it
+    TileRegs<MT> ro, rr_;
+    tile_load(c, a.O, a.ldo, ro);
+    if (a.Ores) tile_load(c, a.Ores, a.ldo, rr_);
+    f32x16 acc[MT];
+    zero_acc(acc);
+    block_mma(c, cur, acc);
+    tile_store(c, ro, fa);
+    if (a.Ores) tile_store(c, rr_, fb);
     __syncthreads();
-    if (kp == 1) return;
-    const float m1 = xch[0], l1 = xch[64];
-    const float mn = fmaxf(m, m1);
-    const float a0 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
-    const float a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - mn);
-    ltot = ltot * a0 + l1 * a1;
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + xch[(2 + d * 16 + r) * 64] * a1;
-    m = mn;
-  }
-  const float inv = ltot > 0.f ? (DROP ? dr.scale : 1.f) / ltot : 0.f;
-  if (q_ok && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
-  if (a.Ores)      // (the tile buffers are free: the lo patches lie behind the hi patches / the key-split exchange area)
-    store_rows_pair<DK>(smem + qw * 32 * DK, smem + (KS == 1 ? 4 * 32 * DK : 256 * DK) + qw * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK,
-                        a.Ores + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32, min(32, lq - (q0 + qw * 32)));
-  else
-    store_rows<DK>(smem + qw * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + qw * 32,
-                   min(32, lq - (q0 + qw * 32)));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward, part 1: dQ (and delta = rowsum(dO * O)).  Same decomposition as the forward.
-//   P^T = exp2(S^T c2 - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta),  dQ^T += K^T dS^T
-// ---------------------------------------------------------------------------------------------
-template <int DK, bool DROP, int KS>
-__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf16* smem) {
-  using G = TileGeo<DK, TILE * KS>;
-  constexpr int NT = DK / 16, ND = DK / 32;
-  constexpr int ROWS = TILE * KS, QROWS = WG_ROWS / KS;   // KS = 2: see attn_fwd_kernel
-
-  int b, h, tile;
-  decode_item(a, bid, b, h, tile);
-  const int lq = a.q_len[b], lk = a.k_len[b];
-  const int q0 = tile * QROWS;
-  if (q0 >= lq) return;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
-  const int qw = KS > 1 ? (wave & 1) : wave, kp = KS > 1 ? (wave >> 1) : 0;
-  const int q = q0 + qw * 32 + (l & 31);
-  const bool q_ok = q < lq;
-  const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
-  const float c2 = a.scale * 1.4426950408889634f;
-  const Drop dr = make_drop(a.drop);
-  const int bh = b * a.H + h;
-
-  const int k_hi = a.causal ? min(lk, q0 + QROWS) : lk;
-  const int ntiles = (k_hi + ROWS - 1) / ROWS;
-  const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;
-  const bf16* vbase = a.V + (size_t)a.k_off[b] * a.ldv + h * DK;
-
-  bf16x8 qf[NT], dof[NT];
-  float dl = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = h * DK + t * 16 + hi * 8;
-    qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + col);
-    dof[t] = *reinterpret_cast<const bf16x8*>(a.dO + qrow * a.lddo + col);
-  }
-  if (a.O != nullptr) {   // delta = rowsum(dO * O) computed (and published) here ...
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + qrow * a.ldo + h * DK + t * 16 + hi * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dl += (float)dof[t][e] * (float)of[e];
-    }
-    dl += wave_xor32(dl);
-    if (q_ok && hi == 0 && kp == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
-  } else {                // ... or already produced by the launch that wrote dO (st_gemm, ST_EPI_BF16_DELTA)
-    dl = a.delta[(size_t)h * a.q_rows_total + qrow];
-  }
-  const float lse = a.lse[(size_t)h * a.q_rows_total + qrow];
-
-  uint32_t offk[G::CH], offv[G::CH];
-  Stage<DK, ROWS>::offsets(offk, a.ldk);
-  Stage<DK, ROWS>::offsets(offv, a.ldv);
-  Stage<DK, ROWS> sk[2], sv[2];
-
-  f32x16 dq[ND];
-#pragma unroll
-  for (int d = 0; d < ND; ++d) dq[d] = zero16();
-
-  auto load = [&](int set, int it) {
-    sk[set].load(offk, kbase, a.ldk, it * ROWS, lk);
-    sv[set].load(offv, vbase, a.ldv, it * ROWS, lk);
-  };
-  auto store = [&](int set) {
-    sk[set].store(smem + set * 2 * G::E);
-    sv[set].store(smem + set * 2 * G::E + G::E);
-  };
-  auto compute = [&](int buf, int it) {
-    const bf16* ks = smem + buf * 2 * G::E + kp * TILE * G::STR;
-    const bf16* vs = ks + G::E;
-    const int kt = it * ROWS + kp * TILE;
-    const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + qw * 32);   // no masks needed
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        s = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s);
-        dp = mfma32(rd_nat<DK>(vs, kb * 32 + (l & 31), t), dof[t], dp);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, -lse);
-      if (!full) {   // masked pairs: exp2(-inf) = 0 (one wave-uniform branch; the exp chain stays straight-line)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt + kb * 32 + acc_row(r, hi);
-          if (key >= lk || (a.causal && key > q)) s[r] = -INFINITY;
-        }
-      }
-      if (DROP) {   // dS = P (M dP / (1-p) - delta)
-        bool keep[16];
-        keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] = keep[r] ? dp[r] * dr.scale : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * (dp[r] - dl);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 dsf = pack_acc8(s, 8 * hf);
-        const int base = kb * 32 + 16 * hf + 4 * hi;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) dq[d] = mfma32(rd_tr<DK>(ks, d * 32, base), dsf, dq[d]);
-      }
-    }
-  };
-  stream_tiles(ntiles, load, store, compute);
-  if (KS > 1) {   // dQ of the two key halves: waves 2,3 -> LDS -> waves 0,1
-    float* xch = reinterpret_cast<float*>(smem + 2 * 32 * DK) + qw * (ND * 16) * 64 + l;
-    if (kp == 1) {
-#pragma unroll
-      for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 64] = dq[d][r];
-    }
-    __syncthreads();
-    if (kp == 1) return;
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dq[d][r] += xch[(d * 16 + r) * 64];
-  }
-  store_rows<DK>(smem + qw * 32 * DK, dq, a.scale, a.dQ + (size_t)a.q_off[b] * a.lddq + h * DK, a.lddq,
-                 q0 + qw * 32, min(32, lq - (q0 + qw * 32)));
-}
-
-template <int DK, bool DROP, int KS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16 smem[4 * TileGeo<DK, TILE * KS>::E];
-  attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward, part 2: dK, dV.  Each wave owns 32 keys (lane & 31) and loops over 64-query tiles
-// (Q rows, dO rows and the tile's 64 lse + 64 delta values).
-//   S = Q K^T (lane = key, registers = queries),  P = exp2(S c2 - lse[q])
-//   dV^T += dO^T P,   dP = dO V^T,   dS = P (dP - delta[q]),   dK^T += Q^T dS
-// ---------------------------------------------------------------------------------------------
-template <int DK, bool DROP>
-__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf16* smem) {
-  using G = TileGeo<DK>;
-  constexpr int NT = DK / 16, ND = DK / 32;
-  constexpr int BUF = 2 * G::E + 256;   // Q tile, dO tile, lse[64] + delta[64] (fp32, counted in bf16 elements)
-
-  int b, h, tile;
-  decode_item(a, bid, b, h, tile);
-  const int lq = a.q_len[b], lk = a.k_len[b];
-  const int k0 = tile * WG_ROWS;
-  if (k0 >= lk) return;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
-  const int key = k0 + wave * 32 + (l & 31);
-  const bool k_ok = key < lk;
-  const size_t krow = (size_t)a.k_off[b] + min(key, lk - 1);
-  const float c2 = a.scale * 1.4426950408889634f;
-  const Drop dr = make_drop(a.drop);
-  const int bh = b * a.H + h;
-
-  const bf16* qbase = a.Q + (size_t)a.q_off[b] * a.ldq + h * DK;
-  const bf16* dobase = a.dO + (size_t)a.q_off[b] * a.lddo + h * DK;
-  // threads 0..63 carry the tile's lse values, 64..127 its delta values (128.. duplicate them)
-  const float* statsrc = ((threadIdx.x & 64) ? a.delta : a.lse) + (size_t)h * a.q_rows_total + a.q_off[b];
-  const int q_begin = a.causal ? (k0 / TILE) * TILE : 0;  // queries before the first key see none of them
-  const int ntiles = (lq - q_begin + TILE - 1) / TILE;
-
-  bf16x8 kf[NT], vf[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = h * DK + t * 16 + hi * 8;
-    kf[t] = *reinterpret_cast<const bf16x8*>(a.K + krow * a.ldk + col);
-    vf[t] = *reinterpret_cast<const bf16x8*>(a.V + krow * a.ldv + col);
-  }
-
-  uint32_t offq[G::CH], offo[G::CH];
-  Stage<DK>::offsets(offq, a.ldq);
-  Stage<DK>::offsets(offo, a.lddo);
-  Stage<DK> sq[2], so[2];
-  float sst[2];
-
-  f32x16 dk[ND], dv[ND];
-#pragma unroll
-  for (int d = 0; d < ND; ++d) { dk[d] = zero16(); dv[d] = zero16(); }
-
-  auto load = [&](int set, int it) {
-    const int qt = q_begin + it * TILE;
-    sq[set].load(offq, qbase, a.ldq, qt, lq);
-    so[set].load(offo, dobase, a.lddo, qt, lq);
-    sst[set] = statsrc[min(qt + (int)(threadIdx.x & 63), lq - 1)];
-  };
-  auto store = [&](int set) {
-    bf16* base = smem + set * BUF;
-    sq[set].store(base);
-    so[set].store(base + G::E);
-    reinterpret_cast<float*>(base + 2 * G::E)[threadIdx.x & 127] = sst[set];
-  };
-  auto compute = [&](int buf, int it) {
-    const bf16* qs = smem + buf * BUF;
-    const bf16* dos = qs + G::E;
-    const float* stat = reinterpret_cast<const float*>(qs + 2 * G::E);   // [0..63] lse, [64..127] delta
-    const int qt = q_begin + it * TILE;
-    // wave-uniform: every (query, key) pair of this tile x this wave's 32 keys is unmasked
-    const bool full = (qt + TILE <= lq) && (k0 + wave * 32 + 32 <= lk) && (!a.causal || k0 + wave * 32 + 31 <= qt);
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        s = mfma32(rd_nat<DK>(qs, qb * 32 + (l & 31), t), kf[t], s);
-        dp = mfma32(rd_nat<DK>(dos, qb * 32 + (l & 31), t), vf[t], dp);
-      }
-      bool keep[16];
-      if (DROP) {   // dS = P (M dP / (1-p) - delta), and dV takes the dropped, rescaled P
-        keep16<false>(dr, bh, key, qt + qb * 32, hi, keep);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] = keep[r] ? dp[r] * dr.scale : 0.f;
-      }
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 32 + c.r;
+      float part = 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int ql = qb * 32 + 8 * g + 4 * hi;
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(stat + ql);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(stat + 64 + ql);
+        const int at = row * AS + c.wave * 32 + 8 * g + 4 * c.hi;
+        const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(fa + at);
+        bf16x4 r4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        if (a.Ores) r4 = *reinterpret_cast<const bf16x4*>(fb + at);
+        bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s[4 * g + e] = fmaf(s[4 * g + e], c2, -ls[e]);
-          dp[4 * g + e] -= dl[e];
+          o[e] = (bf16)acc[mt][4 * g + e];
+          part += (float)o[e] * ((float)o4[e] + (float)r4[e]);
         }
+        *reinterpret_cast<bf16x4*>(cur + at) = o;
       }
-      if (!full) {   // masked pairs: exp2(-inf) = 0 (one wave-uniform branch; the exp chain stays straight-line)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int qq = qt + qb * 32 + acc_row(r, hi);
-          if (!k_ok || qq >= lq || (a.causal && key > qq)) s[r] = -INFINITY;
-        }
-      }
-      f32x16 p;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(s[r]);
-        s[r] = p[r] * dp[r];
-        if (DROP) p[r] = keep[r] ? p[r] * dr.scale : 0.f;
-      }
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack_acc8(p, 8 * hf);
-        const bf16x8 dsf = pack_acc8(s, 8 * hf);
-        const int base = qb * 32 + 16 * hf + 4 * hi;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-          dv[d] = mfma32(rd_tr<DK>(dos, d * 32, base), pf, dv[d]);
-          dk[d] = mfma32(rd_tr<DK>(qs, d * 32, base), dsf, dk[d]);
-        }
-      }
+      part += wave_xor32(part);
+      if (c.hi == 0) red[0][(c.wave * MT + mt) * 32 + c.r] = part;     // this wave's 32 columns of the row: half a head
     }
-  };
-  stream_tiles(ntiles, load, store, compute);
-  const int nrows = min(32, lk - (k0 + wave * 32));
-  store_rows<DK>(smem + wave * 64 * DK, dk, a.scale, a.dK + (size_t)a.k_off[b] * a.lddk + h * DK, a.lddk,
-                 k0 + wave * 32, nrows);
-  store_rows<DK>(smem + wave * 64 * DK + 32 * DK, dv, 1.f, a.dV + (size_t)a.k_off[b] * a.lddv + h * DK, a.lddv,
-                 k0 + wave * 32, nrows);
-}
-
-template <int DK, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (2 * TileGeo<DK>::E + 256)];
-  attn_bwd_dkv_body<DK, DROP>(a, blockIdx.x, smem);
-}
-
-// dQ and dK/dV in ONE launch (possible when delta comes from the producer of dO: no kernel-to-kernel dependency
-// is left).  Workgroups [0, n_k) run the dK/dV body on the key-tile work list (the heavier items: four
-// contractions per tile), the rest the dQ body on the query-tile list, which fills in as the dK/dV items drain
-// (the key-split variant KS = 2 orders them the other way round, see below).
-template <int DK, bool DROP, int KS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, AttnArgs ak, int n_k) {
-  constexpr int EQ = 4 * TileGeo<DK, TILE * KS>::E, EK = 2 * (2 * TileGeo<DK>::E + 256);
-  __shared__ __attribute__((aligned(16))) bf16 smem[EQ > EK ? EQ : EK];
-  if (KS > 1) {
-    // few queries against many keys (decoder-encoder attention): the dQ items are the long serial chains here (one
-    // workgroup streams all keys of an utterance), so they are dispatched first and the one-tile dK/dV items fill in
-    // around them (27.2 -> 23.3 us at config 2)
-    const int n_q = (int)gridDim.x - n_k;
-    if ((int)blockIdx.x < n_q) attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x, smem);
-    else attn_bwd_dkv_body<DK, DROP>(ak, blockIdx.x - n_q, smem);
-    return;
+    __syncthreads();
+    tile_out(c, cur, a.dctx, a.lddc);
+    // delta[h][row]: heads are 64 columns = two waves
+    for (int i = c.tid; i < 4 * RB; i += 512) {
+      const int h = i / RB, row = i % RB, mt = row >> 5, r = row & 31;
+      if (row < c.nvalid)
+        a.delta[(size_t)h * a.M + c.row0 + row] = red[0][((2 * h) * MT + mt) * 32 + r] + red[0][((2 * h + 1) * MT + mt) * 32 + r];
+    }
   }
-  if ((int)blockIdx.x < n_k) attn_bwd_dkv_body<DK, DROP>(ak, blockIdx.x, smem);
-  else attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x - n_k, smem);
+  {
+    int tsum = 0;
+#pragma unroll
+    for (int t = 0; t < NTOUCH; ++t) tsum ^= touched[t];
+    if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;
+  }
 }
 
-int check_common(int d_k, int ldq, int ldk, int ldv) {
-  if (d_k != 32 && d_k != 64) return -1;
-  if ((ldq & 7) || (ldk & 7) || (ldv & 7)) return -2;
-  return 0;
-}
-
-bool set_drop(AttnArgs& a, const unsigned* seed, unsigned salt, int thresh, float scale) {
-  const bool on = seed != nullptr && thresh > 0;
-  a.drop.seed = on ? seed : nullptr;
-  a.drop.salt = salt;
-  a.drop.thresh = on ? thresh : 0;
-  a.drop.scale = on ? scale : 1.f;
-  return on;
-}
-
-// few queries against many keys (decoder-encoder attention): split the keys over the wave pairs
-bool key_split(int max_q, int max_k, int causal) { return !causal && max_q <= 64 && max_k >= 256; }
-
-// grid size and enumeration mode for one family of workgroups
-int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
-  a.work = work;
-  a.H = H;
-  a.tiles_max = (max_rows + WG_ROWS - 1) / WG_ROWS;
-  return (work ? n_work : B * a.tiles_max) * H;
+// Block descriptor table of st_wfrag_build: 4 x int64 per 256 x 256 weight block
+//   [0] address of the block's first element (row n0, column k0 of a row-major bf16 matrix)
+//   [1] leading dimension of that matrix (elements) | transposed << 32: the block is read as its TRANSPOSE (the data
+//       gradient's operand: output index = the weight's column, contraction over its rows)
+//   [2] destination: fragment index of the block inside a wave's stream (block position * 16) | (wave stride in
+//       fragments) << 32
+//   [3] destination: ADDRESS of the chain's wave-0 stream (so one table - one launch - can fill several buffers)
+// piece (block, wave, ks, lane) = 8 consecutive k of weight row n0 + wave*32 + (lane & 31): the MFMA A operand of that lane.
+__global__ __launch_bounds__(256) void wfrag_build_kernel(const long long* __restrict__ table) {
+  const long long* d = table + (size_t)blockIdx.x * 4;
+  const bf16* src = reinterpret_cast<const bf16*>(d[0]);
+  const long long ld = d[1] & 0xffffffffll, frag0 = d[2] & 0xffffffffll, wstride = d[2] >> 32;
+  const bool transposed = (d[1] >> 32) & 1;
+  const int wave = blockIdx.y;
+  bf16x8* dst = reinterpret_cast<bf16x8*>(d[3]) + ((size_t)wave * wstride + frag0) * 64;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int id = p * 256 + threadIdx.x, ks = id >> 6, lane = id & 63;
+    const int o = wave * 32 + (lane & 31), c0 = ks * 16 + (lane >> 5) * 8;      // output index, first contraction index
+    if (!transposed) dst[id] = *reinterpret_cast<const bf16x8*>(src + (size_t)o * ld + c0);
+    else {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(c0 + j) * ld + o];      // (coalesced across the lanes' consecutive o)
+      dst[id] = v;
+    }
+  }
 }
 
 }  // namespace
 
-extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                           void* O, int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off,
-                           const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
-                           float scale, const int* work, int n_work, const unsigned* drop_seed, unsigned drop_salt,
-                           int drop_thresh, float drop_scale) {
-  if (B <= 0 || H <= 0 || max_q <= 0 || (work && n_work <= 0)) return 0;
-  int rc = check_common(d_k, ldq, ldk, ldv);
-  if (rc) return rc;
-  if (ldo & 7) return -3;
-  if (B > 32767) return -4;
-  AttnArgs a = {};
-  a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
-  a.O = (bf16*)O; a.ldo = ldo; a.Ores = (bf16*)Ores; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
-  a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
-  const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
-  a.psplit = (Ores != nullptr && max_q <= 64) ? 1 : 0;     // the decoder's attentions, when a backward will follow
-  dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
-  const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
-#define ST_FWD(DKK, DR) \
-  do { if (ks2) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a); \
-       else hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a); } while (0)
-  if (d_k == 64 && !drop) ST_FWD(64, false);
-  else if (d_k == 64) ST_FWD(64, true);
-  else if (!drop) ST_FWD(32, false);
-  else ST_FWD(32, true);
-#undef ST_FWD
+extern "C" int st_wfrag_depth(void) { return DEPTH; }
+
+extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_blocks) {
+  if (n_blocks <= 0) return 0;
+  if (!table) return -1;
+  hipLaunchKernelGGL(wfrag_build_kernel, dim3(n_blocks, NW), dim3(256), 0, stream, table);
   ST_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                           const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta,
-                           void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int* q_off,
-                           const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q,
-                           int max_k, int q_rows_total, int causal, float scale, int parts, const int* work_q,
-                           int n_work_q, const int* work_k, int n_work_k, const unsigned* drop_seed,
-                           unsigned drop_salt, int drop_thresh, float drop_scale) {
-  if (B <= 0 || H <= 0 || max_q <= 0 || max_k <= 0) return 0;
-  int rc = check_common(d_k, ldq, ldk, ldv);
-  if (rc) return rc;
-  if ((O && (ldo & 7)) || (lddo & 7) || (lddq & 7) || (lddk & 7) || (lddv & 7)) return -3;
-  if (B > 32767) return -4;
-  AttnArgs a = {};
-  a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
-  a.O = (bf16*)O; a.ldo = ldo; a.dO = (const bf16*)dO; a.lddo = lddo; a.lse = (float*)lse; a.delta = delta;
-  a.dQ = (bf16*)dQ; a.lddq = lddq; a.dK = (bf16*)dK; a.lddk = lddk; a.dV = (bf16*)dV; a.lddv = lddv;
-  a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
-  a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
-  const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
-  dim3 block(256);
-  const bool ks2 = key_split(max_q, max_k, causal);
-  const bool run_q = (parts & 1) && !(work_q && n_work_q <= 0), run_k = (parts & 2) && !(work_k && n_work_k <= 0);
-  if (run_q && run_k && O == nullptr) {
-    // delta was produced together with dO (st_gemm, ST_EPI_BF16_DELTA): the two kernels are independent -> one launch
-    AttnArgs ak = a;
-    const int nq = plan(a, work_q, n_work_q, B, H, max_q), nk = plan(ak, work_k, n_work_k, B, H, max_k);
-    dim3 grid(nq + nk);
-#define ST_BWD(DKK, DR) \
-  do { if (ks2) hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a, ak, nk); \
-       else hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a, ak, nk); } while (0)
-    if (d_k == 64 && !drop) ST_BWD(64, false);
-    else if (d_k == 64) ST_BWD(64, true);
-    else if (!drop) ST_BWD(32, false);
-    else ST_BWD(32, true);
+namespace {
+// row tiles per workgroup: the smallest of 1, 2, 3 that gives at most one round of workgroups (256 CUs)
+int row_tiles(int M) { return (M + 31) / 32 <= 256 ? 1 : (M + 63) / 64 <= 256 ? 2 : 3; }
+}  // namespace
+
+// 64-bit words of the relu_bits buffer st_row_chain writes and st_row_chain_bwd reads for M rows and this d_ff
+extern "C" int st_row_chain_mask_words(int M, int d_ff) {
+  if (M <= 0 || d_ff <= 0) return 0;
+  const int mt = row_tiles(M);
+  return ((M + 32 * mt - 1) / (32 * mt)) * (d_ff / 256) * NW * 64;
+}
+
+extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A, int lda,
+                            const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
+                            float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
+                            unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
+                            int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
+                            int post_blocks, const float* bp, void* P, int ldp) {
+  if (M <= 0) return 0;
+  const bool pre = R != nullptr, ffn = d_ff > 0, post = post_blocks > 0;
+  if (!A || !wfrag || (lda & 7) || (!pre && !ffn && !post)) return -1;
+  if (pre && ((ldr & 7) || !bo || !g0 || !be0 || !out0)) return -2;
+  if (ffn && ((d_ff & 255) || !b1 || !b2 || !g1 || !be1 || !H || !out1)) return -3;
+  if (post && (!bp || !P || (ldp & 7) || ldp < 256 * post_blocks)) return -4;
+  if (n_blocks != (pre ? 1 : 0) + (ffn ? 2 * (d_ff / 256) : 0) + post_blocks) return -5;
+  ChainArgs a;
+  a.M = M; a.wfrag = (const bf16x8*)wfrag; a.wave_frags = n_blocks * 16 + DEPTH; a.eps = eps;
+  a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
+  a.A = (const bf16*)A; a.lda = lda; a.R = (const bf16*)R; a.ldr = ldr; a.bo = bo; a.g0 = g0; a.be0 = be0;
+  a.out0 = (bf16*)out0; a.xhat0 = (bf16*)xhat0; a.rstd0 = rstd0;
+  a.nc = d_ff / 256; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.H = (bf16*)H; a.relu_bits = relu_bits; a.out1 = (bf16*)out1; a.xhat1 = (bf16*)xhat1;
+  a.rstd1 = rstd1;
+  const bool on1 = ffn && drop_seed && drop1_thresh > 0, on2 = ffn && drop_seed && drop2_thresh > 0;
+  a.drop1.seed = on1 ? drop_seed : nullptr; a.drop1.salt = drop1_salt; a.drop1.thresh = on1 ? drop1_thresh : 0;
+  a.drop1.scale = on1 ? drop1_scale : 1.f;
+  a.drop2.seed = on2 ? drop_seed : nullptr; a.drop2.salt = drop2_salt; a.drop2.thresh = on2 ? drop2_thresh : 0;
+  a.drop2.scale = on2 ? drop2_scale : 1.f;
+  a.nb = post_blocks; a.bp = bp; a.P = (bf16*)P; a.ldp = ldp;
+  const int mt = row_tiles(M);
+  const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
+  const bool drop = on1 || on2;
+#define ST_CHAIN(PRE_, FFN_, POST_)                                                                               \
+  do {                                                                                                            \
+    if (mt == 3) {                                                                                                \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 3>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 3>), grid, blk, 0, stream, a);          \
+    } else if (mt == 2) {                                                                                         \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 2>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 2>), grid, blk, 0, stream, a);          \
+    } else {                                                                                                      \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 1>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 1>), grid, blk, 0, stream, a);          \
+    }                                                                                                             \
+  } while (0)
+  if (pre && ffn && post) ST_CHAIN(true, true, true);
+  else if (pre && ffn) ST_CHAIN(true, true, false);
+  else if (pre && post) ST_CHAIN(true, false, true);
+  else if (ffn && post) ST_CHAIN(false, true, true);
+  else if (ffn) ST_CHAIN(false, true, false);
+  else if (pre) ST_CHAIN(true, false, false);
+  else ST_CHAIN(false, false, true);
+#undef ST_CHAIN
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks,
+                                int head_blocks, const void* dP, int ldp, const void* G, int ldg, const void* xhat_a,
+                                const float* rstd_a, const float* gamma_a, const unsigned* drop_seed, unsigned drop_salt,
+                                int drop_thresh, float drop_scale, void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a,
+                                const void* DS, int d_ff, const unsigned long long* relu_bits, float mask_scale, void* dH,
+                                const void* xhat_b,
+                                const float* rstd_b, const float* gamma_b, void* ds_b, float* dgamma_b, float* dbeta_b,
+                                float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta) {
+  if (M <= 0) return 0;
+  // HEAD is present iff xhat_a is given; with head_blocks == 0 it is the bare LayerNorm backward of G (the gradient that
+  // reaches the LAST sublayer of a stack from outside)
+  const bool head = xhat_a != nullptr, ffn = d_ff > 0, tail = O != nullptr;
+  if (!wfrag || head_blocks < 0 || (!head && !ffn && !tail)) return -1;
+  if (head && ((head_blocks > 0 && (!dP || (ldp & 7) || ldp < 256 * head_blocks)) || (head_blocks == 0 && !G) || (G && (ldg & 7)) ||
+               !rstd_a || !gamma_a || !ds_a))
+    return -2;
+  if (!head && head_blocks > 0) return -2;
+  if (!head && !DS) return -2;
+  if (ffn && ((d_ff & 255) || !relu_bits || !dH || !xhat_b || !rstd_b || !gamma_b || !ds_b)) return -3;
+  if (tail && ((ldo & 7) || !dctx || (lddc & 7) || !delta)) return -4;
+  if (n_blocks != head_blocks + (ffn ? 2 * (d_ff / 256) : 0) + (tail ? 1 : 0)) return -5;
+  ChainBwdArgs a;
+  a.M = M; a.wfrag = (const bf16x8*)wfrag; a.wave_frags = n_blocks * 16 + DEPTH;
+  a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
+  a.nb = head_blocks; a.dP = (const bf16*)dP; a.ldp = ldp; a.G = (const bf16*)G; a.ldg = ldg; a.xhat_a = (const bf16*)xhat_a;
+  a.rstd_a = rstd_a; a.gamma_a = gamma_a;
+  const bool drop = head && drop_seed != nullptr && drop_thresh > 0;
+  a.drop_a.seed = drop ? drop_seed : nullptr; a.drop_a.salt = drop_salt; a.drop_a.thresh = drop ? drop_thresh : 0;
+  a.drop_a.scale = drop ? drop_scale : 1.f;
+  a.ds_a = (bf16*)ds_a; a.dgamma_a = dgamma_a; a.dbeta_a = dbeta_a; a.dbias_a = dbias_a; a.DS = (const bf16*)DS;
+  a.nc = d_ff / 256; a.relu_bits = relu_bits; a.mask_scale = mask_scale > 0.f ? mask_scale : 1.f; a.dH = (bf16*)dH;
+  a.xhat_b = (const bf16*)xhat_b; a.rstd_b = rstd_b; a.gamma_b = gamma_b; a.ds_b = (bf16*)ds_b; a.dgamma_b = dgamma_b;
+  a.dbeta_b = dbeta_b; a.dbias_b = dbias_b;
+  a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
+  const int mt = row_tiles(M);
+  const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
+#define ST_BWD(HEAD_, FFN_, TAIL_)                                                                                     \
+  do {                                                                                                                 \
+    if (mt == 3) {                                                                                                     \
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 3>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 3>), grid, blk, 0, stream, a);          \
+    } else if (mt == 2) {                                                                                              \
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 2>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 2>), grid, blk, 0, stream, a);          \
+    } else {                                                                                                           \
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, true, 1>), grid, blk, 0, stream, a);      \
+      else hipLaunchKernelGGL((row_chain_bwd_kernel<HEAD_, FFN_, TAIL_, false, 1>), grid, blk, 0, stream, a);          \
+    }                                                                                                                  \
+  } while (0)
+  if (head && ffn && tail) ST_BWD(true, true, true);
+  else if (head && ffn) ST_BWD(true, true, false);
+  else if (head && tail) ST_BWD(true, false, true);
+  else if (ffn && tail) ST_BWD(false, true, true);
+  else if (ffn) ST_BWD(false, true, false);
+  else if (head) ST_BWD(true, false, false);
+  else ST_BWD(false, false, true);
 #undef ST_BWD
-    ST_CHECK_LAUNCH();
-    return 0;
-  }
-  if (run_q) {
-    dim3 gq(plan(a, work_q, n_work_q, B, H, max_q));
-#define ST_DQ(DKK, DR) \
-  do { if (ks2) hipLaunchKernelGGL((attn_bwd_dq_kernel<DKK, DR, 2>), gq, block, 0, stream, a); \
-       else hipLaunchKernelGGL((attn_bwd_dq_kernel<DKK, DR, 1>), gq, block, 0, stream, a); } while (0)
-    if (d_k == 64 && !drop) ST_DQ(64, false);
-    else if (d_k == 64) ST_DQ(64, true);
-    else if (!drop) ST_DQ(32, false);
-    else ST_DQ(32, true);
-#undef ST_DQ
-  }
-  if (run_k) {
-    dim3 gk(plan(a, work_k, n_work_k, B, H, max_k));
-    if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, block, 0, stream, a);
-    else if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, block, 0, stream, a);
-    else if (!drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, false>), gk, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, true>), gk, block, 0, stream, a);
-  }
   ST_CHECK_LAUNCH();
   return 0;
 }
