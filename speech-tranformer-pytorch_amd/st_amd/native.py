@@ -443,7 +443,7 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
 
 def chain_mask_words(M: int, d_ff: int) -> int:
     """int64 words of the ReLU-mask buffer a feed-forward row chain over M rows writes (row_chain) and reads (row_chain_bwd)."""
-    return int(load().st_row_chain_mask_words(int(M), int(d_ff)))
+    return int(load()._cdll.st_row_chain_mask_words(int(M), int(d_ff)))     # host-only: not a launch (bypasses the per-launch timer)
 
 
 def relu_bits_from(H):

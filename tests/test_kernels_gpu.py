@@ -312,7 +312,7 @@ def test_misc_kernels():
         mod.colsum(out, cs)
         sh = torch.zeros(V * D, dtype=BF16, device=dev)
         mod.cast_bf16(mv(emb).view(-1), sh)
-        res = dict(pack=out, unpack=back, pack_grad=pg, pos=pos, embed=eo, demb=demb, colsum=cs, cast=sh)
+        res = dict(pack=out, pack_wide=outw, unpack=back, pack_grad=pg, pos=pos, embed=eo, demb=demb, colsum=cs, cast=sh)
         if dev == "cpu":
             ref = res
     for k in ref:
