@@ -308,6 +308,9 @@ def test_misc_kernels():
         mod.embed_pe_fwd(mv(tok), mv(emb), mv(pe), mv(toff), mv(tl.to(I32)), eo)
         demb = torch.ones(V, D, dtype=F32, device=dev)
         mod.embed_bwd(mv(tok), eo, mv(toff), mv(tl.to(I32)), 0, demb)
+        xw = g(B, T, 1040, seed=2, dtype=F32)        # more float4 chunks per frame than threads in a workgroup
+        outw = torch.zeros(rows, 1040, dtype=BF16, device=dev)
+        mod.pack_rows(mv(xw), mv(off), mv(lens.to(I32)), outw)
         cs = torch.ones(Fd, dtype=F32, device=dev)
         mod.colsum(out, cs)
         sh = torch.zeros(V * D, dtype=BF16, device=dev)
