@@ -201,7 +201,7 @@ int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, co
 /* Fused masked attention forward: softmax(Q K^T * scale, keys >= k_len[b]
  * and (causal) keys > query masked) V, per head; replaces Attention.py:82-90
  * and the dense masks of Utils.py:41-70.  lse (f32 [H, q_rows_total], log2
- * domain) is saved for the backward.  d_k in {32, 64}.
+ * domain) is saved for the backward.  d_k in {32, 64, 128}.
  * work (optional, device int32 [n_work]): the (utterance, 128-query tile)
  * pairs to run, packed (b << 16) | tile and sorted by decreasing cost, so the
  * ragged batch is list-scheduled longest-first; NULL = enumerate every tile

@@ -79,7 +79,8 @@ __device__ __forceinline__ void decode_item(const AttnArgs& a, int bid, int& b, 
 
 // ---- streamed [64 x DK] tiles ----------------------------------------------------------------------
 // LDS image: natural rows, stride DK + 8 elements (144 B / 80 B): ds_read_b128 row fragments over 16 rows
-// and the 4-row groups of ds_read_b64_tr_b16 are both bank-conflict free (DK = 64).
+// and the 4-row groups of ds_read_b64_tr_b16 are both bank-conflict free (DK = 64; 272 B for DK = 128 shifts 16 B per row likewise).
+// DK = 128 (the reference's config/character.yaml: d_model 512, 4 heads) needs > 256 registers per lane: one workgroup per CU.
 template <int DK, int ROWS = TILE> struct TileGeo {
   static constexpr int STR = DK + 8, E = ROWS * STR, CPR = DK / 8, CH = ROWS * CPR / 256;   // CH chunks per thread
 };
@@ -287,7 +288,7 @@ __device__ __forceinline__ void keep16(const Drop& dr, int bh, int fixed, int va
 // paths keep the O accumulators in different registers, and the compiler reconciled them with 64 v_mov_b64 per 64-key
 // tile in the single-term path (a quarter of that loop's VALU instructions).
 template <int DK, bool DROP, int KS, bool PS>
-__global__ __launch_bounds__(256, KS > 1 ? 1 : 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (KS > 1 || DK > 64) ? 1 : 2) void attn_fwd_kernel(AttnArgs a) {
   using G = TileGeo<DK, TILE * KS>;
   constexpr int NT = DK / 16;   // k-steps of the QK^T contraction
   constexpr int ND = DK / 32;   // 32-wide output column tiles
@@ -582,7 +583,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
 }
 
 template <int DK, bool DROP, int KS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, DK > 64 ? 1 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 smem[4 * TileGeo<DK, TILE * KS>::E];
   attn_bwd_dq_body<DK, DROP, KS>(a, blockIdx.x, smem);
 }
@@ -717,7 +718,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
 }
 
 template <int DK, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, DK > 64 ? 1 : 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 smem[2 * (2 * TileGeo<DK>::E + 256)];
   attn_bwd_dkv_body<DK, DROP>(a, blockIdx.x, smem);
 }
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 // contractions per tile), the rest the dQ body on the query-tile list, which fills in as the dK/dV items drain
 // (the key-split variant KS = 2 orders them the other way round, see below).
 template <int DK, bool DROP, int KS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, AttnArgs ak, int n_k) {
+__global__ __launch_bounds__(256, DK > 64 ? 1 : 2) void attn_bwd_kernel(AttnArgs a, AttnArgs ak, int n_k) {
   constexpr int EQ = 4 * TileGeo<DK, TILE * KS>::E, EK = 2 * (2 * TileGeo<DK>::E + 256);
   __shared__ __attribute__((aligned(16))) bf16 smem[EQ > EK ? EQ : EK];
   if (KS > 1) {
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a, AttnArgs a
 }
 
 int check_common(int d_k, int ldq, int ldk, int ldv) {
-  if (d_k != 32 && d_k != 64) return -1;
+  if (d_k != 32 && d_k != 64 && d_k != 128) return -1;
   if ((ldq & 7) || (ldk & 7) || (ldv & 7)) return -2;
   return 0;
 }
@@ -796,6 +797,8 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
        else hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 1, false>), grid, block, 0, stream, a); } while (0)
   if (d_k == 64 && !drop) ST_FWD(64, false);
   else if (d_k == 64) ST_FWD(64, true);
+  else if (d_k == 128 && !drop) ST_FWD(128, false);
+  else if (d_k == 128) ST_FWD(128, true);
   else if (!drop) ST_FWD(32, false);
   else ST_FWD(32, true);
 #undef ST_FWD
@@ -835,6 +838,8 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
        else hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 1>), grid, block, 0, stream, a, ak, nk); } while (0)
     if (d_k == 64 && !drop) ST_BWD(64, false);
     else if (d_k == 64) ST_BWD(64, true);
+    else if (d_k == 128 && !drop) ST_BWD(128, false);
+    else if (d_k == 128) ST_BWD(128, true);
     else if (!drop) ST_BWD(32, false);
     else ST_BWD(32, true);
 #undef ST_BWD
@@ -848,6 +853,8 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
        else hipLaunchKernelGGL((attn_bwd_dq_kernel<DKK, DR, 1>), gq, block, 0, stream, a); } while (0)
     if (d_k == 64 && !drop) ST_DQ(64, false);
     else if (d_k == 64) ST_DQ(64, true);
+    else if (d_k == 128 && !drop) ST_DQ(128, false);
+    else if (d_k == 128) ST_DQ(128, true);
     else if (!drop) ST_DQ(32, false);
     else ST_DQ(32, true);
 #undef ST_DQ
@@ -856,6 +863,8 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
     dim3 gk(plan(a, work_k, n_work_k, B, H, max_k));
     if (d_k == 64 && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gk, block, 0, stream, a);
     else if (d_k == 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, block, 0, stream, a);
+    else if (d_k == 128 && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), gk, block, 0, stream, a);
+    else if (d_k == 128) hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), gk, block, 0, stream, a);
     else if (!drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, false>), gk, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<32, true>), gk, block, 0, stream, a);
   }

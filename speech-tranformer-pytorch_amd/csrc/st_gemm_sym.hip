@@ -49,7 +49,7 @@ struct GemmArgs {
   const bf16* aux; int ldaux;
   const bf16* aux2;   // EPI_BF16_DELTA, optional: second addend of the delta factor (aux + aux2), ld = ldaux
   int c_per_split, tiles_i, tiles_j, splits;
-  int head_dim;    // EPI_BF16_DELTA: columns per attention head (32 or 64)
+  int head_dim;    // EPI_BF16_DELTA: columns per attention head (32, 64 or 128)
   // Y (and the bias) may be a stack of equally spaced blocks - the same weight of consecutive identical layers as it
   // lies in the parameter arena: row r of the stack is row (r & (2^yseg_shift - 1)) of block r >> yseg_shift, blocks
   // yseg_extra + 2^yseg_shift * ldy elements apart (bias blocks: bias_extra + 2^yseg_shift).  yseg_shift = 31: one block.
@@ -420,7 +420,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int ts, int ti, int
       for (int e = 0; e < 8; ++e) part += (float)v[e] * ((float)auxv[p][e] + (float)auxw[p][e]);
       part += __shfl_xor(part, 1, 64);
       part += __shfl_xor(part, 2, 64);
-      if (a.head_dim == 64) part += __shfl_xor(part, 4, 64);
+      if (a.head_dim >= 64) part += __shfl_xor(part, 4, 64);
+      if (a.head_dim == 128) part += __shfl_xor(part, 8, 64);
       const int cph = a.head_dim >> 3;   // 16-byte chunks per head
       if (i < a.M && j < a.N && ((id & 15) % cph) == 0)
         const_cast<float*>(a.bias)[(size_t)(j / a.head_dim) * a.M + i] = part;
@@ -558,7 +559,7 @@ int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int
   if ((x_cmajor && ldx < ((M + 7) & ~7)) || (y_cmajor && ldy < ((N + 7) & ~7))) return -3;
   if (epi != EPI_F32 && epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && ((ldd & 7) || (N & 7))) return -4;
   if ((epi == EPI_BF16_MASK || epi == EPI_BF16_ADD || epi == EPI_BF16_DELTA) && (ldaux & 7)) return -5;
-  if (epi == EPI_BF16_DELTA && (!bias || !aux || (splits != 32 && splits != 64) || (N % splits))) return -6;
+  if (epi == EPI_BF16_DELTA && (!bias || !aux || (splits != 32 && splits != 64 && splits != 128) || (N % splits))) return -6;
   GemmArgs a;
   a.head_dim = epi == EPI_BF16_DELTA ? splits : 0;   // this epilogue takes the head width in the `splits` slot
   if (splits < 1) splits = 1;

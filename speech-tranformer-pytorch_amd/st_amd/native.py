@@ -260,8 +260,8 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
         raise ValueError("gemm: out %s too small for %dx%d" % (tuple(out.shape), need[0], need[1]))
     _vec(bias, F32, N // blocks if not y_cmajor else N, "bias")
     if epi == EPI_BF16_DELTA:
-        if head_dim not in (32, 64) or N % head_dim:
-            raise ValueError("gemm: EPI_BF16_DELTA needs head_dim in {32, 64} dividing N")
+        if head_dim not in (32, 64, 128) or N % head_dim:
+            raise ValueError("gemm: EPI_BF16_DELTA needs head_dim in {32, 64, 128} dividing N")
         _vec(delta, F32, (N // head_dim) * M, "delta")
         bias, splits = delta, head_dim          # the C-ABI passes them in the bias / splits slots of this epilogue
     ldaux = 0

@@ -54,10 +54,9 @@ class MultiHeadAttention(nn.Module):
 
     def _st_bind(self, a):
         d = self.d_model
-        if d not in (128, 256, 512) or self.d_k not in (32, 64):
+        if d not in (128, 256, 512) or self.d_k not in (32, 64, 128):
             raise NotImplementedError(
-                "HIP path: d_model must be 128, 256 or 512 and d_k = d_model / n_head 32 or 64 (got d_model %d, d_k %d; "
-                "e.g. the reference's config/character.yaml - d_model 512 with 4 heads = d_k 128 - needs n_heads: 8)"
+                "HIP path: d_model must be 128, 256 or 512 and d_k = d_model / n_head 32, 64 or 128 (got d_model %d, d_k %d)"
                 % (d, self.d_k))
         q, k, o, ln = self.linear_q, self.linear_k, self.output_linear, self.layernorm
         params = self._st_param_order()

@@ -206,13 +206,13 @@ class Transformer(nn.Module):
         common = dict(n_head=need('n_heads'), d_k=need('d_k'), d_v=need('d_v'), d_model=need('d_model'),
                       d_inner_hid=need('d_inner_hid'), dropout=need('dropout'), emb_scale=opt('emb_scale', 1))
         self.vocab_size, self.d_model = need('vocab_size'), common['d_model']
-        if common['d_model'] not in (128, 256, 512) or common['d_k'] not in (32, 64):
+        if common['d_model'] not in (128, 256, 512) or common['d_k'] not in (32, 64, 128):
             # fail where the model is built, not at the first attention launch (the attention kernels keep a whole
-            # head row per lane: d_k 32 or 64; the LayerNorm-fused GEMMs own full rows: d_model 128 / 256 / 512)
+            # head row per lane: d_k 32, 64 or 128 - the last is the reference's shipped config/character.yaml, d_model 512
+            # with 4 heads; the LayerNorm-fused GEMMs own full rows: d_model 128 / 256 / 512)
             raise NotImplementedError(
-                "Transformer(HIP path): d_model must be 128, 256 or 512 and d_k = d_v = d_model / n_heads 32 or 64; got "
-                "d_model %d, n_heads %d (d_k %d).  The reference's shipped config/character.yaml (d_model 512, 4 heads "
-                "= d_k 128) runs with n_heads: 8." % (common['d_model'], common['n_head'], common['d_k']))
+                "Transformer(HIP path): d_model must be 128, 256 or 512 and d_k = d_v = d_model / n_heads 32, 64 or 128; got "
+                "d_model %d, n_heads %d (d_k %d)." % (common['d_model'], common['n_head'], common['d_k']))
         self.encoder = Encoder(input_size=need('feature_dim'), n_max_seq=need('max_inputs_length', 'max_input_length'),
                                n_layers=need('num_enc_layer'), **common)
         self.decoder = Decoder(vocab_size=self.vocab_size, n_max_seq=need('max_target_length'),

@@ -317,6 +317,12 @@ def test_wide_step_composition():
         run_wide_step("cpu")
 
 
+def test_shipped_config_head_width_composition():
+    """d_model 512 with FOUR heads = d_k 128: the reference's shipped config/character.yaml:28-31."""
+    with emulated_kernels():
+        run_wide_step("cpu", n_head=4)
+
+
 def run_joint_ctc_step(device):
     """BASELINE config 4: joint lambda * CTC + (1 - lambda) * attention loss (transformer/Loss.py:CTCAttentionLoss
     on Transformer.forward_joint).  The encoder gets gradient from BOTH branches; everything is compared with the

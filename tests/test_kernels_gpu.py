@@ -214,6 +214,10 @@ ATTN_CASES = [
     (2, 4, 64, None, [1000, 640], False, True),
     (3, 4, 64, [64, 1, 40], [700, 256, 65], False, True),      # <= 64 queries, >= 256 keys: key-split kernels
     (2, 4, 32, [20, 33], [300, 129], False, False),
+    (3, 2, 128, None, [200, 131, 64], False, True),            # d_k = 128 (config/character.yaml: d_model 512, 4 heads)
+    (2, 2, 128, None, [300, 257], True, True),
+    (3, 2, 128, [64, 1, 40], [700, 256, 65], False, True),     # ... and its key-split kernels
+    (2, 2, 128, [20, 33], [300, 129], False, False),
 ]
 
 
@@ -401,7 +405,8 @@ def test_ln_bwd_dropout_and_mask_scale():
 
 @pytest.mark.parametrize("case", [(2, 2, 32, None, [7, 4], True, True), (3, 4, 64, None, [200, 131, 64], False, True),
                                   (2, 4, 64, [50, 33], [300, 257], False, True),
-                                  (2, 4, 32, None, [129, 70], True, False)])
+                                  (2, 4, 32, None, [129, 70], True, False),
+                                  (2, 2, 128, None, [200, 131], False, True), (2, 2, 128, [50, 33], [300, 257], False, True)])
 def test_attention_dropout(case):
     c = _attn_case(*case, seed=21)
     dn, de = _drops(3, 0.2)
@@ -477,7 +482,7 @@ def test_feat_stack_kernel():
     tf.run_stack_frames("cuda")
 
 
-@pytest.mark.parametrize("M,N,K,hd", [(333, 256, 256, 64), (1000, 128, 128, 32), (130, 512, 512, 64)])
+@pytest.mark.parametrize("M,N,K,hd", [(333, 256, 256, 64), (1000, 128, 128, 32), (130, 512, 512, 64), (260, 512, 512, 128)])
 def test_gemm_dgrad_with_delta_epilogue(M, N, K, hd):
     """ST_EPI_BF16_DELTA: the dgrad that produces d(context) also emits delta[h][i] = rowsum_h(d(context) * context)."""
     dy, W, O = g(M, K, seed=1), g(K, N, seed=2, scale=K ** -0.5), g(M, N, seed=3)
@@ -495,7 +500,8 @@ def test_gemm_dgrad_with_delta_epilogue(M, N, K, hd):
 
 
 @pytest.mark.parametrize("case", [(3, 4, 64, None, [200, 131, 64], False, True), (2, 4, 64, [50, 33], [1000, 517], False, True),
-                                  (2, 4, 32, None, [129, 70], True, True)])
+                                  (2, 4, 32, None, [129, 70], True, True), (2, 2, 128, None, [300, 131], False, True),
+                                  (2, 2, 128, [50, 33], [700, 517], False, True)])
 def test_attention_backward_single_launch(case):
     """O = None: delta comes in precomputed and dQ + dK/dV run as one launch - identical results to the two-kernel path."""
     c = _attn_case(*case, seed=31)

@@ -145,6 +145,12 @@ def test_config3_layer_shape_step_gpu():
     comp.run_wide_step("cuda")
 
 
+def test_shipped_config_head_width_step_gpu():
+    """d_model 512 with 4 heads = d_k 128 (the reference's shipped config/character.yaml:28-31): full step against the
+    fp64 oracle - the d_k = 128 attention instantiations and the 128-column delta epilogue."""
+    comp.run_wide_step("cuda", n_head=4)
+
+
 def test_joint_ctc_attention_step_gpu():
     """BASELINE config 4 objective: CTC head on the HIP encoder output + attention CE, gradients vs the fp64 oracle."""
     comp.run_joint_ctc_step("cuda")
