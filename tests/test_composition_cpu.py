@@ -337,6 +337,10 @@ def run_joint_ctc_step(device):
     x, in_len, tokens, tgt_len, gt = (batch[k] for k in ("x", "in_len", "tokens", "tgt_len", "gt"))
     L = int(tgt_len.max())
     tokens, gt = tokens[:, :L], gt[:, :L]
+    # The CTC projection's nn.Linear init draws from the GLOBAL generator, whose seed differs from process to process:
+    # unseeded, the worst tensor of this test moved between 0.050 and 0.085 with the drawn head (the product itself is
+    # run-to-run and process-to-process identical to 6e-8, tools/dev/determinism_check.py).
+    torch.manual_seed(0)
     head = CTCAttentionLoss(d_model, 30, ctc_weight=0.3)
     # ---- fp64 truth
     leaves = {k: (v.clone().requires_grad_(True) if not k.endswith(".pe") else v) for k, v in p.items()}
@@ -372,11 +376,7 @@ def run_joint_ctc_step(device):
             continue
         assert q.grad is not None and torch.isfinite(q.grad).all(), n
         rels.append((rel(q.grad.detach().cpu(), tg[n]), n))
-    # The CTC branch comes back through PyTorch's CTC backward, whose atomics make the product side differ from run to
-    # run; every encoder gradient inherits that.  55 repetitions on MI355X: the worst tensors (the front-end projection,
-    # layer 1's linear_q) land between 0.075 and 0.085 - 4 runs above the 8e-2 used everywhere else - so this test alone
-    # allows 1.25 x per tensor; the median bound is the common one.
-    assert max(rels)[0] < 1.25 * GRAD_TOL_TENSOR, max(rels)
+    assert max(rels)[0] < GRAD_TOL_TENSOR, max(rels)
     assert sorted(rels)[len(rels) // 2][0] < GRAD_TOL_MEDIAN
     assert rel(head.ctc_proj.weight.grad.cpu(), g_w64) < GRAD_TOL_MEDIAN       # the CTC head sees the bf16 encoder output
     assert rel(head.ctc_proj.bias.grad.cpu(), g_b64) < GRAD_TOL_MEDIAN
