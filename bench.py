@@ -338,9 +338,10 @@ def main():
         "gemm_dgrad": 2.0 * rows_e * n_e * ((d_m + 2 * d_m) + (d_m + 2 * d_ff)),               # delta / mask epilogues
         "gemm_wgrad": 2.0 * rows_e * n_e * (2 * (4 * d_m) + 2 * (d_m + d_ff)) + 4.0 * 2 * arena.total,
         # row chains (encoder-sized launches dominate): forward = context, residual in; LN out + xhat, hidden, LN out + xhat,
-        # next q|k|v out; backward = dqkv, ds, xhat, hidden (mask), xhat, O, Ores in; ds, dH, ds, d(context) out
-        "row_chain": 2.0 * rows_e * (n_e * (2 * d_m + 2 * d_m + d_ff + 2 * d_m) + (n_e - 1) * 3 * d_m),
-        "row_chain_bwd": 2.0 * rows_e * (n_e * (d_m + d_ff + d_m + 2 * d_m + d_m + d_ff + d_m + d_m) + (n_e - 1) * (3 * d_m + d_m + d_m)),
+        # next q|k|v out (+ one ReLU-mask bit per hidden value = d_ff / 16 bf16-sized units); backward = dqkv, ds, xhat, the
+        # mask bits, xhat, O, Ores in; ds, dH, ds, d(context) out
+        "row_chain": 2.0 * rows_e * (n_e * (2 * d_m + 2 * d_m + d_ff + d_ff / 16 + 2 * d_m) + (n_e - 1) * 3 * d_m),
+        "row_chain_bwd": 2.0 * rows_e * (n_e * (d_m + d_ff / 16 + d_m + 2 * d_m + d_m + d_ff + d_m + d_m) + (n_e - 1) * (3 * d_m + d_m + d_m)),
         "attn_fwd": 2.0 * rows_e * n_e * (3 * d_m + 2 * d_m),
         "attn_bwd": 2.0 * rows_e * n_e * (3 * d_m + d_m + 3 * d_m),
     }
