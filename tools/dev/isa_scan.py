@@ -5,7 +5,7 @@ usage: python tools/dev/isa_scan.py [file.hip ...]"""
 import glob, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "speech-tranformer-pytorch_amd", "csrc")
-files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+files = [os.path.abspath(f) for f in sys.argv[1:]] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 for f in files:
     asm = "/tmp/isa_scan_%s.s" % os.path.basename(f)
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-S", "--cuda-device-only", f, "-o", asm],
