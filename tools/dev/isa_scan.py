@@ -25,5 +25,5 @@ for f in files:
         cnt[cur][3] += 1
     for k, v in cnt.items():
         if v[0] or v[1] > 20 or v[2] > 40:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", k], capture_output=True, text=True).stdout.strip() or k
+            name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip() or k
             print("%-18s %-100s scratch %4d  accvgpr %4d  v_mov_b64 %4d  of %5d lines" % (os.path.basename(f), name[:100], *v))
