@@ -48,6 +48,7 @@ class Decode(object):
         self.max_steps = int(getattr(opt, "max_steps", None) or 100)
         ug = getattr(opt, "use_graph", None)
         self.use_graph = torch.device(device).type == "cuda" if ug is None else bool(ug)
+        self._side = None
 
     # ---- one decoder step for all n = B * beam hypotheses; everything that changes from step to step is DEVICE state ---
     @torch.no_grad()
@@ -137,6 +138,20 @@ class Decode(object):
     def decode_batch(self, src_batch):
         """src_batch = (inputs [B, T, F] fp32, input_lengths [B]) -> (all_hyp, all_scores) as Decode.py:168-177:
         all_hyp[b] = the n_best token lists of utterance b, all_scores[b] = their scores (tensor[n_best])."""
+        if not self.use_graph:
+            return self._decode_batch(src_batch)
+        # the whole call runs on this object's side stream: a step can then be captured where it is (graph capture needs
+        # a non-default stream) without hopping streams in the middle of the batch
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            out = self._decode_batch(src_batch)
+        cur.wait_stream(self._side)
+        return out
+
+    def _decode_batch(self, src_batch):
         inputs, in_len = src_batch
         model, dev = self.model, self.device
         inputs = inputs.to(dev)
@@ -187,10 +202,12 @@ class Decode(object):
                 if self.use_graph and steps_done == 1:
                     # step 0 ran eagerly (kernel modules loaded, allocator warm); every later step is a replay of ONE
                     # captured step: the position, the cache length, the tokens and the beams are device state
-                    torch.cuda.synchronize()
+                    # (captured by hand, on decode_batch's side stream: `with torch.cuda.graph(...)` also runs gc.collect() and
+                    # torch.cuda.empty_cache() - 4 ms of every decode_batch call, a tenth of a 32-utterance batch)
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        one_step()
+                    graph.capture_begin(**(dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}))
+                    one_step()
+                    graph.capture_end()
                 if graph is not None:
                     graph.replay()
                 else:
@@ -201,23 +218,27 @@ class Decode(object):
                     break
 
         # ---- per-utterance Beam objects (the reference's read-out API) from the device trellis -------------------------
+        # (the trellis crosses to the host ONCE; the Beam objects are built from the host copy - per utterance the read-out
+        # was a sort, two stacks and three .tolist() synchronisations on the device: 3 ms per 32-utterance batch)
         lengths, done = st.lengths.tolist(), st.done.tolist()
-        all_hyp, all_scores = [], []
+        back_h, toks_h, hist_h, scores_h = st.back.cpu(), st.toks.cpu(), st.hist_scores.cpu(), st.scores.cpu()
+        all_hyp, best = [], []
         for b in range(B):
-            bm = Beam(beam, dev)
+            bm = Beam(beam, "cpu")
             t = lengths[b]
-            bm.prev_ks = list(st.back[:t, b].unbind(0))
-            bm.next_ys += list(st.toks[:t, b].unbind(0))
-            bm.all_scores = list(st.hist_scores[:t, b].unbind(0))
+            bm.prev_ks = list(back_h[:t, b].unbind(0))
+            bm.next_ys += list(toks_h[:t, b].unbind(0))
+            bm.all_scores = list(hist_h[:t, b].unbind(0))
             if t:
-                bm.all_scores[0] = torch.zeros(beam, dtype=F32, device=dev)     # Beam.py:24: the initial scores are zeros
-            bm.scores = st.scores[b]
+                bm.all_scores[0] = torch.zeros(beam, dtype=F32)                  # Beam.py:24: the initial scores are zeros
+            bm.scores = scores_h[b]
             bm.done = done[b]
             if bm.done:
                 bm.all_scores.append(bm.scores)
             scores, tail_idxs = bm.sort_scores()
-            all_scores += [scores[:n_best]]
+            best.append(scores[:n_best])
             all_hyp += [[bm.get_hypothesis(i) for i in tail_idxs[:n_best].tolist()]]
+        all_scores = list(torch.stack(best).to(dev).unbind(0)) if best else []
         self.beams = None
         return all_hyp, all_scores
 
