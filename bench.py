@@ -54,9 +54,11 @@ def step_flops(in_len, tgt_len, c):
 
 
 def kernel_report(records):
-    """Aggregate per-launch HIP-event timings into kernel classes with algorithmic work."""
+    """Aggregate per-launch HIP-event timings into kernel classes with algorithmic work: flops from the launch's shape
+    tag, HBM bytes from the launch's own operand list (native._tag(io=...): every operand once) - nothing here is derived
+    from the model configuration, so a class cannot be credited with traffic its launches did not have."""
     agg = {}
-    for name, tag, ms in records:
+    for name, tag, ms, nbytes in records:
         flops, kind = 0.0, name
         if tag is not None:
             if tag[0] == "gemm":
@@ -82,10 +84,14 @@ def kernel_report(records):
                 # encoder-sized launches (HBM-bound: 96-row workgroups) and decoder-sized ones (bound by one CU's weight
                 # stream and by launch latency) are different regimes: two classes
                 kind, flops = tag[0] + ("" if tag[1] > 8192 else "_dec"), 2.0 * tag[1] * tag[2] * 256 * 256
-        a = agg.setdefault(kind, {"ms": 0.0, "launches": 0, "flops": 0.0})
+        a = agg.setdefault(kind, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "untagged": 0})
         a["ms"] += ms
         a["launches"] += 1
         a["flops"] += flops
+        if nbytes is None:
+            a["untagged"] += 1
+        else:
+            a["bytes"] += nbytes
     return agg
 
 
@@ -164,8 +170,11 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-utts", type=int, default=32, help="utterances of the batch the CPU baseline is timed on")
     ap.add_argument("--cpu-timeout", type=int, default=200)
-    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many utterances of the seed-0 batch "
-                    "split contiguously over the ranks (SURVEY 8e: 32 -> 4 per GPU at N = 8) instead of 32 per GPU")
+    ap.add_argument("--global-batch", type=int, default=None, help="strong scaling: this many utterances of the seed-0 batch "
+                    "split contiguously over the ranks (SURVEY 8e: 32 -> 4 per GPU at N = 8).  Default: 32 - the specified "
+                    "partition (BASELINE config 2 is ONE global B = 32 minibatch, train_multi.py:136-139,161-163)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling as the headline: 32 utterances per GPU (seed = rank); "
+                    "at N > 1 the default run reports this partition as the extra `weak_scaling` block")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--wire-bf16", action="store_true", help="bf16 gradient all-reduce (train_multi.py -fp16_allreduce)")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write per-shape launch timings (JSON) here")
@@ -178,6 +187,10 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args)
+    # the headline partition: the global B = 32 batch split over the ranks (strong scaling; N = 1: the whole batch on one
+    # GPU, the same workload either way) unless --weak
+    if args.global_batch is None:
+        args.global_batch = 0 if args.weak else BATCH
 
     import transformer.Models as M
     import transformer.Utils as U
@@ -218,6 +231,8 @@ def main():
 
     if args.global_batch and (args.global_batch % world or args.global_batch > BATCH):
         raise SystemExit("--global-batch must be a multiple of the rank count and <= %d" % BATCH)
+    if args.global_batch and world == 1 and args.global_batch == BATCH:
+        pass                                       # N = 1: the seed-0 batch, whole (identical to the weak-scaling shard of rank 0)
     x, tokens, in_len, tgt_len, gt = shard(args.global_batch)
     xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()          # inputs resident in HBM before timing
 
@@ -295,7 +310,7 @@ def main():
     agg = kernel_report(records)
     if args.dump_kernels and rank == 0:
         shapes = {}
-        for name, tag, ms in records:
+        for name, tag, ms, _nb in records:
             key = name + ":" + ",".join(str(t) for t in (tag or ()) if not torch.is_tensor(t))
             e = shapes.setdefault(key, [0, 0.0])
             e[0] += 1
@@ -316,40 +331,22 @@ def main():
         with open(pmc[-1]) as f:
             pj = json.load(f)
         traffic = pj.get(dom, {}).get("bytes")
-        traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload at git %s)" % (
+        traffic_src = "offline: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload at git %s; not measured in this run)" % (
             os.path.basename(pmc[-1]), pj.get("git_sha", "unrecorded"))
     kernels = {k: {"ms_per_step": round(v["ms"] / 2, 3), "launches": v["launches"] // 2,
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] else None}
                for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-    # HBM side (SURVEY 8d "report both"): algorithmic bytes per step of the streaming kernels and of the GEMM / attention
-    # classes (operands once, bf16 activations) -> achieved GB/s and its fraction of the 8 TB/s peak
-    rows_e, rows_d, d_m, d_ff, n_e, n_d = float(in_len.sum()), float(tgt_len.sum()), C2["d_model"], C2["d_inner_hid"], \
-        C2["num_enc_layer"], C2["num_dec_layer"]
-    hbm_bytes = {
-        "st_adam_clip": 32.0 * arena.total,                               # p, g, m, v read + written (fp32)
-        "st_cast_bf16": 6.0 * arena.total,
-        "st_pack_rows": rows_e * C2["feature_dim"] * (4 + 2),
-        "ln_bwd": 3 * 6.0 * rows_e * d_m,                                 # dy, xhat in, dx out (3 launches, encoder-sized bound)
-        "st_embed_pe_fwd": rows_d * d_m * (4 + 4 + 2), "st_embed_bwd": rows_d * d_m * (2 + 8),
-        # per encoder layer: q/k/v (in d, out 3d), fc1 (in d, out d_ff) + the stacked K/V projection (in d, out 2 d n_dec)
-        "gemm_fwd": 2.0 * rows_e * (n_e * (4 * d_m + d_m + d_ff) + d_m + 2 * d_m * n_d),
-        "gemm_ln": 2.0 * rows_e * n_e * ((d_m + d_m + 2 * d_m) + (d_ff + d_m + 2 * d_m)),     # X, residual in; out, xhat
-        "gemm_lnbwd": 2.0 * rows_e * n_e * ((3 * d_m + 3 * d_m) + (d_ff + 3 * d_m)),           # dY, aux, xhat in; dx out
-        "gemm_dgrad": 2.0 * rows_e * n_e * ((d_m + 2 * d_m) + (d_m + 2 * d_ff)),               # delta / mask epilogues
-        "gemm_wgrad": 2.0 * rows_e * n_e * (2 * (4 * d_m) + 2 * (d_m + d_ff)) + 4.0 * 2 * arena.total,
-        # row chains (encoder-sized launches dominate): forward = context, residual in; LN out + xhat, hidden, LN out + xhat,
-        # next q|k|v out (+ one ReLU-mask bit per hidden value = d_ff / 16 bf16-sized units); backward = dqkv, ds, xhat, the
-        # mask bits, xhat, O, Ores in; ds, dH, ds, d(context) out
-        "row_chain": 2.0 * rows_e * (n_e * (2 * d_m + 2 * d_m + d_ff + d_ff / 16 + 2 * d_m) + (n_e - 1) * 3 * d_m),
-        "row_chain_bwd": 2.0 * rows_e * (n_e * (d_m + d_ff / 16 + d_m + 2 * d_m + d_m + d_ff + d_m + d_m) + (n_e - 1) * (3 * d_m + d_m + d_m)),
-        "attn_fwd": 2.0 * rows_e * n_e * (3 * d_m + 2 * d_m),
-        "attn_bwd": 2.0 * rows_e * n_e * (3 * d_m + d_m + 3 * d_m),
-    }
-    for k, nbytes in hbm_bytes.items():
-        if k in kernels and kernels[k]["ms_per_step"] > 0:
-            gbs = nbytes / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
+    # HBM side (SURVEY 8d "report both"): algorithmic bytes of every launch of a class (its own operands, each once:
+    # native._tag(io=...)) / the class's summed event time -> achieved GB/s and its fraction of the 8 TB/s peak.  Classes
+    # with an untagged launch report no figure rather than a partial one.
+    hbm_bytes = {}
+    for k, v in agg.items():
+        if v["bytes"] > 0 and v["untagged"] == 0 and v["ms"] > 0:
+            hbm_bytes[k] = v["bytes"] / 2          # per step (the pass ran two steps)
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             kernels[k]["hbm_gbs"] = round(gbs, 1)
             kernels[k]["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 3)
+            kernels[k]["hbm_mb_per_launch"] = round(v["bytes"] / v["launches"] / 1e6, 2)
     # the roofline that bounds the dominant class: HBM when its algorithmic intensity (flops / bytes, both per step) lies below
     # the machine balance 2500 TFLOP/s : 8 TB/s = 312 flop/byte (the row chains: ~160), else the MFMA peak (attention)
     dom_bytes = hbm_bytes.get(dom)
@@ -440,12 +437,14 @@ def main():
         except Exception as e:  # noqa: BLE001 - the headline line must still be printed
             loader_proof = {"error": "%s: %s" % (type(e).__name__, e)}
 
-    # ---- N > 1, default (weak) mode: also time the SPECIFIED partition - the global B = 32 batch of BASELINE config 2
-    # split contiguously over the ranks (4 utterances per GPU at N = 8, SURVEY 8e / north star) - in the same run
-    strong = None
-    if world > 1 and not args.global_batch and BATCH % world == 0:
+    # ---- N > 1: also time the OTHER partition in the same run - headline strong (global B = 32 split contiguously, 4
+    # utterances per GPU at N = 8: SURVEY 8e / north star) -> extra block weak (32 utterances per GPU, seed = rank), and
+    # the other way round under --weak
+    strong = weak = None
+    other_gb = 0 if args.global_batch else BATCH
+    if world > 1 and (other_gb == 0 or BATCH % world == 0):
         try:
-            xs, ts, ils, tls, gs = shard(BATCH)
+            xs, ts, ils, tls, gs = shard(other_gb)
             xsg, tsg, gsg = xs.cuda(), ts.cuda(), gs.cuda()
             step_s = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
             for _ in range(max(args.warmup, 4)):
@@ -459,12 +458,21 @@ def main():
             fr = torch.tensor([float(ils.sum())], device="cuda")
             dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
             dist.all_reduce(fr, op=dist.ReduceOp.SUM)
-            strong = {"value": round(fr.item() * args.steps / ts_.item(), 1), "unit": "frames/s", "scaling": "strong",
-                      "ms_per_step": round(ts_.item() / args.steps * 1e3, 3), "global_batch": BATCH,
-                      "per_gpu_batch": BATCH // world,
-                      "note": "the seed-0 batch of BASELINE config 2 split contiguously by rank (SURVEY 8e)"}
+            blk = {"value": round(fr.item() * args.steps / ts_.item(), 1), "unit": "frames/s",
+                   "scaling": "strong" if other_gb else "weak", "ms_per_step": round(ts_.item() / args.steps * 1e3, 3),
+                   "global_batch": other_gb or BATCH * world, "per_gpu_batch": (other_gb or BATCH * world) // world,
+                   "note": ("the seed-0 batch of BASELINE config 2 split contiguously by rank (SURVEY 8e)" if other_gb else
+                            "32 utterances per GPU, seed = rank (DistributedSampler semantics with the per-rank batch fixed)")}
+            if other_gb:
+                strong = blk
+            else:
+                weak = blk
         except Exception as e:  # noqa: BLE001 - the headline line must still be printed
-            strong = {"error": "%s: %s" % (type(e).__name__, e)}
+            blk = {"error": "%s: %s" % (type(e).__name__, e)}
+            if other_gb:
+                strong = blk
+            else:
+                weak = blk
 
     out = None
     if rank == 0:
@@ -490,9 +498,12 @@ def main():
             "step_frac_of_bf16_peak": round(flops / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "kernel_ms_per_step": round(total_ms / 2, 3),
             "roofline": roofline, "kernels": kernels,
+            "hbm_bytes_source": "per launch: the launch's own operands, each counted once (st_amd.native._tag io lists)",
         }
         if strong is not None:
             out["strong_scaling"] = strong
+        if weak is not None:
+            out["weak_scaling"] = weak
         if train_mode is not None:
             out["train_mode"] = train_mode
         if decode is not None:

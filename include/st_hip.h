@@ -198,14 +198,22 @@ int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, co
               const void* mask, void* dx, int lddx, float* dgamma, float* dbeta, float* dbias, int M, int N,
               const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, float mask_scale);
 
+/* Rows per work-list tile of the attention kernel that serves a problem of
+ * this shape (the kernels are chosen by shape: long non-causal problems with
+ * 64-wide heads run 256-row workgroups, everything else 128-row ones).
+ * which: 0 = st_attn_fwd (query tiles), 1 = st_attn_bwd work_q (query tiles),
+ * 2 = st_attn_bwd work_k (key tiles). */
+int st_attn_tile_rows(int which, int d_k, int max_q, int max_k, int causal);
+
 /* Fused masked attention forward: softmax(Q K^T * scale, keys >= k_len[b]
  * and (causal) keys > query masked) V, per head; replaces Attention.py:82-90
  * and the dense masks of Utils.py:41-70.  lse (f32 [H, q_rows_total], log2
  * domain) is saved for the backward.  d_k in {32, 64, 128}.
- * work (optional, device int32 [n_work]): the (utterance, 128-query tile)
- * pairs to run, packed (b << 16) | tile and sorted by decreasing cost, so the
- * ragged batch is list-scheduled longest-first; NULL = enumerate every tile
- * of every utterance up to max_q.  drop_*: dropout on the attention
+ * work (optional, device int32 [n_work]): the (utterance, query tile) pairs
+ * to run, packed (b << 16) | tile and sorted by decreasing cost, so the
+ * ragged batch is list-scheduled longest-first; a tile is
+ * st_attn_tile_rows(0, ...) query rows; NULL = enumerate every tile of every
+ * utterance up to max_q.  drop_*: dropout on the attention
  * probabilities (Attention.py:89); pass the same values to st_attn_bwd. */
 int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
                 int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
@@ -216,8 +224,8 @@ int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
  * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:
  * parts & 1 = dQ (also writes delta), parts & 2 = dK/dV (reads delta); 3 = both.
  * O == NULL: delta is an input (st_gemm ST_EPI_BF16_DELTA wrote it with dO) and parts == 3 runs as ONE launch.
- * work_q / work_k: optional work lists (see st_attn_fwd) over 128-query tiles
- * (dQ kernel) and 128-key tiles (dK/dV kernel). */
+ * work_q / work_k: optional work lists (see st_attn_fwd) over query tiles
+ * (dQ kernel) and key tiles (dK/dV kernel) of st_attn_tile_rows(1 / 2, ...) rows. */
 int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                 const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
                 void* dK, int lddk, void* dV, int lddv, const int* q_off, const int* q_len, const int* k_off,

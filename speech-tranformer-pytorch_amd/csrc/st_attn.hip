@@ -28,256 +28,12 @@
 // global -> registers (two tiles in flight) -> padded LDS double buffer, with byte offsets fixed for the whole
 // kernel - the steady-state loop has no address arithmetic, no guards and one barrier per tile.  Rows past
 // the end of a sequence are CLAMPED onto its last row (finite data); the mask path zeroes their weight.
-#include "st_common.cuh"
+#include "st_attn_common.cuh"
+
+// st_attn64.hip (AttnArgs passed by address: the type is local to each translation unit, the layout is shared)
+extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop, int var);
 
 namespace {
-
-constexpr int TILE = 64;      // rows (keys or queries) per streamed tile
-constexpr int WG_ROWS = 128;  // rows owned by a workgroup (4 waves x 32)
-
-struct AttnArgs {
-  const bf16* Q; int ldq;
-  const bf16* K; int ldk;
-  const bf16* V; int ldv;
-  bf16* O; int ldo;               // forward: output; backward: forward output (for delta)
-  bf16* Ores;                     // forward, optional: bf16(O_fp32 - bf16(O_fp32)), same layout as O - with it the
-                                  // backward's delta = rowsum(dO * (O + Ores)) sees O to ~16 mantissa bits
-  const bf16* dO; int lddo;
-  bf16* dQ; int lddq;
-  bf16* dK; int lddk;
-  bf16* dV; int lddv;
-  float* lse;                     // [H][q_rows_total], log2 domain: m + log2(l)
-  float* delta;                   // [H][q_rows_total]
-  const int* q_off; const int* q_len;
-  const int* k_off; const int* k_len;
-  const int* work;                // (b << 16) | tile, sorted by decreasing cost; or null
-  int tiles_max;                  // without a work list: tiles per utterance enumerated
-  int H;
-  int q_rows_total;
-  int causal;
-  int psplit;                     // forward: P enters the P V product as two bf16 terms (hi + lo): the context, and with it
-                                  // the backward's delta = rowsum(dO * O), is then consistent with the fp32 P the backward
-                                  // recomputes - sum_k dS(q, k) = 0 to ~2^-16 instead of ~2^-9 (matters where the keys
-                                  // are nearly identical and dQ / dK are differences of almost equal terms); small-Lq only
-  float scale;                    // 1/sqrt(d_k)
-  DropArgs drop;                  // attention-probability dropout (Attention.py:89), training mode only
-};
-
-// blockIdx.x -> (utterance, head, tile)
-__device__ __forceinline__ void decode_item(const AttnArgs& a, int bid, int& b, int& h, int& tile) {
-  const int idx = bid / a.H;
-  h = bid % a.H;
-  if (a.work) {
-    const int w = a.work[idx];
-    b = w >> 16;
-    tile = w & 0xffff;
-  } else {
-    b = idx / a.tiles_max;
-    tile = idx % a.tiles_max;
-  }
-}
-
-// ---- streamed [64 x DK] tiles ----------------------------------------------------------------------
-// LDS image: natural rows, stride DK + 8 elements (144 B / 80 B): ds_read_b128 row fragments over 16 rows
-// and the 4-row groups of ds_read_b64_tr_b16 are both bank-conflict free (DK = 64; 272 B for DK = 128 shifts 16 B per row likewise).
-// DK = 128 (the reference's config/character.yaml: d_model 512, 4 heads) needs > 256 registers per lane: one workgroup per CU.
-template <int DK, int ROWS = TILE> struct TileGeo {
-  static constexpr int STR = DK + 8, E = ROWS * STR, CPR = DK / 8, CH = ROWS * CPR / 256;   // CH chunks per thread
-};
-
-template <int DK, int ROWS = TILE>
-struct Stage {
-  using G = TileGeo<DK, ROWS>;
-  bf16x8 v[G::CH];
-  // chunk id = tid + p*256 -> tile row id / CPR, 16-byte chunk id % CPR
-  static __device__ __forceinline__ void offsets(uint32_t (&off)[G::CH], int ld) {
-#pragma unroll
-    for (int p = 0; p < G::CH; ++p) {
-      const int id = threadIdx.x + p * 256;
-      off[p] = ((uint32_t)(id / G::CPR) * (uint32_t)ld + (id % G::CPR) * 8) * 2u;
-    }
-  }
-  // rows r0 .. r0+ROWS-1 of the utterance's column slice `base`; rows >= nvalid read row nvalid-1
-  __device__ __forceinline__ void load(const uint32_t (&off)[G::CH], const bf16* __restrict__ base, int ld, int r0,
-                                       int nvalid) {
-    if (r0 + ROWS <= nvalid) {
-      const char* tb = reinterpret_cast<const char*>(base + (size_t)r0 * ld);
-#pragma unroll
-      for (int p = 0; p < G::CH; ++p) v[p] = *reinterpret_cast<const bf16x8*>(tb + off[p]);
-    } else {
-#pragma unroll
-      for (int p = 0; p < G::CH; ++p) {
-        const int id = threadIdx.x + p * 256;
-        const int row = min(r0 + id / G::CPR, nvalid - 1);
-        v[p] = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + (id % G::CPR) * 8);
-      }
-    }
-  }
-  __device__ __forceinline__ void store(bf16* tile) const {
-#pragma unroll
-    for (int p = 0; p < G::CH; ++p) {
-      const int id = threadIdx.x + p * 256;
-      *reinterpret_cast<bf16x8*>(tile + (id / G::CPR) * G::STR + (id % G::CPR) * 8) = v[p];
-    }
-  }
-};
-
-// Row fragment: elements t16*16 + hi*8 .. +7 of tile row R (A or B operand, contraction along DK).
-template <int DK>
-__device__ __forceinline__ bf16x8 rd_nat(const bf16* tile, int R, int t16) {
-  const int hi = (threadIdx.x & 63) >> 5;
-  return frag_nat(tile, TileGeo<DK>::STR, R, t16 * 16 + hi * 8);
-}
-// Transposing fragment: for column d0 + (lane & 31), the 8 tile rows base+0..3 and base+8..11
-// (base already includes 4*hi) - the contraction runs over the tile's ROWS.
-template <int DK>
-__device__ __forceinline__ bf16x8 rd_tr(const bf16* tile, int d0, int base) {
-  return frag_tr(tile, TileGeo<DK>::STR, d0, base, base + 8);
-}
-
-// The software pipeline shared by the three kernels.  load(set, tile) fills register set `set`,
-// store(set) writes it to LDS buffer `set`, compute(buf, tile) consumes LDS buffer `buf`.
-// Steady state has no conditionals, so the compiler's s_waitcnt vmcnt() stays counted: the loads of
-// tile it+2 remain in flight across the LDS store of tile it+1.
-template <typename L, typename S, typename C>
-__device__ __forceinline__ void stream_tiles(int ntiles, L load, S store, C compute) {
-  if (ntiles <= 0) return;   // (workgroup-uniform) nothing visible: the accumulators stay zero
-  load(0, 0);
-  if (ntiles > 1) load(1, 1);
-  store(0);
-  __syncthreads();
-  int it = 0;
-  for (; it + 3 < ntiles; it += 2) {
-    load(0, it + 2);
-    compute(0, it);
-    store(1);
-    __syncthreads();
-    load(1, it + 3);
-    compute(1, it + 1);
-    store(0);
-    __syncthreads();
-  }
-  // tail: 1..3 tiles left; tile `it` is in LDS buffer 0, tile it+1 (if any) in register set 1
-  if (it + 2 < ntiles) load(0, it + 2);
-  compute(0, it);
-  if (it + 1 < ntiles) {
-    store(1);
-    __syncthreads();
-    compute(1, it + 1);
-    if (it + 2 < ntiles) {
-      store(0);
-      __syncthreads();
-      compute(0, it + 2);
-    }
-  }
-  __syncthreads();   // the epilogue reuses the tile buffers
-}
-
-// Store a transposed accumulator tile (lane = row, registers = DK columns) as coalesced rows:
-// through a wave-private [32][DK] LDS patch so HBM sees whole DK*2-byte row segments instead of
-// 64 scattered 8-byte writes per instruction.  `patch` is this wave's private 32*DK elements.
-template <int DK, bool RESID = false>
-__device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float mul, bf16* gbase, int ld, int row0,
-                                           int nvalid_rows) {
-  constexpr int ND = DK / 32, CPR = DK / 8;
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
-#pragma unroll
-  for (int d = 0; d < ND; ++d)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = acc[d][4 * g + e] * mul;
-        v[e] = RESID ? (bf16)(x - (float)(bf16)x) : (bf16)x;      // RESID: what the bf16 rounding of x dropped
-      }
-      const int col = d * 32 + 8 * g + 4 * hi;
-      *reinterpret_cast<bf16x4*>(patch + r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7)) = v;
-    }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < 32 * CPR / 64; ++p) {
-    const int id = p * 64 + l, rr = id / CPR, c = id % CPR;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rr * DK + ((c ^ (rr & (CPR - 1))) << 3));
-    if (rr < nvalid_rows) *reinterpret_cast<bf16x8*>(gbase + (size_t)(row0 + rr) * ld + c * 8) = v;
-  }
-}
-
-// The same for a value AND what its bf16 rounding dropped (O, Ores), in ONE pass: both images are written to two
-// patches, one LDS wait, both are read back and stored - half the dependent LDS round trips of two store_rows calls
-// (the attention epilogue is a latency tail: every wave of the workgroup is in it at the same time).
-template <int DK>
-__device__ __forceinline__ void store_rows_pair(bf16* patch_hi, bf16* patch_lo, const f32x16* acc, float mul, bf16* g_hi,
-                                                bf16* g_lo, int ld, int row0, int nvalid_rows) {
-  constexpr int ND = DK / 32, CPR = DK / 8;
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
-#pragma unroll
-  for (int d = 0; d < ND; ++d)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 vh, vl;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = acc[d][4 * g + e] * mul;
-        vh[e] = (bf16)x;
-        vl[e] = (bf16)(x - (float)vh[e]);
-      }
-      const int col = d * 32 + 8 * g + 4 * hi;
-      const int at = r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7);
-      *reinterpret_cast<bf16x4*>(patch_hi + at) = vh;
-      *reinterpret_cast<bf16x4*>(patch_lo + at) = vl;
-    }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < 32 * CPR / 64; ++p) {
-    const int id = p * 64 + l, rr = id / CPR, c = id % CPR;
-    const int at = rr * DK + ((c ^ (rr & (CPR - 1))) << 3);
-    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(patch_hi + at);
-    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(patch_lo + at);
-    if (rr < nvalid_rows) {
-      *reinterpret_cast<bf16x8*>(g_hi + (size_t)(row0 + rr) * ld + c * 8) = vh;
-      *reinterpret_cast<bf16x8*>(g_lo + (size_t)(row0 + rr) * ld + c * 8) = vl;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Forward.  Each wave owns 32 query rows (lane & 31); key / value tiles are streamed.
-// ---------------------------------------------------------------------------------------------
-// Keep decisions of one lane's 16 accumulator registers: register r <-> pair (fixed, var0 + acc_row(r, hi)).
-// FIXED_IS_Q: the lane's own index is the query (forward / dQ: registers run over keys), else it is the key.
-template <bool FIXED_IS_Q>
-__device__ __forceinline__ void keep16(const Drop& dr, int bh, int fixed, int var0, int hi, bool (&keep)[16]) {
-  // Lanes l and l ^ 1 hold neighbouring fixed indices (2f, 2f + 1: tile origins are even) and therefore need the SAME
-  // eight hashes (a 2 x 2 block serves both).  Each computes four - the even lane register groups g = 0, 1, the odd
-  // lane g = 2, 3 - and fetches the other four from its neighbour with a DPP move (the hash costs two quarter-rate
-  // v_mul_lo_u32; this halves what dropout adds to the VALU-bound softmax).
-  const int par = threadIdx.x & 1, fx = fixed & 1;
-  uint32_t own[4], nb[4];
-#pragma unroll
-  for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int v = var0 + 8 * (2 * par + gi) + 4 * hi + 2 * hb;
-      own[gi * 2 + hb] = FIXED_IS_Q ? dr.bits(drop_counter_qk(bh, fixed, v)) : dr.bits(drop_counter_qk(bh, v, fixed));
-    }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) nb[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)own[j], 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = (g & 1) * 2 + hb;
-      uint32_t bits = ((g >> 1) == par) ? own[j] : nb[j];
-      // byte of (q, k) inside its block = 2 * (q & 1) + (k & 1); this lane's two elements differ in the variable index
-      bits >>= FIXED_IS_Q ? 16 * fx : 8 * fx;
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-        keep[4 * g + 2 * hb + e] = (int)((bits >> (FIXED_IS_Q ? 8 * e : 16 * e)) & 0xffu) >= dr.thresh;
-    }
-}
 
 // KS = 2 ("few queries, many keys": the decoder-encoder attention, <= 64 queries against ~1000 keys): the workgroup
 // owns 64 query rows and streams 128-key stages; waves 0,1 take the first 64 keys of a stage, waves 2,3 the second
@@ -763,14 +519,32 @@ bool set_drop(AttnArgs& a, const unsigned* seed, unsigned salt, int thresh, floa
 bool key_split(int max_q, int max_k, int causal) { return !causal && max_q <= 64 && max_k >= 256; }
 
 // grid size and enumeration mode for one family of workgroups
-int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows) {
+int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows, int wg_rows = WG_ROWS) {
   a.work = work;
   a.H = H;
-  a.tiles_max = (max_rows + WG_ROWS - 1) / WG_ROWS;
+  a.tiles_max = (max_rows + wg_rows - 1) / wg_rows;
   return (work ? n_work : B * a.tiles_max) * H;
 }
 
+// development switch (ST_ATTN_IMPL=1: the 128-row kernels everywhere), read once
+int attn_impl() {
+  static const int v = [] { const char* e = getenv("ST_ATTN_IMPL"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+// long non-causal problems with 64-wide heads take the 64-rows-per-wave forward (256-row work-list tiles)
+bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
+  return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1;
+}
+
 }  // namespace
+
+extern "C" int st_attn_tile_rows(int which, int d_k, int max_q, int max_k, int causal) {
+  // rows per work-list tile of the kernel that will serve this problem: which = 0 forward (query tiles),
+  // 1 backward dQ (query tiles), 2 backward dK/dV (key tiles)
+  if (which == 0) return fwd_long64(d_k, max_q, max_k, causal) && !(attn_impl() >= 30 && attn_impl() < 50) ? F64_WG : WG_ROWS;
+  return WG_ROWS;
+}
 
 extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                            void* O, int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off,
@@ -788,6 +562,10 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   a.psplit = (Ores != nullptr && max_q <= 64) ? 1 : 0;     // the decoder's attentions, when a backward will follow
+  if (fwd_long64(d_k, max_q, max_k, causal)) {
+    dim3 grid(plan(a, work, n_work, B, H, max_q, st_attn_tile_rows(0, d_k, max_q, max_k, causal))), block(256);
+    return st_attn64_fwd_launch(stream, &a, (int)grid.x, drop ? 1 : 0, attn_impl());
+  }
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
 #define ST_FWD(DKK, DR) \

@@ -3,26 +3,41 @@
 hipcc cross-compiles without a GPU, so this runs in the CPU-only build
 container; the resulting .so travels to the GPU box with the source tree.
 Staleness is decided by a content hash of csrc/ stored next to the library
-(file mtimes do not survive the copy to the GPU box).
+(file mtimes do not survive the copy to the GPU box).  Every source is compiled
+to its own object (in parallel; objects are cached by content hash under
+lib/obj/), then linked.
 """
 import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libst_hip.so")
 STAMP = LIB + ".srchash"
 SOURCES = ["st_gemm_sym.hip", "st_wgrad.hip", "st_gemm_ws.hip", "st_gemm_ln.hip", "st_gemm_lnbwd.hip", "st_rowchain.hip", "st_attn.hip",
-           "st_misc.hip"]
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-shared",
-         "-Wno-unused-result"]
+           "st_attn64.hip", "st_misc.hip"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result"]
+# per-file additions.  st_attn64.hip: one workgroup per CU owns all 512 registers per lane; left to its heuristics the
+# compiler puts the score accumulators into AGPRs and pays one v_accvgpr_read per score in front of the exponential.
+EXTRA = {"st_attn64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+
+
+def _headers() -> bytes:
+    h = b""
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".cuh", ".h")):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h += name.encode() + f.read()
+    return h
 
 
 def source_hash() -> str:
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(" ".join(FLAGS + sorted(sum(([k] + v for k, v in EXTRA.items()), []))).encode())
     for name in sorted(os.listdir(CSRC)):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode())
@@ -37,6 +52,23 @@ def _stale() -> bool:
         return f.read().strip() != source_hash()
 
 
+def _compile(hipcc: str, src: str, headers: bytes, verbose: bool) -> str:
+    flags = FLAGS + EXTRA.get(src, [])
+    with open(os.path.join(CSRC, src), "rb") as f:
+        key = hashlib.sha256(" ".join(flags).encode() + headers + f.read()).hexdigest()[:24]
+    obj = os.path.join(OBJDIR, "%s.%s.o" % (os.path.splitext(src)[0], key))
+    if not os.path.exists(obj):
+        for old in os.listdir(OBJDIR):
+            if old.startswith(os.path.splitext(src)[0] + "."):
+                os.remove(os.path.join(OBJDIR, old))
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(obj + ".tmp", obj)
+    return obj
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """Compile the library if it is missing or was built from different sources."""
     if not force and not _stale():
@@ -44,8 +76,11 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libst_hip.so")
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = _headers()
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(hipcc, s, headers, verbose), SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

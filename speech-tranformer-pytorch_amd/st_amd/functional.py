@@ -143,33 +143,39 @@ class Rows:
         return self._pos
 
 
-def attn_work(q_rows: Rows, k_rows: Rows, causal: bool):
-    """Work lists of the attention kernels for one (query layout, key layout, causal) combination:
-    int32 device vectors of (b << 16) | tile over 128-query tiles (forward, dQ) and 128-key tiles (dK/dV),
-    sorted by decreasing number of streamed 64-row tiles - the dispatcher hands workgroups out in this
-    order, i.e. longest-first list scheduling of the ragged batch.  Cached on the query layout; the model
-    calls this while it builds the layouts, before the first kernel of a step (no H2D copy mid-step)."""
-    key = (id(k_rows), bool(causal))
+def attn_work(q_rows: Rows, k_rows: Rows, causal: bool, d_k: int = 64):
+    """Work lists of the attention kernels for one (query layout, key layout, causal, head width) combination:
+    int32 device vectors of (b << 16) | tile over query tiles (forward; backward dQ) and key tiles (backward dK/dV),
+    sorted by decreasing number of streamed 64-row tiles - the dispatcher hands workgroups out in this order, i.e.
+    longest-first list scheduling of the ragged batch.  The rows per tile are the kernels' own (``native.attn_tile_rows``:
+    the kernel is chosen by problem shape).  -> (forward, backward dQ, backward dK/dV).  Cached on the query layout;
+    the model calls this while it builds the layouts, before the first kernel of a step (no H2D copy mid-step)."""
+    key = (id(k_rows), bool(causal), int(d_k))
     hit = q_rows._work.get(key)
     if hit is not None and hit[0] is k_rows:
-        return hit[1], hit[2]
+        return hit[1]
     lq = q_rows.lens_host.tolist() if q_rows.lens_host is not None else [q_rows.max_len] * q_rows.B
     lk = k_rows.lens_host.tolist() if k_rows.lens_host is not None else [k_rows.max_len] * k_rows.B
-    wq, wk = [], []
+    rows = [nv.attn_tile_rows(w, d_k, q_rows.max_len, k_rows.max_len, causal) for w in range(3)]
+    lists = ([], [], [])
     for b in range(q_rows.B):
-        for t in range((lq[b] + 127) // 128):
-            seen = min(lk[b], (t + 1) * 128) if causal else lk[b]
-            wq.append(((seen + 63) // 64, (b << 16) | t))
-        for t in range((lk[b] + 127) // 128):
-            q_begin = (t * 128 // 64) * 64 if causal else 0
-            wk.append(((lq[b] - q_begin + 63) // 64, (b << 16) | t))
+        for w in (0, 1):          # query tiles: cost = 64-key tiles streamed
+            R = rows[w]
+            for t in range((lq[b] + R - 1) // R):
+                seen = min(lk[b], (t + 1) * R) if causal else lk[b]
+                lists[w].append(((seen + 63) // 64, (b << 16) | t))
+        R = rows[2]               # key tiles: cost = 64-query tiles streamed
+        for t in range((lk[b] + R - 1) // R):
+            q_begin = (t * R // 64) * 64 if causal else 0
+            lists[2].append(((lq[b] - q_begin + 63) // 64, (b << 16) | t))
     dev = q_rows.off.device
     out = []
-    for w in (wq, wk):
+    for w in lists:
         w.sort(key=lambda c: -c[0])
         out.append(torch.tensor([c[1] for c in w], dtype=I32).to(dev))
-    q_rows._work[key] = (k_rows, out[0], out[1])
-    return out[0], out[1]
+    out = tuple(out)
+    q_rows._work[key] = (k_rows, out)
+    return out
 
 
 def _splits(M: int, N: int, K: int) -> int:
@@ -439,6 +445,13 @@ class MhaFn(torch.autograd.Function):
         ctx.chain = (pre.bwd, pre.key) if pre is not None and pre.bwd is not None else None   # chains.ChainBackward
         if down is not None:
             down.offer(mod, xhat, rstd, s.g_b_o)
+        if pre is not None:
+            # autograd puts its grad_fn on the tensor object returned here.  Were that pre.out itself, the reference
+            # chain out -> grad_fn -> ctx.chain -> ChainBackward.pres -> SubPre.out would close THROUGH C++, where
+            # Python's gc cannot see it: every grad-enabled forward would leak the stack's activations.  Return an
+            # alias (same storage: ChainBackward recognises gradients by address) and drop the back-reference.
+            pre.bwd = None
+            return out.view_as(out)
         return out
 
     @staticmethod
@@ -471,7 +484,7 @@ class MhaFn(torch.autograd.Function):
         ores = (_empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)) if need_bwd else None
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
-                    scale, work=attn_work(q_rows, k_rows, causal)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
+                    scale, work=attn_work(q_rows, k_rows, causal, d // H)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
@@ -525,7 +538,7 @@ class MhaFn(torch.autograd.Function):
                 dkv = _empty(x_kv.shape[0], 2 * d, x_q) if k_rows.dense else \
                     torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
-        work_q, work_k = attn_work(q_rows, k_rows, ctx.causal)
+        _, work_q, work_k = attn_work(q_rows, k_rows, ctx.causal, d // H)
         nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
                     q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop)
         dx_kv = None
@@ -590,6 +603,9 @@ class FfnFn(torch.autograd.Function):
         ctx.chain = (pre.bwd, pre.key) if pre is not None and pre.bwd is not None else None   # chains.ChainBackward
         if down is not None:
             down.offer(mod, xhat, rstd, s.g_b2, drop2)
+        if pre is not None:      # see MhaFn.forward: never hand autograd the tensor object the SubPre owns
+            pre.bwd = None
+            return out.view_as(out)
         return out
 
     @staticmethod

@@ -58,6 +58,7 @@ SIGNATURES = {
                       _c_void_p, _c_uint, _c_int, _c_float],
     "st_ln_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                   _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_float],
+    "st_attn_tile_rows": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
@@ -93,8 +94,9 @@ SIGNATURES = {
 }
 
 _LIB = None
-_TIMING = None   # list of (kernel name, tag, start event, end event) while bench.py profiles a step
+_TIMING = None   # list of (kernel name, tag, algorithmic bytes, start event, end event) while bench.py profiles a step
 _TAG = None
+_TAG_BYTES = None
 
 
 class _Timed:
@@ -105,15 +107,15 @@ class _Timed:
         self.name, self.fn = name, fn
 
     def __call__(self, *args):
-        global _TAG
+        global _TAG, _TAG_BYTES
         if _TIMING is None:
             return self.fn(*args)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = self.fn(*args)
         e.record()
-        _TIMING.append((self.name, _TAG, s, e))
-        _TAG = None
+        _TIMING.append((self.name, _TAG, _TAG_BYTES, s, e))
+        _TAG = _TAG_BYTES = None
         return rc
 
 
@@ -127,18 +129,41 @@ def timing_start() -> None:
 
 
 def timing_stop():
-    """-> list of (name, tag, milliseconds); synchronises the device."""
+    """-> list of (name, tag, milliseconds, algorithmic HBM bytes of the launch or None); synchronises the device."""
     global _TIMING
     torch.cuda.synchronize()
-    out = [(n, t, s.elapsed_time(e)) for n, t, s, e in (_TIMING or [])]
+    out = [(n, t, s.elapsed_time(e), nb) for n, t, nb, s, e in (_TIMING or [])]
     _TIMING = None
     return out
 
 
-def _tag(*info) -> None:
-    global _TAG
+def _io_bytes(io) -> float:
+    """Bytes of a launch's operands, each counted once: items are tensors (whole), (tensor, rows) (the first ``rows`` rows
+    of a row matrix / elements of a vector), plain byte counts, or None."""
+    n = 0.0
+    for item in io:
+        if item is None:
+            continue
+        if isinstance(item, (int, float)):
+            n += item
+            continue
+        t, rows = item if isinstance(item, tuple) else (item, None)
+        if t is None:
+            continue
+        if t.dim() == 2:
+            n += (t.shape[0] if rows is None else min(int(rows), t.shape[0])) * t.shape[1] * t.element_size()
+        else:
+            n += (t.numel() if rows is None else min(int(rows), t.numel())) * t.element_size()
+    return n
+
+
+def _tag(*info, io=None) -> None:
+    """Label the next launch for bench.py's per-launch timing pass: ``info`` = (class, shape numbers ...), ``io`` = the
+    operands the launch must move through HBM once (its ALGORITHMIC traffic - see _io_bytes)."""
+    global _TAG, _TAG_BYTES
     if _TIMING is not None:
         _TAG = info
+        _TAG_BYTES = _io_bytes(io) if io is not None else None
 
 
 def lib_path() -> str:
@@ -272,7 +297,9 @@ def gemm(X, Y, out, bias=None, aux=None, epi=EPI_BF16, x_cmajor=False, y_cmajor=
             _mat(aux2, BF16, "aux2")
             if epi != EPI_BF16_DELTA or aux2.stride(0) != ldaux or aux2.shape != aux.shape:
                 raise ValueError("gemm: aux2 goes with EPI_BF16_DELTA and must have aux's shape and stride")
-    _tag("gemm", int(x_cmajor), int(y_cmajor), M, N, Kc, epi)
+    esz = 4 if epi in (EPI_F32, EPI_F32_ATOMIC, EPI_F32_ATOMIC_T) else 2
+    _tag("gemm", int(x_cmajor), int(y_cmajor), M, N, Kc, epi,
+         io=(2.0 * M * Kc, 2.0 * N * Kc, float(esz) * M * N, 2.0 * M * N if aux is not None else 0, 2.0 * M * N if aux2 is not None else 0))
     dropargs = _drop(drop) if epi in (EPI_BF16_RELU, EPI_BF16_MASK) else _drop(None)
     if stack is None:
         rc = load().st_gemm(_stream(), int(x_cmajor), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(),
@@ -299,7 +326,7 @@ def gemm_ws(X, W, out, bias=None, relu=False, drop=None, stack=None):
     if out.shape[0] < M or out.shape[1] < N:
         raise ValueError("gemm_ws: out %s too small for %dx%d" % (tuple(out.shape), M, N))
     _vec(bias, F32, N // blocks, "bias")
-    _tag("gemm", 0, 0, M, N, K, EPI_BF16_RELU if relu else EPI_BF16)
+    _tag("gemm", 0, 0, M, N, K, EPI_BF16_RELU if relu else EPI_BF16, io=(2.0 * M * K, 2.0 * N * K, 2.0 * M * N))
     rc = load().st_gemm_ws(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
                            M, N, K, _p(bias), int(relu), *(_drop(drop) if relu else _drop(None)), block_rows, w_stride, b_stride)
     _check(rc, "st_gemm_ws")
@@ -333,7 +360,8 @@ def wgrad_group(problems, wide=False):
         ldx[q], lddy[q], lddw[q] = x.stride(0), dy.stride(0), gw.stride(0)
         tokens[q], k_in[q], n_out[q], splits[q] = x.shape[0], x.shape[1], rows, sp
     name = "st_wgrad_wide" if wide else "st_wgrad_group"
-    _tag(name[3:], n, sum(2.0 * pr[0].shape[0] * pr[0].shape[1] * pr[5] for pr in problems))
+    _tag(name[3:], n, sum(2.0 * pr[0].shape[0] * pr[0].shape[1] * pr[5] for pr in problems),
+         io=[2.0 * pr[0].shape[0] * (pr[0].shape[1] + pr[5]) + 8.0 * pr[5] * pr[0].shape[1] for pr in problems])   # X, dY in; gW read + written (fp32)
     rc = getattr(load(), name)(_stream(), n, X, ldx, dY, lddy, dW, lddw, dB, tokens, k_in, n_out, splits)
     _check(rc, name)
 
@@ -360,7 +388,7 @@ def gemm_ln(X, W, bias, res, gamma, beta, out, xhat, rstd, eps=1e-6, relu=False,
         _mat(pe, F32, "pe")
         assert pe.stride(0) == N
         _vec(pos, I32, M, "pos")
-    _tag("gemm_ln", M, N, K)
+    _tag("gemm_ln", M, N, K, io=((X, M), W, (res, M), (out, M), (xhat, M), (pre, M), (rstd, M)))
     rc = load().st_gemm_ln(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), M, N, K, bias.data_ptr(), _p(res),
                            0 if res is None else res.stride(0), gamma.data_ptr(), beta.data_ptr(), float(eps),
                            int(relu), _p(pe), _p(pos), out.data_ptr(), out.stride(0), _p(xhat), _p(rstd), _p(pre),
@@ -386,7 +414,7 @@ def wfrag_build(table):
     wave stream | wave stride in fragments << 32, address of the chain's buffer) - see st_amd/chains.py."""
     if table.dtype != torch.int64 or table.dim() != 2 or table.shape[1] != 4 or not table.is_contiguous() or not table.is_cuda:
         raise ValueError("wfrag_build: table must be a contiguous int64 [n, 4] device tensor")
-    _tag("wfrag_build", table.shape[0], 0, 0)
+    _tag("wfrag_build", table.shape[0], 0, 0, io=(4.0 * 256 * 256 * table.shape[0],))
     _check(load().st_wfrag_build(_stream(), table.data_ptr(), table.shape[0]), "st_wfrag_build")
 
 
@@ -433,7 +461,8 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
                 raise ValueError("row_chain: both dropout sites must read the same device seed")
             seed = dr.seed
     s1, s2 = _drop(drop1), _drop(drop2)
-    _tag("row_chain", M, n_blocks, d_ff)
+    _tag("row_chain", M, n_blocks, d_ff, io=((A, M), (R, M), (out0, M), (xhat0, M), (H, M), relu_bits, (out1, M), (xhat1, M), (P, M),
+                                             (rstd0, M), (rstd1, M), 2.0 * 256 * 256 * n_blocks))
     rc = load().st_row_chain(_stream(), M, wfrag.data_ptr(), n_blocks, int(chain.next_blocks), float(eps), A.data_ptr(), A.stride(0), _p(R),
                              0 if R is None else R.stride(0), _p(bo), _p(g0), _p(be0), _p(out0), _p(xhat0), _p(rstd0),
                              int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(relu_bits), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
@@ -502,7 +531,8 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     if head is None and ds_in is None:
         raise ValueError("row_chain_bwd: without head the chain needs ds_in")
     sd = _drop(drop)
-    _tag("row_chain_bwd", M, n_blocks, d_ff)
+    _tag("row_chain_bwd", M, n_blocks, d_ff, io=((dP, M), (G, M), (xa, M), (dsa, M), (ds_in, M), bits, (dH, M), (xb, M), (dsb, M), (O, M),
+                                                 (Ores, M), (dctx, M), (delta, 4 * M), (ra, M), (rb, M), 2.0 * 256 * 256 * n_blocks))
     rc = load().st_row_chain_bwd(
         _stream(), M, chain.stream.data_ptr(), n_blocks, int(chain.next_blocks), int(nb), _p(dP), 0 if dP is None else dP.stride(0),
         _p(G), 0 if G is None else G.stride(0), _p(xa), _p(ra), _p(ga), sd[0], sd[1], sd[2], sd[3], _p(dsa), _p(dga), _p(dba),
@@ -524,7 +554,7 @@ def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias
         _mat(aux, BF16, "aux")
     _vec(rstd, F32, M, "rstd"), _vec(gamma, F32, N, "gamma")
     _vec(dgamma, F32, N, "dgamma"), _vec(dbeta, F32, N, "dbeta"), _vec(dbias, F32, N, "dbias")
-    _tag("gemm_lnbwd", M, N, Kc)
+    _tag("gemm_lnbwd", M, N, Kc, io=((dY, M), 2.0 * N * Kc, (aux, M), (xhat, M), (dx, M), (rstd, M)))
     rc = load().st_gemm_lnbwd(_stream(), dY.data_ptr(), dY.stride(0), W.data_ptr(), W.stride(0), M, N, Kc, _p(aux),
                               0 if aux is None else aux.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                               dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias), *_drop(drop))
@@ -542,7 +572,7 @@ def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=
         assert mask.stride(0) == N
     _vec(rstd, F32, M, "rstd"), _vec(gamma, F32, N, "gamma")
     _vec(dgamma, F32, N, "dgamma"), _vec(dbeta, F32, N, "dbeta"), _vec(dbias, F32, N, "dbias")
-    _tag("ln_bwd", M, N)
+    _tag("ln_bwd", M, N, io=((dy, M), (xhat, M), (dx, M), (mask, M), (rstd, M)))
     rc = load().st_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                           _p(mask), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), _p(dbias), M, N, *_drop(drop),
                           float(mask_scale))
@@ -555,6 +585,12 @@ def _work(w):
         return None, 0
     _vec(w, I32, w.numel(), "work")
     return w.data_ptr(), w.numel()
+
+
+def attn_tile_rows(which: int, d_k: int, max_q: int, max_k: int, causal: bool) -> int:
+    """Rows per work-list tile of the kernel st_attn_fwd (which = 0) / st_attn_bwd's dQ (1) and dK/dV (2) parts will
+    run for a problem of this shape (host-side query, no launch)."""
+    return int(load().st_attn_tile_rows(int(which), int(d_k), int(max_q), int(max_k), int(bool(causal))))
 
 
 def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None,
@@ -575,7 +611,7 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
         _vec(t, I32, B, nm)
     rows = Q.shape[0]
     _vec(lse, F32, n_head * rows, "lse")
-    _tag("attn_fwd", n_head, d_k, int(causal), q_len, k_len)
+    _tag("attn_fwd", n_head, d_k, int(causal), q_len, k_len, io=(Q, K, V, O, ores, lse))
     rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), _p(ores), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
                             k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), rows, int(causal),
@@ -600,7 +636,7 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
             attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal,
                      scale, parts=part, work_q=work_q, work_k=work_k, drop=drop)
         return
-    _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts)
+    _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts, io=(Q, K, V, O, dO, dQ, dK, dV, lse, delta))
     rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             _p(O), 0 if O is None else O.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(),
                             delta.data_ptr(),
@@ -651,6 +687,7 @@ def pack_rows(x, off, length, out):
     B, T, Fd = x.shape
     _mat(out, BF16, "out")
     assert out.stride(0) == Fd
+    _tag("pack_rows", out.shape[0], Fd, io=(float(out.shape[0]) * Fd * x.element_size(), out))
     _check(load().st_pack_rows(_stream(), x.data_ptr(), B, T, Fd, off.data_ptr(), length.data_ptr(), out.data_ptr()),
            "st_pack_rows")
     return out
@@ -680,6 +717,7 @@ def embed_pe_fwd(tok, emb, pe, off, length, out):
     _mat(emb, F32, "emb"), _mat(pe, F32, "pe"), _mat(out, BF16, "out")
     D = emb.shape[1]
     assert emb.stride(0) == D and pe.stride(0) == D and out.stride(0) == D and pe.shape[0] >= L
+    _tag("embed_pe_fwd", out.shape[0], D, io=(8.0 * out.shape[0] * D, out))
     _check(load().st_embed_pe_fwd(_stream(), tok.data_ptr(), B, L, emb.data_ptr(), emb.shape[0], pe.data_ptr(), D,
                                   off.data_ptr(), length.data_ptr(), out.data_ptr()), "st_embed_pe_fwd")
     return out
@@ -691,6 +729,7 @@ def embed_bwd(tok, dy, off, length, pad_idx, demb):
     _mat(dy, BF16, "dy"), _mat(demb, F32, "demb")
     D = demb.shape[1]
     assert demb.stride(0) == D
+    _tag("embed_bwd", dy.shape[0], D, io=(dy, 8.0 * dy.shape[0] * D))
     _check(load().st_embed_bwd(_stream(), tok.data_ptr(), B, L, dy.data_ptr(), dy.stride(0), D, off.data_ptr(),
                                length.data_ptr(), int(pad_idx), demb.data_ptr(), demb.shape[0]), "st_embed_bwd")
     return demb
@@ -767,7 +806,7 @@ def ce_fwd(logits, target, ignore_index, lse, sums, V=None):
     V = logits.shape[1] if V is None else V
     _vec(target, I64, R, "target"), _vec(lse, F32, R, "lse"), _vec(sums, F32, 2, "sums")
     row_loss = torch.empty(R, dtype=F32, device=logits.device)       # scratch: summed by the call's second launch
-    _tag("ce_fwd", R, V, 0)
+    _tag("ce_fwd", R, V, 0, io=(2.0 * R * V, 8.0 * R))
     _check(load().st_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), int(ignore_index),
                             lse.data_ptr(), row_loss.data_ptr(), sums.data_ptr()), "st_ce_fwd")
 
@@ -780,7 +819,7 @@ def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None):
     if dlogits.shape[0] != R or dlogits.shape[1] < V or dlogits.stride(0) % 8 or dlogits.shape[1] != dlogits.stride(0):
         raise ValueError("ce_bwd: dlogits must be a contiguous bf16 [R, >= V] matrix with a row length that is a multiple of 8")
     _vec(grad_out, F32, 1, "grad_out")
-    _tag("ce_bwd", R, V, 0)
+    _tag("ce_bwd", R, V, 0, io=(4.0 * R * V, 8.0 * R))
     _check(load().st_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), int(ignore_index),
                             lse.data_ptr(), sums.data_ptr(), grad_out.data_ptr(), dlogits.data_ptr(), dlogits.stride(0)),
            "st_ce_bwd")
@@ -789,6 +828,7 @@ def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None):
 def cast_bf16(src, dst):
     assert src.is_cuda and dst.is_cuda and src.dtype == F32 and dst.dtype == BF16
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    _tag("cast_bf16", src.numel(), io=(src, dst))
     _check(load().st_cast_bf16(_stream(), src.data_ptr(), dst.data_ptr(), src.numel()), "st_cast_bf16")
     return dst
 
@@ -800,6 +840,7 @@ def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps):
         assert t.is_cuda and t.dtype == F32 and t.is_contiguous() and t.numel() == p.numel()
     for t in (lr, step) + ((gnorm,) if gnorm is not None else ()):
         assert t.is_cuda and t.dtype == F32 and t.numel() == 1
+    _tag("adam_clip", p.numel(), io=(32.0 * p.numel(),))      # p, g, m, v read; p, m, v written; g zeroed (fp32)
     _check(load().st_adam_clip(_stream(), p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr.data_ptr(),
                                step.data_ptr(), _p(gnorm), float(max_norm), float(beta1), float(beta2), float(eps)),
            "st_adam_clip")

@@ -186,7 +186,8 @@ class TrainStep:
                 from .functional import attn_work
                 self.model.prepare_layouts(torch.full((B,), T_cap), torch.full((B,), L_cap), L_cap, dev)
                 ir, tr = st.layouts
-                attn_work(ir, ir, False), attn_work(tr, tr, True), attn_work(tr, ir, False)
+                dk = getattr(self.model, "_d_k", 64)
+                attn_work(ir, ir, False, dk), attn_work(tr, tr, True, dk), attn_work(tr, ir, False, dk)
                 tr.scatter_index(L_cap)
             self._buckets[key] = st
         st.x[:, :T].copy_(inputs, non_blocking=True)

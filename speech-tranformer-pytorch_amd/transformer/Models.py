@@ -206,6 +206,7 @@ class Transformer(nn.Module):
         common = dict(n_head=need('n_heads'), d_k=need('d_k'), d_v=need('d_v'), d_model=need('d_model'),
                       d_inner_hid=need('d_inner_hid'), dropout=need('dropout'), emb_scale=opt('emb_scale', 1))
         self.vocab_size, self.d_model = need('vocab_size'), common['d_model']
+        self._d_k = common['d_k']
         if common['d_model'] not in (128, 256, 512) or common['d_k'] not in (32, 64, 128):
             # fail where the model is built, not at the first attention launch (the attention kernels keep a whole
             # head row per lane: d_k 32, 64 or 128 - the last is the reference's shipped config/character.yaml, d_model 512
@@ -251,9 +252,10 @@ class Transformer(nn.Module):
         t_rows = F_.Rows.packed(targets_pos, device)
         t_rows.scatter_index(l_max)
         in_rows.pos, t_rows.pos
-        F_.attn_work(in_rows, in_rows, False)     # encoder self-attention
-        F_.attn_work(t_rows, t_rows, True)        # decoder self-attention (causal)
-        F_.attn_work(t_rows, in_rows, False)      # decoder-encoder attention
+        dk = self._d_k
+        F_.attn_work(in_rows, in_rows, False, dk)     # encoder self-attention
+        F_.attn_work(t_rows, t_rows, True, dk)        # decoder self-attention (causal)
+        F_.attn_work(t_rows, in_rows, False, dk)      # decoder-encoder attention
         self.encoder.row_chains(arena_of(self))   # the chain plans' block tables (a host->device copy the first time)
         self.decoder.row_chains(arena_of(self))
         return in_rows, t_rows

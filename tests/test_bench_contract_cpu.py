@@ -16,7 +16,7 @@ def test_committed_bench_line_follows_the_contract():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong")
     assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     # value = frames of the timed steps / wall time, consistent with ms_per_step
@@ -25,5 +25,9 @@ def test_committed_bench_line_follows_the_contract():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    if "hbm_bytes_source" in d:      # round 3 on: per-class HBM figures come from the launches' own operand lists
+        for k, v in d["kernels"].items():
+            assert v.get("hbm_frac", 0.0) <= 1.0, (k, v)      # > 1 means the accounting, not the kernel, did the work
+            assert v.get("tflops") is None or v["tflops"] <= 2500.0, (k, v)
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c

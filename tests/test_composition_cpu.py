@@ -567,6 +567,61 @@ def test_row_chains_on_off_composition():
         run_row_chains_on_off("cpu", exact=True)
 
 
+def run_no_activation_leak(device):
+    """with row chains on, every grad-enabled forward used to leak the layer stacks' activations
+    (SubPre.out carried the grad_fn, closing a reference cycle through C++ that gc cannot traverse).  The number of live
+    tensors must be flat over eager steps - with a backward, and with a forward that is never followed by one."""
+    import gc
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import functional as F_
+    from st_amd.arena import arena_of
+    torch.manual_seed(3)
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=20, num_enc_layer=2, num_dec_layer=2,
+                          n_heads=4, d_k=64, d_v=64, d_model=256, d_inner_hid=512, dropout=0.0, vocab_size=30))
+    m = M.Transformer(cfg)
+    U.init_parameters(m)
+    m = m.to(device).eval()
+    batch = orc.synthetic_batch(3, 40, 7, 80, 30, seed=4, t_min=20, l_min=4)
+    x, tok, gt = batch["x"].to(device), batch["tokens"].to(device), batch["gt"].to(device)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+
+    def live():
+        gc.collect()
+        n = b = 0
+        for o in gc.get_objects():
+            try:
+                if torch.is_tensor(o) and o.device.type == torch.device(device).type:
+                    n += 1
+                    b += o.numel() * o.element_size()
+            except Exception:
+                pass
+        return n, b
+
+    def step(backward):
+        arena_of(m).zero_grads()
+        logits, t_rows = m.forward_packed(x, batch["in_len"], tok, batch["tgt_len"])
+        loss = crit(logits, gt.contiguous().view(-1).index_select(0, t_rows.scatter_index(gt.shape[1])))
+        if backward:
+            with F_.deferred_wgrads(True):
+                loss.backward()
+
+    for backward in (True, False):
+        step(backward)
+        step(backward)
+        n0, b0 = live()
+        for _ in range(4):
+            step(backward)
+        n1, b1 = live()
+        assert m.decoder._st_chains[1] is not None and m.encoder._st_chains[1] is not None
+        assert n1 <= n0 and b1 <= b0, ("activations leak across eager steps", backward, n0, n1, b0, b1)
+
+
+def test_no_activation_leak_composition():
+    with emulated_kernels():
+        run_no_activation_leak("cpu")
+
+
 def run_row_chain_step_narrow_heads(device):
     """d_model 256 with 8 heads (d_k 32): the forward runs as row chains, the backward falls back to the per-GEMM path with the
     LayerNorm hand-over links (the backward chains' delta epilogue is written for 64-wide heads) - against the fp64 oracle."""

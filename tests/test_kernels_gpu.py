@@ -254,14 +254,14 @@ def test_attention_work_lists_match_plain_enumeration():
         c = _attn_case(4, 4, 64, None if self_attn else q_lens.tolist(), k_lens.tolist(), causal, True, seed=3)
         q_rows = Rows.packed(q_lens, "cuda")
         k_rows = q_rows if self_attn else Rows.packed(k_lens, "cuda")
-        wq, wk = attn_work(q_rows, k_rows, causal)
+        wf, wq, wk = attn_work(q_rows, k_rows, causal, 64)
         outs = []
         for use in (False, True):
             Q, K, V, dO = cu(c["Q"]), cu(c["K"]), cu(c["V"]), cu(c["dO"])
             meta = [cu(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
             O = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
             lse = torch.zeros(c["H"] * c["Mq"], dtype=F32, device="cuda")
-            nv.attn_fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], causal, c["scale"], work=wq if use else None,
+            nv.attn_fwd(Q, K, V, O, lse, *meta, c["H"], c["max_q"], causal, c["scale"], work=wf if use else None,
                         max_k=c["max_k"])
             delta = torch.zeros_like(lse)
             dQ = torch.zeros(c["Mq"], c["d"], dtype=BF16, device="cuda")
@@ -286,6 +286,30 @@ def test_attention_softmax_rescale_branch():
     nv.attn_fwd(cu(Q), cu(K), cu(c["V"]), Og, lg, *[cu(m) for m in meta], 1, 300, False, c["scale"])
     check(Og, O, 1.5e-2, "attention rescale O")
     check(lg, lse, 2e-3, "attention rescale lse")
+
+
+def test_attention_long64_range_fallback():
+    """The 64-rows-per-wave forward subtracts no maximum and repeats an item with the running-maximum loop when a row sum
+    leaves fp32's comfort zone: force both ends - one score at ~ +260 (log2 units; exp2 overflows), one query whose
+    scores are all ~ -300 (every exp2 underflows) - and a workgroup that needs no repeat next to them."""
+    c = _attn_case(2, 2, 64, None, [300, 520], False, True, seed=9)
+    Q, K = c["Q"].clone(), c["K"].clone()
+    K[250, :64] = Q[17, :64] * 90.0            # head 0, utterance 0: one huge positive score for query 17
+    K[300:820, 64] += 30.0                     # head 1, utterance 1: query 400 far below every key
+    Q[300 + 400, 64] = -60.0
+    Mq = c["Mq"]
+    O = torch.zeros(Mq, c["d"], dtype=BF16)
+    lse = torch.zeros(c["H"] * Mq, dtype=F32)
+    meta = [c[k] for k in ("q_off", "q_len", "k_off", "k_len")]
+    em.attn_fwd(Q, K, c["V"], O, lse, *meta, c["H"], c["max_q"], False, c["scale"])
+    s17 = (Q[17, :64].float() @ K[250, :64].float()) * c["scale"] * 1.4426950408889634
+    assert s17 > 150, s17
+    Og, lg = torch.zeros(Mq, c["d"], dtype=BF16, device="cuda"), torch.zeros(c["H"] * Mq, dtype=F32, device="cuda")
+    nv.attn_fwd(cu(Q), cu(K), cu(c["V"]), Og, lg, *[cu(m) for m in meta], c["H"], c["max_q"], False, c["scale"], max_k=c["max_k"])
+    assert torch.isfinite(Og.float()).all() and torch.isfinite(lg).all()
+    check(Og, O, 1.5e-2, "attention long64 fallback O")
+    check(lg, lse, 2e-3, "attention long64 fallback lse")
+    assert lse.min() < -150 and lse.max() > 150        # the case really leaves the plain-exponential range
 
 
 # ---- streaming kernels ----------------------------------------------------------------------

@@ -15,28 +15,33 @@ def test_work_lists_cover_every_tile_once_and_sort_by_cost():
     q_rows, k_rows = Rows.packed(lq, "cpu"), Rows.packed(lk, "cpu")
     for qr, kr, causal, a, b in ((k_rows, k_rows, False, lk, lk), (q_rows, q_rows, True, lq, lq),
                                  (q_rows, k_rows, False, lq, lk)):
-        wq, wk = attn_work(qr, kr, causal)
-        assert wq.dtype == torch.int32 and wk.dtype == torch.int32
-        want_q = {(i, t) for i in range(len(a)) for t in range((int(a[i]) + 127) // 128)}
-        want_k = {(i, t) for i in range(len(b)) for t in range((int(b[i]) + 127) // 128)}
-        got_q, got_k = _decode(wq), _decode(wk)
-        assert len(got_q) == len(want_q) and set(got_q) == want_q
-        assert len(got_k) == len(want_k) and set(got_k) == want_k
+        from st_amd import native as nv
+        wf, wq, wk = attn_work(qr, kr, causal, 64)
+        Rf, Rq, Rk = (nv.attn_tile_rows(w, 64, int(a.max()), int(b.max()), causal) for w in range(3))
+        assert Rf in (128, 256) and Rq in (128, 256) and Rk in (128, 256)
+        if not causal and int(a.max()) > 128:
+            assert Rf == 256          # the long non-causal forward runs 64 query rows per wave
+        for w, R, L in ((wf, Rf, a), (wq, Rq, a), (wk, Rk, b)):
+            assert w.dtype == torch.int32
+            want = {(i, t) for i in range(len(L)) for t in range((int(L[i]) + R - 1) // R)}
+            got = _decode(w)
+            assert len(got) == len(want) and set(got) == want
 
-        def cost_q(i, t):
-            seen = min(int(b[i]), (t + 1) * 128) if causal else int(b[i])
-            return (seen + 63) // 64
+        def cost_q(R):
+            def f(i, t):
+                seen = min(int(b[i]), (t + 1) * R) if causal else int(b[i])
+                return (seen + 63) // 64
+            return f
 
         def cost_k(i, t):
-            q_begin = (t * 128 // 64) * 64 if causal else 0
+            q_begin = (t * Rk // 64) * 64 if causal else 0
             return (int(a[i]) - q_begin + 63) // 64
 
-        cq = [cost_q(*it) for it in got_q]
-        ck = [cost_k(*it) for it in got_k]
-        assert cq == sorted(cq, reverse=True) and ck == sorted(ck, reverse=True)
-        assert min(cq) >= 1 and min(ck) >= 1
+        for w, cf in ((wf, cost_q(Rf)), (wq, cost_q(Rq)), (wk, cost_k)):
+            c = [cf(*it) for it in _decode(w)]
+            assert c == sorted(c, reverse=True) and min(c) >= 1
         # cached on the query layout
-        assert attn_work(qr, kr, causal)[0] is wq
+        assert attn_work(qr, kr, causal, 64)[0] is wf
 
 
 def test_dropout_hash_statistics():

@@ -124,7 +124,7 @@ if "attn" in which:
              ("dec self causal", Md, Md, to, tl, to, tl, 50, 50, True, True, t_rows, t_rows),
              ("cross", Md, M, to, tl, qo, ql, 50, int(in_len.max()), False, False, t_rows, in_rows)]
     for name, mq, mk, q_off, q_len, k_off, k_len, maxq, maxk, causal, self_attn, qr, kr in cases:
-        wq, wk = attn_work(qr, kr, causal) if use_work else (None, None)
+        wf, wq, wk = attn_work(qr, kr, causal, 64) if use_work else (None, None, None)
         if self_attn:
             qkv = rnd(mq, 3 * d)
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
@@ -137,7 +137,7 @@ if "attn" in which:
         dK, dV = torch.empty(mk, d, dtype=BF16, device=dev), torch.empty(mk, d, dtype=BF16, device=dev)
         pairs = float((q_len.double() * k_len.double()).sum()) * (0.5 if causal else 1.0)
         fl = 4.0 * pairs * d
-        us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale, work=wq, max_k=maxk))
+        us = timeit(lambda: nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, H, maxq, causal, scale, work=wf, max_k=maxk))
         report("attn fwd  " + name, us, fl)
         for part, nm in ((1, "dq "), (2, "dkv"), (3, "all")):
             us = timeit(lambda: nv.attn_bwd(Q, K, V, None if part == 3 else O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, H, maxq,
