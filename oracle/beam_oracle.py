@@ -1,9 +1,11 @@
 """CPU restatement of the reference's beam-search decode (transformer/Beam.py, transformer/Decode.py).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  **Parity unpinned**: the reference's decode cannot run as
-shipped (D12 - true division yields float back-pointers -> IndexError, `Decode.__init__`
-calls an obsolete `Transformer(...)` signature, `prob_projection` is undefined), so there is no golden to
-generate by import; this file restates the INTENDED semantics line by line and is itself the checker:
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Parity: ``Beam`` is **pinned** - tests/golden/beam_trellis.npz is the
+trellis the reference's own Beam class produces (tools/make_beam_goldens.py imports /root/reference/transformer/Beam.py and
+applies repair R5, the floor division of line 65) and tests/test_decode_cpu.py holds this class, the product's
+transformer/Beam.py and st_beam_advance to it (indices bit-exact, scores <= 1e-6).  ``beam_search`` stays **unpinned**:
+`Decode.__init__` calls an obsolete `Transformer(...)` signature and `prob_projection` is undefined, so the reference's
+search driver cannot run and this part restates the INTENDED semantics line by line:
 
 * ``Beam`` (Beam.py:13-116): scores start at 0, ``next_ys[0] = [BOS]*size``; ``advance(word_lk)`` takes
   ``[beam, V]`` log-probabilities, first step uses row 0 only (:48-51), top-k over the flattened beam x V array

@@ -31,7 +31,7 @@
 #include "st_attn_common.cuh"
 
 // st_attn64.hip (AttnArgs passed by address: the type is local to each translation unit, the layout is shared)
-extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop, int var);
+extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop);
 
 namespace {
 
@@ -526,13 +526,13 @@ int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows, i
   return (work ? n_work : B * a.tiles_max) * H;
 }
 
-// development switch (ST_ATTN_IMPL=1: the 128-row kernels everywhere), read once
+// development switch (ST_ATTN_IMPL=1: the general kernels everywhere), read once
 int attn_impl() {
   static const int v = [] { const char* e = getenv("ST_ATTN_IMPL"); return e ? atoi(e) : 0; }();
   return v;
 }
 
-// long non-causal problems with 64-wide heads take the 64-rows-per-wave forward (256-row work-list tiles)
+// long non-causal problems with 64-wide heads take the plain-exponential forward of st_attn64.hip
 bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
   return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1;
 }
@@ -541,8 +541,9 @@ bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
 
 extern "C" int st_attn_tile_rows(int which, int d_k, int max_q, int max_k, int causal) {
   // rows per work-list tile of the kernel that will serve this problem: which = 0 forward (query tiles),
-  // 1 backward dQ (query tiles), 2 backward dK/dV (key tiles)
-  if (which == 0) return fwd_long64(d_k, max_q, max_k, causal) && !(attn_impl() >= 30 && attn_impl() < 50) ? F64_WG : WG_ROWS;
+  // 1 backward dQ (query tiles), 2 backward dK/dV (key tiles).  Every kernel shipped today runs 128-row workgroups;
+  // hosts must ask anyway (the answer is allowed to depend on the shape).
+  (void)which; (void)d_k; (void)max_q; (void)max_k; (void)causal;
   return WG_ROWS;
 }
 
@@ -563,8 +564,8 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   a.psplit = (Ores != nullptr && max_q <= 64) ? 1 : 0;     // the decoder's attentions, when a backward will follow
   if (fwd_long64(d_k, max_q, max_k, causal)) {
-    dim3 grid(plan(a, work, n_work, B, H, max_q, st_attn_tile_rows(0, d_k, max_q, max_k, causal))), block(256);
-    return st_attn64_fwd_launch(stream, &a, (int)grid.x, drop ? 1 : 0, attn_impl());
+    dim3 grid(plan(a, work, n_work, B, H, max_q));
+    return st_attn64_fwd_launch(stream, &a, (int)grid.x, drop ? 1 : 0);
   }
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0

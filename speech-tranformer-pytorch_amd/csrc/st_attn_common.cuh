@@ -8,8 +8,6 @@ namespace {
 
 constexpr int TILE = 64;      // rows (keys or queries) per streamed tile
 constexpr int WG_ROWS = 128;  // rows owned by a workgroup (4 waves x 32)
-constexpr int F64_QW = 64;             // st_attn64.hip: query rows per wave
-constexpr int F64_WG = 4 * F64_QW;     // ... per workgroup (its work-list tile)
 
 struct AttnArgs {
   const bf16* Q; int ldq;

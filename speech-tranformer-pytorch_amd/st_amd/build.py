@@ -22,9 +22,9 @@ STAMP = LIB + ".srchash"
 SOURCES = ["st_gemm_sym.hip", "st_wgrad.hip", "st_gemm_ws.hip", "st_gemm_ln.hip", "st_gemm_lnbwd.hip", "st_rowchain.hip", "st_attn.hip",
            "st_attn64.hip", "st_misc.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result"]
-# per-file additions.  st_attn64.hip: one workgroup per CU owns all 512 registers per lane; left to its heuristics the
-# compiler puts the score accumulators into AGPRs and pays one v_accvgpr_read per score in front of the exponential.
-EXTRA = {"st_attn64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+# per-file additions (none today; a kernel that owns all 512 registers per lane would want "-mllvm -amdgpu-mfma-vgpr-form":
+# left to its heuristics the compiler then puts score accumulators into AGPRs and pays a v_accvgpr_read per score)
+EXTRA = {}
 
 
 def _headers() -> bytes:

@@ -11,8 +11,9 @@ HIP-graph mode (``use_graph=True``): the step launches ~190 kernels; the decoder
 (M ~ 1.2k rows) is launch-bound from Python (~10 us of host time per launch vs 2-4 us of
 GPU time).  The step is therefore captured per batch SIGNATURE (same tensors, same length
 vectors) into a HIP graph and replayed; the Noam rate is a device scalar updated before each
-replay.  Up to ``max_graphs`` signatures are kept (least recently used evicted), each with
-its own memory pool and with references to the ragged layouts its kernels read by address,
+replay.  Up to ``max_graphs`` signatures are kept (default 4; least recently used evicted; every
+signature owns a private memory pool with a full step of activations - ~5 GB at config 2 -
+so the cap is a memory bound), each with its own memory pool and with references to the ragged layouts its kernels read by address,
 so a loader that cycles through a set of pre-collated batches (bench.py; an epoch over a
 bucketed, cached dataset) replays, and one whose length vectors never repeat runs the eager
 path - whose ms/step bench.py reports next to the replay figure.  With data parallelism the
@@ -49,7 +50,7 @@ def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
 class TrainStep:
     def __init__(self, model: nn.Module, optimizer, vocab_size: int, max_grad_norm: float,
                  reducer: Optional[GradReducer] = None, use_graph: bool = False, graph_warmup: int = 2,
-                 max_graphs: int = 8, bucket=None):
+                 max_graphs: int = 4, bucket=None):
         self.model, self.optimizer = model, optimizer
         self.vocab_size, self.max_grad_norm = vocab_size, max_grad_norm
         self.crit = nn.CrossEntropyLoss(ignore_index=0)          # train.py:120
@@ -191,6 +192,8 @@ class TrainStep:
                 tr.scatter_index(L_cap)
             self._buckets[key] = st
         st.x[:, :T].copy_(inputs, non_blocking=True)
+        if T < T_cap:
+            st.x[:, T:].zero_()                                  # no frame of an earlier batch survives behind a length
         st.tok.zero_()
         st.tok[:, :L].copy_(targets, non_blocking=True)
         st.gt.zero_()                                            # padding positions: ground truth 0 = ignore_index
@@ -234,6 +237,9 @@ class TrainStep:
             cap.keep = layouts
         elif hasattr(self.model, "prepare_layouts"):
             cap.keep = self.model.prepare_layouts(batch[1], batch[3], batch[2].shape[1], batch[0].device)
+        # ... and the batch tensors themselves: the signature matches on their addresses, so the memory must not be
+        # recycled for something else while a capture that reads it is alive
+        cap.keep = (cap.keep, batch[0], batch[2], batch[4])
         pool = torch.cuda.graph_pool_handle()           # one pool per signature: replays of different signatures interleave freely
         cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         split = self.reducer is not None and self.reducer.active and hasattr(self.model, "forward_packed") \

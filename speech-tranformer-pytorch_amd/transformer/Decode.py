@@ -204,9 +204,21 @@ class Decode(object):
                     # captured step: the position, the cache length, the tokens and the beams are device state
                     # (captured by hand, on decode_batch's side stream: `with torch.cuda.graph(...)` also runs gc.collect() and
                     # torch.cuda.empty_cache() - 4 ms of every decode_batch call, a tenth of a 32-utterance batch)
+                    torch.cuda.current_stream().synchronize()      # (as torch.cuda.graph does before a capture)
                     graph = torch.cuda.CUDAGraph()
                     graph.capture_begin(**(dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}))
-                    one_step()
+                    try:
+                        one_step()
+                    except BaseException:
+                        # a wrapper raised mid-capture (non-zero status, out of memory in the private pool): leave
+                        # capture mode before the error travels on, or every later call on this stream fails with
+                        # errors that hide this one
+                        try:
+                            graph.capture_end()
+                        except Exception:  # noqa: BLE001 - the original error is the one to report
+                            pass
+                        graph = None
+                        raise
                     graph.capture_end()
                 if graph is not None:
                     graph.replay()

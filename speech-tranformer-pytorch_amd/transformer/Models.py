@@ -207,13 +207,6 @@ class Transformer(nn.Module):
                       d_inner_hid=need('d_inner_hid'), dropout=need('dropout'), emb_scale=opt('emb_scale', 1))
         self.vocab_size, self.d_model = need('vocab_size'), common['d_model']
         self._d_k = common['d_k']
-        if common['d_model'] not in (128, 256, 512) or common['d_k'] not in (32, 64, 128):
-            # fail where the model is built, not at the first attention launch (the attention kernels keep a whole
-            # head row per lane: d_k 32, 64 or 128 - the last is the reference's shipped config/character.yaml, d_model 512
-            # with 4 heads; the LayerNorm-fused GEMMs own full rows: d_model 128 / 256 / 512)
-            raise NotImplementedError(
-                "Transformer(HIP path): d_model must be 128, 256 or 512 and d_k = d_v = d_model / n_heads 32, 64 or 128; got "
-                "d_model %d, n_heads %d (d_k %d)." % (common['d_model'], common['n_head'], common['d_k']))
         self.encoder = Encoder(input_size=need('feature_dim'), n_max_seq=need('max_inputs_length', 'max_input_length'),
                                n_layers=need('num_enc_layer'), **common)
         self.decoder = Decoder(vocab_size=self.vocab_size, n_max_seq=need('max_target_length'),
@@ -224,6 +217,16 @@ class Transformer(nn.Module):
         return [(self.tgt_word_proj.weight, (self.vocab_size + 7) // 8 * 8)]
 
     def _st_bind(self, a):
+        d_model, d_k = self.d_model, self._d_k
+        if d_model not in (128, 256, 512) or d_k not in (32, 64, 128):
+            # raised when the HIP path is bound (first forward on a GPU), not at construction: building the module tree,
+            # loading / saving its state_dict and handing its weights to the oracle work for any size the reference
+            # accepts.  The attention kernels keep a whole head row per lane (d_k 32, 64 or 128 - the last is the
+            # reference's shipped config/character.yaml), the LayerNorm-fused GEMMs own full rows (d_model 128 / 256 / 512);
+            # the fused row chains serve d_model 256, other widths run one launch per GEMM (README.md "Supported shapes").
+            raise NotImplementedError(
+                "Transformer(HIP path): d_model must be 128, 256 or 512 and d_k = d_v = d_model / n_heads 32, 64 or 128; got "
+                "d_model %d (d_k %d)." % (d_model, d_k))
         w = self.tgt_word_proj.weight
         v_pad = (self.vocab_size + 7) // 8 * 8
         lo, hi = a.span([w])

@@ -858,6 +858,13 @@ def test_beam_advance_matches_torch_formulation(B, beam, V):
     assert bool(b["done"][0]) and not bool(b["done"][1:].all())
 
 
+def test_beam_advance_vs_reference_trellis_golden():
+    """st_beam_advance against tests/golden/beam_trellis.npz - the trellis the reference's own Beam class produced
+    (tools/make_beam_goldens.py, repair R5): back-pointers and tokens bit-exact, scores to fp32 rounding."""
+    from tests.test_decode_cpu import run_beam_advance_vs_trellis
+    run_beam_advance_vs_trellis(nv, "cuda")
+
+
 @pytest.mark.parametrize("R,V", [(7, 30), (1206, 4337)])
 def test_cross_entropy_rows_matches_torch(R, V):
     """st_ce_fwd / st_ce_bwd (functional.cross_entropy_rows) == nn.CrossEntropyLoss(ignore_index=0) on fp32 logits rows whose

@@ -19,8 +19,6 @@ def test_work_lists_cover_every_tile_once_and_sort_by_cost():
         wf, wq, wk = attn_work(qr, kr, causal, 64)
         Rf, Rq, Rk = (nv.attn_tile_rows(w, 64, int(a.max()), int(b.max()), causal) for w in range(3))
         assert Rf in (128, 256) and Rq in (128, 256) and Rk in (128, 256)
-        if not causal and int(a.max()) > 128:
-            assert Rf == 256          # the long non-causal forward runs 64 query rows per wave
         for w, R, L in ((wf, Rf, a), (wq, Rq, a), (wk, Rk, b)):
             assert w.dtype == torch.int32
             want = {(i, t) for i in range(len(L)) for t in range((int(L[i]) + R - 1) // R)}

@@ -17,7 +17,7 @@ for d in ("pa", "pb", "pc"):
         c = sqlite3.connect(db)
         try:
             q = ("select kernel_name, grid_size, counter_name, avg(value), avg(duration) from counters_collection "
-                 "where kernel_name like '%attn_fwd%' group by kernel_name, grid_size, counter_name")
+                 "where kernel_name like '%attn_%' group by kernel_name, grid_size, counter_name")
             for name, grid, cn, val, dur in c.execute(q):
                 rows.setdefault((name, grid), {})[cn] = val
                 rows[(name, grid)]["duration_ns"] = dur
