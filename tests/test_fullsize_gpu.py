@@ -165,3 +165,214 @@ def test_config2_trainstep_graph_full_size_vs_fp64_oracle():
 def test_config3_depth_trainstep_vs_fp64_oracle():
     """BASELINE config 3's depth and width (12+6 layers, d_model 512, 8 heads) on its per-GPU shard (4 utterances)."""
     run_step_parity(C3, 4, "c3_b4")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Training mode at the benchmarked size: the product draws its counter-based dropout masks (attention probabilities, both
+# FFN sites per layer, the front-end's 0.5), the fp64 oracle is handed EXACTLY those masks (re-derived on the GPU from the
+# recorded call sites with the host implementation of the hash in tests/_emul.py).  VERDICT r2 "missing 6".
+# ------------------------------------------------------------------------------------------------------------------
+def _gpu_masks(sites, in_len, tgt_len, H):
+    """-> provider(site, shape) for oracle.dropout_masks, replayable (``provider.rewind()``)."""
+    from st_amd.functional import Rows
+    from tests import _emul as em
+    dev = "cuda"
+    T, L = int(in_len.max()), int(tgt_len.max())
+    rows_of = {T: Rows.packed(in_len, "cpu"), L: Rows.packed(tgt_len, "cpu")}
+    drops = [em.Drop(d.seed.detach().cpu(), d.salt, d.thresh / 256.0) for d in sites]
+    state = {"i": 0}
+
+    def provider(site, shape):
+        d = drops[state["i"]]
+        state["i"] += 1
+        key = em._key(d)
+        if site == "attn":
+            B, h, lq, lk = shape
+            q = torch.arange(lq, dtype=torch.int64, device=dev).view(1, -1, 1)
+            k = torch.arange(lk, dtype=torch.int64, device=dev).view(1, 1, -1)
+            bh = torch.arange(B * h, dtype=torch.int64, device=dev).view(-1, 1, 1)
+            cnt = ((((q >> 1) << 15) | (k >> 1)) + bh * 0x85ebca6b) & em._M32
+            bits = em._hash32(cnt ^ key)
+            keep = ((bits >> (8 * (2 * (q & 1) + (k & 1)))) & 0xFF) >= d.thresh
+            return keep.view(B, h, lq, lk).double() * d.scale
+        B, t, n = shape
+        r = rows_of[t]
+        off = r.off.to(dev).long().view(-1, 1, 1)
+        rows = off + torch.arange(t, dtype=torch.int64, device=dev).view(1, -1, 1)          # packed row of (b, i)
+        cols = torch.arange(n, dtype=torch.int64, device=dev).view(1, 1, -1)
+        cnt = (rows * (n >> 2) + (cols >> 2)) & em._M32
+        bits = em._hash32(cnt ^ key)
+        keep = (((bits >> (8 * (cols & 3))) & 0xFF) >= d.thresh).double() * d.scale
+        valid = (torch.arange(t, device=dev).view(1, -1) < r.len.to(dev).view(-1, 1)).view(B, t, 1)
+        return torch.where(valid, keep, torch.ones_like(keep))      # padded frames: nobody reads them
+
+    provider.rewind = lambda: state.update(i=0)
+    provider.count = lambda: state["i"]
+    return provider
+
+
+def test_config2_training_mode_full_size_vs_fp64_oracle():
+    """BASELINE config 2 at the benchmarked size under model.train() (how train.py:21 runs the reference): loss, logits and
+    every gradient against the fp64 oracle with the kernels' own masks."""
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import functional as F_, rng, synthetic
+    from st_amd.arena import arena_of
+
+    cfg = C2
+    torch.manual_seed(0)
+    model = M.Transformer(U.AttrDict(cfg))
+    U.init_parameters(model)
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(32, 1000, 50, cfg["feature_dim"], cfg["vocab_size"], seed=0,
+                                                          t_min=500, l_min=25)
+    xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()
+    L = int(tgt_len.max())
+    valid = (torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)).cuda()
+    rng.seed_tensor("cuda")
+    rng.manual_seed(20260928)
+    sites, orig_site = [], rng.site
+
+    def recording_site(dev, p):
+        d = orig_site(dev, p)
+        sites.append(d)
+        return d
+
+    rng.site = recording_site
+    try:
+        arena_of(model).zero_grads()
+        lg, t_rows = model.forward_packed(xg, in_len, tg[:, :L], tgt_len)
+    finally:
+        rng.site = orig_site
+    truth_gt = gg[:, :L].contiguous().view(-1).index_select(0, t_rows.scatter_index(L))
+    loss = torch.nn.CrossEntropyLoss(ignore_index=0)(lg.float(), truth_gt)
+    with F_.deferred_wgrads(True):
+        loss.backward()
+    torch.cuda.synchronize()
+    n_e, n_d = cfg["num_enc_layer"], cfg["num_dec_layer"]
+    assert len(sites) == 1 + 3 * n_e + 4 * n_d and all(d is not None for d in sites)
+    assert sites[0].thresh == 128 and all(d.thresh == 26 for d in sites[1:])      # p = 0.5 and round(256 * 0.1)
+
+    provider = _gpu_masks(sites, in_len, tgt_len, cfg["n_heads"])
+    p64 = {k: v.double().cuda() for k, v in w.items()}
+    b64 = {"x": xg.double(), "in_len": in_len, "tokens": tg[:, :L], "tgt_len": tgt_len, "gt": gg[:, :L]}
+    with orc.dropout_masks(provider):
+        truth = orc.train_step(p64, b64, cfg["n_heads"], cfg["d_model"], 12000, 1, 5.0)
+    assert provider.count() == len(sites)
+    # the same masks under bf16 autocast: the noise floor of this configuration in training mode
+    names = [k for k in w if not k.endswith(".pe")]
+    leaves = {k: (v.float().cuda().requires_grad_(True) if k in names else v.float().cuda()) for k, v in w.items()}
+    provider.rewind()
+    with orc.dropout_masks(provider), torch.autocast("cuda", dtype=torch.bfloat16):
+        lg_ac, _ = orc.transformer(leaves, xg, in_len, tg[:, :L], tgt_len, cfg["n_heads"])
+        loss_ac = orc.cross_entropy(lg_ac.float(), gg[:, :L])
+    g_ac = dict(zip(names, torch.autograd.grad(loss_ac, [leaves[k] for k in names])))
+    floor = {n: rel(g_ac[n], truth["grads"][n]) for n in names if "linear_k.bias" not in n}
+    fl = sorted(floor.values())
+    floor_glob = rel(torch.cat([g_ac[n].reshape(-1) for n in floor]), torch.cat([truth["grads"][n].reshape(-1) for n in floor]))
+
+    arena = arena_of(model)
+    logit_rel = rel(lg.double(), truth["logits"][valid])
+    rows, fg, ft = [], [], []
+    for n, p in model.named_parameters():
+        if "linear_k.bias" in n:
+            continue
+        g, t = arena.grad_view(p).detach().double(), truth["grads"][n]
+        assert torch.isfinite(g).all(), n
+        rows.append((rel(g, t), floor[n], n, t.norm().item()))
+        fg.append(g.reshape(-1))
+        ft.append(t.reshape(-1))
+    glob = rel(torch.cat(fg), torch.cat(ft))
+    rows.sort(reverse=True)
+    med = rows[len(rows) // 2][0]
+    lines = ["# c2_b32_train: model.train() forward + CE + backward vs the fp64 oracle with the kernels' dropout masks",
+             "loss %.6f (oracle %.6f)  logits rel-L2 %.3e  (%d dropout sites)" % (loss.item(), truth["loss"].item(), logit_rel, len(sites)),
+             "gradients: global rel-L2 %.3e, per-tensor median %.3e, max %.3e" % (glob, med, rows[0][0]),
+             "reference under bf16 autocast, same masks: global %.3e, median %.3e, max %.3e" % (floor_glob, fl[len(fl) // 2], fl[-1]),
+             "per-tensor rel-L2 (worst first):   HIP path | reference-in-bf16 | tensor"]
+    lines += ["  %.3e  %.3e  %-58s |g| = %.3e" % r for r in rows]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_c2_b32_train.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    head = "\n".join(lines[:12])
+    # training-mode tolerances: twice the eval-mode ones (dropout thins every reduction), or the bf16 reference's own error
+    assert logit_rel < 2 * LOGIT_TOL, head
+    assert abs(loss.item() - truth["loss"].item()) < 2e-2 * truth["loss"].item(), head
+    assert glob < max(2 * GRAD_TOL_GLOBAL, 1.5 * floor_glob) and med < max(2 * GRAD_TOL_MEDIAN, 1.5 * fl[len(fl) // 2]), head
+    bad = [r for r in rows if r[0] > max(2 * GRAD_TOL_TENSOR, 2.0 * r[1])]
+    assert not bad, "\n".join([head, "outside max(1.6e-1, 2 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
+
+
+def test_config4_joint_ctc_attention_at_stated_shape_vs_fp64_oracle():
+    """BASELINE config 4 at its stated shape (6+6 layers, d_model 256: the row-chain path): joint 0.3 CTC + 0.7 attention
+    objective (train_attn_and_ctc.py); the encoder output receives gradient from the CTC head AND from the decoder's
+    shared cross-K/V gradient buffer.  8 utterances of the benchmark batch, oracle in fp64 on the GPU."""
+    import torch.nn.functional as func
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import synthetic
+    from transformer.Loss import CTCAttentionLoss
+
+    cfg, n = C2, 8
+    torch.manual_seed(0)
+    model = M.Transformer(U.AttrDict(cfg))
+    U.init_parameters(model)
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.eval().cuda()
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(32, 1000, 50, cfg["feature_dim"], cfg["vocab_size"], seed=0,
+                                                          t_min=500, l_min=25)
+    x, tokens, in_len, tgt_len, gt = x[:n], tokens[:n], in_len[:n], tgt_len[:n], gt[:n]
+    L, T = int(tgt_len.max()), int(in_len.max())
+    xg, tg, gg = x[:, :T].cuda(), tokens[:, :L].cuda(), gt[:, :L].cuda()
+    torch.manual_seed(0)
+    head = CTCAttentionLoss(cfg["d_model"], cfg["vocab_size"], ctc_weight=0.3).cuda()
+    H = cfg["n_heads"]
+
+    def objective(leaves, wc, bc, xin, autocast=False):
+        enc, _ = orc.encoder(leaves, xin, in_len, H)
+        dec, _, _ = orc.decoder(leaves, tg, tgt_len, in_len, enc, H)
+        logits = func.linear(dec, leaves["tgt_word_proj.weight"])
+        att = orc.cross_entropy(logits.float() if autocast else logits, gg)
+        z = func.linear(enc, wc, bc)
+        logp = func.log_softmax(z.float() if autocast else z, -1).transpose(0, 1)
+        ctc = func.ctc_loss(logp, gg, in_len, tgt_len, blank=0, reduction="mean", zero_infinity=True)
+        return 0.3 * ctc + 0.7 * att, ctc
+
+    names = [k for k in w if not k.endswith(".pe")]
+    l64 = {k: (v.double().cuda().requires_grad_(True) if k in names else v.double().cuda()) for k, v in w.items()}
+    w64 = head.ctc_proj.weight.detach().double().clone().requires_grad_(True)
+    b64 = head.ctc_proj.bias.detach().double().clone().requires_grad_(True)
+    truth, ctc64 = objective(l64, w64, b64, xg.double())
+    g64 = torch.autograd.grad(truth, [l64[k] for k in names] + [w64, b64], allow_unused=True)
+    tgd = dict(zip(names, g64))
+    l32 = {k: (v.float().cuda().requires_grad_(True) if k in names else v.float().cuda()) for k, v in w.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        obj_ac, _ = objective(l32, head.ctc_proj.weight.detach().float(), head.ctc_proj.bias.detach().float(), xg, autocast=True)
+    gac = dict(zip(names, torch.autograd.grad(obj_ac, [l32[k] for k in names], allow_unused=True)))
+
+    logits_h, enc_h = model.forward_joint(xg, in_len, tg, tgt_len)
+    assert enc_h.shape == (n, T, cfg["d_model"]) and logits_h.shape == (n, L, cfg["vocab_size"])
+    loss, att_h, ctc_h = head(enc_h, in_len, logits_h, gg, tgt_len, gg)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert model.encoder._st_chains[1] is not None and model.decoder._st_chains[1] is not None      # the row-chain path
+    assert abs(loss.item() - truth.item()) < 2e-2 * abs(truth.item()), (loss.item(), truth.item())
+    assert abs(ctc_h.item() - ctc64.item()) < 2e-2 * abs(ctc64.item())
+    rows = []
+    for nme, q in model.named_parameters():
+        if "linear_k.bias" in nme or tgd[nme] is None:
+            continue
+        assert q.grad is not None and torch.isfinite(q.grad).all(), nme
+        rows.append((rel(q.grad.detach(), tgd[nme]), rel(gac[nme], tgd[nme]), nme))
+    rows.sort(reverse=True)
+    lines = ["# c4_b8: joint 0.3 CTC + 0.7 attention objective, 6+6 / d256, 8 utterances: loss %.5f (oracle %.5f), ctc %.4f (%.4f)"
+             % (loss.item(), truth.item(), ctc_h.item(), ctc64.item()),
+             "per-tensor rel-L2 (worst first):   HIP path | reference-in-bf16 | tensor"] + ["  %.3e  %.3e  %s" % r for r in rows]
+    with open(os.path.join(ROOT, "gpurun_out", "parity_c4_b8.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 2.0 * r[1])]
+    assert not bad, "\n".join(lines[:2] + ["  %.3e  %.3e  %s" % r for r in bad])
+    med = sorted(r[0] for r in rows)[len(rows) // 2]
+    assert med < max(GRAD_TOL_MEDIAN, 1.5 * sorted(r[1] for r in rows)[len(rows) // 2]), med
+    assert rel(head.ctc_proj.weight.grad, g64[-2]) < GRAD_TOL_MEDIAN and rel(head.ctc_proj.bias.grad, g64[-1]) < GRAD_TOL_MEDIAN
