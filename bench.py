@@ -37,6 +37,11 @@ import torch.distributed as dist  # noqa: E402
 
 C2 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_layer=6, num_dec_layer=6, n_heads=4,
           d_k=64, d_v=64, d_model=256, d_inner_hid=1024, dropout=0.1, vocab_size=4337)
+# BASELINE config 3 (configs[2]; train_multi.py path): 12+6 layers, d_model 512, 8 heads of 64, d_ff 1024 (the reference's default;
+# BASELINE.json does not fix it - SURVEY section 5), same synthetic batch.  `--config 3` times it.
+C3 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_layer=12, num_dec_layer=6, n_heads=8,
+          d_k=64, d_v=64, d_model=512, d_inner_hid=1024, dropout=0.1, vocab_size=4337)
+CFG = C2          # the configuration being timed (main() rebinds it for --config 3)
 BATCH, T_MAX, L_MAX, T_MIN, L_MIN = 32, 1000, 50, 500, 25
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -111,24 +116,24 @@ def cpu_worker(args):
     cores = max(1, min(avail, 64))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    model = M.Transformer(U.AttrDict(C2))
+    model = M.Transformer(U.AttrDict(CFG))
     U.init_parameters(model)
     p = {k: v.detach().float().clone() for k, v in model.state_dict().items()}
-    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"],
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"],
                                                           seed=0, t_min=T_MIN, l_min=L_MIN)
     n = args.cpu_utts
     b = {"x": x[:n], "in_len": in_len[:n], "tokens": tokens[:n], "tgt_len": tgt_len[:n], "gt": gt[:n]}
     # the oracle's forward / loss (autograd backward) + the stock CPU optimiser path of train.py:44-46
     leaves = {k: (v.requires_grad_(True) if not k.endswith(".pe") else v) for k, v in p.items()}
     params = [v for k, v in leaves.items() if not k.endswith(".pe")]
-    opt = torch.optim.Adam(params, lr=orc.noam_lr(C2["d_model"], 12000, 1), betas=(0.9, 0.98), eps=1e-9)
+    opt = torch.optim.Adam(params, lr=orc.noam_lr(CFG["d_model"], 12000, 1), betas=(0.9, 0.98), eps=1e-9)
     frames = int(in_len[:n].sum())
     t_start = time.perf_counter()
 
     def one_step():
         t = time.perf_counter()
         opt.zero_grad()
-        logits, _ = orc.transformer(leaves, b["x"], b["in_len"], b["tokens"], b["tgt_len"], C2["n_heads"])
+        logits, _ = orc.transformer(leaves, b["x"], b["in_len"], b["tokens"], b["tgt_len"], CFG["n_heads"])
         loss = orc.cross_entropy(logits, b["gt"])
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 5.0)
@@ -136,7 +141,7 @@ def cpu_worker(args):
         return time.perf_counter() - t, loss.item()
 
     def bernoulli(site, shape):       # nn.Dropout: keep / (1 - p), p = 0.5 in the front-end (Models.py:31), 0.1 elsewhere
-        pr = 0.5 if site == "front" else C2["dropout"]
+        pr = 0.5 if site == "front" else CFG["dropout"]
         return torch.empty(shape).bernoulli_(1.0 - pr).div_(1.0 - pr)
 
     times, loss = [], None
@@ -164,6 +169,8 @@ def cpu_worker(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE config: 2 = 6+6 d256 h4 (the metric's "
+                    "configuration, default), 3 = 12+6 d512 h8 (the train_multi.py configuration)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,6 +192,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
                                                             "the captured HIP graph of the step")
     args = ap.parse_args()
+    global CFG
+    CFG = {2: C2, 3: C3}[args.config]
+    if args.config != 2:          # the extras below are config 2's; config 3 reports its own 4-utterance shard instead
+        args.no_decode = True
     if args.cpu_worker:
         return cpu_worker(args)
     # the headline partition: the global B = 32 batch split over the ranks (strong scaling; N = 1: the whole batch on one
@@ -205,7 +216,7 @@ def main():
     native.load(build_if_missing=False)
 
     torch.manual_seed(0)
-    model = M.Transformer(U.AttrDict(C2))
+    model = M.Transformer(U.AttrDict(CFG))
     U.init_parameters(model)                      # train.py:116
     model = model.eval().cuda()                   # eval(): every Dropout is identity; autograd still runs
     arena = arena_of(model)
@@ -216,16 +227,16 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1)
     reducer = dp.GradReducer(arena, wire_dtype=torch.bfloat16 if args.wire_bf16 else None,
                              force=args.force_dp) if (world > 1 or args.force_dp) else None
-    optim = ScheduledOptim(model, C2["d_model"], U.AttrDict(n_warmup_steps=12000))
-    step = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
+    optim = ScheduledOptim(model, CFG["d_model"], U.AttrDict(n_warmup_steps=12000))
+    step = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
 
     def shard(global_batch):
         """global_batch = 0: weak scaling, 32 utterances per GPU (seed = rank, train_multi.py:136-139 keeps the per-rank
         batch fixed); else the seed-0 batch's first `global_batch` utterances split contiguously by rank."""
         if not global_batch:
-            return synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"], seed=rank, t_min=T_MIN,
+            return synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"], seed=rank, t_min=T_MIN,
                                         l_min=L_MIN)
-        full = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"], seed=0, t_min=T_MIN, l_min=L_MIN)
+        full = synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"], seed=0, t_min=T_MIN, l_min=L_MIN)
         per = global_batch // world
         return tuple(t[rank * per:(rank + 1) * per] for t in full)
 
@@ -288,7 +299,7 @@ def main():
     exposed_ms = None
     if reducer is not None and reducer.active:
         # exposed gradient exchange = step time with the reducer minus the same step without any exchange (timing only)
-        plain = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=None, use_graph=not args.no_graph)
+        plain = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, reducer=None, use_graph=not args.no_graph)
         for _ in range(4):
             plain(xg, in_len, tg, tgt_len, gg)
         barrier()
@@ -370,7 +381,7 @@ def main():
     train_mode = None
     if world == 1 and not args.no_train_mode:
         model.train()
-        step_t = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, use_graph=not args.no_graph)
+        step_t = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, use_graph=not args.no_graph)
         for _ in range(4):
             step_t(xg, in_len, tg, tgt_len, gg)
         torch.cuda.synchronize()
@@ -418,13 +429,13 @@ def main():
         try:
             bs = []
             for sd in range(6):
-                bx, bt, bil, btl, bgt = synthetic.make_batch(BATCH, T_MAX, L_MAX, C2["feature_dim"], C2["vocab_size"], seed=100 + sd,
+                bx, bt, bil, btl, bgt = synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"], seed=100 + sd,
                                                              t_min=T_MIN, l_min=L_MIN)
                 bs.append((bx.cuda(), bil, bt.cuda(), btl, bgt.cuda()))
             res = {}
             for name, kw in (("bucket_graph_ms_per_step", dict(use_graph=True, graph_warmup=1, bucket=(T_MAX, L_MAX))),
                              ("eager_ms_per_step", dict(use_graph=False))):
-                st_l = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, **kw)
+                st_l = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, **kw)
                 for k in range(6):
                     st_l(*bs[k])
                 torch.cuda.synchronize()
@@ -439,6 +450,66 @@ def main():
         except Exception as e:  # noqa: BLE001 - the headline line must still be printed
             loader_proof = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- config 3 (N = 1): its per-GPU shard of the DP = 8 run (the first 4 utterances of the global batch) on one GPU -
+    # what every rank of the specified partition executes between two all-reduces
+    shard4 = None
+    if world == 1 and args.config == 3:
+        try:
+            full = synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"], seed=0, t_min=T_MIN, l_min=L_MIN)
+            xs, ts, ils, tls, gs = (t[:4] for t in full)
+            xsg, tsg, gsg = xs.cuda(), ts.cuda(), gs.cuda()
+            step_s = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, use_graph=not args.no_graph)
+            for _ in range(4):
+                step_s(xsg, ils, tsg, tls, gsg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_s(xsg, ils, tsg, tls, gsg)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            shard4 = {"ms_per_step": round(dt / args.steps * 1e3, 3), "value": round(float(ils.sum()) * args.steps / dt, 1), "unit": "frames/s",
+                      "frames": int(ils.sum()), "note": "4 utterances = one rank's shard of the global B = 32 batch at DP = 8 (train_multi.py:136-139)"}
+        except Exception as e:  # noqa: BLE001
+            shard4 = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- BASELINE config 4 (N = 1, config 2's model): the joint 0.3 CTC + 0.7 attention objective of train_attn_and_ctc.py -
+    # Transformer.forward_joint + transformer/Loss.py:CTCAttentionLoss (PyTorch-ROCm CTC, as the north star prescribes) +
+    # backward + clip + Adam, launched eagerly (the CTC head is not part of the captured step)
+    ctc_joint = None
+    if world == 1 and args.config == 2 and not args.no_decode:
+        try:
+            from transformer.Loss import CTCAttentionLoss
+            from st_amd import functional as F_
+            torch.manual_seed(0)
+            head = CTCAttentionLoss(CFG["d_model"], CFG["vocab_size"], ctc_weight=0.3).cuda()
+            Lm = int(tgt_len.max())
+
+            def joint_step():
+                arena.zero_grads()
+                head.zero_grad(set_to_none=True)
+                lg_j, enc_j = model.forward_joint(xg, in_len, tg[:, :Lm], tgt_len)
+                l_j, _, _ = head(enc_j, in_len, lg_j, gg[:, :Lm], tgt_len, gg[:, :Lm])
+                with F_.deferred_wgrads(True):
+                    l_j.backward()
+                optim.step_captured(grad_norm=torch.linalg.vector_norm(arena.grad), max_norm=5.0)     # clip + Adam (st_adam_clip)
+                return l_j
+            for _ in range(3):
+                lj = joint_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nj = max(args.steps // 2, 5)
+            for _ in range(nj):
+                lj = joint_step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            ctc_joint = {"ms_per_step": round(dt / nj * 1e3, 3), "value": round(float(in_len.sum()) * nj / dt, 1), "unit": "frames/s",
+                         "loss": round(float(lj), 4),
+                         "note": "BASELINE config 4: forward_joint + 0.3 CTC (torch ctc_loss over [T, B, V] log-probs) + 0.7 CE + backward + "
+                                 "Adam, eager launches (host-bound like eager_ms_per_step); parity: tests/test_fullsize_gpu.py::"
+                                 "test_config4_joint_ctc_attention_at_stated_shape_vs_fp64_oracle"}
+        except Exception as e:  # noqa: BLE001
+            ctc_joint = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- N > 1: also time the OTHER partition in the same run - headline strong (global B = 32 split contiguously, 4
     # utterances per GPU at N = 8: SURVEY 8e / north star) -> extra block weak (32 utterances per GPU, seed = rank), and
     # the other way round under --weak
@@ -448,7 +519,7 @@ def main():
         try:
             xs, ts, ils, tls, gs = shard(other_gb)
             xsg, tsg, gsg = xs.cuda(), ts.cuda(), gs.cuda()
-            step_s = TrainStep(model, optim, C2["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
+            step_s = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
             for _ in range(max(args.warmup, 4)):
                 step_s(xsg, ils, tsg, tls, gsg)
             barrier()
@@ -478,9 +549,10 @@ def main():
 
     out = None
     if rank == 0:
-        flops = step_flops(in_len, tgt_len, C2)
+        flops = step_flops(in_len, tgt_len, CFG)
         out = {
-            "metric": "frames/sec/step (80-d fbank, 6+6L d256) at 1/2/4/8 MI355X vs CPU ref",
+            "metric": "frames/sec/step (80-d fbank, 6+6L d256) at 1/2/4/8 MI355X vs CPU ref" if args.config == 2 else
+                      "frames/sec/step (80-d fbank, 12+6L d512 h8: BASELINE config 3) at 1/2/4/8 MI355X vs CPU ref",
             "value": round(frames * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "ms_per_step_median_synced": round(ms_median, 3),
@@ -488,9 +560,9 @@ def main():
             "eager_ms_per_step_synced": None if eager_ms_synced is None else round(eager_ms_synced, 3),
             "allreduce_exposed_ms": exposed_ms,
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 6+6L d256 h4 dff1024 V4337, 80-d fbank, %s, "
+            "config": {"workload": "BASELINE config %s, 80-d fbank, %s, "
                                    "T<=1000 (%d valid frames on rank 0), L<=50; fwd+CE+bwd+clip+Adam, dropout off"
-                                   % (("global B=%d split %d per GPU (strong scaling, SURVEY 8e)" % (args.global_batch, args.global_batch // world))
+                                   % ("2: 6+6L d256 h4 dff1024 V4337" if args.config == 2 else "3: 12+6L d512 h8 dff1024 V4337", ("global B=%d split %d per GPU (strong scaling, SURVEY 8e)" % (args.global_batch, args.global_batch // world))
                                       if args.global_batch else "B=32 per GPU (weak scaling, train_multi.py:136-139)", int(in_len.sum())),
                        "global_batch": args.global_batch or BATCH * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
@@ -512,6 +584,10 @@ def main():
             out["decode"] = decode
         if loader_proof is not None:
             out["loader_proof"] = loader_proof
+        if shard4 is not None:
+            out["shard4"] = shard4
+        if ctc_joint is not None:
+            out["ctc_joint"] = ctc_joint
 
     # ---- CPU baseline: the oracle restatement on this box's host cores (rank 0, N = 1 only) -------
     # Runs in a child process with a hard timeout so that a slow / oversubscribed host can never
@@ -519,9 +595,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-steps",
-                                str(args.cpu_steps), "--cpu-utts", str(args.cpu_utts), "--cpu-timeout",
-                                str(args.cpu_timeout)], capture_output=True, text=True, timeout=args.cpu_timeout)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--config", str(args.config), "--cpu-steps",
+                                str(args.cpu_steps), "--cpu-utts", str(args.cpu_utts if args.config == 2 else min(args.cpu_utts, 8)),
+                                "--cpu-timeout", str(args.cpu_timeout)], capture_output=True, text=True, timeout=args.cpu_timeout)
             out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001 - the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
