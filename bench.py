@@ -558,7 +558,7 @@ def main():
             "ms_per_step_median_synced": round(ms_median, 3),
             "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
             "eager_ms_per_step_synced": None if eager_ms_synced is None else round(eager_ms_synced, 3),
-            "allreduce_exposed_ms": exposed_ms,
+            "allreduce_exposed_ms": exposed_ms, "dp_mode": getattr(step, "dp_mode", None),
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE config %s, 80-d fbank, %s, "
                                    "T<=1000 (%d valid frames on rank 0), L<=50; fwd+CE+bwd+clip+Adam, dropout off"

@@ -17,11 +17,13 @@ so the cap is a memory bound), each with its own memory pool and with references
 so a loader that cycles through a set of pre-collated batches (bench.py; an epoch over a
 bucketed, cached dataset) replays, and one whose length vectors never repeat runs the eager
 path - whose ms/step bench.py reports next to the replay figure.  With data parallelism the
-gradient all-reduce stays eager BETWEEN graphs, and the backward is cut at the encoder
-output into two of them: forward + loss + decoder backward | encoder backward | clip+Adam.
-The decoder's and the vocabulary projection's gradients (the tail ~2/3 of the flat buffer)
-are final after the first graph, so their RCCL all-reduce runs while the second graph - the
-encoder's backward, ~40 % of the step - is executing.
+backward is cut at the encoder output: forward + loss + decoder backward | encoder backward |
+clip+Adam.  The decoder's and the vocabulary projection's gradients (the tail ~2/3 of the flat
+buffer) are final after the first part, so their RCCL all-reduce runs while the encoder's
+backward - ~40 % of the step - is executing.  The bucket all-reduces are captured INSIDE the
+step graph (``dp_in_graph``; RCCL collectives are stream-capturable), so a DP step is one graph
+replay; where that capture is refused the three parts become three graphs with eager
+collectives between them.
 """
 from __future__ import annotations
 
@@ -50,13 +52,19 @@ def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
 class TrainStep:
     def __init__(self, model: nn.Module, optimizer, vocab_size: int, max_grad_norm: float,
                  reducer: Optional[GradReducer] = None, use_graph: bool = False, graph_warmup: int = 2,
-                 max_graphs: int = 4, bucket=None):
+                 max_graphs: int = 4, bucket=None, dp_in_graph: bool = True):
         self.model, self.optimizer = model, optimizer
         self.vocab_size, self.max_grad_norm = vocab_size, max_grad_norm
         self.crit = nn.CrossEntropyLoss(ignore_index=0)          # train.py:120
         self.reducer = reducer
         self.global_step = 0
         self.use_graph, self.graph_warmup, self.max_graphs = use_graph, graph_warmup, max_graphs
+        # data parallelism in graph mode: the bucket all-reduces are CAPTURED with the step (RCCL collectives are
+        # stream-capturable: ProcessGroupNCCL forks its stream off the capturing one and joins it again in wait()), so a DP
+        # step is ONE graph replay with no host in the loop; False (or a capture that fails) = three graphs with eager
+        # collectives in between
+        self.dp_in_graph = dp_in_graph
+        self.dp_mode = None                            # "in-graph" / "split" after the first DP capture (introspection)
         # bucket = (T_cap, L_cap): ONE captured step serves every batch of B utterances with at most T_cap frames and L_cap
         # target tokens - the batch is staged into static padded buffers, the lengths live on the device (Rows.bucket), so
         # a loader whose batches never repeat a length signature still replays a graph.  Costs the padding rows
@@ -218,8 +226,9 @@ class TrainStep:
             self.reducer.fire_from(cap.dec_lo)           # decoder-side buckets: exchanged while the encoder's backward runs
             cap.g_enc.replay()
             self.reducer.synchronize()
-        elif self.reducer is not None:
+        elif self.reducer is not None and cap.g_opt is not None:
             self.reducer.reduce_all()
+        # (cap.g_opt None with a reducer: the collectives were captured inside g_fb - nothing happens on the host)
         if cap.g_opt is not None:
             cap.g_opt.replay()
         return cap.loss, cap.gnorm
@@ -250,7 +259,30 @@ class TrainStep:
         # default "global" capture mode that call from ANOTHER thread aborts the process ("operation not permitted
         # when stream is capturing").  With a process group alive, only this thread's unsafe calls are policed.
         mode = dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}
+        if split and self.dp_in_graph:
+            # ONE graph: forward + loss + decoder backward | decoder-side buckets start on RCCL's stream (a forked branch
+            # of the graph) | encoder backward runs beside them | remaining buckets | join | clip + Adam
+            try:
+                g_all = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_all, pool=pool, **mode):
+                    cap.loss = self._forward_decoder_backward(*batch, layouts=layouts)
+                    self.reducer.fire_from(self._decoder_grad_start())
+                    self._encoder_backward()
+                    self.reducer.synchronize()
+                    cap.gnorm = self._clip_and_update()
+                cap.g_fb, cap.g_enc, cap.g_opt = g_all, None, None
+                self.dp_mode = "in-graph"
+                return cap
+            except Exception as e:  # noqa: BLE001 - a process group / RCCL build that cannot be captured: eager collectives
+                import warnings
+                warnings.warn("TrainStep: capturing the gradient all-reduces failed (%s: %s); using eager collectives "
+                              "between three graphs" % (type(e).__name__, e))
+                self.reducer._work, self.reducer._fired = [], [False] * len(self.reducer.buckets)
+                torch.cuda.synchronize()
+                pool = torch.cuda.graph_pool_handle()
+                cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if split:
+            self.dp_mode = "split"
             cap.g_enc, cap.dec_lo = torch.cuda.CUDAGraph(), self._decoder_grad_start()
             with torch.cuda.graph(cap.g_fb, pool=pool, **mode):
                 cap.loss = self._forward_decoder_backward(*batch, layouts=layouts)

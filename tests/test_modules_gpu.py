@@ -254,24 +254,33 @@ def test_split_backward_graphs_with_reducer_match_single_graph():
                             vocab_size=30))
         inputs, targets, in_len, tgt_len, truth = synthetic.make_batch(4, 160, 20, 80, 30, seed=1, t_min=60, l_min=6)
         results = []
-        for with_reducer, bucket in ((False, None), (True, None), (True, (160, 20))):    # (last: + the loader-proof capture)
+        # (no reducer) | eager collectives between three graphs | the same over the loader-proof bucket capture | the
+        # collectives CAPTURED inside the one step graph (the default: a DP step is one replay)
+        for with_reducer, bucket, in_graph in ((False, None, False), (True, None, False), (True, (160, 20), False), (True, None, True)):
             torch.manual_seed(0)
             model = Transformer(cfg).cuda()
             init_parameters(model)
             model.eval()
             opt = ScheduledOptim(model, 128, AttrDict(n_warmup_steps=4000))
             red = dp.GradReducer(arena_of(model), bucket_bytes=64 << 10, force=True) if with_reducer else None
-            step = TrainStep(model, opt, 30, 5.0, reducer=red, use_graph=True, graph_warmup=1, bucket=bucket)
+            step = TrainStep(model, opt, 30, 5.0, reducer=red, use_graph=True, graph_warmup=1, bucket=bucket, dp_in_graph=in_graph)
             x, t, gt = inputs.cuda(), targets.cuda(), truth.cuda()
             out = []
             for _ in range(4):
                 loss, gnorm = step(x, in_len, t, tgt_len, gt)
                 out.append((float(loss), float(gnorm)))
-            if with_reducer:
-                assert step._g_enc is not None and 0 < step._dec_lo < arena_of(model).total
+            if with_reducer and not in_graph:
+                assert step.dp_mode == "split" and step._g_enc is not None and 0 < step._dec_lo < arena_of(model).total
                 assert len(red.buckets) > 4
+            if in_graph:
+                assert step.dp_mode == "in-graph" and step._g_enc is None and step._g_opt is None, step.dp_mode
             results.append(([l for l, _ in out], [g for _, g in out], arena_of(model).flat.detach().float().cpu().clone()))
-        (l0, g0, p0), (l1, g1, p1), (l2, g2, p2) = results
+        (l0, g0, p0), (l1, g1, p1), (l2, g2, p2), (l3, g3, p3) = results
+        # the captured collectives execute the split-graph step's kernels in the same order: same numbers
+        assert abs(l1[0] - l3[0]) <= 1e-5 * abs(l1[0]) and abs(g1[0] - g3[0]) <= 1e-4 * g1[0], (l1, l3, g1, g3)
+        for a, b in zip(l1, l3):
+            assert abs(a - b) <= 1e-3 * abs(a), (l1, l3)
+        assert float((p1 - p3).norm() / p1.norm()) < 5e-3
         # Step 1 starts from identical weights: the two paths (one graph with grouped weight gradients and the stacked
         # K/V GEMM | eager hooks, then split graphs around the all-reduce) differ by kernel-composition rounding only
         # (measured 4e-4 on the gradient).  Later steps see weights that differ in the sign of a few Adam updates and
