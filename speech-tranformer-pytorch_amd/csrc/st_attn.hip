@@ -363,7 +363,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
   if (k0 >= lk) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
   const int key = k0 + wave * 32 + (l & 31);
-  const bool k_ok = key < lk;
   const size_t krow = (size_t)a.k_off[b] + min(key, lk - 1);
   const float c2 = a.scale * 1.4426950408889634f;
   const Drop dr = make_drop(a.drop);
@@ -411,8 +410,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
     const bf16* dos = qs + G::E;
     const float* stat = reinterpret_cast<const float*>(qs + 2 * G::E);   // [0..63] lse, [64..127] delta
     const int qt = q_begin + it * TILE;
-    // wave-uniform: every (query, key) pair of this tile x this wave's 32 keys is unmasked
-    const bool full = (qt + TILE <= lq) && (k0 + wave * 32 + 32 <= lk) && (!a.causal || k0 + wave * 32 + 31 <= qt);
+    // wave-uniform: every (query, key) pair of this tile x this wave's 32 keys is unmasked.  Keys past lk need no mask:
+    // lane = key here, so such a lane (its K / V rows are clamped, finite) only fills its OWN dK / dV rows, which are never
+    // stored - a partial last key block runs the plain path on every tile (it took the masked one on all of them)
+    const bool full = (qt + TILE <= lq) && (!a.causal || k0 + wave * 32 + 31 <= qt);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s = zero16(), dp = zero16();
@@ -442,7 +443,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int qq = qt + qb * 32 + acc_row(r, hi);
-          if (!k_ok || qq >= lq || (a.causal && key > qq)) s[r] = -INFINITY;
+          if (qq >= lq || (a.causal && key > qq)) s[r] = -INFINITY;
         }
       }
       f32x16 p;
