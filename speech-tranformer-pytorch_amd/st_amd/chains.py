@@ -319,7 +319,7 @@ class EncoderChains:
         s0 = layers[0].slf_attn._st
         H = s0.n_head
         scale = 1.0 / math.sqrt(d // H)
-        work = attn_work(rows, rows, False, d // H)[0]
+        work = attn_work(rows, rows, False, d // H, H)[0]
         qkv = E(M, 3 * d)
         linear_fwd(x, s0.w_qkv, qkv, s0.b_qkv)
         pres = []
@@ -415,7 +415,7 @@ class DecoderChains:
         s0 = layers[0].slf_attn._st
         H = s0.n_head
         scale = 1.0 / math.sqrt(d // H)
-        work_self, work_cross = attn_work(t_rows, t_rows, True, d // H)[0], attn_work(t_rows, in_rows, False, d // H)[0]
+        work_self, work_cross = attn_work(t_rows, t_rows, True, d // H, H)[0], attn_work(t_rows, in_rows, False, d // H, H)[0]
         qkv = E(M, 3 * d)
         nv.gemm(x, s0.w_qkv, qkv, bias=s0.b_qkv)
         pres = []

@@ -17,6 +17,7 @@ parameter anchor (the Megatron "main_grad" idiom).
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -143,36 +144,55 @@ class Rows:
         return self._pos
 
 
-def attn_work(q_rows: Rows, k_rows: Rows, causal: bool, d_k: int = 64):
+def attn_work(q_rows: Rows, k_rows: Rows, causal: bool, d_k: int = 64, n_head: int = 0):
     """Work lists of the attention kernels for one (query layout, key layout, causal, head width) combination:
     int32 device vectors of (b << 16) | tile over query tiles (forward; backward dQ) and key tiles (backward dK/dV),
     sorted by decreasing number of streamed 64-row tiles - the dispatcher hands workgroups out in this order, i.e.
     longest-first list scheduling of the ragged batch.  The rows per tile are the kernels' own (``native.attn_tile_rows``:
     the kernel is chosen by problem shape).  -> (forward, backward dQ, backward dK/dV).  Cached on the query layout;
-    the model calls this while it builds the layouts, before the first kernel of a step (no H2D copy mid-step)."""
-    key = (id(k_rows), bool(causal), int(d_k))
+    the model calls this while it builds the layouts, before the first kernel of a step (no H2D copy mid-step).
+
+    XCD affinity (n_head in {1, 2, 4, 8}): workgroup ``bid`` runs on XCD ``bid % 8`` and the kernels enumerate
+    ``bid = position * n_head + head``, so with the utterances dealt into 8 / n_head cost-balanced groups and group g
+    holding the list positions = g (mod 8 / n_head), every (utterance, head) is served by ONE XCD: its K / V (Q / dO)
+    rows are fetched into one L2 instead of up to eight.  Shorter groups are padded with no-op entries (tile 0xffff)."""
+    key = (id(k_rows), bool(causal), int(d_k), int(n_head))
     hit = q_rows._work.get(key)
     if hit is not None and hit[0] is k_rows:
         return hit[1]
     lq = q_rows.lens_host.tolist() if q_rows.lens_host is not None else [q_rows.max_len] * q_rows.B
     lk = k_rows.lens_host.tolist() if k_rows.lens_host is not None else [k_rows.max_len] * k_rows.B
     rows = [nv.attn_tile_rows(w, d_k, q_rows.max_len, k_rows.max_len, causal) for w in range(3)]
-    lists = ([], [], [])
+    ng = 8 // n_head if n_head in (1, 2, 4, 8) and not os.environ.get("ST_NO_XCD_AFFINITY") else 1
+    # deal the utterances into ng groups of equal total cost (longest first onto the lightest group)
+    group, load = [0] * q_rows.B, [0.0] * ng
+    if ng > 1:
+        for b in sorted(range(q_rows.B), key=lambda b: -lq[b] * lk[b]):
+            g = min(range(ng), key=lambda g: load[g])
+            group[b] = g
+            load[g] += lq[b] * lk[b]
+    lists = tuple([[] for _ in range(ng)] for _ in range(3))
     for b in range(q_rows.B):
         for w in (0, 1):          # query tiles: cost = 64-key tiles streamed
             R = rows[w]
             for t in range((lq[b] + R - 1) // R):
                 seen = min(lk[b], (t + 1) * R) if causal else lk[b]
-                lists[w].append(((seen + 63) // 64, (b << 16) | t))
+                lists[w][group[b]].append(((seen + 63) // 64, (b << 16) | t))
         R = rows[2]               # key tiles: cost = 64-query tiles streamed
         for t in range((lk[b] + R - 1) // R):
             q_begin = (t * R // 64) * 64 if causal else 0
-            lists[2].append(((lq[b] - q_begin + 63) // 64, (b << 16) | t))
+            lists[2][group[b]].append(((lq[b] - q_begin + 63) // 64, (b << 16) | t))
     dev = q_rows.off.device
     out = []
-    for w in lists:
-        w.sort(key=lambda c: -c[0])
-        out.append(torch.tensor([c[1] for c in w], dtype=I32).to(dev))
+    for per_group in lists:
+        for g in per_group:
+            g.sort(key=lambda c: -c[0])
+        n = max(len(g) for g in per_group)
+        flat = []
+        for i in range(n):        # position i * ng + g <- group g's i-th heaviest item (a no-op where the group ran out)
+            for g in per_group:
+                flat.append(g[i][1] if i < len(g) else 0xffff)
+        out.append(torch.tensor(flat, dtype=I32).to(dev))
     out = tuple(out)
     q_rows._work[key] = (k_rows, out)
     return out
@@ -484,7 +504,7 @@ class MhaFn(torch.autograd.Function):
         ores = (_empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)) if need_bwd else None
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
-                    scale, work=attn_work(q_rows, k_rows, causal, d // H)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
+                    scale, work=attn_work(q_rows, k_rows, causal, d // H, H)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
@@ -538,7 +558,7 @@ class MhaFn(torch.autograd.Function):
                 dkv = _empty(x_kv.shape[0], 2 * d, x_q) if k_rows.dense else \
                     torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
-        _, work_q, work_k = attn_work(q_rows, k_rows, ctx.causal, d // H)
+        _, work_q, work_k = attn_work(q_rows, k_rows, ctx.causal, d // H, H)
         nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
                     q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop)
         dx_kv = None

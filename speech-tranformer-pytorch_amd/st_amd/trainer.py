@@ -195,8 +195,8 @@ class TrainStep:
                 from .functional import attn_work
                 self.model.prepare_layouts(torch.full((B,), T_cap), torch.full((B,), L_cap), L_cap, dev)
                 ir, tr = st.layouts
-                dk = getattr(self.model, "_d_k", 64)
-                attn_work(ir, ir, False, dk), attn_work(tr, tr, True, dk), attn_work(tr, ir, False, dk)
+                dk, nh = getattr(self.model, "_d_k", 64), getattr(self.model, "_n_head", 0)
+                attn_work(ir, ir, False, dk, nh), attn_work(tr, tr, True, dk, nh), attn_work(tr, ir, False, dk, nh)
                 tr.scatter_index(L_cap)
             self._buckets[key] = st
         st.x[:, :T].copy_(inputs, non_blocking=True)

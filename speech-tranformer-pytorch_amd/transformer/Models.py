@@ -206,7 +206,7 @@ class Transformer(nn.Module):
         common = dict(n_head=need('n_heads'), d_k=need('d_k'), d_v=need('d_v'), d_model=need('d_model'),
                       d_inner_hid=need('d_inner_hid'), dropout=need('dropout'), emb_scale=opt('emb_scale', 1))
         self.vocab_size, self.d_model = need('vocab_size'), common['d_model']
-        self._d_k = common['d_k']
+        self._d_k, self._n_head = common['d_k'], common['n_head']
         self.encoder = Encoder(input_size=need('feature_dim'), n_max_seq=need('max_inputs_length', 'max_input_length'),
                                n_layers=need('num_enc_layer'), **common)
         self.decoder = Decoder(vocab_size=self.vocab_size, n_max_seq=need('max_target_length'),
@@ -256,9 +256,9 @@ class Transformer(nn.Module):
         t_rows.scatter_index(l_max)
         in_rows.pos, t_rows.pos
         dk = self._d_k
-        F_.attn_work(in_rows, in_rows, False, dk)     # encoder self-attention
-        F_.attn_work(t_rows, t_rows, True, dk)        # decoder self-attention (causal)
-        F_.attn_work(t_rows, in_rows, False, dk)      # decoder-encoder attention
+        F_.attn_work(in_rows, in_rows, False, dk, self._n_head)     # encoder self-attention
+        F_.attn_work(t_rows, t_rows, True, dk, self._n_head)        # decoder self-attention (causal)
+        F_.attn_work(t_rows, in_rows, False, dk, self._n_head)      # decoder-encoder attention
         self.encoder.row_chains(arena_of(self))   # the chain plans' block tables (a host->device copy the first time)
         self.decoder.row_chains(arena_of(self))
         return in_rows, t_rows

@@ -16,30 +16,36 @@ def test_work_lists_cover_every_tile_once_and_sort_by_cost():
     for qr, kr, causal, a, b in ((k_rows, k_rows, False, lk, lk), (q_rows, q_rows, True, lq, lq),
                                  (q_rows, k_rows, False, lq, lk)):
         from st_amd import native as nv
-        wf, wq, wk = attn_work(qr, kr, causal, 64)
-        Rf, Rq, Rk = (nv.attn_tile_rows(w, 64, int(a.max()), int(b.max()), causal) for w in range(3))
-        assert Rf in (128, 256) and Rq in (128, 256) and Rk in (128, 256)
-        for w, R, L in ((wf, Rf, a), (wq, Rq, a), (wk, Rk, b)):
-            assert w.dtype == torch.int32
-            want = {(i, t) for i in range(len(L)) for t in range((int(L[i]) + R - 1) // R)}
-            got = _decode(w)
-            assert len(got) == len(want) and set(got) == want
+        for H in (4, 3):          # 4 heads: two XCD-affinity groups; 3 heads: no grouping (one plain longest-first list)
+            wf, wq, wk = attn_work(qr, kr, causal, 64, H)
+            ng = 8 // H if H in (1, 2, 4, 8) else 1
+            Rf, Rq, Rk = (nv.attn_tile_rows(w, 64, int(a.max()), int(b.max()), causal) for w in range(3))
+            assert Rf in (128, 256) and Rq in (128, 256) and Rk in (128, 256)
 
-        def cost_q(R):
-            def f(i, t):
-                seen = min(int(b[i]), (t + 1) * R) if causal else int(b[i])
-                return (seen + 63) // 64
-            return f
+            def cost_q(R):
+                def f(i, t):
+                    seen = min(int(b[i]), (t + 1) * R) if causal else int(b[i])
+                    return (seen + 63) // 64
+                return f
 
-        def cost_k(i, t):
-            q_begin = (t * Rk // 64) * 64 if causal else 0
-            return (int(a[i]) - q_begin + 63) // 64
+            def cost_k(i, t):
+                q_begin = (t * Rk // 64) * 64 if causal else 0
+                return (int(a[i]) - q_begin + 63) // 64
 
-        for w, cf in ((wf, cost_q(Rf)), (wq, cost_q(Rq)), (wk, cost_k)):
-            c = [cf(*it) for it in _decode(w)]
-            assert c == sorted(c, reverse=True) and min(c) >= 1
-        # cached on the query layout
-        assert attn_work(qr, kr, causal, 64)[0] is wf
+            for w, R, L, cf in ((wf, Rf, a, cost_q(Rf)), (wq, Rq, a, cost_q(Rq)), (wk, Rk, b, cost_k)):
+                assert w.dtype == torch.int32 and w.numel() % ng == 0
+                want = {(i, t) for i in range(len(L)) for t in range((int(L[i]) + R - 1) // R)}
+                got = [it for it in _decode(w) if it[1] != 0xffff]              # (no-op padding entries: tile 0xffff)
+                assert len(got) == len(want) and set(got) == want
+                owner = {}
+                for g in range(ng):      # group g holds the positions = g (mod ng): each sorted by cost, utterances disjoint
+                    items = [it for it in _decode(w)[g::ng] if it[1] != 0xffff]
+                    c = [cf(*it) for it in items]
+                    assert c == sorted(c, reverse=True) and (not c or min(c) >= 1)
+                    for i, _ in items:
+                        assert owner.setdefault(i, g) == g, "an utterance is served by two XCD groups"
+            # cached on the query layout
+            assert attn_work(qr, kr, causal, 64, H)[0] is wf
 
 
 def test_dropout_hash_statistics():

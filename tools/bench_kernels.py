@@ -124,7 +124,7 @@ if "attn" in which:
              ("dec self causal", Md, Md, to, tl, to, tl, 50, 50, True, True, t_rows, t_rows),
              ("cross", Md, M, to, tl, qo, ql, 50, int(in_len.max()), False, False, t_rows, in_rows)]
     for name, mq, mk, q_off, q_len, k_off, k_len, maxq, maxk, causal, self_attn, qr, kr in cases:
-        wf, wq, wk = attn_work(qr, kr, causal, 64) if use_work else (None, None, None)
+        wf, wq, wk = attn_work(qr, kr, causal, 64, H) if use_work else (None, None, None)
         if self_attn:
             qkv = rnd(mq, 3 * d)
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
