@@ -13,110 +13,44 @@
 //     that held: a workgroup that finds an l outside [1e-30, 1e30] (or inf / nan) repeats its item with the classical
 //     running-maximum loop.  Per score that leaves exp + sum + half a convert (8.2 VALU per MFMA by PMC, prologue and
 //     epilogue included): 43.1 -> 37.8 us on the encoder shape of config 2.
-// Everything else is the general kernel's: 4 waves x 32 query rows, 64-key tiles through two register stages and a
-// padded LDS double buffer, two workgroups per CU.  Tried on the same box and NOT kept (tools/dev/st_attn64_variants.hip,
+//   * a LEAN body: <= 168 registers per lane, i.e. three workgroups (12 waves) per CU instead of two - with waits at
+//     35-40 % of every wave's time a third wave per SIMD is what fills the issue slots (37.8 -> 35.2 us).  One register
+//     stage, one 32-key block live at a time; the K / V tiles are fetched with buffer loads (a descriptor per tile whose
+//     range ends at the utterance's last key: rows past it read as zeros - no clamping, no address arithmetic, no
+//     branches in the loop); only the last tile runs the masking path; the hot tile is 165 instructions for 16 MFMAs.
+// Work decomposition as in the general kernel: 4 waves x 32 query rows per (utterance, head, 128-row tile), 64-key
+// tiles through a padded LDS double buffer.  Tried on the same box and NOT kept (tools/dev/st_attn64_variants.hip,
 // DESIGN.md section 5): 64 query rows per wave with one workgroup per CU (44-46 us: nothing hides a single wave's
 // s_waitcnt time), with two (spills at 256 registers: 59 us), a hand-staggered instruction stream pinned with
-// sched_group_barrier (44 us), 128-key stages (54 us), all fragment reads of a tile issued up front (39 us).
+// sched_group_barrier (44 us), 128-key stages (54 us), all fragment reads of a tile issued up front (39 us), packed adds
+// for the row sums written by hand (38.4 vs 37.8 us), waves without a valid row skipping the tile body (54 us: the
+// early return re-shuffled the compiler's register assignment).
 #include "st_attn_common.cuh"
+#include <type_traits>
 
 namespace {
 
 constexpr float F64_BIG = 1e30f, F64_SMALL = 1e-30f;
 
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnArgs a) {
-  constexpr int DK = 64, NT = 4, ND = 2;
-  using G = TileGeo<DK>;
-  __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];   // 2 buffers x (K tile, V tile)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-  int b, h, tile;
-  decode_item(a, blockIdx.x, b, h, tile);
-  const int lq = a.q_len[b], lk = a.k_len[b];
-  const int q0 = tile * WG_ROWS;
-  if (q0 >= lq) return;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
-  const int q = q0 + wave * 32 + (l & 31);
-  const bool q_ok = q < lq;
-  const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
-  const float c2 = a.scale * 1.4426950408889634f;
-  const Drop dr = make_drop(a.drop);
-  const int bh = b * a.H + h;
-  const int ntiles = (lk + TILE - 1) / TILE;
-  const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;
-  const bf16* vbase = a.V + (size_t)a.k_off[b] * a.ldv + h * DK;
-
-  bf16x8 qf[NT];     // log2 domain
+// one 64-key tile, plain exponentials (EXACT = false) or the classical running-maximum update (EXACT = true)
+template <bool DROP, bool MASK, bool EXACT>
+__device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], float& m, float& lsum,
+                                          int kt, int lk, int q, const Drop& dr, int bh) {
+  constexpr int DK = 64;
+  const int l = threadIdx.x & 63, hi = l >> 5;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8);
+  for (int kb = 0; kb < 2; ++kb) {
+    f32x16 s = zero16();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qf[t][e] = (bf16)((float)v[e] * c2);
-  }
-  uint32_t offk[G::CH], offv[G::CH];
-  Stage<DK>::offsets(offk, a.ldk);
-  Stage<DK>::offsets(offv, a.ldv);
-  Stage<DK> sk[2], sv[2];
-  f32x16 o[ND];
-  float m = 0.f, lsum = 0.f;
-
-  auto load = [&](int set, int it) {
-    sk[set].load(offk, kbase, a.ldk, it * TILE, lk);
-    sv[set].load(offv, vbase, a.ldv, it * TILE, lk);
-  };
-  auto store = [&](int set) {
-    sk[set].store(smem + set * 2 * G::E);
-    sv[set].store(smem + set * 2 * G::E + G::E);
-  };
-  auto fast = [&](int buf, int it) {
-    const bf16* ks = smem + buf * 2 * G::E;
-    const bf16* vs = ks + G::E;
-    const int kt = it * TILE;
-    const bool full = kt + TILE <= lk;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = zero16();
-#pragma unroll
-      for (int t = 0; t < NT; ++t) s = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s);
-      if (!full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt + kb * 32 + acc_row(r, hi) >= lk) s[r] = -INFINITY;
-      }
-      float ps = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f(s[r]);
-        ps += s[r];
-      }
-      lsum += ps;
-      if (DROP) {
-        bool keep[16];
-        keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = keep[r] ? s[r] : 0.f;
-      }
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack_acc8(s, 8 * hf);
-        const int base = kb * 32 + 16 * hf + 4 * hi;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
-      }
-    }
-  };
-  auto exact = [&](int buf, int it) {
-    const bf16* ks = smem + buf * 2 * G::E;
-    const bf16* vs = ks + G::E;
-    const int kt = it * TILE;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = zero16();
-#pragma unroll
-      for (int t = 0; t < NT; ++t) s = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s);
+    for (int t = 0; t < 4; ++t) s = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s);
+    if (MASK) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (kt + kb * 32 + acc_row(r, hi) >= lk) s[r] = -INFINITY;
+    }
+    if (EXACT) {
       float mx = s[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -126,46 +60,130 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnArgs a) {
       const float alpha = __builtin_amdgcn_exp2f(m - m_fin);
       lsum *= alpha;
 #pragma unroll
-      for (int d = 0; d < ND; ++d)
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
       m = m_new;
-      float ps = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f(s[r] - m_fin);
-        ps += s[r];
-      }
-      lsum += ps;
-      if (DROP) {
-        bool keep[16];
-        keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
+      for (int r = 0; r < 16; ++r) s[r] -= m_fin;
+    }
+    float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = keep[r] ? s[r] : 0.f;
-      }
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r]);
+      ps += s[r];
+    }
+    lsum += ps;
+    if (DROP) {   // dropped probabilities leave the normaliser untouched; the 1/(1-p) scale is folded into the final 1/l
+      bool keep[16];
+      keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack_acc8(s, 8 * hf);
-        const int base = kb * 32 + 16 * hf + 4 * hi;
+      for (int r = 0; r < 16; ++r) s[r] = keep[r] ? s[r] : 0.f;
+    }
 #pragma unroll
-        for (int d = 0; d < ND; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
-      }
+    for (int hf = 0; hf < 2; ++hf) {
+      const bf16x8 pf = pack_acc8(s, 8 * hf);
+      const int base = kb * 32 + 16 * hf + 4 * hi;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // one block live at a time: hoisting the next block's reads costs the third workgroup
+  }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
+  constexpr int DK = 64, NT = 4, ND = 2;
+  using G = TileGeo<DK>;
+  __shared__ __attribute__((aligned(16))) bf16 smem[4 * G::E];   // 2 buffers x (K tile, V tile); the row patches afterwards
+
+  int b, h, tile;
+  decode_item(a, blockIdx.x, b, h, tile);
+  const int lq = a.q_len[b], lk = a.k_len[b];
+  const int q0 = tile * WG_ROWS;
+  if (q0 >= lq) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
+  const int q = q0 + wave * 32 + (l & 31);
+  const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
+  const float c2 = a.scale * 1.4426950408889634f;
+  const Drop dr = make_drop(a.drop);
+  const int bh = b * a.H + h;
+  const int ntiles = (lk + TILE - 1) / TILE;
+  const char* kbase = reinterpret_cast<const char*>(a.K + (size_t)a.k_off[b] * a.ldk + h * DK);
+  const char* vbase = reinterpret_cast<const char*>(a.V + (size_t)a.k_off[b] * a.ldv + h * DK);
+
+  bf16x8 qf[NT];     // log2 domain: q * scale * log2(e), rounded to bf16 once more (the scores then need no multiply)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[t][e] = (bf16)((float)v[e] * c2);
+  }
+  // staging: thread -> two 16-byte chunks of the K tile and two of the V tile (chunk id = tid + p * 256: row id / 8)
+  uint32_t vk[2], vv[2];
+  int lds_at[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int id = threadIdx.x + p * 256, row = id >> 3, c8 = id & 7;
+    vk[p] = (uint32_t)(row * a.ldk + c8 * 8) * 2u;
+    vv[p] = (uint32_t)(row * a.ldv + c8 * 8) * 2u;
+    lds_at[p] = row * G::STR + c8 * 8;
+  }
+  u32x4 rk[2], rv[2];
+  auto load = [&](int it) {     // rows >= lk lie beyond the descriptor's range: they arrive as zeros
+    const int left = lk - it * TILE;          // >= 1
+    const __amdgpu_buffer_rsrc_t dk = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(kbase + (size_t)it * TILE * a.ldk * 2), 0, ((left - 1) * a.ldk + DK) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dv = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vbase + (size_t)it * TILE * a.ldv * 2), 0, ((left - 1) * a.ldv + DK) * 2, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      rk[p] = __builtin_amdgcn_raw_buffer_load_b128(dk, vk[p], 0, 0);
+      rv[p] = __builtin_amdgcn_raw_buffer_load_b128(dv, vv[p], 0, 0);
     }
   };
+  auto store = [&](bf16* ks) {
 #pragma unroll
-  for (int d = 0; d < ND; ++d) o[d] = zero16();
-  stream_tiles(ntiles, load, store, fast);
-  float ltot = lsum + wave_xor32(lsum);
-  if (__syncthreads_or(!(ltot > F64_SMALL && ltot < F64_BIG))) {      // leave the plain-exponential range: classical loop
-#pragma unroll
-    for (int d = 0; d < ND; ++d) o[d] = zero16();
-    m = -INFINITY;
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<u32x4*>(ks + lds_at[p]) = rk[p];
+      *reinterpret_cast<u32x4*>(ks + G::E + lds_at[p]) = rv[p];
+    }
+  };
+
+  f32x16 o[ND];
+  float m = 0.f, lsum, ltot;
+  // (two instantiations of the whole loop, not one loop with a run-time switch: the two sides of such a switch keep the
+  // accumulators in different registers and the compiler reconciles them with ~50 moves per tile)
+  auto run = [&](auto exact_tag) {
+    constexpr bool EXACT = decltype(exact_tag)::value;
+    o[0] = zero16();
+    o[1] = zero16();
     lsum = 0.f;
-    stream_tiles(ntiles, load, store, exact);
+    load(0);
+    for (int it = 0; it + 1 < ntiles; ++it) {       // every tile but the last: no key is masked
+      bf16* ks = smem + (it & 1) * 2 * G::E;
+      store(ks);
+      load(it + 1);
+      __syncthreads();
+      lean_tile<DROP, false, EXACT>(ks, ks + G::E, qf, o, m, lsum, it * TILE, lk, q, dr, bh);
+    }
+    {
+      const int it = ntiles - 1;
+      bf16* ks = smem + (it & 1) * 2 * G::E;
+      store(ks);
+      __syncthreads();
+      lean_tile<DROP, true, EXACT>(ks, ks + G::E, qf, o, m, lsum, it * TILE, lk, q, dr, bh);
+    }
+    __syncthreads();           // the tile buffers are free (epilogue patches, or the second attempt)
     ltot = lsum + wave_xor32(lsum);
+  };
+  run(std::false_type{});
+  if (__syncthreads_or(q < lq && !(ltot > F64_SMALL && ltot < F64_BIG))) {      // left the plain-exponential range
+    m = -INFINITY;
+    run(std::true_type{});
   }
   const float inv = ltot > 0.f ? (DROP ? dr.scale : 1.f) / ltot : 0.f;
-  if (q_ok && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
+  if (q < lq && hi == 0 && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow] = m + log2f(ltot);
   if (a.Ores)
     store_rows_pair<DK>(smem + wave * 32 * DK, smem + 4 * 32 * DK + wave * 32 * DK, o, inv, a.O + (size_t)a.q_off[b] * a.ldo + h * DK,
                         a.Ores + (size_t)a.q_off[b] * a.ldo + h * DK, a.ldo, q0 + wave * 32, min(32, lq - (q0 + wave * 32)));
