@@ -233,9 +233,6 @@ int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
                 float scale, int parts, const int* work_q, int n_work_q, const int* work_k, int n_work_k,
                 const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
-/* out[N] (f32) += column sums of x (bf16 [M, N]) - bias gradients. */
-int st_colsum(st_stream_t stream, const void* x, int ld, int M, int N, float* out);
-
 /* row_pos[off[b]+t] = t (and row_seq[...] = b if non-null), t < len[b]:
  * the per-row position the PE add needs (Embedding.py:21-29). */
 int st_row_index(st_stream_t stream, const int* off, const int* len, int B, int max_len, int* row_pos, int* row_seq);

@@ -102,36 +102,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   }
 }
 
-// Column sums of a bf16 [M, N] matrix accumulated into fp32 out[N] (bias gradients).
-// Each workgroup streams a slab of rows with 16-byte loads: thread = (column group of 8, row
-// sub-lane); partials are combined through LDS and one atomic per column per workgroup.
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int ld, int M, int N, float* out,
-                                                     int rows_per_block) {
-  __shared__ float red[256 * 8];
-  const int CG = N / 8;                 // column groups (N <= 2048 -> CG <= 256)
-  const int RS = 256 / CG;              // row sub-lanes
-  const int cg = threadIdx.x % CG, rs = threadIdx.x / CG;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float acc[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  if (rs < RS) {
-    for (int r = r0 + rs; r < r1; r += RS) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (size_t)r * ld + cg * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[rs * N + cg * 8 + e] = acc[e];
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < N; c += 256) {
-    float t = 0.f;
-    for (int k = 0; k < RS; ++k) t += red[k * N + c];
-    atomicAdd(out + c, t);
-  }
-}
-
 // row_pos[off[b] + t] = t, row_seq[off[b] + t] = b  for t < len[b]
 __global__ void row_index_kernel(const int* off, const int* len, int* row_pos, int* row_seq) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -355,16 +325,6 @@ extern "C" int st_ln_bwd(hipStream_t stream, const void* dy, int lddy, const voi
   else return -2;
 #undef ST_LN_BWD
 #undef ST_LN_BWD_
-  ST_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int st_colsum(hipStream_t stream, const void* x, int ld, int M, int N, float* out) {
-  if (M <= 0 || N <= 0) return 0;
-  if ((ld & 7) || (N & 7) || N > 2048) return -1;
-  const int rpb = 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3((M + rpb - 1) / rpb), dim3(256), 0, stream, (const bf16*)x, ld, M, N, out,
-                     rpb);
   ST_CHECK_LAUNCH();
   return 0;
 }

@@ -66,7 +66,6 @@ SIGNATURES = {
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
-    "st_colsum": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_feat_stack": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
@@ -662,14 +661,6 @@ def feat_stack(x, in_len, stats, left, right, interval, out_off, out_len, max_ou
                               int(interval), out_off.data_ptr(), out_len.data_ptr(), int(max_out_len), out.data_ptr(),
                               out.stride(0))
     _check(rc, "st_feat_stack")
-    return out
-
-
-def colsum(x, out):
-    _mat(x, BF16, "x")
-    M, N = x.shape
-    _vec(out, F32, N, "out")
-    _check(load().st_colsum(_stream(), x.data_ptr(), x.stride(0), M, N, out.data_ptr()), "st_colsum")
     return out
 
 

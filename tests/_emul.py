@@ -373,11 +373,6 @@ def feat_stack(x, in_len, stats, left, right, interval, out_off, out_len, max_ou
     return out
 
 
-def colsum(x, out):
-    out += x.float().sum(0)
-    return out
-
-
 def row_index(off, length, max_len, row_pos, row_seq=None):
     for b in range(off.numel()):
         n, o = int(length[b]), int(off[b])
@@ -495,7 +490,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "colsum", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "decode_self_attn", "embed_step"]
 
 

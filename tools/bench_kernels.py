@@ -151,10 +151,6 @@ if "misc" in which:
         a, b, c = (torch.zeros(d, dtype=F32, device=dev) for _ in range(3))
         us = timeit(lambda: nv.ln_bwd(dy, xh, rs, gm, dx, a, b, c))
         report("ln_bwd [%d,%d]" % (m, d), us, 0, 2.0 * 3 * m * d)
-    for (m, n) in ((M, 768), (M, 1024), (Md, 768)):
-        x, o = rnd(m, n), torch.zeros(n, dtype=F32, device=dev)
-        us = timeit(lambda: nv.colsum(x, o))
-        report("colsum [%d,%d]" % (m, n), us, 0, 2.0 * m * n)
 
 if "chain" in which:
     # row chains (csrc/st_rowchain.hip): the encoder layer's chain at 24,060 rows and the decoder's at 1,206, forward and
