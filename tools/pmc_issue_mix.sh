@@ -3,9 +3,13 @@
 # per-kernel micro-benchmark; no other trace domains).  Run through gpurun; summary -> gpurun_out/pmc_issue_mix.txt
 export TMPDIR=/tmp
 cd /root/repo
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/pmc2 -o p -- python tools/bench_kernels.py gemm attn chain > gpurun_out/pmc2.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA --kernel-trace -d /tmp/pmc3 -o p -- python tools/bench_kernels.py gemm attn chain > gpurun_out/pmc3.log 2>&1
-python - <<'PY' > gpurun_out/pmc_issue_mix.txt
+# ST_PMC_CMD: the profiled command (default: the per-kernel micro-benchmark at config 2's shapes); ST_PMC_OUT: summary name
+CMD=${ST_PMC_CMD:-python tools/bench_kernels.py gemm attn chain}
+OUT=${ST_PMC_OUT:-pmc_issue_mix}
+rm -rf /tmp/pmc2 /tmp/pmc3
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d /tmp/pmc2 -o p -- $CMD > gpurun_out/pmc2.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA --kernel-trace -d /tmp/pmc3 -o p -- $CMD > gpurun_out/pmc3.log 2>&1
+python - <<'PY' > gpurun_out/$OUT.txt
 import sqlite3
 rows = {}
 for db in ("/tmp/pmc2/p_results.db", "/tmp/pmc3/p_results.db"):
@@ -35,4 +39,4 @@ for name, (grid, v) in sorted(best.items()):
         100 * v["SQ_ACTIVE_INST_ANY"] / wc, 100 * v["SQ_WAIT_ANY"] / wc, 100 * v["SQ_WAIT_INST_ANY"] / wc,
         100 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["duration_ns"] * 2.4)))
 PY
-cat gpurun_out/pmc_issue_mix.txt | head -60
+cat gpurun_out/$OUT.txt | head -60
