@@ -360,6 +360,14 @@ extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void
     else hipLaunchKernelGGL((gemm_ln_kernel<256, 0, 1, true>), grid, blk, 0, stream, a);
   }
   else if (N == 256) { if (split) ST_LN(256, 2); else ST_LN(256, 1); }
+  else if (N == 512 && M > 64 * 128) {
+    // (round 3) 64-row tiles on 8 waves for encoder-sized M: the 512 x 32 weight k-tile that goes through LDS serves twice
+    // the rows (BM = 32 re-staged the whole weight matrix for every 32 rows: 752 workgroups x 0.5-1 MB at config 3)
+    const dim3 grid((M + 63) / 64), blk(512);
+    if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<512, 1, 1, true>), grid, blk, 0, stream, a);
+    else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<512, 2, 1, true>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_ln_kernel<512, 0, 1, true>), grid, blk, 0, stream, a);
+  }
   else if (N == 512) ST_LN(512, 1);
   else return -3;
 #undef ST_LN

@@ -388,6 +388,13 @@ extern "C" int st_gemm_lnbwd(hipStream_t stream, const void* dY, int lddy, const
     ST_CHECK_LAUNCH();
     return 0;
   }
+  if (N == 512 && M > 64 * 128) {      // (round 3) d_model 512, encoder-sized M: 64-row tiles on 8 waves, as in st_gemm_ln.hip
+    const dim3 grid((M + 63) / 64);
+    if (drop) hipLaunchKernelGGL((gemm_lnbwd_kernel<512, true, true>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_lnbwd_kernel<512, false, true>), grid, dim3(512), 0, stream, a);
+    ST_CHECK_LAUNCH();
+    return 0;
+  }
 #define ST_LB(NN)                                                                                                  \
   do {                                                                                                             \
     const dim3 grid((M + Geo<NN>::BM - 1) / Geo<NN>::BM);                                                          \

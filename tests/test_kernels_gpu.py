@@ -132,7 +132,8 @@ def test_gemm_wgrad(M, N, K, splits):
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 128), (1000, 256, 256), (130, 256, 1024), (70, 512, 512), (500, 256, 80),
                                      (1206, 256, 1024), (1206, 256, 544), (700, 128, 1000), (9000, 256, 1024),   # K >= 512, M <= 8192: 8-wave K split
-                                     (16500, 256, 544)])                                                        # 8-wave 128-row tiles
+                                     (16500, 256, 544),                                                         # 8-wave 128-row tiles
+                                     (8250, 512, 512), (8230, 512, 1024)])                                      # d_model 512, M > 8192: 8-wave 64-row tiles
 @pytest.mark.parametrize("variant", ["res", "relu_pe"])
 def test_gemm_ln(M, N, K, variant):
     X, W = g(M, K, seed=1), g(N, K, seed=2, scale=K ** -0.5)
@@ -549,7 +550,8 @@ def test_attention_backward_single_launch(case):
 @pytest.mark.parametrize("M,N,K,with_aux,p", [(300, 128, 128, True, 0), (1000, 256, 1024, True, 0), (130, 256, 768, False, 0),
                                                (70, 512, 512, True, 0), (999, 256, 256, True, 0),
                                                (999, 256, 768, True, 0.1), (130, 128, 256, True, 0.3), (200, 512, 512, False, 0.2),
-                                               (16500, 256, 768, True, 0), (16450, 256, 512, True, 0.1)])      # 8-wave 128-row tiles
+                                               (16500, 256, 768, True, 0), (16450, 256, 512, True, 0.1),       # 8-wave 128-row tiles
+                                               (8250, 512, 512, True, 0), (8230, 512, 1024, True, 0.1)])        # d_model 512: 8-wave 64-row tiles
 def test_gemm_lnbwd(M, N, K, with_aux, p):
     """st_gemm_lnbwd == st_gemm (dgrad, + aux) followed by st_ln_bwd, in one launch; p > 0: the LayerNorm output was
     dropped in the forward (the mask is regenerated from the same counters as st_ln_bwd's)."""
