@@ -58,6 +58,13 @@ def step_flops(in_len, tgt_len, c):
     return 3.0 * fwd
 
 
+def shard_batch(full, rank, world, global_batch):
+    """The specified partition (SURVEY 8e / train_multi.py:136-139): the first `global_batch` utterances of `full` (a tuple
+    of per-utterance tensors) split contiguously, rank r taking utterances [r * per, (r + 1) * per)."""
+    per = global_batch // world
+    return tuple(t[rank * per:(rank + 1) * per] for t in full)
+
+
 def kernel_report(records):
     """Aggregate per-launch HIP-event timings into kernel classes with algorithmic work: flops from the launch's shape
     tag, HBM bytes from the launch's own operand list (native._tag(io=...): every operand once) - nothing here is derived
@@ -237,8 +244,7 @@ def main():
             return synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"], seed=rank, t_min=T_MIN,
                                         l_min=L_MIN)
         full = synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"], seed=0, t_min=T_MIN, l_min=L_MIN)
-        per = global_batch // world
-        return tuple(t[rank * per:(rank + 1) * per] for t in full)
+        return shard_batch(full, rank, world, global_batch)
 
     if args.global_batch and (args.global_batch % world or args.global_batch > BATCH):
         raise SystemExit("--global-batch must be a multiple of the rank count and <= %d" % BATCH)
