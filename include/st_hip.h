@@ -301,16 +301,25 @@ int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);
 int st_adam_clip(st_stream_t stream, long long n, float* p, float* g, float* m, float* v, const float* lr,
                  const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps);
 
+/* total_norm of clip_grad_norm_ (train.py:45) over the flat fp32 gradient buffer g [n] (n % 4 == 0) as one launch:
+ * *gnorm = ||g||_2 (partials added in a fixed order, fp64), and - when step is not NULL - *step += 1, the optimiser's
+ * step count st_adam_clip then reads.  scratch: st_grad_norm_blocks() + 1 floats owned by the caller, the last one
+ * zero before the first call (the kernel leaves it zero). */
+int st_grad_norm_blocks(void);
+int st_grad_norm(st_stream_t stream, const float* g, long long n, float* scratch, float* gnorm, float* step);
+
 /* Cross-entropy over ragged logits rows (train.py:40,120: nn.CrossEntropyLoss(ignore_index = 0), mean over the
  * non-ignored tokens).  logits f32 [R, ldl] (V valid columns; padding columns holding -1e30 may be counted as valid),
- * target i64 [R].  st_ce_fwd: lse[r] = logsumexp(logits[r, :V]) (f32 [R], kept for the backward); row_loss[r] (f32 [R],
- * scratch) = lse[r] - logits[r, target[r]] on the non-ignored rows; sums[0] = their sum, sums[1] = their number
- * (loss = sums[0] / sums[1]).  st_ce_bwd: dlogits (bf16 [R, ldd], ldd % 8 == 0, columns >= V zero) = (softmax - onehot) * *grad_out /
+ * target i64 [R], or - with target_index (i64 [R]) - any i64 vector read as target[target_index[r]] (the padded
+ * ground truth of train.py:40 addressed through the ragged rows' positions: no gather launch).  st_ce_fwd: lse[r] = logsumexp(logits[r, :V]) (f32 [R], kept for the backward); row_loss[r] (f32 [R],
+ * scratch) = lse[r] - logits[r, target[r]] on the non-ignored rows; sums (f32 [3]): [0] = their sum, [1] = their number,
+ * [2] = the loss sums[0] / sums[1].  st_ce_bwd: dlogits (bf16 [R, ldd], ldd % 8 == 0, columns >= V zero) = (softmax - onehot) * *grad_out /
  * sums[1] on the non-ignored rows, 0 elsewhere - the operand of the vocabulary projection's backward GEMMs. */
-int st_ce_fwd(st_stream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
-              float* lse, float* row_loss, float* sums);
-int st_ce_bwd(st_stream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
-              const float* lse, const float* sums, const float* grad_out, void* dlogits, int ldd);
+int st_ce_fwd(st_stream_t stream, const float* logits, int ldl, int R, int V, const long long* target,
+              const long long* target_index, int ignore_index, float* lse, float* row_loss, float* sums);
+int st_ce_bwd(st_stream_t stream, const float* logits, int ldl, int R, int V, const long long* target,
+              const long long* target_index, int ignore_index, const float* lse, const float* sums, const float* grad_out,
+              void* dlogits, int ldd);
 
 /* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
 int st_probe_tr16(st_stream_t stream, const void* in, void* out);

@@ -276,6 +276,51 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, f
   }
 }
 
+// Global L2 norm of the flat gradient buffer (clip_grad_norm_'s total_norm, train.py:45) as ONE launch: every workgroup
+// leaves the sum of squares of its grid-stride slice in `partial`, takes a ticket, and the last one adds the partials up (in
+// index order: the result does not depend on the arrival order), writes *gnorm, advances the optimiser's step counter
+// (*step += 1, optional) and resets the ticket for the next launch.  Replaces torch.linalg.vector_norm (52 MB at 2.6 TB/s
+// plus a memset) and the separate step increment: three graph nodes -> one.
+__global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict__ g, size_t n4, float* partial, unsigned* ticket,
+                                                        float* __restrict__ gnorm, float* step) {
+  __shared__ float red[4];
+  __shared__ bool last;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = blockIdx.x * (size_t)256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[e], v[e], acc[e]);
+  }
+  float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();                                          // the partial is visible device-wide before the ticket
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double t = 0.0;
+  for (int i = tid; i < (int)gridDim.x; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __shared__ double redd[256];
+  redd[tid] = t;
+  __syncthreads();
+  for (int o = 128; o; o >>= 1) {
+    if (tid < o) redd[tid] += redd[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *gnorm = (float)sqrt(redd[0]);
+    if (step) *step += 1.0f;
+    *ticket = 0u;
+  }
+}
+
 // ---- hardware probes (tests/test_probe_gpu.py): pin the fragment layouts the kernels rely on -------
 __global__ void probe_tr16_kernel(const bf16* in, bf16* out) {
   __shared__ __attribute__((aligned(16))) bf16 tile[16 * 64];
@@ -726,7 +771,8 @@ extern "C" int st_cache_reorder(hipStream_t stream, void* cache, const long long
 // forward: lse[r] = logsumexp(logits[r, :V]); row_loss[r] = lse[r] - logits[r, target[r]] (0 for target == ignore); a second,
 // one-workgroup kernel sums them (1,200 workgroups adding to ONE address serialise in the L2: 43 us measured that way).
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ldl, int V, const long long* __restrict__ target,
-                                                     int ignore, float* __restrict__ lse, float* __restrict__ row_loss) {
+                                                     const long long* __restrict__ index, int ignore, float* __restrict__ lse,
+                                                     float* __restrict__ row_loss) {
   __shared__ float red[4];
   const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* row = logits + (size_t)r * ldl;
@@ -762,37 +808,40 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   if (tid == 0) {
     const float l = gm + __logf(red[0] + red[1] + red[2] + red[3]);
     lse[r] = l;
-    const long long t = target[r];
+    const long long t = target[index ? index[r] : r];
     if (t != ignore && (t < 0 || t >= V)) __builtin_trap();
     row_loss[r] = t != ignore ? l - row[t] : 0.f;
   }
 }
-__global__ __launch_bounds__(256) void ce_sum_kernel(const float* __restrict__ row_loss, const long long* __restrict__ target, int ignore,
-                                                     int R, float* __restrict__ sums) {
+__global__ __launch_bounds__(256) void ce_sum_kernel(const float* __restrict__ row_loss, const long long* __restrict__ target,
+                                                     const long long* __restrict__ index, int ignore, int R, float* __restrict__ sums) {
   __shared__ float red[2][4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float a = 0.f, n = 0.f;
   for (int r = tid; r < R; r += 256) {
     a += row_loss[r];
-    n += target[r] != ignore ? 1.f : 0.f;
+    n += target[index ? index[r] : r] != ignore ? 1.f : 0.f;
   }
 #pragma unroll
   for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o, 64); n += __shfl_xor(n, o, 64); }
   if (lane == 0) { red[0][wave] = a; red[1][wave] = n; }
   __syncthreads();
   if (tid == 0) {
-    sums[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    sums[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float tot = red[0][0] + red[0][1] + red[0][2] + red[0][3], cnt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    sums[0] = tot;
+    sums[1] = cnt;
+    sums[2] = tot / cnt;      // the loss (nn.CrossEntropyLoss: mean over the non-ignored tokens; 0 / 0 = nan as there)
   }
 }
 // backward: dlogits[r][v] = (exp(logits[r][v] - lse[r]) - [v == target[r]]) * go / count for target[r] != ignore, else 0 (bf16)
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ldl, int V, const long long* __restrict__ target,
-                                                     int ignore, const float* __restrict__ lse, const float* __restrict__ sums,
+                                                     const long long* __restrict__ index, int ignore, const float* __restrict__ lse,
+                                                     const float* __restrict__ sums,
                                                      const float* __restrict__ go, bf16* __restrict__ dl, int ldd) {
   const int r = blockIdx.x, tid = threadIdx.x;
   const float* row = logits + (size_t)r * ldl;
   bf16* out = dl + (size_t)r * ldd;
-  const long long t = target[r];
+  const long long t = target[index ? index[r] : r];
   const float scale = (t != ignore && sums[1] > 0.f) ? *go / sums[1] : 0.f;
   const float l = lse[r];
   for (int v = tid * 8; v < ldd; v += 256 * 8) {      // ldd % 8 == 0; columns >= V get zeros
@@ -808,22 +857,23 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
-extern "C" int st_ce_fwd(hipStream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
-                         float* lse, float* row_loss, float* sums) {
+extern "C" int st_ce_fwd(hipStream_t stream, const float* logits, int ldl, int R, int V, const long long* target,
+                         const long long* target_index, int ignore_index, float* lse, float* row_loss, float* sums) {
   if (R <= 0) return 0;
   if (!logits || !target || !lse || !row_loss || !sums || V <= 0 || ldl < V) return -1;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, target, ignore_index, lse, row_loss);
-  hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, stream, row_loss, target, ignore_index, R, sums);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, target, target_index, ignore_index, lse,
+                     row_loss);
+  hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(256), 0, stream, row_loss, target, target_index, ignore_index, R, sums);
   ST_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int st_ce_bwd(hipStream_t stream, const float* logits, int ldl, int R, int V, const long long* target, int ignore_index,
-                         const float* lse, const float* sums, const float* grad_out, void* dlogits, int ldd) {
+extern "C" int st_ce_bwd(hipStream_t stream, const float* logits, int ldl, int R, int V, const long long* target,
+                         const long long* target_index, int ignore_index, const float* lse, const float* sums, const float* grad_out, void* dlogits, int ldd) {
   if (R <= 0) return 0;
   if (!logits || !target || !lse || !sums || !grad_out || !dlogits || V <= 0 || ldl < V || ldd < V || (ldd & 7)) return -1;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, target, ignore_index, lse, sums, grad_out,
-                     (bf16*)dlogits, ldd);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, target, target_index, ignore_index, lse, sums,
+                     grad_out, (bf16*)dlogits, ldd);
   ST_CHECK_LAUNCH();
   return 0;
 }
@@ -835,6 +885,20 @@ extern "C" int st_cast_bf16(hipStream_t stream, const float* src, void* dst, lon
   int blocks = (int)((n8 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, stream, src, (bf16*)dst, n8);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_grad_norm_blocks(void) { return 1024; }
+
+extern "C" int st_grad_norm(hipStream_t stream, const float* g, long long n, float* scratch, float* gnorm, float* step) {
+  // scratch: st_grad_norm_blocks() + 1 floats, the last one (the ticket) zero before the first call
+  if (n <= 0 || (n & 3) || !g || !scratch || !gnorm) return -1;
+  const size_t n4 = (size_t)n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(grad_norm_kernel, dim3(blocks), dim3(256), 0, stream, g, n4, scratch, reinterpret_cast<unsigned*>(scratch + 1024),
+                     gnorm, step);
   ST_CHECK_LAUNCH();
   return 0;
 }

@@ -758,31 +758,31 @@ class VocabCeFn(torch.autograd.Function):
     would cast it to the logits' fp32 and VocabFn back to bf16: two more passes over [rows, V])."""
 
     @staticmethod
-    def forward(ctx, x, anchor, mod, target, ignore_index):
+    def forward(ctx, x, anchor, mod, target, ignore_index, index=None):
         s = mod._st
         R = x.shape[0]
         logits = torch.empty(R, s.v_pad, dtype=F32, device=x.device)
         nv.gemm(x, s.w_vocab, logits, epi=nv.EPI_F32, bias=s.pad_bias)      # padding columns at -1e30: probability 0
         lse = torch.empty(R, dtype=F32, device=x.device)
-        sums = torch.empty(2, dtype=F32, device=x.device)
-        nv.ce_fwd(logits, target, ignore_index, lse, sums)
-        ctx.save_for_backward(x, logits, target, lse, sums)
+        sums = torch.empty(3, dtype=F32, device=x.device)
+        nv.ce_fwd(logits, target, ignore_index, lse, sums, index=index)
+        ctx.save_for_backward(x, logits, target, lse, sums, index)
         ctx.mod, ctx.ignore_index = mod, ignore_index
-        return sums[0] / sums[1]
+        return sums[2]
 
     @staticmethod
     def backward(ctx, go):
-        x, logits, target, lse, sums = ctx.saved_tensors
+        x, logits, target, lse, sums, index = ctx.saved_tensors
         mod = ctx.mod
         s, arena = mod._st, mod._st_arena
         arena.attach_grads(s.vocab_params, s.vocab_lo, s.vocab_hi)
         dl = torch.empty(logits.shape, dtype=BF16, device=logits.device)
-        nv.ce_bwd(logits, target, ctx.ignore_index, lse, sums, go.reshape(1).float(), dl)
+        nv.ce_bwd(logits, target, ctx.ignore_index, lse, sums, go.reshape(1).float(), dl, index=index)
         wgrad(dl, x, s.g_w_vocab)
         dx = _empty(x.shape[0], x.shape[1], x)
         dgrad(dl, s.w_vocab, dx)
         arena.grads_ready(s.vocab_lo, s.vocab_hi)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 class CeFn(torch.autograd.Function):
@@ -795,11 +795,11 @@ class CeFn(torch.autograd.Function):
     def forward(ctx, logits, target, ignore_index):
         R = logits.shape[0]
         lse = torch.empty(R, dtype=F32, device=logits.device)
-        sums = torch.empty(2, dtype=F32, device=logits.device)
+        sums = torch.empty(3, dtype=F32, device=logits.device)
         nv.ce_fwd(logits, target, ignore_index, lse, sums)
         ctx.save_for_backward(logits, target, lse, sums)
         ctx.ignore_index = ignore_index
-        return sums[0] / sums[1]
+        return sums[2]
 
     @staticmethod
     def backward(ctx, go):
@@ -820,7 +820,8 @@ class PackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rows: Rows):
-        out = torch.zeros(rows.total, x.shape[2], dtype=BF16, device=x.device)
+        # (a packed layout has no row outside an utterance: nothing to zero)
+        out = (torch.empty if rows.dense else torch.zeros)(rows.total, x.shape[2], dtype=BF16, device=x.device)
         nv.pack_rows(x.contiguous(), rows.off, rows.len, out)
         ctx.rows, ctx.shape = rows, x.shape
         return out

@@ -82,9 +82,11 @@ SIGNATURES = {
                             _c_float],
     "st_beam_advance": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
-    "st_ce_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
-    "st_ce_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                  _c_int],
+    "st_ce_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "st_ce_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                  _c_void_p, _c_int],
+    "st_grad_norm_blocks": [],
+    "st_grad_norm": [_c_void_p, _c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p],
     "st_cache_reorder": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int],
     "st_adam_clip": [_c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_float, _c_float, _c_float, _c_float],
@@ -789,31 +791,63 @@ def cache_reorder(cache, order, step, beam):
     return cache
 
 
-def ce_fwd(logits, target, ignore_index, lse, sums, V=None):
-    """lse[r] = logsumexp(logits[r, :V]); sums = (sum of the non-ignored rows' losses, their count) - see st_ce_fwd."""
+def _ce_target(target, index, R, who):
+    """target i64 [R], or any i64 vector addressed through index (i64 [R])."""
+    if index is None:
+        _vec(target, I64, R, "target")
+    else:
+        _vec(index, I64, R, "target_index")
+        if not (target.is_cuda and target.dtype == I64 and target.is_contiguous()):
+            raise ValueError("%s: target must be a contiguous int64 tensor on the GPU" % who)
+
+
+def ce_fwd(logits, target, ignore_index, lse, sums, V=None, index=None):
+    """lse[r] = logsumexp(logits[r, :V]); sums = (sum of the non-ignored rows' losses, their count, the mean = the loss)
+    - see st_ce_fwd.  index: row r's target is target.view(-1)[index[r]]."""
     if not (logits.is_cuda and logits.dtype == F32 and logits.dim() == 2 and logits.stride(1) == 1):
         raise ValueError("ce_fwd: logits must be an fp32 row matrix on the GPU")
     R = logits.shape[0]
     V = logits.shape[1] if V is None else V
-    _vec(target, I64, R, "target"), _vec(lse, F32, R, "lse"), _vec(sums, F32, 2, "sums")
+    _ce_target(target, index, R, "ce_fwd")
+    _vec(lse, F32, R, "lse"), _vec(sums, F32, 3, "sums")
     row_loss = torch.empty(R, dtype=F32, device=logits.device)       # scratch: summed by the call's second launch
     _tag("ce_fwd", R, V, 0, io=(2.0 * R * V, 8.0 * R))
-    _check(load().st_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), int(ignore_index),
+    _check(load().st_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), _p(index), int(ignore_index),
                             lse.data_ptr(), row_loss.data_ptr(), sums.data_ptr()), "st_ce_fwd")
 
 
-def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None):
+def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None, index=None):
     """dlogits (bf16, same shape as logits) = d(mean loss) / d(logits) * grad_out - see st_ce_bwd."""
     R = logits.shape[0]
     V = logits.shape[1] if V is None else V
     _mat(dlogits, BF16, "dlogits")
     if dlogits.shape[0] != R or dlogits.shape[1] < V or dlogits.stride(0) % 8 or dlogits.shape[1] != dlogits.stride(0):
         raise ValueError("ce_bwd: dlogits must be a contiguous bf16 [R, >= V] matrix with a row length that is a multiple of 8")
+    _ce_target(target, index, R, "ce_bwd")
     _vec(grad_out, F32, 1, "grad_out")
     _tag("ce_bwd", R, V, 0, io=(4.0 * R * V, 8.0 * R))
-    _check(load().st_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), int(ignore_index),
+    _check(load().st_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), _p(index), int(ignore_index),
                             lse.data_ptr(), sums.data_ptr(), grad_out.data_ptr(), dlogits.data_ptr(), dlogits.stride(0)),
            "st_ce_bwd")
+
+
+def grad_norm_scratch(device):
+    """Zeroed scratch of st_grad_norm (block partials + the ticket): allocate once per gradient buffer."""
+    return torch.zeros(int(load().st_grad_norm_blocks()) + 1, dtype=F32, device=device)
+
+
+def grad_norm(g, scratch, out, step=None):
+    """out (fp32 scalar tensor) = ||g||_2 over the flat fp32 buffer g; step (fp32 scalar tensor, optional) += 1 - see
+    st_grad_norm."""
+    if not (g.is_cuda and g.dtype == F32 and g.is_contiguous() and g.numel() % 4 == 0):
+        raise ValueError("grad_norm: g must be a contiguous fp32 GPU buffer of a multiple of 4 elements")
+    _vec(scratch, F32, int(load().st_grad_norm_blocks()) + 1, "scratch")
+    for t, nm in ((out, "out"), (step, "step")):
+        if t is not None and not (t.is_cuda and t.dtype == F32 and t.numel() == 1):
+            raise ValueError("grad_norm: %s must be an fp32 scalar on the GPU" % nm)
+    _tag("grad_norm", g.numel(), io=(4.0 * g.numel(),))
+    _check(load().st_grad_norm(_stream(), g.data_ptr(), g.numel(), scratch.data_ptr(), out.data_ptr(), _p(step)), "st_grad_norm")
+    return out
 
 
 def cast_bf16(src, dst):

@@ -76,6 +76,13 @@ class TrainStep:
         self._g_fb = self._g_enc = self._g_opt = None
         self._loss = self._gnorm = None
         self._cut = None
+        self._seed = None
+
+    def _backward(self, loss):
+        """loss.backward() with a resident gradient seed (autograd's own ones_like(loss) is a fill launch per step)."""
+        if self._seed is None or self._seed.device != loss.device or self._seed.dtype != loss.dtype:
+            self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)
+        torch.autograd.backward(loss, grad_tensors=self._seed)
 
     # ---- the two halves of a step -------------------------------------------------------------
     def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, captured=False, layouts=None):
@@ -98,7 +105,7 @@ class TrainStep:
         # are live (they assume a weight gradient is enqueued when its layer's backward returns)
         hooks_live = self.reducer is not None and not captured
         with deferred_wgrads(not hooks_live):
-            loss.backward()
+            self._backward(loss)
         return loss.detach()
 
     # ---- data-parallel graph mode: the backward in two captures -----------------------------------
@@ -111,7 +118,7 @@ class TrainStep:
                                                                 cut_encoder=True, ce_truth=ground_truth,
                                                                 ignore_index=self.crit.ignore_index, layouts=layouts)
         with deferred_wgrads(True):
-            loss.backward()
+            self._backward(loss)
         self._cut = (enc, enc_leaf.grad)
         return loss.detach()
 
@@ -131,10 +138,9 @@ class TrainStep:
 
     def _clip_and_update(self):
         if getattr(self.optimizer, "arena", None) is not None:
-            # global norm (one reduction over the flat buffer), then clip + Adam as one pass (st_adam_clip)
-            grad_norm = torch.linalg.vector_norm(arena_of(self.model).grad)
-            self.optimizer.step_captured(grad_norm=grad_norm, max_norm=self.max_grad_norm)
-            return grad_norm
+            # global norm (one launch over the flat buffer: st_grad_norm, which also advances the step count), then clip +
+            # Adam as one pass (st_adam_clip)
+            return self.optimizer.step_captured(grad_norm=True, max_norm=self.max_grad_norm)
         grad_norm = clip_grad_norm_flat(arena_of(self.model), self.max_grad_norm)
         self.optimizer.step_captured()
         return grad_norm

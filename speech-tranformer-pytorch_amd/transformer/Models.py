@@ -287,8 +287,9 @@ class Transformer(nn.Module):
             if ce_truth is not None:
                 # ce_truth [B, L] int64 (the padded ground truth of train.py:40): the first return value is the token-mean
                 # cross-entropy (train.py:40,120) instead of the logits - projection + loss as one autograd node
-                truth = ce_truth.contiguous().view(-1).index_select(0, t_rows.scatter_index(ce_truth.shape[1]))
-                logits = F_.VocabCeFn.apply(dec, self.tgt_word_proj.weight, self, truth, ignore_index)
+                # (the ragged rows read their ground-truth entries through their padded positions: no gather launch)
+                logits = F_.VocabCeFn.apply(dec, self.tgt_word_proj.weight, self, ce_truth.contiguous().view(-1), ignore_index,
+                                            t_rows.scatter_index(ce_truth.shape[1]))
             else:
                 logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self, padded_logits)   # [sum(tgt_len), v_pad]
         if not padded_logits and ce_truth is None:

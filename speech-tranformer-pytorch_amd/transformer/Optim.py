@@ -22,6 +22,7 @@ class ScheduledOptim(object):
         params = list(model.parameters())
         self._params = params
         self.arena = None
+        self._norm_scratch = None
         if params and (all(p.is_cuda for p in params) or ScheduledOptim._allow_cpu_arena):
             # HIP path: every parameter is a view of one flat buffer (st_amd.arena), so Adam runs as a
             # single fused kernel over it instead of one multi-tensor launch chain over 258 tensors.
@@ -56,20 +57,27 @@ class ScheduledOptim(object):
 
     def step_captured(self, grad_norm=None, max_norm=None):
         """The update alone (rate already set with update_learning_rate) - what a HIP graph captures.
-        With ``grad_norm`` (device scalar: the global gradient norm) and ``max_norm`` on the flat-arena path, gradient
-        clipping (train.py:45) and the Adam update are ONE pass over the buffers (``st_adam_clip``: the arithmetic of
-        torch's fused Adam, on this optimizer's own state tensors)."""
+        With ``grad_norm`` and ``max_norm`` on the flat-arena path, gradient clipping (train.py:45) and the Adam update are
+        two launches over the buffers: ``st_grad_norm`` (the global norm; also advances the step count) and
+        ``st_adam_clip`` (clip + the arithmetic of torch's fused Adam, on this optimizer's own state tensors).
+        grad_norm: True = compute it here (returned as a device scalar), or a device scalar already computed."""
         group = self.optimizer.param_groups[0]
         plain = not (group["weight_decay"] or group["amsgrad"] or group["maximize"])
         if self.arena is None or grad_norm is None or not plain:
             self.optimizer.step()
-            return
+            return None
         from st_amd import native as nv
         p, st = self._flat_state()
-        st["step"].add_(1)
+        if grad_norm is True:
+            if self._norm_scratch is None or self._norm_scratch.device != p.device:
+                self._norm_scratch = nv.grad_norm_scratch(p.device)
+            grad_norm = nv.grad_norm(p.grad, self._norm_scratch, torch.empty((), dtype=torch.float32, device=p.device), step=st["step"])
+        else:
+            st["step"].add_(1)
         beta1, beta2 = group["betas"]
         nv.adam_clip(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], self.lr_tensor, st["step"], grad_norm, max_norm,
                      beta1, beta2, group["eps"])
+        return grad_norm
 
     def zero_grad(self):
         if self.arena is not None:

@@ -460,23 +460,37 @@ def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist
     order.copy_((origin + (torch.arange(B) * beam).unsqueeze(1)).view(-1))
 
 
-def ce_fwd(logits, target, ignore_index, lse, sums, V=None):
+def ce_fwd(logits, target, ignore_index, lse, sums, V=None, index=None):
     V = logits.shape[1] if V is None else V
+    target = target if index is None else target.reshape(-1)[index]
     l = torch.logsumexp(logits[:, :V].float(), -1)
     lse.copy_(l)
     valid = target != ignore_index
     picked = logits[:, :V].float().gather(1, target.clamp(0, V - 1).view(-1, 1)).squeeze(1)
     sums[0] = ((l - picked) * valid).sum()
     sums[1] = valid.sum().float()
+    sums[2] = sums[0] / sums[1]
 
 
-def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None):
+def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None, index=None):
     V = logits.shape[1] if V is None else V
+    target = target if index is None else target.reshape(-1)[index]
     valid = (target != ignore_index).float().view(-1, 1)
     g = torch.exp(logits[:, :V].float() - lse.view(-1, 1))
     g.scatter_add_(1, target.clamp(0, V - 1).view(-1, 1), -torch.ones(len(target), 1))
     dlogits.zero_()
     dlogits[:, :V] = (g * valid * (grad_out.float() / sums[1])).to(BF16)
+
+
+def grad_norm_scratch(device):
+    return torch.zeros(1025, dtype=torch.float32, device=device)
+
+
+def grad_norm(g, scratch, out, step=None):
+    out.copy_(torch.linalg.vector_norm(g.double()).float())
+    if step is not None:
+        step.add_(1)
+    return out
 
 
 def cache_reorder(cache, order, step, beam):
@@ -491,7 +505,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "decode_self_attn", "embed_step"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "decode_self_attn", "embed_step"]
 
 
 @contextlib.contextmanager

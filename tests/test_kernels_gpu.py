@@ -633,6 +633,27 @@ def test_adam_clip_matches_torch_clip_and_fused_adam():
     assert float(step) == float(st["step"])
 
 
+@pytest.mark.parametrize("n", [4, 1000, 262144 + 8, 13_000_004])
+def test_grad_norm_matches_torch_and_advances_the_step(n):
+    """st_grad_norm == torch.linalg.vector_norm over the flat gradient buffer (fp64 reference), repeated launches on the same
+    scratch (the ticket resets itself), the optional step counter advanced by one per launch; bit-identical from launch to
+    launch (the partials are added in index order, not in arrival order)."""
+    torch.manual_seed(n % 1000)
+    gbuf = torch.randn(n, device="cuda") * 0.3
+    scratch = nv.grad_norm_scratch("cuda")
+    out, step = torch.zeros((), device="cuda"), torch.full((), 41.0, device="cuda")
+    seen = []
+    for it in range(3):
+        nv.grad_norm(gbuf, scratch, out, step=step if it else None)
+        seen.append(float(out))
+        ref = float(torch.linalg.vector_norm(gbuf.double()))
+        assert abs(seen[-1] - ref) <= 2e-6 * ref, (n, it, seen[-1], ref)
+    assert seen[0] == seen[1] == seen[2] and float(step) == 43.0
+    assert float(scratch[-1].view(torch.int32)) == 0
+    gbuf.zero_()
+    assert float(nv.grad_norm(gbuf, scratch, out)) == 0.0
+
+
 # ---- st_gemm_ws: the weight-stationary streaming GEMM -------------------------------------------------------
 @pytest.mark.parametrize("M,N", [(32, 256), (33, 256), (1206, 768), (4097, 1024), (24060, 768), (13000, 256)])
 @pytest.mark.parametrize("relu", [False, True])
@@ -888,6 +909,22 @@ def test_cross_entropy_rows_matches_torch(R, V):
         assert float(x.grad[:, V:].abs().max()) == 0.0
     check(x.grad[:, :V], ref_in.grad, 6e-3, "cross-entropy gradient")
     assert float(x.grad[::5].abs().max()) == 0.0
+    # the indexed form (row r's target = truth[index[r]]: the padded ground truth read through the ragged rows' positions)
+    # against the gathered form: same kernels, same bits
+    idx = torch.randperm(2 * R, generator=gen)[:R]
+    truth = torch.zeros(2 * R, dtype=torch.long)
+    truth[idx] = target
+    lg = logits.cuda()
+    outs = []
+    for tgt, index in ((target.cuda(), None), (truth.cuda(), idx.cuda())):
+        lse, sums = torch.empty(R, device="cuda"), torch.empty(3, device="cuda")
+        nv.ce_fwd(lg, tgt, 0, lse, sums, index=index)
+        dl = torch.empty(R, vp, dtype=BF16, device="cuda")
+        nv.ce_bwd(lg, tgt, 0, lse, sums, torch.ones(1, device="cuda"), dl, index=index)
+        outs.append((lse, sums, dl))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert abs(float(outs[0][1][2]) - ref.item()) < 1e-5 * abs(ref.item())
 
 
 @pytest.mark.parametrize("t", [0, 1, 37, 63, 64, 99])

@@ -177,7 +177,8 @@ if "chain" in which:
         ra, rb = torch.rand(rows, device=dev) + 0.5, torch.rand(rows, device=dev) + 0.5
         dsa, dH, dsb, dctx, delta = E(rows, d_), E(rows, dff), E(rows, d_), E(rows, d_), E(4 * rows, dtype=F32)
         acc = [torch.zeros(d_, device=dev) for _ in range(6)]
+        bits = nv.relu_bits_from(Hm)
         us = timeit(lambda: nv.row_chain_bwd(chb, rows, head=(3, dqkv, dss, xc, ra, g0, None, dsa, acc[0], acc[1], acc[2]),
-                                             ffn=(dff, nv.relu_bits_from(Hm), 1.0, dH, xy, rb, g1, dsb, acc[3], acc[4], acc[5]), tail=(O_, Or, dctx, delta)))
+                                             ffn=(dff, bits, 1.0, dH, xy, rb, g1, dsb, acc[3], acc[4], acc[5]), tail=(O_, Or, dctx, delta)))
         report("row_chain bwd  qkv^T+LNbwd, FFN^T+LNbwd, wo^T+delta [%d]" % rows, us, fl,
                2.0 * rows * (3 * d_ + 2 * d_ + dff + d_ + 2 * d_ + d_ + dff + d_ + d_))

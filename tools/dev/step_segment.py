@@ -24,3 +24,8 @@ for n, t in tm.most_common(60):
 gaps = sorted(((seg[i + 1][1] - seg[i][2]) / 1e3, seg[i][0][:40], seg[i + 1][0][:40]) for i in range(len(seg) - 1))
 print("largest gaps:", [(round(g, 1), a, b) for g, a, b in gaps[-6:]])
 print("median gap %.2f us" % gaps[len(gaps) // 2][0])
+if len(sys.argv) > 3:      # full sequence: start offset, duration, gap to the next kernel
+    with open(sys.argv[3], "w") as f:
+        for i, (n, s, e) in enumerate(seg):
+            gap = (seg[i + 1][1] - e) / 1e3 if i + 1 < len(seg) else 0.0
+            f.write("%8.1f %7.2f %6.2f  %s\n" % ((s - seg[0][1]) / 1e3, (e - s) / 1e3, gap, n.replace("(anonymous namespace)::", "").replace("void ", "")[:90]))
