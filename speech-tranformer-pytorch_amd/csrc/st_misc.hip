@@ -287,7 +287,18 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict_
   __shared__ bool last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (size_t i = blockIdx.x * (size_t)256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = blockIdx.x * (size_t)256 + tid;
+  for (; i + 3 * stride < n4; i += 4 * stride) {      // four 16-byte loads in flight per thread
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(g + (i + u * stride) * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[u][e], v[u][e], acc[e]);
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[e], v[e], acc[e]);
@@ -298,13 +309,15 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict_
   if (lane == 0) red[wave] = s;
   __syncthreads();
   if (tid == 0) {
-    partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    __threadfence();                                          // the partial is visible device-wide before the ticket
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    // write-through store, acknowledged before the ticket is drawn; the last workgroup reads with device-scope loads.  No
+    // fence: an agent-scope release writes the whole L2 back (tools/dev/merge_probe.hip: +60-80 us on 512 workgroups)
+    __hip_atomic_store(partial + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   double t = 0.0;
   for (int i = tid; i < (int)gridDim.x; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __shared__ double redd[256];
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict_
   if (tid == 0) {
     *gnorm = (float)sqrt(redd[0]);
     if (step) *step += 1.0f;
-    *ticket = 0u;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -895,8 +908,10 @@ extern "C" int st_grad_norm(hipStream_t stream, const float* g, long long n, flo
   // scratch: st_grad_norm_blocks() + 1 floats, the last one (the ticket) zero before the first call
   if (n <= 0 || (n & 3) || !g || !scratch || !gnorm) return -1;
   const size_t n4 = (size_t)n / 4;
+  // one workgroup per CU: the tickets are same-address atomics, which serialise (~15 ns each: 1024 workgroups spent 15 us on
+  // them, ce_fwd's 1,200 once 43 us)
   int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(grad_norm_kernel, dim3(blocks), dim3(256), 0, stream, g, n4, scratch, reinterpret_cast<unsigned*>(scratch + 1024),
                      gnorm, step);
   ST_CHECK_LAUNCH();

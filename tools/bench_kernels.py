@@ -145,6 +145,8 @@ if "attn" in which:
             report("attn bwd %s " % nm + name, us, fl)
 
 if "misc" in which:
+    gbuf, scratch, out1 = torch.randn(13_000_000, device=dev), nv.grad_norm_scratch(dev), torch.zeros((), device=dev)
+    report("grad_norm [13 M fp32]", timeit(lambda: nv.grad_norm(gbuf, scratch, out1)), 0, 4.0 * gbuf.numel())
     for m in (M, Md):
         dy, xh, rs, gm = rnd(m, d), rnd(m, d), rnd(m, dtype=F32).abs() + 0.5, rnd(d, dtype=F32)
         dx = torch.empty(m, d, dtype=BF16, device=dev)
