@@ -72,15 +72,23 @@ template <int MT> struct Ctx {
 // (every weight fragment feeds MT MFMAs), refilling the ring DEPTH fragments ahead.
 template <int MT>
 __device__ __forceinline__ void block_mma(Ctx<MT>& c, const bf16* act, f32x16 (&acc)[MT]) {
+  // two k-steps per group: the 2 MT activation reads, then the 2 MT MFMAs, then the two refills (one k-step per group
+  // measured 1-3 % slower on the backward chains; without the scheduling barrier 5-12 % slower: hoisted refills double the
+  // live registers)
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    bf16x8 xf[MT];
+  for (int k2 = 0; k2 < 8; ++k2) {
+    bf16x8 xf[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xf[mt] = frag_nat(act, AS, mt * 32 + c.r, ks * 16 + c.hi * 8);
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(c.ring[ks % Ring<MT>::D], xf[mt], acc[mt]);
-    c.ring[ks % Ring<MT>::D] = c.ws[ks * 64 + c.l];
-    __builtin_amdgcn_sched_barrier(0);   // keep each refill next to its MFMAs: hoisted refills double the live registers
+      for (int mt = 0; mt < MT; ++mt) xf[u][mt] = frag_nat(act, AS, mt * 32 + c.r, (2 * k2 + u) * 16 + c.hi * 8);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(c.ring[(2 * k2 + u) % Ring<MT>::D], xf[u][mt], acc[mt]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) c.ring[(2 * k2 + u) % Ring<MT>::D] = c.ws[(2 * k2 + u) * 64 + c.l];
+    __builtin_amdgcn_sched_barrier(0);
   }
   c.ws += 16 * 64;
 }

@@ -176,7 +176,7 @@ def load(build_if_missing: bool = True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = lib_path()
+    path = os.environ.get("ST_HIP_LIB") or lib_path()      # (development: A/B a library built from variant sources)
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError("libst_hip.so not built: run `python __graft_entry__.py` (build())")

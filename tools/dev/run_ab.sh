@@ -1,4 +1,3 @@
 cd /root/repo
-python -m pytest tests/test_kernels_gpu.py -x -q -k "grad_norm" 2>&1 | tail -3
-python tools/bench_kernels.py misc 2>&1 | grep "grad_norm"
-python tools/bench_kernels.py misc 2>&1 | grep "grad_norm"
+L=/root/repo/speech-tranformer-pytorch_amd/lib
+for rep in 1 2; do for v in "" _v1 _v2; do echo "== lib$v"; ST_HIP_LIB=$L/libst_hip$v.so python tools/bench_kernels.py chain 2>&1 | grep "row_chain"; done; done
