@@ -13,6 +13,7 @@
 // the lane): LayerNorm's row statistics are an in-lane sum, one exchange with lane ^ 32 and (N > 128) one
 // LDS round between the waves that share a row.  Values leave through an LDS patch as 256-byte row segments.
 #include "st_common.cuh"
+#include <cstdlib>
 
 namespace {
 
@@ -43,8 +44,11 @@ struct GemmLnArgs {
 // N = 256: 2 x 2 (BM = 64), N = 512: 1 x 4 (BM = 32).
 // TALL (N = 256, encoder-sized M): 8 waves, 4 x 2, BM = 128 - twice the rows per weight tile that goes through LDS and
 // two waves per SIMD inside ONE workgroup (M / 64 = 376 tiles leave 136 of the 256 CUs with a single 4-wave workgroup).
-template <int N, bool TALL = false> struct Geo {
-  static constexpr int WN = N / 128, WM = (TALL ? 8 : 4) / WN, BM = 32 * WM, NT = 64 * WM * WN;
+// MB = 2 (N = 512, encoder-sized M): every wave owns TWO 32-row blocks of its 128 columns - 128-row tiles, so that the
+// 512 x 32 weight k-tile (32 KB through one CU's 64 B/clk vector-memory path) feeds 16 MFMAs per wave instead of 8: the
+// 64-row tile asked for 70 B/clk at full MFMA rate.
+template <int N, bool TALL = false, int MB = 1> struct Geo {
+  static constexpr int WN = N / 128, WM = (TALL ? 8 : 4) / WN, BM = 32 * WM * MB, NT = 64 * WM * WN;
   static constexpr int XE = BM * NS, YE = N * NS, BUF = XE + YE;
   static constexpr int SMEM_E = 2 * BUF > WM * WN * 4096 ? 2 * BUF : WM * WN * 4096;   // operand double buffer | one patch per wave
 };
@@ -211,23 +215,26 @@ __device__ __forceinline__ void ln_epilogue(const GemmLnArgs& a, f32x16 (&acc)[4
 // KG = 2 (decoder-sized M, long K: ~20 workgroups whose k-loop is a serial latency chain): 8 waves, the second
 // 4-wave group takes the second half of K with its own LDS buffers and hands its accumulators to the first through
 // LDS; the first group alone runs the LayerNorm epilogue.  One such workgroup per CU.
-template <int N, int DROPW, int KG, bool TALL = false>
+template <int N, int DROPW, int KG, bool TALL = false, int MB = 1>
 __global__ __launch_bounds__((TALL ? 512 : 256 * KG), ((KG > 1 || TALL) ? 1 : 2)) void gemm_ln_kernel(GemmLnArgs a) {
   static_assert(!(TALL && KG > 1), "one or the other");
-  using G = Geo<N, TALL>;
+  static_assert(MB == 1 || TALL, "two row blocks per wave: 8-wave workgroups only");
+  using G = Geo<N, TALL, MB>;
   __shared__ __attribute__((aligned(16))) bf16 smem_all[KG > 1 ? KG * 2 * G::BUF : G::SMEM_E];
   __shared__ float red[2 * G::WM * G::WN * 32];
   const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
   bf16* smem = smem_all + grp * 2 * G::BUF;
   const int wave = (threadIdx.x >> 6) & (G::WM * G::WN - 1), l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
   const int wm = wave / G::WN, wn = wave % G::WN;
-  const int i0 = blockIdx.x * G::BM, i_base = i0 + wm * 32;
+  const int i0 = blockIdx.x * G::BM, i_base = i0 + wm * 32 * MB;      // the wave's rows: i_base + mb * 32 + (lane & 31)
   auto xs = [&](int buf) { return smem + buf * G::BUF; };
   auto ys = [&](int buf) { return smem + buf * G::BUF + G::XE; };
 
-  f32x16 acc[4];
+  f32x16 acc[MB][4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] = zero16();
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[mb][b] = zero16();
 
   using SX = Stage<G::BM, G::NT>;
   using SY = Stage<N, G::NT>;
@@ -247,12 +254,15 @@ __global__ __launch_bounds__((TALL ? 512 : 256 * KG), ((KG > 1 || TALL) ? 1 : 2)
   auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      const bf16x8 xf = frag_nat(xs(buf), NS, wm * 32 + r, kk * 16 + hi * 8);
-      bf16x8 yf[4];
+      bf16x8 xf[MB], yf[4];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) xf[mb] = frag_nat(xs(buf), NS, (wm * MB + mb) * 32 + r, kk * 16 + hi * 8);
 #pragma unroll
       for (int b = 0; b < 4; ++b) yf[b] = frag_nat(ys(buf), NS, wn * 128 + b * 32 + r, kk * 16 + hi * 8);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = mfma32(yf[b], xf, acc[b]);
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[mb][b] = mfma32(yf[b], xf[mb], acc[mb][b]);
     }
   };
   loadA(0);
@@ -275,13 +285,14 @@ __global__ __launch_bounds__((TALL ? 512 : 256 * KG), ((KG > 1 || TALL) ? 1 : 2)
   // this lane's 8 residual chunks of the wave's [32][128] block (chunk id = p*64 + lane -> row id >> 4,
   // 16-byte column chunk id & 15): requested now, parked in the wave's patch after the k-loop
   bf16x8 resv[8];
-  if (a.res && grp == 0) {
+  auto load_res = [&](int mb) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int id = p * 64 + l, rr = min(i_base + (id >> 4), a.M - 1), c = id & 15;
+      const int id = p * 64 + l, rr = min(i_base + mb * 32 + (id >> 4), a.M - 1), c = id & 15;
       resv[p] = *reinterpret_cast<const bf16x8*>(a.res + (size_t)rr * a.ldres + wn * 128 + c * 8);
     }
-  }
+  };
+  if (a.res && grp == 0) load_res(0);
   compute(0);
   if (kt + 1 < nk) {
     storeB();
@@ -300,27 +311,31 @@ __global__ __launch_bounds__((TALL ? 512 : 256 * KG), ((KG > 1 || TALL) ? 1 : 2)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) xch[(b * 16 + t) * 64] = acc[b][t];
+        for (int t = 0; t < 16; ++t) xch[(b * 16 + t) * 64] = acc[0][b][t];
     }
     __syncthreads();
     if (grp == 1) return;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc[b][t] += xch[(b * 16 + t) * 64];
+      for (int t = 0; t < 16; ++t) acc[0][b][t] += xch[(b * 16 + t) * 64];
     __syncthreads();   // (the four remaining waves) every hand-over block is read before a patch overwrites it
   }
   bf16* patch = smem + wave * 4096;
-  if (a.res) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int id = p * 64 + l, rr = id >> 4, c = id & 15;
-      *reinterpret_cast<bf16x8*>(patch + rr * 128 + ((c ^ (rr & 15)) << 3)) = resv[p];
+  for (int mb = 0; mb < MB; ++mb) {      // one 32-row block at a time through the wave's patch
+    if (a.res) {
+      if (mb > 0) load_res(mb);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int id = p * 64 + l, rr = id >> 4, c = id & 15;
+        *reinterpret_cast<bf16x8*>(patch + rr * 128 + ((c ^ (rr & 15)) << 3)) = resv[p];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    ln_epilogue<N, DROPW, TALL>(a, acc[mb], a.res != nullptr, i_base + mb * 32, wm, wn, patch, red);
   }
-  ln_epilogue<N, DROPW, TALL>(a, acc, a.res != nullptr, i_base, wm, wn, patch, red);
 }
 
 }  // namespace
@@ -361,12 +376,21 @@ extern "C" int st_gemm_ln(hipStream_t stream, const void* X, int ldx, const void
   }
   else if (N == 256) { if (split) ST_LN(256, 2); else ST_LN(256, 1); }
   else if (N == 512 && M > 64 * 128) {
-    // (round 3) 64-row tiles on 8 waves for encoder-sized M: the 512 x 32 weight k-tile that goes through LDS serves twice
-    // the rows (BM = 32 re-staged the whole weight matrix for every 32 rows: 752 workgroups x 0.5-1 MB at config 3)
-    const dim3 grid((M + 63) / 64), blk(512);
-    if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<512, 1, 1, true>), grid, blk, 0, stream, a);
-    else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<512, 2, 1, true>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((gemm_ln_kernel<512, 0, 1, true>), grid, blk, 0, stream, a);
+    // (round 3) 128-row tiles on 8 waves for encoder-sized M and long contractions (two row blocks per wave, see Geo): BM = 32
+    // re-staged the whole weight matrix for every 32 rows (752 workgroups x 0.5-1 MB at config 3), BM = 64 still asked more of
+    // the vector-memory path than it delivers (M = 24060, K = 2048: 117 -> 96 us)
+    static const bool mb1 = getenv("ST_GEMM_LN_MB1") != nullptr;      // development: the 64-row tiles
+    if (mb1 || K < 1024) {      // short contractions are epilogue-bound: 47.4 us (64 rows) vs 48.8 (128) at K = 512
+      const dim3 grid((M + 63) / 64), blk(512);
+      if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<512, 1, 1, true>), grid, blk, 0, stream, a);
+      else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<512, 2, 1, true>), grid, blk, 0, stream, a);
+      else hipLaunchKernelGGL((gemm_ln_kernel<512, 0, 1, true>), grid, blk, 0, stream, a);
+    } else {
+      const dim3 grid((M + 127) / 128), blk(512);
+      if (a.drop_where == 1) hipLaunchKernelGGL((gemm_ln_kernel<512, 1, 1, true, 2>), grid, blk, 0, stream, a);
+      else if (a.drop_where == 2) hipLaunchKernelGGL((gemm_ln_kernel<512, 2, 1, true, 2>), grid, blk, 0, stream, a);
+      else hipLaunchKernelGGL((gemm_ln_kernel<512, 0, 1, true, 2>), grid, blk, 0, stream, a);
+    }
   }
   else if (N == 512) ST_LN(512, 1);
   else return -3;

@@ -19,6 +19,7 @@
 // the column sums of dy / dy*xhat are taken in the coalesced layout (8 columns per thread); pass 2 forms dx, which
 // leaves as 256-byte row segments while its column sum is taken.
 #include "st_common.cuh"
+#include <cstdlib>
 
 namespace {
 
@@ -41,8 +42,10 @@ struct LnBwdArgs {
 };
 
 // TALL (N = 256, encoder-sized M, long contraction): 8 waves, 4 x 2, BM = 128 - as in st_gemm_ln.hip.
-template <int N, bool TALL = false> struct Geo {
-  static constexpr int WN = N / 128, WM = (TALL ? 8 : 4) / WN, BM = 32 * WM, NT = 64 * WM * WN;
+// MB = 2 (N = 512, encoder-sized M, long contraction): two 32-row blocks per wave = 128-row tiles, as in st_gemm_ln.hip (the
+// 32 x 512 weight k-tile then feeds 16 MFMAs per wave instead of 8).
+template <int N, bool TALL = false, int MB = 1> struct Geo {
+  static constexpr int WN = N / 128, WM = (TALL ? 8 : 4) / WN, BM = 32 * WM * MB, NT = 64 * WM * WN;
   static constexpr int XE = BM * NS, YE = BK * N, BUF = XE + YE;
   static constexpr int SMEM_E = 2 * BUF > WM * WN * 2 * 4096 ? 2 * BUF : WM * WN * 2 * 4096;   // operand buffers | 2 patches per wave
 };
@@ -136,21 +139,24 @@ __device__ __forceinline__ bf16x8 frag_w(const bf16* tile, int col0, int kk) {
 // wave-private [32][128] patch, 16-byte chunks XOR-swizzled by the row: element (row, col)
 __device__ __forceinline__ int patch_at(int row, int col) { return row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7)); }
 
-template <int N, bool DROP, bool TALL = false>
+template <int N, bool DROP, bool TALL = false, int MB = 1>
 __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd_kernel(LnBwdArgs a) {
-  using G = Geo<N, TALL>;
+  static_assert(MB == 1 || TALL, "two row blocks per wave: 8-wave workgroups only");
+  using G = Geo<N, TALL, MB>;
   __shared__ __attribute__((aligned(16))) bf16 smem[G::SMEM_E];
-  __shared__ float red[2 * G::WM * G::WN * 32];
+  __shared__ float red_all[MB * 2 * G::WM * G::WN * 32];     // one exchange area per row block (one barrier each)
   __shared__ float csum[3][G::WM][N];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
   const int wm = wave / G::WN, wn = wave % G::WN;
-  const int i0 = blockIdx.x * G::BM, i_base = i0 + wm * 32;
+  const int i0 = blockIdx.x * G::BM, i_base0 = i0 + wm * 32 * MB;      // the wave's rows: i_base0 + mb * 32 + (lane & 31)
   auto xs = [&](int buf) { return smem + buf * G::BUF; };
   auto ys = [&](int buf) { return smem + buf * G::BUF + G::XE; };
 
-  f32x16 acc[4];
+  f32x16 accs[MB][4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] = zero16();
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) accs[mb][b] = zero16();
 
   using SX = StageX<G::BM, G::NT>;
   using SW = StageW<N, G::NT>;
@@ -166,12 +172,15 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
   auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      const bf16x8 xf = frag_nat(xs(buf), NS, wm * 32 + r, kk * 16 + hi * 8);
-      bf16x8 wf[4];
+      bf16x8 xf[MB], wf[4];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) xf[mb] = frag_nat(xs(buf), NS, (wm * MB + mb) * 32 + r, kk * 16 + hi * 8);
 #pragma unroll
       for (int b = 0; b < 4; ++b) wf[b] = frag_w<N>(ys(buf), wn * 128 + b * 32, kk);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = mfma32(wf[b], xf, acc[b]);
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) accs[mb][b] = mfma32(wf[b], xf[mb], accs[mb][b]);
     }
   };
   const int nk = (a.Kc + BK - 1) / BK;
@@ -194,13 +203,14 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
   // coalesced chunks of this wave's [32][128] block (chunk id = p*64 + lane -> row id >> 4, 16-byte chunk id & 15):
   // the addend now (its latency hides under the tail), xhat right after the last MFMAs
   bf16x8 auxv[8];
-  if (a.aux) {
+  auto load_aux = [&](int mb) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int id = p * 64 + l, rr = min(i_base + (id >> 4), a.M - 1), c = id & 15;
+      const int id = p * 64 + l, rr = min(i_base0 + mb * 32 + (id >> 4), a.M - 1), c = id & 15;
       auxv[p] = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)rr * a.ldaux + wn * 128 + c * 8);
     }
-  }
+  };
+  if (a.aux) load_aux(0);
   compute(0);
   if (kt + 1 < nk) {
     storeB();
@@ -213,15 +223,33 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
     }
   }
   bf16x8 xhv[8];
+  auto load_xhat = [&](int mb) {
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int id = p * 64 + l, rr = min(i_base + (id >> 4), a.M - 1), c = id & 15;
-    xhv[p] = *reinterpret_cast<const bf16x8*>(a.xhat + (size_t)rr * N + wn * 128 + c * 8);
-  }
+    for (int p = 0; p < 8; ++p) {
+      const int id = p * 64 + l, rr = min(i_base0 + mb * 32 + (id >> 4), a.M - 1), c = id & 15;
+      xhv[p] = *reinterpret_cast<const bf16x8*>(a.xhat + (size_t)rr * N + wn * 128 + c * 8);
+    }
+  };
+  load_xhat(0);
   __syncthreads();   // the patches reuse the operand buffers
 
   bf16* p1 = smem + wave * 8192;        // xhat
   bf16* p2 = p1 + 4096;                 // aux -> dy -> dx
+  const float* gm = a.gamma + wn * 128;
+  const Drop dr = make_drop(a.drop);
+  const int cc = l & 15;
+  float ag[8], ab[8], axs[8];           // column sums over all the wave's row blocks
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ag[e] = ab[e] = axs[e] = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {     // one 32-row block at a time through the wave's two patches
+  f32x16 (&acc)[4] = accs[mb];
+  float* red = red_all + mb * 2 * G::WM * G::WN * 32;
+  const int i_base = i_base0 + mb * 32;
+  if (mb > 0) {
+    if (a.aux) load_aux(mb);
+    load_xhat(mb);
+  }
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int id = p * 64 + l, rr = id >> 4, c = id & 15;
@@ -233,9 +261,6 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
 
   // ---- pass 1 (row per lane): dy = bf16(acc + aux); row sums of g = dy*gamma and g*xhat; dy back into the patch
   const int i = i_base + r;
-  const bool row_ok = i < a.M;
-  const float* gm = a.gamma + wn * 128;
-  const Drop dr = make_drop(a.drop);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -283,10 +308,6 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
 
   // ---- column sums of dy and dy*xhat in the coalesced layout: thread = 8 columns (chunk lane & 15), 8 of the 32 rows
   const int nvalid = min(32, a.M - i_base);
-  const int cc = l & 15;
-  float ag[8], ab[8], axs[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ag[e] = ab[e] = axs[e] = 0.f;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int rr = (p * 64 + l) >> 4;
@@ -336,6 +357,9 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
       for (int e = 0; e < 8; ++e) axs[e] += (float)dxv[e];
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the next row block rewrites the patches)
+  __builtin_amdgcn_sched_barrier(0);
+  }   // mb
   // ---- reduce the column sums: lanes l, l^16, l^32 share a chunk; then the WM waves of a column block through LDS
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -360,7 +384,6 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
     if (a.dbeta) atomicAdd(a.dbeta + c, t1);
     if (a.dbias) atomicAdd(a.dbias + c, t2);
   }
-  (void)row_ok;
 }
 
 }  // namespace
@@ -388,10 +411,17 @@ extern "C" int st_gemm_lnbwd(hipStream_t stream, const void* dY, int lddy, const
     ST_CHECK_LAUNCH();
     return 0;
   }
-  if (N == 512 && M > 64 * 128) {      // (round 3) d_model 512, encoder-sized M: 64-row tiles on 8 waves, as in st_gemm_ln.hip
-    const dim3 grid((M + 63) / 64);
-    if (drop) hipLaunchKernelGGL((gemm_lnbwd_kernel<512, true, true>), grid, dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((gemm_lnbwd_kernel<512, false, true>), grid, dim3(512), 0, stream, a);
+  if (N == 512 && M > 64 * 128) {      // (round 3) d_model 512, encoder-sized M: 8 waves, as in st_gemm_ln.hip
+    static const bool mb1 = getenv("ST_GEMM_LN_MB1") != nullptr;      // development: the 64-row tiles everywhere
+    if (mb1 || Kc < 1024) {            // 64-row tiles
+      const dim3 grid((M + 63) / 64);
+      if (drop) hipLaunchKernelGGL((gemm_lnbwd_kernel<512, true, true>), grid, dim3(512), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_lnbwd_kernel<512, false, true>), grid, dim3(512), 0, stream, a);
+    } else {                           // 128-row tiles: two row blocks per wave
+      const dim3 grid((M + 127) / 128);
+      if (drop) hipLaunchKernelGGL((gemm_lnbwd_kernel<512, true, true, 2>), grid, dim3(512), 0, stream, a);
+      else hipLaunchKernelGGL((gemm_lnbwd_kernel<512, false, true, 2>), grid, dim3(512), 0, stream, a);
+    }
     ST_CHECK_LAUNCH();
     return 0;
   }

@@ -93,6 +93,25 @@ if "gemm" in which:
         dx, acc = torch.empty(m, d, dtype=BF16, device=dev), [torch.zeros(d, dtype=F32, device=dev) for _ in range(3)]
         us = timeit(lambda: nv.gemm_lnbwd(dY, W, aux, xh, rstd, gm, dx, acc[0], acc[1], acc[2]))
         report("gemm_lnbwd %-10s [%d,%d]" % (tag, m, k), us, 2.0 * m * d * k, 2.0 * (m * k + 3 * m * d))
+    # config 3 (d_model 512, d_ff 2048): the LayerNorm-fused GEMMs it runs instead of row chains
+    d5 = 512
+    for (m, k, tag) in [(M, 512, "wo"), (M, 2048, "ffn2")]:
+        X, W = rnd(m, k), rnd(d5, k)
+        b, gm, bt = rnd(d5, dtype=F32), rnd(d5, dtype=F32), rnd(d5, dtype=F32)
+        res, out, xh = rnd(m, d5), torch.empty(m, d5, dtype=BF16, device=dev), torch.empty(m, d5, dtype=BF16, device=dev)
+        rstd = torch.empty(m, dtype=F32, device=dev)
+        us = timeit(lambda: nv.gemm_ln(X, W, b, res, gm, bt, out, xh, rstd))
+        report("gemm_ln d512 %-6s [%d,%d]" % (tag, m, k), us, 2.0 * m * d5 * k, 2.0 * (m * k + 3 * m * d5))
+    for (m, k, tag) in [(M, 2048, "dh*W1"), (M, 1536, "dqkv*Wqkv")]:
+        dY, W, aux, xh = rnd(m, k), rnd(k, d5), rnd(m, d5), rnd(m, d5)
+        rstd, gm = rnd(m, dtype=F32).abs() + 0.5, rnd(d5, dtype=F32)
+        dx, acc = torch.empty(m, d5, dtype=BF16, device=dev), [torch.zeros(d5, dtype=F32, device=dev) for _ in range(3)]
+        us = timeit(lambda: nv.gemm_lnbwd(dY, W, aux, xh, rstd, gm, dx, acc[0], acc[1], acc[2]))
+        report("gemm_lnbwd d512 %-10s [%d,%d]" % (tag, m, k), us, 2.0 * m * d5 * k, 2.0 * (m * k + 3 * m * d5))
+    for (m, n, k, tag) in [(M, 2048, 512, "h=x*W1^T"), (M, 1536, 512, "qkv"), (M, 512, 2048, "y=h*W2^T (no LN)")]:
+        X, W, out = rnd(m, k), rnd(n, k), torch.empty(m, n, dtype=BF16, device=dev)
+        us = timeit(lambda: nv.gemm(X, W, out, bias=rnd(n, dtype=F32)))
+        report("gemm d512 %-18s [%d,%d]x[%d,%d]" % (tag, m, k, n, k), us, 2.0 * m * n * k, 2.0 * (m * k + n * k + m * n))
     # the encoder's weight gradients as the step issues them: 6 layers x (qkv, wo, w1, w2) in ONE grouped launch
     from st_amd.functional import _Deferred
     probs, fl = [], 0.0
