@@ -831,9 +831,19 @@ def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None, i
            "st_ce_bwd")
 
 
+_NORM_BLOCKS = None
+
+
+def _norm_blocks() -> int:
+    global _NORM_BLOCKS
+    if _NORM_BLOCKS is None:      # (a host-side query: asked once, through the untimed handle)
+        _NORM_BLOCKS = int(load()._cdll.st_grad_norm_blocks())
+    return _NORM_BLOCKS
+
+
 def grad_norm_scratch(device):
     """Zeroed scratch of st_grad_norm (block partials + the ticket): allocate once per gradient buffer."""
-    return torch.zeros(int(load().st_grad_norm_blocks()) + 1, dtype=F32, device=device)
+    return torch.zeros(_norm_blocks() + 1, dtype=F32, device=device)
 
 
 def grad_norm(g, scratch, out, step=None):
@@ -841,7 +851,7 @@ def grad_norm(g, scratch, out, step=None):
     st_grad_norm."""
     if not (g.is_cuda and g.dtype == F32 and g.is_contiguous() and g.numel() % 4 == 0):
         raise ValueError("grad_norm: g must be a contiguous fp32 GPU buffer of a multiple of 4 elements")
-    _vec(scratch, F32, int(load().st_grad_norm_blocks()) + 1, "scratch")
+    _vec(scratch, F32, _norm_blocks() + 1, "scratch")
     for t, nm in ((out, "out"), (step, "step")):
         if t is not None and not (t.is_cuda and t.dtype == F32 and t.numel() == 1):
             raise ValueError("grad_norm: %s must be an fp32 scalar on the GPU" % nm)
