@@ -1,4 +1,4 @@
-"""Dev: per-workgroup timeline of the long attention forward (st_attn64.hip, DEV trace hook): item durations, prologue /
+"""Dev: per-workgroup timeline of the long attention forward (needs st_dev_fwd64_trace: a temporary stamp hook in attn_fwd64_kernel (not in the tree; see DESIGN.md section 4, "Round 3, where the time of a launch goes" for what it measured)): item durations, prologue /
 loop / epilogue split, concurrency per CU over time."""
 import ctypes, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
