@@ -28,7 +28,7 @@ import transformer.Constants as Constants
 from st_amd import functional as F_
 from st_amd import native as nv
 from st_amd.arena import arena_of
-from transformer.Beam import Beam
+from transformer.Beam import Beam  # noqa: F401  (re-exported: the reference's Decode module exposes it)
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 LN_EPS = 1e-6
@@ -49,6 +49,7 @@ class Decode(object):
         ug = getattr(opt, "use_graph", None)
         self.use_graph = torch.device(device).type == "cuda" if ug is None else bool(ug)
         self._side = None
+        self._warm = False        # a step has run eagerly on this object: later calls capture before their step 0
 
     # ---- one decoder step for all n = B * beam hypotheses; everything that changes from step to step is DEVICE state ---
     @torch.no_grad()
@@ -198,13 +199,17 @@ class Decode(object):
                 self._advance(st, self._step(st))
 
             graph, steps_done = None, 0
+            # the first call on this object runs step 0 eagerly (kernel modules loaded, allocator warm) and captures at step
+            # 1; later calls capture before step 0 - the host records the step while the GPU is still busy with the encoder
+            capture_at = 0 if self._warm else 1
             while steps_done < S:
-                if self.use_graph and steps_done == 1:
-                    # step 0 ran eagerly (kernel modules loaded, allocator warm); every later step is a replay of ONE
-                    # captured step: the position, the cache length, the tokens and the beams are device state
+                if self.use_graph and steps_done == capture_at and graph is None:
+                    # every later step is a replay of ONE captured step: the position, the cache length, the tokens and the
+                    # beams are device state
                     # (captured by hand, on decode_batch's side stream: `with torch.cuda.graph(...)` also runs gc.collect() and
                     # torch.cuda.empty_cache() - 4 ms of every decode_batch call, a tenth of a 32-utterance batch)
-                    torch.cuda.current_stream().synchronize()      # (as torch.cuda.graph does before a capture)
+                    if not self._warm:
+                        torch.cuda.current_stream().synchronize()      # (as torch.cuda.graph does before a capture)
                     graph = torch.cuda.CUDAGraph()
                     graph.capture_begin(**(dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}))
                     try:
@@ -220,6 +225,7 @@ class Decode(object):
                         graph = None
                         raise
                     graph.capture_end()
+                    self._warm = True
                 if graph is not None:
                     graph.replay()
                 else:
@@ -229,27 +235,27 @@ class Decode(object):
                 if (steps_done % 8 == 0 or not self.use_graph) and bool(st.done.all()):
                     break
 
-        # ---- per-utterance Beam objects (the reference's read-out API) from the device trellis -------------------------
-        # (the trellis crosses to the host ONCE; the Beam objects are built from the host copy - per utterance the read-out
-        # was a sort, two stacks and three .tolist() synchronisations on the device: 3 ms per 32-utterance batch)
-        lengths, done = st.lengths.tolist(), st.done.tolist()
-        back_h, toks_h, hist_h, scores_h = st.back.cpu(), st.toks.cpu(), st.hist_scores.cpu(), st.scores.cpu()
+        # ---- read-out (Beam.sort_scores / Beam.get_hypothesis, Beam.py:76-116) from the device trellis ------------------
+        # The trellis crosses to the host ONCE and is walked as plain lists: per utterance the scores are sorted as
+        # Beam.sort_scores does and each of the n_best slots is followed back through the back-pointers.  (Building a Beam
+        # object per utterance - three lists of per-step tensor views, a stack + tolist per hypothesis - was 3.0 of the
+        # 28.6 ms of a 32-utterance call; before that the read-out ran on the device: a sort, two stacks and three
+        # synchronising .tolist() per utterance.)
+        lengths = st.lengths.tolist()
+        back_h, toks_h, scores_h = st.back.cpu().tolist(), st.toks.cpu().tolist(), st.scores.cpu()
         all_hyp, best = [], []
         for b in range(B):
-            bm = Beam(beam, "cpu")
-            t = lengths[b]
-            bm.prev_ks = list(back_h[:t, b].unbind(0))
-            bm.next_ys += list(toks_h[:t, b].unbind(0))
-            bm.all_scores = list(hist_h[:t, b].unbind(0))
-            if t:
-                bm.all_scores[0] = torch.zeros(beam, dtype=F32)                  # Beam.py:24: the initial scores are zeros
-            bm.scores = scores_h[b]
-            bm.done = done[b]
-            if bm.done:
-                bm.all_scores.append(bm.scores)
-            scores, tail_idxs = bm.sort_scores()
+            scores, slots = torch.sort(scores_h[b], 0, True)
             best.append(scores[:n_best])
-            all_hyp += [[bm.get_hypothesis(i) for i in tail_idxs[:n_best].tolist()]]
+            hyps = []
+            for slot in slots[:n_best].tolist():
+                out = []
+                for step in range(lengths[b] - 1, -1, -1):
+                    out.append(toks_h[step][b][slot])
+                    slot = back_h[step][b][slot]
+                out.reverse()
+                hyps.append(out)
+            all_hyp.append(hyps)
         all_scores = list(torch.stack(best).to(dev).unbind(0)) if best else []
         self.beams = None
         return all_hyp, all_scores
