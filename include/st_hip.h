@@ -301,6 +301,12 @@ int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);
 int st_adam_clip(st_stream_t stream, long long n, float* p, float* g, float* m, float* v, const float* lr,
                  const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps);
 
+/* Zero the unassigned tail rows of a list of row matrices in one launch (packed bucket layouts: the rows behind the
+ * batch's last utterance belong to nobody; the kernels never write them, so they must read as zeros).  table (device,
+ * int64 [n_max][4]): base address, bytes per row (% 16 == 0), capacity in rows, address of a device int32 holding the
+ * number of valid rows; entries with a null base address are skipped. */
+int st_zero_tails(st_stream_t stream, const long long* table, int n_max);
+
 /* total_norm of clip_grad_norm_ (train.py:45) over the flat fp32 gradient buffer g [n] (n % 4 == 0) as one launch:
  * *gnorm = ||g||_2 (partials added in a fixed order, fp64), and - when step is not NULL - *step += 1, the optimiser's
  * step count st_adam_clip then reads.  scratch: st_grad_norm_blocks() + 1 floats owned by the caller, the last one

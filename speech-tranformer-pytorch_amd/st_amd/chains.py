@@ -306,7 +306,7 @@ class EncoderChains:
     def forward(self, layers, x, rows, need_bwd: bool):
         """The encoder's layer stack on frame rows x [M, 256] (front-end output): per layer self-attention, then the chain.
         -> (output rows, [(self-attention, feed-forward) SubPre per layer]); nothing here is recorded by autograd."""
-        from .functional import attn_work, linear_fwd
+        from .functional import attn_work, linear_fwd, rows_buffer
         M, d = x.shape
         dev = x.device
 
@@ -314,7 +314,7 @@ class EncoderChains:
             return torch.empty(*shape, dtype=dt, device=dev)
 
         def EZ(m, n, layout):      # attention outputs: rows past a length are never written - zeros on padded layouts
-            return (torch.empty if layout.dense else torch.zeros)(m, n, dtype=BF16, device=dev)
+            return rows_buffer(m, n, layout, dev)
 
         s0 = layers[0].slf_attn._st
         H = s0.n_head
@@ -402,7 +402,7 @@ class DecoderChains:
         (every layer's K | V projection of the encoder output): per layer  causal self-attention, chain F1,
         encoder-decoder attention, chain F2.  -> (output rows, [(self-attention, encoder-decoder attention, feed-forward)
         SubPre per layer]) - nothing here is recorded by autograd; the caller replays the Functions over the SubPre's."""
-        from .functional import attn_work
+        from .functional import attn_work, rows_buffer
         M, d = x.shape
         dev = x.device
 
@@ -410,7 +410,7 @@ class DecoderChains:
             return torch.empty(*shape, dtype=dt, device=dev)
 
         def EZ(m, n, layout):      # attention outputs: rows past a length are never written - zeros on padded layouts
-            return (torch.empty if layout.dense else torch.zeros)(m, n, dtype=BF16, device=dev)
+            return rows_buffer(m, n, layout, dev)
 
         s0 = layers[0].slf_attn._st
         H = s0.n_head

@@ -39,7 +39,7 @@ class Rows:
     loader revisits the same bucket shapes, bench.py the same batch) and the model builds
     every layout it needs BEFORE launching the first kernel of a step."""
 
-    __slots__ = ("B", "off", "len", "max_len", "total", "_pos", "lens_host", "dense", "_scatter", "_work")
+    __slots__ = ("B", "off", "len", "max_len", "total", "_pos", "lens_host", "dense", "_scatter", "_work", "_seq", "valid_rows")
 
     def __init__(self, off, length, max_len, total, lens_host=None, dense=True):
         self.dense = dense  # every row of the matrix belongs to some utterance (no padding rows)
@@ -49,6 +49,8 @@ class Rows:
         self._pos = None
         self._scatter = None
         self._work = {}
+        self._seq = None      # (packed bucket layouts) row -> utterance, -1 on the unassigned tail rows
+        self.valid_rows = None   # (packed bucket layouts) device int32: rows owned by the current batch's utterances
         self.lens_host = lens_host
 
     @staticmethod
@@ -93,24 +95,85 @@ class Rows:
         return Rows(off, ln, T, B * T, host, dense=lengths is None)
 
     @staticmethod
-    def bucket(B: int, T: int, device) -> "Rows":
-        """Padded layout whose LENGTHS live only on the device (``set_lengths`` refreshes them in place): the layout of a
+    def bucket(B: int, T: int, device, rows: Optional[int] = None) -> "Rows":
+        """Layout whose LENGTHS live only on the device (``set_lengths`` refreshes them in place): the layout of a
         captured step that serves every batch of a (B, T) bucket - nothing the kernels are launched with depends on the
-        lengths (grids and work lists cover all B x T rows; the kernels skip what lies past a length)."""
-        off = torch.arange(B, dtype=I32, device=device) * T
-        r = Rows(off, torch.full((B,), T, dtype=I32, device=device), T, B * T, None, dense=False)
+        lengths (grids and work lists cover every tile an utterance of T rows could have; the kernels skip what lies past a
+        length).  rows = None: padded, utterance b owns rows b*T ... (B x T rows).  rows = R: PACKED into R rows - the
+        offsets live on the device too, utterance b starts where b - 1 ends, and the rows past the batch's total belong to
+        nobody (they carry zero inputs and zero gradients, like the padding rows of the padded form): a step then costs
+        what R rows cost, not B x T."""
+        if rows is None:
+            off = torch.arange(B, dtype=I32, device=device) * T
+            r = Rows(off, torch.full((B,), T, dtype=I32, device=device), T, B * T, None, dense=False)
+        else:
+            if rows < T or rows > B * T:
+                raise ValueError("Rows.bucket: a packed capacity of %d rows does not suit %d utterances of up to %d" % (rows, B, T))
+            r = Rows(torch.zeros(B, dtype=I32, device=device), torch.zeros(B, dtype=I32, device=device), T, int(rows), None,
+                     dense=False)
+            r._seq = torch.full((int(rows),), -1, dtype=I32, device=device)
+            r.valid_rows = torch.zeros(1, dtype=I32, device=device)
         r.pos        # the position table exists before the capture; set_lengths rewrites it in place
         return r
 
+    _PIN = {}      # device -> ring of (pinned int32 staging buffer, event of the copy that last read it)
+
+    @staticmethod
+    def _h2d(dst: torch.Tensor, src: torch.Tensor) -> None:
+        """dst (device, int32) <- src (host, any integer dtype), WITHOUT blocking the host: a copy from pageable memory waits
+        for the stream to drain (the host then cannot stage batch k + 1 while the GPU runs batch k), so the values go
+        through a small ring of pinned buffers; a slot is reused only after the copy that read it has run."""
+        if not dst.is_cuda:
+            dst.copy_(src.to(dtype=dst.dtype))
+            return
+        key = str(dst.device)
+        ring = Rows._PIN.setdefault(key, {"slots": [], "next": 0})
+        n = src.numel()
+        if len(ring["slots"]) < 8:
+            ring["slots"].append([torch.empty(max(n, 1024), dtype=I32).pin_memory(), None])
+        i = ring["next"] % len(ring["slots"])
+        ring["next"] += 1
+        slot = ring["slots"][i]
+        if slot[0].numel() < n:
+            slot[0], slot[1] = torch.empty(n, dtype=I32).pin_memory(), None
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:n].copy_(src.reshape(-1))
+        dst.copy_(slot[0][:n].view(dst.shape), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dst.device))
+        slot[1] = ev
+
     def set_lengths(self, lengths: torch.Tensor) -> None:
-        """(bucket layout) new utterance lengths, 1 <= len <= T: device vector and position table rewritten in place."""
+        """(bucket layout) new utterance lengths, 1 <= len <= T: device vectors and position table rewritten in place."""
         if self.lens_host is not None or self.dense:
             raise RuntimeError("Rows.set_lengths: only for Rows.bucket layouts")
         if int(lengths.min()) < 1 or int(lengths.max()) > self.max_len or lengths.numel() != self.B:
             raise ValueError("Rows.set_lengths: lengths must lie in [1, %d] for %d utterances" % (self.max_len, self.B))
-        self.len.copy_(lengths.to(dtype=I32), non_blocking=True)
+        if self._seq is not None:      # packed: the offsets follow the lengths
+            host = lengths.detach().to("cpu", torch.int64)
+            if int(host.sum()) > self.total:
+                raise ValueError("Rows.set_lengths: %d rows do not fit the packed capacity of %d" % (int(host.sum()), self.total))
+            off = torch.zeros_like(host)
+            off[1:] = torch.cumsum(host, 0)[:-1]
+            Rows._h2d(self.off, off)
+            Rows._h2d(self.valid_rows, host.sum().reshape(1))
+            self._seq.fill_(-1)
+        if lengths.is_cuda:
+            self.len.copy_(lengths.to(dtype=I32), non_blocking=True)
+        else:
+            Rows._h2d(self.len, lengths)
         self._pos.zero_()
-        nv.row_index(self.off, self.len, self.max_len, self._pos)
+        nv.row_index(self.off, self.len, self.max_len, self._pos, self._seq)
+        if self._seq is not None and self._scatter is not None:
+            self._fill_scatter()
+
+    def _fill_scatter(self) -> None:
+        """(packed bucket) row r -> position seq[r] * L + pos[r] of the padded [B, L] layout; B * L (one element past it: the
+        caller appends an ignored target there) on the unassigned tail rows."""
+        L, buf = self._scatter[0][1], self._scatter[1]
+        seq = self._seq.long()
+        torch.where(seq >= 0, seq * L + self._pos.long(), torch.full_like(seq, self.B * L), out=buf)
 
     @property
     def is_bucket(self) -> bool:
@@ -118,6 +181,11 @@ class Rows:
 
     def scatter_index(self, L: int) -> torch.Tensor:
         """Row b*L + t of a padded [B, L, *] tensor for every packed row (int64, on device)."""
+        if self.is_bucket and self._seq is not None:
+            if self._scatter is None or self._scatter[0] != ("scatter", L):
+                self._scatter = (("scatter", L), torch.empty(self.total, dtype=torch.int64, device=self.off.device))
+                self._fill_scatter()
+            return self._scatter[1]
         if self.is_bucket:
             if L != self.max_len:
                 raise ValueError("Rows.scatter_index: a bucket layout of %d rows per utterance cannot index a [B, %d] tensor"
@@ -162,8 +230,16 @@ def attn_work(q_rows: Rows, k_rows: Rows, causal: bool, d_k: int = 64, n_head: i
         return hit[1]
     lq = q_rows.lens_host.tolist() if q_rows.lens_host is not None else [q_rows.max_len] * q_rows.B
     lk = k_rows.lens_host.tolist() if k_rows.lens_host is not None else [k_rows.max_len] * k_rows.B
+    dev = q_rows.off.device
+    out = tuple(torch.tensor(flat, dtype=I32).to(dev) for flat in _work_lists(q_rows, k_rows, causal, d_k, n_head, lq, lk))
+    q_rows._work[key] = (k_rows, out)
+    return out
+
+
+def _work_lists(q_rows, k_rows, causal, d_k, n_head, lq, lk, xcd_groups=True):
+    """The three lists of attn_work as Python lists, for the utterance lengths lq / lk."""
     rows = [nv.attn_tile_rows(w, d_k, q_rows.max_len, k_rows.max_len, causal) for w in range(3)]
-    ng = 8 // n_head if n_head in (1, 2, 4, 8) and not os.environ.get("ST_NO_XCD_AFFINITY") else 1
+    ng = 8 // n_head if xcd_groups and n_head in (1, 2, 4, 8) and not os.environ.get("ST_NO_XCD_AFFINITY") else 1
     # deal the utterances into ng groups of equal total cost (longest first onto the lightest group)
     group, load = [0] * q_rows.B, [0.0] * ng
     if ng > 1:
@@ -182,7 +258,6 @@ def attn_work(q_rows: Rows, k_rows: Rows, causal: bool, d_k: int = 64, n_head: i
         for t in range((lk[b] + R - 1) // R):
             q_begin = (t * R // 64) * 64 if causal else 0
             lists[2][group[b]].append(((lq[b] - q_begin + 63) // 64, (b << 16) | t))
-    dev = q_rows.off.device
     out = []
     for per_group in lists:
         for g in per_group:
@@ -192,10 +267,25 @@ def attn_work(q_rows: Rows, k_rows: Rows, causal: bool, d_k: int = 64, n_head: i
         for i in range(n):        # position i * ng + g <- group g's i-th heaviest item (a no-op where the group ran out)
             for g in per_group:
                 flat.append(g[i][1] if i < len(g) else 0xffff)
-        out.append(torch.tensor(flat, dtype=I32).to(dev))
-    out = tuple(out)
-    q_rows._work[key] = (k_rows, out)
+        out.append(flat)
     return out
+
+
+def refresh_attn_work(q_rows: Rows, k_rows: Rows, causal: bool, d_k: int, n_head: int, lq, lk) -> None:
+    """(bucket layouts) the cached work lists of this combination re-ordered for the current batch's lengths lq / lk (host
+    lists) - longest first again, the tiles the batch does not have as no-op entries at the end - and copied over the
+    device vectors in place (their size is fixed: every tile an utterance of max_len rows could have), without blocking the
+    host.  A captured step then dispatches this batch's workgroups in this batch's best order."""
+    hit = q_rows._work.get((id(k_rows), bool(causal), int(d_k), int(n_head)))
+    if hit is None or hit[0] is not k_rows:
+        raise RuntimeError("refresh_attn_work: no cached lists for this combination (call attn_work first)")
+    lists = _work_lists(q_rows, k_rows, causal, d_k, n_head, list(lq), list(lk))
+    if any(len(flat) > dst.numel() for dst, flat in zip(hit[1], lists)):
+        # the XCD groups of this batch are less even than the padding of the fixed-size vectors allows: one plain
+        # longest-first list (never longer than the vectors: they hold every tile of B utterances of max_len rows)
+        lists = _work_lists(q_rows, k_rows, causal, d_k, n_head, list(lq), list(lk), xcd_groups=False)
+    for dst, flat in zip(hit[1], lists):
+        Rows._h2d(dst, torch.tensor(flat + [0xffff] * (dst.numel() - len(flat)), dtype=I32))
 
 
 def _splits(M: int, N: int, K: int) -> int:
@@ -305,6 +395,54 @@ def dgrad(dY, W, out, epi=nv.EPI_BF16, aux=None, kc=None, drop=None):
 
 def _empty(rows, cols, like, dtype=BF16):
     return torch.empty(rows, cols, dtype=dtype, device=like.device)
+
+
+class TailBuffers:
+    """The row matrices of a step whose rows outside every utterance must read as zeros (attention outputs and gradients:
+    the kernels write utterance rows only).  On a dense layout nothing needs zeroing; on a padded one the whole buffer is
+    zero-filled.  On a PACKED bucket layout only the tail behind the batch's last utterance is unassigned, and a captured
+    step can do better than one memset node per buffer: while the step runs eagerly once, ``record`` notes every request;
+    before the capture ``materialize`` allocates them all, persistently and exclusively (a buffer from the graph's pool
+    could alias memory another tensor used earlier in the step, and its tail would then not be zero when it is read);
+    during the capture ``request`` hands them out in the same order, and the captured step begins with ONE
+    ``st_zero_tails`` launch over the whole list."""
+    active = None
+    N_MAX = 256
+
+    def __init__(self):
+        self.mode, self.specs, self.bufs, self.i, self.table, self.missed = "record", [], [], 0, None, 0
+
+    def request(self, m, n, layout, device):
+        if self.mode == "record":
+            self.specs.append((int(m), int(n), layout))
+            return torch.zeros(m, n, dtype=BF16, device=device)
+        if self.i < len(self.bufs) and self.specs[self.i][:2] == (int(m), int(n)) and self.specs[self.i][2] is layout:
+            self.i += 1
+            return self.bufs[self.i - 1]
+        self.missed += 1          # (a request the recorded step did not make: served the plain way)
+        return torch.zeros(m, n, dtype=BF16, device=device)
+
+    def materialize(self, device):
+        self.specs = self.specs[:TailBuffers.N_MAX]
+        self.bufs = [torch.zeros(m, n, dtype=BF16, device=device) for m, n, _ in self.specs]
+        rows = []
+        for buf, (m, n, layout) in zip(self.bufs, self.specs):
+            rows += [buf.data_ptr(), n * buf.element_size(), m, layout.valid_rows.data_ptr()]
+        rows += [0, 0, 0, 0] * (TailBuffers.N_MAX - len(self.bufs))
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.mode, self.i = "serve", 0
+        return self
+
+
+def rows_buffer(m, n, layout, device):
+    """bf16 [m, n] for a kernel that writes utterance rows only: uninitialised on a dense layout, else zero outside the
+    utterances (see TailBuffers)."""
+    if layout.dense:
+        return torch.empty(m, n, dtype=BF16, device=device)
+    tb = TailBuffers.active
+    if tb is not None and layout._seq is not None and n * 2 % 16 == 0:
+        return tb.request(m, n, layout, device)
+    return torch.zeros(m, n, dtype=BF16, device=device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -496,12 +634,12 @@ class MhaFn(torch.autograd.Function):
             Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
         # (rows past a length are never written by the attention kernel: on padded layouts they must still hold finite
         # values - they are operands of the weight-gradient GEMMs, multiplied by exact zeros)
-        attn_ctx = _empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)
+        attn_ctx = rows_buffer(Mq, d, q_rows, x_q.device)
         # what rounding the context to bf16 drops (kept only when a backward follows): delta = rowsum(dO * O) is a
         # difference partner of dP in dS = P (dP - delta); with O to ~16 bits the two stay consistent
         # (every attention takes it: at config 3's depth the late ENCODER layers' keys are nearly identical across
         # positions too, and their q / k gradients come out 5x off without it - tests/test_fullsize_gpu.py)
-        ores = (_empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)) if need_bwd else None
+        ores = rows_buffer(Mq, d, q_rows, x_q.device) if need_bwd else None
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
                     scale, work=attn_work(q_rows, k_rows, causal, d // H, H)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
@@ -542,21 +680,20 @@ class MhaFn(torch.autograd.Function):
         if x_kv is None:
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             # key rows past k_len (padded layout only) get no gradient: they must read as zeros
-            dqkv = _empty(Mq, 3 * d, x_q) if k_rows.dense else torch.zeros(Mq, 3 * d, dtype=BF16, device=x_q.device)
+            dqkv = rows_buffer(Mq, 3 * d, k_rows, x_q.device)
             dQ, dK, dV = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
         else:
             Q, K, V = qkv, kvbuf[:, :d], kvbuf[:, d:]
             # (query rows past a length - padded layouts - get no gradient from the kernel: they must read as zeros)
-            dqkv = _empty(Mq, d, x_q) if q_rows.dense else torch.zeros(Mq, d, dtype=BF16, device=x_q.device)
+            dqkv = rows_buffer(Mq, d, q_rows, x_q.device)
             slot = ctx.kv_acc if isinstance(ctx.kv_acc, CrossKvSlot) else None
             if slot is not None:
                 st = slot.state
                 if st.dkv is None:
-                    st.dkv = _empty(*x_kv.shape, x_q) if k_rows.dense else torch.zeros_like(x_kv)
+                    st.dkv = rows_buffer(x_kv.shape[0], x_kv.shape[1], k_rows, x_q.device)
                 dkv = st.dkv[:, slot.idx * 2 * d:(slot.idx + 1) * 2 * d]
             else:
-                dkv = _empty(x_kv.shape[0], 2 * d, x_q) if k_rows.dense else \
-                    torch.zeros(x_kv.shape[0], 2 * d, dtype=BF16, device=x_q.device)
+                dkv = rows_buffer(x_kv.shape[0], 2 * d, k_rows, x_q.device)
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
         _, work_q, work_k = attn_work(q_rows, k_rows, ctx.causal, d // H, H)
         nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
@@ -707,7 +844,7 @@ class EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, mod, tokens, rows: Rows):
         s = mod._st
-        out = (torch.empty if rows.dense else torch.zeros)(rows.total, s.d_model, dtype=BF16, device=tokens.device)
+        out = rows_buffer(rows.total, s.d_model, rows, tokens.device)
         nv.embed_pe_fwd(tokens, s.emb, s.pe, rows.off, rows.len, out)
         ctx.mod, ctx.rows = mod, rows
         ctx.save_for_backward(tokens)
@@ -821,7 +958,7 @@ class PackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rows: Rows):
         # (a packed layout has no row outside an utterance: nothing to zero)
-        out = (torch.empty if rows.dense else torch.zeros)(rows.total, x.shape[2], dtype=BF16, device=x.device)
+        out = rows_buffer(rows.total, x.shape[2], rows, x.device)
         nv.pack_rows(x.contiguous(), rows.off, rows.len, out)
         ctx.rows, ctx.shape = rows, x.shape
         return out

@@ -85,6 +85,7 @@ SIGNATURES = {
     "st_ce_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_ce_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                   _c_void_p, _c_int],
+    "st_zero_tails": [_c_void_p, _c_void_p, _c_int],
     "st_grad_norm_blocks": [],
     "st_grad_norm": [_c_void_p, _c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p],
     "st_cache_reorder": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int],
@@ -829,6 +830,15 @@ def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None, i
     _check(load().st_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), R, V, target.data_ptr(), _p(index), int(ignore_index),
                             lse.data_ptr(), sums.data_ptr(), grad_out.data_ptr(), dlogits.data_ptr(), dlogits.stride(0)),
            "st_ce_bwd")
+
+
+def zero_tails(table, n_max):
+    """table: int64 device tensor [n_max * 4] of (address, bytes per row, capacity rows, address of the valid-row count) - see
+    st_zero_tails."""
+    if not (table.is_cuda and table.dtype == I64 and table.is_contiguous() and table.numel() >= 4 * n_max):
+        raise ValueError("zero_tails: table must be a contiguous int64 GPU tensor of 4 * n_max elements")
+    _tag("zero_tails", n_max)
+    _check(load().st_zero_tails(_stream(), table.data_ptr(), int(n_max)), "st_zero_tails")
 
 
 _NORM_BLOCKS = None

@@ -37,7 +37,8 @@ import torch.nn as nn
 from .arena import arena_of
 from .dp import GradReducer
 from . import rng
-from .functional import deferred_wgrads
+from . import native as nv
+from .functional import TailBuffers, deferred_wgrads
 
 
 def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
@@ -52,7 +53,7 @@ def clip_grad_norm_flat(arena, max_norm: float) -> torch.Tensor:
 class TrainStep:
     def __init__(self, model: nn.Module, optimizer, vocab_size: int, max_grad_norm: float,
                  reducer: Optional[GradReducer] = None, use_graph: bool = False, graph_warmup: int = 2,
-                 max_graphs: int = 4, bucket=None, dp_in_graph: bool = True):
+                 max_graphs: int = 4, bucket=None, dp_in_graph: bool = True, bucket_rows=None):
         self.model, self.optimizer = model, optimizer
         self.vocab_size, self.max_grad_norm = vocab_size, max_grad_norm
         self.crit = nn.CrossEntropyLoss(ignore_index=0)          # train.py:120
@@ -70,6 +71,14 @@ class TrainStep:
         # a loader whose batches never repeat a length signature still replays a graph.  Costs the padding rows
         # (B * T_cap instead of sum(len) rows through the row-wise kernels): for length-bucketed loaders.
         self.bucket = None if bucket is None else (int(bucket[0]), int(bucket[1]))
+        # bucket_rows = (input rows, target rows): the bucket's layouts are PACKED into that many rows (Rows.bucket(rows=...)) -
+        # offsets on the device as well - so the captured step runs over about the batch's real row count instead of
+        # B * T_cap.  A batch with more rows than the capacity takes the padded bucket (a second capture).  Pick the
+        # capacities from the loader's length statistics AND the kernels' tile rounds: the encoder-sized row chains run one
+        # 96-row workgroup per CU, so 256 x 96 = 24,576 rows are one round and 24,577 are two.
+        self.bucket_rows = None if bucket_rows is None else (int(bucket_rows[0]), int(bucket_rows[1]))
+        if self.bucket_rows is not None and self.bucket is None:
+            raise ValueError("TrainStep: bucket_rows needs bucket=(T_cap, L_cap)")
         self._buckets = {}
         self._graphs = collections.OrderedDict()      # signature -> captured step (LRU)
         self._seen = collections.OrderedDict()        # signature -> eager sightings before the capture
@@ -85,7 +94,21 @@ class TrainStep:
         torch.autograd.backward(loss, grad_tensors=self._seed)
 
     # ---- the two halves of a step -------------------------------------------------------------
+    @staticmethod
+    def _zero_tails():
+        """First launch of a captured packed-bucket step: the unassigned tail rows of every registered buffer (one launch)."""
+        tb = TailBuffers.active
+        if tb is not None and tb.mode == "serve" and tb.bufs:
+            nv.zero_tails(tb.table, TailBuffers.N_MAX)
+
+    def _single_graph(self) -> bool:
+        """The whole step is captured as ONE graph (no data-parallel split into several captures that share a memory pool)."""
+        split = self.reducer is not None and self.reducer.active and hasattr(self.model, "forward_packed") \
+            and hasattr(self.model, "encoder")
+        return not split or self.dp_in_graph
+
     def _forward_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, captured=False, layouts=None):
+        self._zero_tails()
         self.optimizer.zero_grad()
         rng.advance()                          # next step's dropout masks (an in-place device add: capturable)
         if layouts is not None:
@@ -112,6 +135,7 @@ class TrainStep:
     def _forward_decoder_backward(self, inputs, input_lengths, targets, target_lengths, ground_truth, layouts=None):
         """zero_grad, forward, loss, and the backward down to the encoder output (weight gradients of the decoder
         flushed).  Leaves (encoder output, its gradient) in ``self._cut`` for :meth:`_encoder_backward`."""
+        self._zero_tails()
         self.optimizer.zero_grad()
         rng.advance()
         loss, t_rows, enc, enc_leaf = self.model.forward_packed(inputs, input_lengths, targets, target_lengths,
@@ -154,8 +178,8 @@ class TrainStep:
 
     def __call__(self, inputs, input_lengths, targets, target_lengths, ground_truth):
         """inputs [B, T, F] / targets, ground_truth [B, L] on the GPU; lengths on host or GPU."""
-        self.global_step += 1
         t_max, l_max = int(input_lengths.max()), int(target_lengths.max())     # host ints when lengths are CPU tensors
+        self.global_step += 1
         batch = (inputs[:, :t_max], input_lengths, targets[:, :l_max], target_lengths, ground_truth[:, :l_max])
         if self.bucket is not None:
             return self._bucket_call(*batch)
@@ -187,7 +211,9 @@ class TrainStep:
         L = targets.shape[1]
         if T > T_cap or L > L_cap or ground_truth.shape[1] > L_cap:
             raise ValueError("TrainStep(bucket=%r): batch of %d frames / %d tokens does not fit" % (self.bucket, T, L))
-        key = (B, Fd, inputs.dtype, str(inputs.device))
+        packed = self.bucket_rows is not None and int(input_lengths.sum()) <= self.bucket_rows[0] and \
+            int(target_lengths.sum()) <= self.bucket_rows[1]
+        key = (B, Fd, inputs.dtype, str(inputs.device), packed)
         st = self._buckets.get(key)
         if st is None:
             from .functional import Rows
@@ -195,8 +221,12 @@ class TrainStep:
             st = _Bucket()
             st.x = torch.zeros(B, T_cap, Fd, dtype=inputs.dtype, device=dev)
             st.tok = torch.zeros(B, L_cap, dtype=targets.dtype, device=dev)
-            st.gt = torch.zeros(B, L_cap, dtype=ground_truth.dtype, device=dev)
-            st.layouts = (Rows.bucket(B, T_cap, dev), Rows.bucket(B, L_cap, dev))
+            # (one spare element behind the padded ground truth: the target of the rows a packed bucket leaves unassigned;
+            # it stays 0 = ignore_index)
+            st.gt_flat = torch.zeros(B * L_cap + 1, dtype=ground_truth.dtype, device=dev)
+            st.gt = st.gt_flat[:B * L_cap].view(B, L_cap)
+            in_cap, tgt_cap = self.bucket_rows if packed else (None, None)
+            st.layouts = (Rows.bucket(B, T_cap, dev, rows=in_cap), Rows.bucket(B, L_cap, dev, rows=tgt_cap))
             if hasattr(self.model, "prepare_layouts"):          # chain plans, work lists: before any capture
                 from .functional import attn_work
                 self.model.prepare_layouts(torch.full((B,), T_cap), torch.full((B,), L_cap), L_cap, dev)
@@ -214,14 +244,35 @@ class TrainStep:
         st.gt[:, :ground_truth.shape[1]].copy_(ground_truth, non_blocking=True)
         st.layouts[0].set_lengths(input_lengths)
         st.layouts[1].set_lengths(target_lengths)
-        batch = (st.x, input_lengths, st.tok, target_lengths, st.gt)
+        if hasattr(self.model, "prepare_layouts"):
+            # the encoder self-attention's work lists follow the batch (longest utterance first); the decoder's attentions
+            # are a handful of short workgroups either way
+            from .functional import refresh_attn_work
+            ir = st.layouts[0]
+            refresh_attn_work(ir, ir, False, getattr(self.model, "_d_k", 64), getattr(self.model, "_n_head", 0),
+                              input_lengths.tolist(), input_lengths.tolist())
+        batch = (st.x, input_lengths, st.tok, target_lengths, st.gt_flat if packed else st.gt)
         if not self.use_graph:
             return self._eager(batch, layouts=st.layouts)
         if st.cap is None:
             st.seen += 1
             if st.seen <= self.graph_warmup:
+                if packed and st.seen == self.graph_warmup:
+                    # the last eager step notes the buffers whose unassigned tail rows must read as zeros: the capture
+                    # serves them from persistent memory and zeroes all tails with one launch (functional.TailBuffers)
+                    st.tails = TailBuffers()
+                    TailBuffers.active = st.tails
+                    try:
+                        return self._eager(batch, layouts=st.layouts)
+                    finally:
+                        TailBuffers.active = None
                 return self._eager(batch, layouts=st.layouts)
-            st.cap = self._capture(batch, layouts=st.layouts)
+            if packed and st.tails is not None and self._single_graph():
+                TailBuffers.active = st.tails.materialize(inputs.device)
+            try:
+                st.cap = self._capture(batch, layouts=st.layouts)
+            finally:
+                TailBuffers.active = None
         return self._replay(st.cap)
 
     def _replay(self, cap):
@@ -311,10 +362,10 @@ class TrainStep:
 
 class _Bucket:
     """Bucket mode: static staging buffers, device-length layouts and the captured step of one (B, feature) shape."""
-    __slots__ = ("x", "tok", "gt", "layouts", "cap", "seen")
+    __slots__ = ("x", "tok", "gt", "gt_flat", "layouts", "cap", "seen", "tails")
 
     def __init__(self):
-        self.x = self.tok = self.gt = self.layouts = self.cap = None
+        self.x = self.tok = self.gt = self.gt_flat = self.layouts = self.cap = self.tails = None
         self.seen = 0
 
 

@@ -288,8 +288,11 @@ class Transformer(nn.Module):
                 # ce_truth [B, L] int64 (the padded ground truth of train.py:40): the first return value is the token-mean
                 # cross-entropy (train.py:40,120) instead of the logits - projection + loss as one autograd node
                 # (the ragged rows read their ground-truth entries through their padded positions: no gather launch)
+                # (a 1-D ce_truth is the padded [B, L] ground truth flattened, L = the target layout's rows per utterance,
+                # with spare elements behind it for rows that belong to no utterance: trainer.TrainStep's packed buckets)
+                L_gt = ce_truth.shape[1] if ce_truth.dim() == 2 else t_rows.max_len
                 logits = F_.VocabCeFn.apply(dec, self.tgt_word_proj.weight, self, ce_truth.contiguous().view(-1), ignore_index,
-                                            t_rows.scatter_index(ce_truth.shape[1]))
+                                            t_rows.scatter_index(L_gt))
             else:
                 logits = F_.VocabFn.apply(dec, self.tgt_word_proj.weight, self, padded_logits)   # [sum(tgt_len), v_pad]
         if not padded_logits and ce_truth is None:

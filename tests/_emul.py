@@ -482,6 +482,10 @@ def ce_bwd(logits, target, ignore_index, lse, sums, grad_out, dlogits, V=None, i
     dlogits[:, :V] = (g * valid * (grad_out.float() / sums[1])).to(BF16)
 
 
+def zero_tails(table, n_max):
+    raise RuntimeError("zero_tails: the emulation never registers tail buffers (functional.TailBuffers serves captures only)")
+
+
 def grad_norm_scratch(device):
     return torch.zeros(1025, dtype=torch.float32, device=device)
 
@@ -505,7 +509,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_bwd", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "decode_self_attn", "embed_step"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 
 @contextlib.contextmanager

@@ -633,10 +633,11 @@ def test_row_chain_step_narrow_heads_composition():
         run_row_chain_step_narrow_heads("cpu")
 
 
-def run_bucket_mode(device, use_graph):
+def run_bucket_mode(device, use_graph, bucket_rows=None):
     """TrainStep(bucket=(T_cap, L_cap)): ONE captured step (padded layouts, lengths on the device) must serve batches whose
     lengths never repeat - six seeded batches through it against the eager packed step on a twin model: loss, clip norm
-    and the weights after every update."""
+    and the weights after every update.  bucket_rows: the same with the bucket's rows PACKED into a fixed capacity (offsets
+    on the device too; the rows behind the batch's total belong to nobody)."""
     import copy
     import transformer.Models as M
     import transformer.Utils as U
@@ -652,10 +653,12 @@ def run_bucket_mode(device, use_graph):
     oa = ScheduledOptim(ma, 256, U.AttrDict(n_warmup_steps=50))
     ob = ScheduledOptim(mb, 256, U.AttrDict(n_warmup_steps=50))
     T_cap, L_cap = 96, 12
-    sa = TrainStep(ma, oa, 30, 5.0, use_graph=use_graph, graph_warmup=1, bucket=(T_cap, L_cap))
+    sa = TrainStep(ma, oa, 30, 5.0, use_graph=use_graph, graph_warmup=1, bucket=(T_cap, L_cap), bucket_rows=bucket_rows)
     sb = TrainStep(mb, ob, 30, 5.0, use_graph=False)
     for i in range(6):
-        b = orc.synthetic_batch(4, T_cap, L_cap, 80, 30, seed=20 + i, t_min=40, l_min=4)
+        # (packed buckets: batch 3 is four full-length utterances - more rows than the capacity: it takes the padded bucket)
+        full = bucket_rows is not None and i == 3
+        b = orc.synthetic_batch(4, T_cap, L_cap, 80, 30, seed=20 + i, t_min=T_cap if full else 40, l_min=L_cap if full else 4)
         T, L = int(b["in_len"].max()), int(b["tgt_len"].max())
         x, tok, gt = b["x"][:, :T].to(device), b["tokens"][:, :L].to(device), b["gt"][:, :L].to(device)
         la, ga = sa(x, b["in_len"], tok, b["tgt_len"], gt)
@@ -669,9 +672,15 @@ def run_bucket_mode(device, use_graph):
         db = torch.cat([p.detach().reshape(-1) for p in mb.parameters()]).double()
         assert float((da - db).norm() / db.norm()) < 2e-3, (i, float((da - db).norm() / db.norm()))
     if use_graph:
-        assert len(sa._buckets) == 1 and next(iter(sa._buckets.values())).cap is not None
+        assert len(sa._buckets) == (1 if bucket_rows is None else 2)
+        assert sum(st.cap is not None for st in sa._buckets.values()) >= 1
 
 
 def test_bucket_mode_composition():
     with emulated_kernels():
         run_bucket_mode("cpu", use_graph=False)
+
+
+def test_packed_bucket_mode_composition():
+    with emulated_kernels():
+        run_bucket_mode("cpu", use_graph=False, bucket_rows=(340, 44))

@@ -633,6 +633,31 @@ def test_adam_clip_matches_torch_clip_and_fused_adam():
     assert float(step) == float(st["step"])
 
 
+def test_zero_tails_zeroes_exactly_the_unassigned_rows():
+    """st_zero_tails: rows [valid, capacity) of every listed matrix become zero, nothing else is touched; the valid-row counts
+    are read from device memory at launch time (a captured launch follows the batch); entries with a null address are
+    skipped."""
+    dev = "cuda"
+    valid_a, valid_b = torch.tensor([37], dtype=I32, device=dev), torch.tensor([0], dtype=I32, device=dev)
+    bufs = [(torch.full((100, 256), 3.0, dtype=BF16, device=dev), valid_a), (torch.full((64, 768), 5.0, dtype=BF16, device=dev), valid_b),
+            (torch.full((100, 8), 7.0, dtype=BF16, device=dev), valid_a)]
+    rows = []
+    for i, (t, v) in enumerate(bufs):
+        if i == 2:
+            rows += [0, 0, 0, 0]                        # an unused slot in the middle of the table
+        rows += [t.data_ptr(), t.shape[1] * 2, t.shape[0], v.data_ptr()]
+    table = torch.tensor(rows + [0] * (4 * 8 - len(rows)), dtype=torch.int64, device=dev)
+    nv.zero_tails(table, 8)
+    for (t, v), fill in zip(bufs, (3.0, 5.0, 7.0)):
+        k = int(v)
+        assert bool((t[:k].float() == fill).all()), "a valid row was touched"
+        assert bool((t[k:].float() == 0).all()), "an unassigned row survived"
+    valid_a.fill_(100)                      # nothing unassigned: untouched
+    bufs[0][0].fill_(2.0)
+    nv.zero_tails(table, 8)
+    assert bool((bufs[0][0].float() == 2.0).all())
+
+
 @pytest.mark.parametrize("n", [4, 1000, 262144 + 8, 13_000_004])
 def test_grad_norm_matches_torch_and_advances_the_step(n):
     """st_grad_norm == torch.linalg.vector_norm over the flat gradient buffer (fp64 reference), repeated launches on the same
