@@ -15,7 +15,8 @@ ill-conditioned for ANY bf16 implementation (near-uniform attention makes the de
 1e-4 fraction of the gradient norm: differences of nearly equal terms).  The test therefore ALSO runs the oracle under
 ``torch.autocast("cuda", bfloat16)`` - the reference arithmetic with bf16 matmuls, fp32 softmax / LayerNorm / residual
 stream - on the same batch and prints its per-tensor error next to the HIP path's: a tensor passes when it is within
-8e-2 OR within 2x what the bf16 reference itself shows on that tensor; the global and median figures must be within
+8e-2 OR within 1.5x what the bf16 reference itself shows on that tensor (round 3: was 2x; the worst ratio among the
+tensors above 8e-2 is 1.39, profiles/r03_parity_c2_b32.txt); the global and median figures must be within
 3e-2 / 4e-2 OR 1.5x the bf16 reference's.  The table is written to ``gpurun_out/parity_<config>.txt`` (and shown
 when an assertion fails); a copy per round lives under ``profiles/``.
 """
@@ -144,8 +145,8 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
     assert abs(loss - truth["loss"].item()) < 2e-2 * truth["loss"].item(), head
     assert abs(gnorm - truth["grad_norm"].item()) < 2e-2 * truth["grad_norm"].item(), head
     assert glob < max(GRAD_TOL_GLOBAL, 1.5 * floor_glob) and med < max(GRAD_TOL_MEDIAN, 1.5 * floor_med), head
-    bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 2.0 * r[1])]
-    assert not bad, "\n".join([head, "outside max(8e-2, 2 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
+    bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 1.5 * r[1])]
+    assert not bad, "\n".join([head, "outside max(8e-2, 1.5 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
     for g, q, n in kbias:
         assert g < 2.5e-1 * q + 1e-6, (n, g, q)
     assert dev_sum / n_el < 0.08, head          # a sign flip of an Adam first-step update costs 2
@@ -296,12 +297,13 @@ def test_config2_training_mode_full_size_vs_fp64_oracle():
     with open(os.path.join(ROOT, "gpurun_out", "parity_c2_b32_train.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     head = "\n".join(lines[:12])
-    # training-mode tolerances: twice the eval-mode ones (dropout thins every reduction), or the bf16 reference's own error
+    # training-mode tolerances: logits / global / median twice the eval-mode ones (dropout thins every reduction) or 1.5x the
+    # bf16 reference's own error; per tensor 1e-1 or 1.5x the bf16 reference's
     assert logit_rel < 2 * LOGIT_TOL, head
     assert abs(loss.item() - truth["loss"].item()) < 2e-2 * truth["loss"].item(), head
     assert glob < max(2 * GRAD_TOL_GLOBAL, 1.5 * floor_glob) and med < max(2 * GRAD_TOL_MEDIAN, 1.5 * fl[len(fl) // 2]), head
-    bad = [r for r in rows if r[0] > max(2 * GRAD_TOL_TENSOR, 2.0 * r[1])]
-    assert not bad, "\n".join([head, "outside max(1.6e-1, 2 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
+    bad = [r for r in rows if r[0] > max(1.25 * GRAD_TOL_TENSOR, 1.5 * r[1])]      # (measured worst: 7.6e-2 vs 9.5e-2 for the bf16 reference)
+    assert not bad, "\n".join([head, "outside max(1e-1, 1.5 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
 
 
 def test_config4_joint_ctc_attention_at_stated_shape_vs_fp64_oracle():
@@ -371,7 +373,7 @@ def test_config4_joint_ctc_attention_at_stated_shape_vs_fp64_oracle():
              "per-tensor rel-L2 (worst first):   HIP path | reference-in-bf16 | tensor"] + ["  %.3e  %.3e  %s" % r for r in rows]
     with open(os.path.join(ROOT, "gpurun_out", "parity_c4_b8.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
-    bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 2.0 * r[1])]
+    bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 1.5 * r[1])]
     assert not bad, "\n".join(lines[:2] + ["  %.3e  %.3e  %s" % r for r in bad])
     med = sorted(r[0] for r in rows)[len(rows) // 2]
     assert med < max(GRAD_TOL_MEDIAN, 1.5 * sorted(r[1] for r in rows)[len(rows) // 2]), med
