@@ -23,6 +23,7 @@
 // sublayer alone 25.5 us as two launches -> 15.9 us, bound by one CU's 64 B/clk vector-memory path (1 MB of weights
 // per workgroup).
 #include "st_common.cuh"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -705,7 +706,22 @@ extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_
 
 namespace {
 // row tiles per workgroup: the smallest of 1, 2, 3 that gives at most one round of workgroups (256 CUs)
-int row_tiles(int M) { return (M + 31) / 32 <= 256 ? 1 : (M + 63) / 64 <= 256 ? 2 : 3; }
+// row tiles of 32 per workgroup (1, 2 or 3): the choice that needs the least time for M rows at one workgroup per CU -
+// rounds of 256 workgroups x the time a workgroup of that height takes (forward chain, measured: 27 / 41 / 59 us; the
+// backward's ratios are the same).  One round of the tallest tile that fits wins (24,060 rows: 251 x 96), but just past a
+// full round the shorter tile's two rounds beat the taller one's (26,880 rows: 94.5 us with 96-row tiles, 75.1 with 64-row
+// ones; 32,000: 97.2 vs 84.2).
+int row_tiles(int M) {
+  static const int force = [] { const char* e = getenv("ST_CHAIN_MT"); return e ? atoi(e) : 0; }();      // development switch
+  if (force >= 1 && force <= 3) return force;
+  const int cost[4] = {0, 27, 41, 59};
+  int best = 1, best_cost = 1 << 30;
+  for (int mt = 1; mt <= 3; ++mt) {
+    const int tiles = (M + 32 * mt - 1) / (32 * mt), c = ((tiles + 255) / 256) * cost[mt];
+    if (c < best_cost) { best = mt; best_cost = c; }
+  }
+  return best;
+}
 }  // namespace
 
 // 64-bit words of the relu_bits buffer st_row_chain writes and st_row_chain_bwd reads for M rows and this d_ff

@@ -733,7 +733,7 @@ def test_gemm_ws_stacked_weights():
 
 
 # ---- row chains (csrc/st_rowchain.hip) -----------------------------------------------------------------------------
-@pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000])
+@pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["pre+post1", "pre+ffn+post3", "pre+ffn", "ffn", "ffn+post1", "pre+ffn+post3+drop"])
 def test_row_chain_matches_the_separate_kernels(M, variant):
     """One st_row_chain launch == output_linear + residual + LayerNorm, feed-forward sublayer and the next projection as
@@ -810,7 +810,7 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
         _zero_pattern_equal(got["H"], h, "row_chain dropout1 vs st_gemm")
 
 
-@pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000])
+@pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail",
                                      "head0+ffn+tail+drop"])
 def test_row_chain_bwd_matches_the_separate_kernels(M, variant):

@@ -187,7 +187,7 @@ if "chain" in which:
     cs.finalize().rebuild()
     chf, chb = cs.chain(cf), cs.chain(cb)
     E = lambda *s, dtype=BF16: torch.empty(*s, dtype=dtype, device=dev)
-    for rows in (M, Md):
+    for rows in (M, Md) + tuple(int(r) for r in os.environ.get("ST_CHAIN_ROWS", "").split(",") if r):
         ctx, x = rnd(rows, d_), rnd(rows, d_)
         c_, xc, rc, h_, y_, xy, ry, p_ = E(rows, d_), E(rows, d_), E(rows, dtype=F32), E(rows, dff), E(rows, d_), E(rows, d_), E(rows, dtype=F32), E(rows, 3 * d_)
         us = timeit(lambda: nv.row_chain(ctx, chf, pre=(x, bo, g0, be0, c_, xc, rc), ffn=(dff, b1, b2, g1, be1, h_, y_, xy, ry, None, None),
