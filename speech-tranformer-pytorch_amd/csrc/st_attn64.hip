@@ -18,11 +18,26 @@
 //     stage, one 32-key block live at a time; the K / V tiles are fetched with buffer loads (a descriptor per tile whose
 //     range ends at the utterance's last key: rows past it read as zeros - no clamping, no address arithmetic, no
 //     branches in the loop); only the last tile runs the masking path; the hot tile is 165 instructions for 16 MFMAs.
+//   * (round 3, late) ROW SUMS ON THE MATRIX PIPE and a HAND-LAID hot tile.  The normaliser l = sum_k p(q, k) was 32 adds
+//     per lane and tile (the compiler packs them: 16 v_pk_add_f32); one extra MFMA per P fragment against a fragment of
+//     ones (A = 1: every accumulator row of lane q then holds the row sum of the bf16-rounded P - the very weights the
+//     P V product uses) takes them off the VALU: 4 MFMAs more, 16 packed adds + the cross-half exchange less per tile.
+//     The hot tile (no key masked, plain exponentials, no dropout) is written as ONE straight-line stream: the
+//     exponentials + converts of a 32-key block sit between the matrix instructions of the next contraction (Q K1^T under
+//     exp(S0); P0 V0 + row sums under exp(S1)), groups fenced with sched_barrier(0) so the order in the source is the order
+//     in the binary (168 registers, no spill, still three workgroups per CU).  Same box, A/B: 34.8 -> 34.3 (sums) ->
+//     32.9 us.  What this kernel's time is made of (same-box ablations of this very body, profiles/r03_attn_fwd_ablation.txt):
+//     an empty kernel of the same grid 2.8 us; + prologue / epilogue 7.2; + the last (masked) tile 10.3; the loop with
+//     ONLY its 20 MFMAs per tile (no loads, stores, barrier, LDS reads, VALU) 25.7; with the staging back 29.0; with
+//     everything 33.7.  Replacing every v_exp_f32 by a v_fma_f32, or every LDS read by a broadcast read of one address,
+//     changes nothing (+-0.5 us): no single unit is the limiter - 30 % of the launch is fixed cost per item, and the loop is
+//     the sum of a matrix-pipe part at ~70 % efficiency, a staging part and an issue part of comparable size.
 // Work decomposition as in the general kernel: 4 waves x 32 query rows per (utterance, head, 128-row tile), 64-key
 // tiles through a padded LDS double buffer.  Tried on the same box and NOT kept (tools/dev/st_attn64_variants.hip,
 // DESIGN.md section 5): 64 query rows per wave with one workgroup per CU (44-46 us: nothing hides a single wave's
 // s_waitcnt time), with two (spills at 256 registers: 59 us), a hand-staggered instruction stream pinned with
-// sched_group_barrier (44 us), 128-key stages (54 us), all fragment reads of a tile issued up front (39 us), packed adds
+// sched_group_barrier (44 us; the sched_barrier(0) fences above are what finally held an order), 128-key stages (54 us),
+// all fragment reads of a tile issued up front (39 us), packed adds
 // for the row sums written by hand (38.4 vs 37.8 us), waves without a valid row skipping the tile body (54 us: the
 // early return re-shuffled the compiler's register assignment).
 #include "st_attn_common.cuh"
@@ -37,7 +52,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // one 64-key tile, plain exponentials (EXACT = false) or the classical running-maximum update (EXACT = true)
 template <bool DROP, bool MASK, bool EXACT>
 __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], float& m, float& lsum,
-                                          int kt, int lk, int q, const Drop& dr, int bh) {
+                                          f32x16& lacc, const bf16x8& ones, int kt, int lk, int q, const Drop& dr, int bh) {
+  constexpr bool MSUM = !DROP && !EXACT;   // row sums on the matrix pipe (see the kernel's header)
   constexpr int DK = 64;
   const int l = threadIdx.x & 63, hi = l >> 5;
 #pragma unroll
@@ -67,13 +83,18 @@ __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] -= m_fin;
     }
-    float ps = 0.f;
+    if (MSUM) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = __builtin_amdgcn_exp2f(s[r]);
-      ps += s[r];
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+    } else {
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r]);
+        ps += s[r];
+      }
+      lsum += ps;
     }
-    lsum += ps;
     if (DROP) {   // dropped probabilities leave the normaliser untouched; the 1/(1-p) scale is folded into the final 1/l
       bool keep[16];
       keep16<true>(dr, bh, q, kt + kb * 32, hi, keep);
@@ -86,9 +107,84 @@ __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const 
       const int base = kb * 32 + 16 * hf + 4 * hi;
 #pragma unroll
       for (int d = 0; d < 2; ++d) o[d] = mfma32(rd_tr<DK>(vs, d * 32, base), pf, o[d]);
+      if (MSUM) lacc = mfma32(ones, pf, lacc);
     }
     __builtin_amdgcn_sched_barrier(0);      // one block live at a time: hoisting the next block's reads costs the third workgroup
   }
+}
+
+
+// The hot tile (no key masked, plain exponentials, no dropout) with the instruction stream laid out by hand: the
+// exponentials + converts of one 32-key block sit BETWEEN the matrix instructions of the next contraction (a wave's own
+// VALU work hides under its own MFMAs - up to ~5 issues per 32-clock MFMA; VALU work of another wave of the SIMD does
+// not), every group fenced with sched_barrier(0) so the order below is the order in the binary.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], f32x16& lacc,
+                                               const bf16x8& ones) {
+  constexpr int DK = 64;
+  const int l = threadIdx.x & 63, hi = l >> 5;
+  bf16x8 kf[4];
+  f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) kf[t] = rd_nat<DK>(ks, (l & 31), t);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    s0 = mfma32(kf[t], qf[t], s0);
+    kf[t] = rd_nat<DK>(ks, 32 + (l & 31), t);
+  }
+  SB();
+  // V fragments of key block 0, first half
+  bf16x8 va0 = rd_tr<DK>(vs, 0, 4 * hi), va1 = rd_tr<DK>(vs, 32, 4 * hi);
+  bf16x8 vb0 = rd_tr<DK>(vs, 0, 16 + 4 * hi), vb1 = rd_tr<DK>(vs, 32, 16 + 4 * hi);
+  SB();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {      // S1 = Q K1^T under exp(S0)
+    s1 = mfma32(kf[t], qf[t], s1);
+#pragma unroll
+    for (int r = 4 * t; r < 4 * t + 4; ++r) s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+    SB();
+  }
+  bf16x8 pa = pack_acc8(s0, 0), pb = pack_acc8(s0, 8);
+  SB();
+  // P0 V0 (+ row sums) under exp(S1)
+  o[0] = mfma32(va0, pa, o[0]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  SB();
+  o[1] = mfma32(va1, pa, o[1]);
+#pragma unroll
+  for (int r = 3; r < 6; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  SB();
+  lacc = mfma32(ones, pa, lacc);
+  va0 = rd_tr<DK>(vs, 0, 32 + 4 * hi);
+  va1 = rd_tr<DK>(vs, 32, 32 + 4 * hi);
+#pragma unroll
+  for (int r = 6; r < 8; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  SB();
+  o[0] = mfma32(vb0, pb, o[0]);
+#pragma unroll
+  for (int r = 8; r < 11; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  SB();
+  o[1] = mfma32(vb1, pb, o[1]);
+#pragma unroll
+  for (int r = 11; r < 14; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  SB();
+  lacc = mfma32(ones, pb, lacc);
+  vb0 = rd_tr<DK>(vs, 0, 48 + 4 * hi);
+  vb1 = rd_tr<DK>(vs, 32, 48 + 4 * hi);
+#pragma unroll
+  for (int r = 14; r < 16; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  SB();
+  pa = pack_acc8(s1, 0);
+  pb = pack_acc8(s1, 8);
+  SB();
+  o[0] = mfma32(va0, pa, o[0]);
+  o[1] = mfma32(va1, pa, o[1]);
+  lacc = mfma32(ones, pa, lacc);
+  o[0] = mfma32(vb0, pb, o[0]);
+  o[1] = mfma32(vb1, pb, o[1]);
+  lacc = mfma32(ones, pb, lacc);
+  SB();
 }
 
 template <bool DROP>
@@ -150,7 +246,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
     }
   };
 
-  f32x16 o[ND];
+  f32x16 o[ND], lacc;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.f;
   float m = 0.f, lsum, ltot;
   // (two instantiations of the whole loop, not one loop with a run-time switch: the two sides of such a switch keep the
   // accumulators in different registers and the compiler reconciles them with ~50 moves per tile)
@@ -158,6 +257,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
     constexpr bool EXACT = decltype(exact_tag)::value;
     o[0] = zero16();
     o[1] = zero16();
+    lacc = zero16();
     lsum = 0.f;
     load(0);
     for (int it = 0; it + 1 < ntiles; ++it) {       // every tile but the last: no key is masked
@@ -165,17 +265,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
       store(ks);
       load(it + 1);
       __syncthreads();
-      lean_tile<DROP, false, EXACT>(ks, ks + G::E, qf, o, m, lsum, it * TILE, lk, q, dr, bh);
+      if constexpr (!DROP && !EXACT) lean_tile_pipe(ks, ks + G::E, qf, o, lacc, ones);
+      else lean_tile<DROP, false, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh);
     }
     {
       const int it = ntiles - 1;
       bf16* ks = smem + (it & 1) * 2 * G::E;
       store(ks);
       __syncthreads();
-      lean_tile<DROP, true, EXACT>(ks, ks + G::E, qf, o, m, lsum, it * TILE, lk, q, dr, bh);
+      lean_tile<DROP, true, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh);
     }
     __syncthreads();           // the tile buffers are free (epilogue patches, or the second attempt)
-    ltot = lsum + wave_xor32(lsum);
+    // matrix-pipe sums: every accumulator row of lane q holds the whole row sum (both key halves: the contraction spans them)
+    ltot = (!DROP && !EXACT) ? lacc[0] : lsum + wave_xor32(lsum);
   };
   run(std::false_type{});
   if (__syncthreads_or(q < lq && !(ltot > F64_SMALL && ltot < F64_BIG))) {      // left the plain-exponential range
