@@ -152,48 +152,87 @@ class Decode(object):
         cur.wait_stream(self._side)
         return out
 
-    def _decode_batch(self, src_batch):
+    def _init_state(self, src_batch, beam, arena):
+        """Encoder pass + the device state of a search over ``beam`` hypotheses per utterance (call inside ``arena.scope()``)."""
         inputs, in_len = src_batch
         model, dev = self.model, self.device
         inputs = inputs.to(dev)
+        B = inputs.shape[0]
+        t_max = int(in_len.max())
+        enc, in_rows = model.encoder.forward_rows(inputs[:, :t_max], in_len)        # packed [sum T, d]
+        dec = model.decoder
+        d, S, n = dec.d_model, self.max_steps, B * beam
+        if S > dec.position_enc.pe.shape[1]:
+            raise ValueError("Decode: max_steps %d exceeds the decoder's positional-encoding table" % S)
+        st = _DecodeState()
+        st.B, st.beam, st.n = B, beam, n
+        st.chains = dec.row_chains(arena)          # None: the layers do not fit the row-chain kernel
+        st.need_c_len = not (dec.d_model // dec.layer_stack[0].slf_attn.n_head == 64 and self.max_steps <= 128)
+        st.cross = []
+        for layer in dec.layer_stack:                                               # once per utterance
+            s = layer.enc_attn._st
+            kv = torch.empty(enc.shape[0], 2 * d, dtype=BF16, device=dev)
+            nv.gemm(enc, s.w_kv, kv, bias=s.b_kv)
+            st.cross.append(kv)
+        H = dec.layer_stack[0].slf_attn.n_head
+        ar = torch.arange(n, dtype=I32, device=dev)
+        st.q_off, st.q_one, st.c_off = ar, torch.ones(n, dtype=I32, device=dev), ar * S
+        st.c_len = torch.ones(n, dtype=I32, device=dev)
+        st.u_off = torch.arange(B, dtype=I32, device=dev) * beam
+        st.u_len = torch.full((B,), beam, dtype=I32, device=dev)
+        st.k_off, st.k_len, st.max_k = in_rows.off, in_rows.len, int(in_rows.max_len)
+        st.lse = torch.empty(H * n, dtype=F32, device=dev)
+        st.caches = torch.zeros(len(dec.layer_stack), n, S, 2 * d, dtype=BF16, device=dev)
+        st.tokens = torch.full((n,), Constants.BOS, dtype=torch.long, device=dev)
+        st.step = torch.zeros(1, dtype=torch.long, device=dev)
+        st.scores = torch.full((B, beam), float("-inf"), dtype=F32, device=dev)
+        st.scores[:, 0] = 0.0
+        st.done = torch.zeros(B, dtype=torch.bool, device=dev)
+        st.lengths = torch.zeros(B, dtype=torch.long, device=dev)
+        st.hist_scores = torch.zeros(S, B, beam, dtype=F32, device=dev)
+        st.back = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
+        st.toks = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
+        st.order = torch.zeros(n, dtype=torch.long, device=dev)
+        return st
+
+    @torch.no_grad()
+    def score_hypotheses(self, src_batch, hyps):
+        """Teacher-forced log-probability of ONE given token list per utterance, computed by the DECODE path (the step
+        kernels of ``decode_batch``: KV cache, shared encoder keys, row chains) with the search switched off - the tokens
+        are fed, not chosen.  -> tensor [B] fp32.  Not in the reference (its Decode has no scoring entry point): this is what
+        lets the decode kernels be held to the fp64 oracle WITHOUT the selection bias of an arg-max over noisy scores
+        (tests/test_decode_cpu.py::run_decode), and it rescores n-best lists."""
+        B = src_batch[0].shape[0]
+        assert len(hyps) == B and all(len(h) <= self.max_steps for h in hyps)
+        V, dev = self.model.vocab_size, self.device
+        arena = arena_of(self.model)
+        total = torch.zeros(B, dtype=torch.float64, device=dev)
+        with arena.scope():
+            st = self._init_state(src_batch, 1, arena)
+            steps = max(len(h) for h in hyps)
+            fed = torch.full((steps, B), Constants.PAD, dtype=torch.long)
+            live = torch.zeros(steps, B, dtype=torch.float64)
+            for b, h in enumerate(hyps):
+                fed[:len(h), b] = torch.tensor(h, dtype=torch.long)
+                live[:len(h), b] = 1.0
+            fed, live = fed.to(dev), live.to(dev)
+            for t in range(steps):
+                lp = torch.log_softmax(self._step(st)[:, :V].double(), -1)
+                total += lp.gather(1, fed[t].unsqueeze(1)).squeeze(1) * live[t]
+                st.tokens.copy_(fed[t])                 # beam 1: no back-pointers, the cache row stays where it is
+                st.step.add_(1)
+                if st.need_c_len:
+                    st.c_len.add_(1)
+        return total.float()
+
+    def _decode_batch(self, src_batch):
+        inputs, in_len = src_batch
+        model, dev = self.model, self.device
         B, beam, n_best = inputs.shape[0], int(self.opt.beam_size), int(self.opt.n_best)
         arena = arena_of(model)
         with arena.scope():
-            t_max = int(in_len.max())
-            enc, in_rows = model.encoder.forward_rows(inputs[:, :t_max], in_len)        # packed [sum T, d]
-            dec = model.decoder
-            d, S, n = dec.d_model, self.max_steps, B * beam
-            if S > dec.position_enc.pe.shape[1]:
-                raise ValueError("Decode: max_steps %d exceeds the decoder's positional-encoding table" % S)
-            st = _DecodeState()
-            st.B, st.beam, st.n = B, beam, n
-            st.chains = dec.row_chains(arena)          # None: the layers do not fit the row-chain kernel
-            st.need_c_len = not (dec.d_model // dec.layer_stack[0].slf_attn.n_head == 64 and self.max_steps <= 128)
-            st.cross = []
-            for layer in dec.layer_stack:                                               # once per utterance
-                s = layer.enc_attn._st
-                kv = torch.empty(enc.shape[0], 2 * d, dtype=BF16, device=dev)
-                nv.gemm(enc, s.w_kv, kv, bias=s.b_kv)
-                st.cross.append(kv)
-            H = dec.layer_stack[0].slf_attn.n_head
-            ar = torch.arange(n, dtype=I32, device=dev)
-            st.q_off, st.q_one, st.c_off = ar, torch.ones(n, dtype=I32, device=dev), ar * S
-            st.c_len = torch.ones(n, dtype=I32, device=dev)
-            st.u_off = torch.arange(B, dtype=I32, device=dev) * beam
-            st.u_len = torch.full((B,), beam, dtype=I32, device=dev)
-            st.k_off, st.k_len, st.max_k = in_rows.off, in_rows.len, int(in_rows.max_len)
-            st.lse = torch.empty(H * n, dtype=F32, device=dev)
-            st.caches = torch.zeros(len(dec.layer_stack), n, S, 2 * d, dtype=BF16, device=dev)
-            st.tokens = torch.full((n,), Constants.BOS, dtype=torch.long, device=dev)
-            st.step = torch.zeros(1, dtype=torch.long, device=dev)
-            st.scores = torch.full((B, beam), float("-inf"), dtype=F32, device=dev)
-            st.scores[:, 0] = 0.0
-            st.done = torch.zeros(B, dtype=torch.bool, device=dev)
-            st.lengths = torch.zeros(B, dtype=torch.long, device=dev)
-            st.hist_scores = torch.zeros(S, B, beam, dtype=F32, device=dev)
-            st.back = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
-            st.toks = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
-            st.order = torch.zeros(n, dtype=torch.long, device=dev)
+            st = self._init_state(src_batch, beam, arena)
+            S = self.max_steps
 
             def one_step():
                 self._advance(st, self._step(st))
