@@ -32,6 +32,9 @@
 
 // st_attn64.hip (AttnArgs passed by address: the type is local to each translation unit, the layout is shared)
 extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop);
+// st_attn_xs.hip: few queries against many keys (the decoder-encoder attention), 64-wide heads
+extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop);
+extern "C" int st_attn_xs_tile_rows();
 
 namespace {
 
@@ -538,13 +541,16 @@ bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
   return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1;
 }
 
+// few queries against many keys with 64-wide heads (the decoder-encoder attention) take the forward of st_attn_xs.hip
+bool fwd_xs(int d_k, int max_q, int max_k, int causal) { return d_k == 64 && key_split(max_q, max_k, causal) && attn_impl() != 1; }
+
 }  // namespace
 
 extern "C" int st_attn_tile_rows(int which, int d_k, int max_q, int max_k, int causal) {
   // rows per work-list tile of the kernel that will serve this problem: which = 0 forward (query tiles),
-  // 1 backward dQ (query tiles), 2 backward dK/dV (key tiles).  Every kernel shipped today runs 128-row workgroups;
-  // hosts must ask anyway (the answer is allowed to depend on the shape).
-  (void)which; (void)d_k; (void)max_q; (void)max_k; (void)causal;
+  // 1 backward dQ (query tiles), 2 backward dK/dV (key tiles).  128-row workgroups except the few-queries forward of
+  // st_attn_xs.hip (32): hosts must ask (the answer depends on the shape).
+  if (which == 0 && fwd_xs(d_k, max_q, max_k, causal)) return st_attn_xs_tile_rows();
   return WG_ROWS;
 }
 
@@ -568,8 +574,10 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
     dim3 grid(plan(a, work, n_work, B, H, max_q));
     return st_attn64_fwd_launch(stream, &a, (int)grid.x, drop ? 1 : 0);
   }
-  dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
+  if (fwd_xs(d_k, max_q, max_k, causal))
+    return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0);
+  dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
 #define ST_FWD(DKK, DR) \
   do { if (ks2 && a.psplit) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2, true>), grid, block, 0, stream, a); \
        else if (ks2) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2, false>), grid, block, 0, stream, a); \

@@ -1,0 +1,243 @@
+// Attention forward for FEW queries against MANY keys with 64-wide heads: the decoder-encoder attention of a training step
+// (<= 64 target positions against ~1000 encoder frames, Attention.py:82-90 as called from Layers.py:41) and of a beam-search
+// step (the `beam` hypotheses of an utterance against its encoder keys, Decode.py:75-112).
+//
+// Such a launch is ~1 GFLOP in total: its duration is launch + prologue + the SERIAL chain of key tiles + epilogue, not
+// arithmetic, and the chain is memory LATENCY: a workgroup must pull its (utterance, head)'s K and V (192 KB for 750 keys) through
+// one CU, and a load issued when its data is needed costs ~2 us.  The general kernel (st_attn.hip, KS = 2) walks the chain with
+// 4 waves - two halves of a 128-key stage per step behind one workgroup barrier, ~6 steps for 750 keys.  Here:
+//   * one workgroup = 8 waves per (utterance, head, 32-QUERY tile) - 256 workgroups at config 2 (two tiles per utterance),
+//     128 in a beam-10 decode step; wave w owns the 32-key blocks w, w + 8, w + 16, ... and keeps THREE blocks in flight in
+//     registers: for <= 768 keys every load of the problem is issued in the prologue and the latency is paid once;
+//   * K fragments go straight from global memory to the MFMA A operand (lane = key row: one 16-byte load per k-step);
+//     V needs the transposing LDS read, so each wave stages ITS 32 x 64 V block in a private 4.5 KB LDS patch -
+//     LDS operations of one wave execute in order, so there is NO barrier and no wait between waves inside the loop;
+//   * each wave keeps its own running (m, l, O); after the loop the eight partial states meet in LDS (70 KB, aliasing the V
+//     patches behind one barrier), wave w combines four of the 32 output registers of all eight, and the rows leave as whole
+//     128-byte segments.  The exchange with the lane's other half (l ^ 32) is a v_permlane32_swap, not a ds_bpermute.
+//     Two-term P (AttnArgs::psplit), Ores, the LSE and attention dropout as in the general kernel.
+// Served through st_attn_fwd (same C-ABI entry, same arguments; st_attn_tile_rows tells the host the 32-row tile).
+// Measured on the way (same box, config 2's decoder-encoder shape, general kernel 14.7 us): 64 queries per workgroup with one
+// register stage 14.0-14.7 us - prologue 3.1, merge + stores 2.5, first block 3.7, every further block 2.35 us whatever its
+// arithmetic (reduction trees and lockstep query blocks: no change): each block waited for loads issued half a block earlier.
+#include "st_attn_common.cuh"
+
+namespace {
+
+constexpr int XW = 8;                 // waves per workgroup
+constexpr int XQ = 32;                // query rows per workgroup
+constexpr int XNS = 3;                // 32-key blocks in flight per wave
+constexpr int XVS = 72;               // V patch row stride (elements): as TileGeo<64>::STR
+constexpr int XSLOTS = 34;            // exchange slots per (wave, query block): m, l, 32 output registers
+
+// max / sum of a value with its partner lane (l ^ 32: the other half of the same query's scores) as ONE v_permlane32_swap
+// instead of a ds_bpermute round trip through the LDS crossbar: swap(v, v) yields {lower half's v in both halves, upper
+// half's v in both halves}
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+struct XStage {                       // one 32-key block in flight: K fragments + this lane's four V chunks
+  bf16x8 k[4];
+  bf16x8 v[4];
+};
+
+template <bool DROP, bool PS>
+__global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a) {
+  constexpr int DK = 64;
+  __shared__ __attribute__((aligned(16))) float xch[XW * XSLOTS * 64];          // 69,632 B (the V patches alias its head)
+  __shared__ __attribute__((aligned(16))) bf16 patch[2 * 32 * DK];              // O rows (hi), Ores rows (lo)
+
+  int b, h, tile;
+  decode_item(a, blockIdx.x, b, h, tile);
+  const int lq = a.q_len[b], lk = a.k_len[b];
+  const int q0 = tile * XQ;
+  if (q0 >= lq) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5, r32 = l & 31;
+  const float c2 = a.scale * 1.4426950408889634f;
+  const Drop dr = make_drop(a.drop);
+  const int bh = b * a.H + h;
+  const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;
+  const bf16* vbase = a.V + (size_t)a.k_off[b] * a.ldv + h * DK;
+  const size_t qrow0 = (size_t)a.q_off[b];
+  const int q = q0 + r32;
+
+  bf16x8 qf[4];
+  {
+    const size_t row = qrow0 + min(q, lq - 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + row * a.ldq + h * DK + t * 16 + hi * 8);
+  }
+
+  bf16* vpatch = reinterpret_cast<bf16*>(xch) + wave * 32 * XVS;
+  const int nblk = (lk + 31) >> 5;
+  auto fetch = [&](XStage& st, int blk) {       // rows past the last key are clamped onto it (finite data; masked below)
+    const int k0 = blk * 32;
+    const size_t krow = (size_t)min(k0 + r32, lk - 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st.k[t] = *reinterpret_cast<const bf16x8*>(kbase + krow * a.ldk + t * 16 + hi * 8);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int id = l + p * 64;
+      st.v[p] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)min(k0 + (id >> 3), lk - 1) * a.ldv + (id & 7) * 8);
+    }
+  };
+
+  f32x16 o[2];
+  o[0] = zero16();
+  o[1] = zero16();
+  float m = -INFINITY, lsum = 0.f;
+
+  // one 32-key block: V -> the wave's LDS patch, the scores (that frees the K fragments), THEN the request for the block three
+  // ahead into the same registers, then softmax + P V
+  auto block = [&](XStage& st, int blk) {
+    const int k0 = blk * 32;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int id = l + p * 64;
+      *reinterpret_cast<bf16x8*>(vpatch + (id >> 3) * XVS + (id & 7) * 8) = st.v[p];
+    }
+    asm volatile("" ::: "memory");     // (compiler order only: the hardware runs one wave's LDS operations in issue order)
+    f32x16 s = zero16();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s = mfma32(st.k[t], qf[t], s);
+    if (blk + XNS * XW < nblk) fetch(st, blk + XNS * XW);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] *= c2;
+    if (k0 + 32 > lk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (k0 + acc_row(r, hi) >= lk) s[r] = -INFINITY;
+    }
+    const float a0 = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), a1 = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+    const float a2 = fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), a3 = fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]));
+    const float m_new = fmaxf(m, half_max(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3))));      // finite: key k0 itself is visible
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+    const float b0 = (s[0] + s[1]) + (s[2] + s[3]), b1 = (s[4] + s[5]) + (s[6] + s[7]);
+    const float b2 = (s[8] + s[9]) + (s[10] + s[11]), b3 = (s[12] + s[13]) + (s[14] + s[15]);
+    lsum = lsum * alpha + ((b0 + b1) + (b2 + b3));
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    if (DROP) {   // dropped probabilities leave the normaliser untouched; the 1/(1-p) scale is folded into the final 1/l
+      bool keep[16];
+      keep16<true>(dr, bh, q, k0, hi, keep);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = keep[r] ? s[r] : 0.f;
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const bf16x8 pf = pack_acc8(s, 8 * hf);
+      bf16x8 pl;
+      if (PS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pl[j] = (bf16)(s[8 * hf + j] - (float)pf[j]);
+      }
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const bf16x8 vf = frag_tr(vpatch, XVS, d * 32, 16 * hf + 4 * hi, 16 * hf + 4 * hi + 8);
+        o[d] = mfma32(vf, pf, o[d]);
+        if (PS) o[d] = mfma32(vf, pl, o[d]);
+      }
+    }
+    asm volatile("" ::: "memory");     // the next block's V store stays behind this block's transposing reads
+  };
+
+  XStage st0, st1, st2;
+  int blk = wave;
+  if (blk < nblk) fetch(st0, blk);
+  if (blk + XW < nblk) fetch(st1, blk + XW);
+  if (blk + 2 * XW < nblk) fetch(st2, blk + 2 * XW);
+  while (blk < nblk) {
+    block(st0, blk);
+    blk += XW;
+    if (blk >= nblk) break;
+    block(st1, blk);
+    blk += XW;
+    if (blk >= nblk) break;
+    block(st2, blk);
+    blk += XW;
+  }
+  __syncthreads();            // every wave is done with its V patch: the exchange area may overwrite them
+
+  // ---- the eight partial states -> LDS ------------------------------------------------------------------------------
+  {
+    float* x = xch + (size_t)(wave * XSLOTS) * 64 + l;
+    x[0] = m;
+    x[64] = half_sum(lsum);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[(2 + d * 16 + r) * 64] = o[d][r];
+  }
+  __syncthreads();
+  // ---- wave w combines output registers [4 w, 4 w + 4): column block w >> 2, register group w & 3 -------------------------
+  {
+    float mu[XW], lu[XW];
+    float M = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < XW; ++u) {
+      const float* x = xch + (size_t)(u * XSLOTS) * 64 + l;
+      mu[u] = x[0];
+      lu[u] = x[64];
+      M = fmaxf(M, mu[u]);
+    }
+    float L = 0.f, au[XW];
+#pragma unroll
+    for (int u = 0; u < XW; ++u) {
+      au[u] = (mu[u] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mu[u] - M);
+      L += au[u] * lu[u];
+    }
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < XW; ++u) {
+      const float* x = xch + (size_t)(u * XSLOTS + 2 + 4 * wave) * 64 + l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] += au[u] * x[e * 64];
+    }
+    const float inv = L > 0.f ? (DROP ? dr.scale : 1.f) / L : 0.f;
+    bf16x4 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xv = val[e] * inv;
+      vh[e] = (bf16)xv;
+      vl[e] = (bf16)(xv - (float)vh[e]);
+    }
+    const int col = (wave >> 2) * 32 + 8 * (wave & 3) + 4 * hi;
+    *reinterpret_cast<bf16x4*>(patch + r32 * DK + col) = vh;
+    *reinterpret_cast<bf16x4*>(patch + 32 * DK + r32 * DK + col) = vl;
+    if (wave == 0 && hi == 0 && q < lq && a.lse) a.lse[(size_t)h * a.q_rows_total + qrow0 + q] = M + log2f(L);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int row = threadIdx.x >> 3, c8 = threadIdx.x & 7;
+    if (q0 + row < lq) {
+      const size_t at = (qrow0 + q0 + row) * a.ldo + h * DK + c8 * 8;
+      *reinterpret_cast<bf16x8*>(a.O + at) = *reinterpret_cast<const bf16x8*>(patch + row * DK + c8 * 8);
+      if (a.Ores) *reinterpret_cast<bf16x8*>(a.Ores + at) = *reinterpret_cast<const bf16x8*>(patch + 32 * DK + row * DK + c8 * 8);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int st_attn_xs_tile_rows() { return XQ; }
+
+extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args_, int grid_x, int drop) {
+  const AttnArgs& a = *static_cast<const AttnArgs*>(args_);
+  dim3 grid(grid_x), block(512);
+  if (drop && a.psplit) hipLaunchKernelGGL((attn_xs_fwd_kernel<true, true>), grid, block, 0, stream, a);
+  else if (drop) hipLaunchKernelGGL((attn_xs_fwd_kernel<true, false>), grid, block, 0, stream, a);
+  else if (a.psplit) hipLaunchKernelGGL((attn_xs_fwd_kernel<false, true>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_xs_fwd_kernel<false, false>), grid, block, 0, stream, a);
+  return (int)hipGetLastError();
+}
