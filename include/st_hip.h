@@ -199,8 +199,9 @@ int st_ln_bwd(st_stream_t stream, const void* dy, int lddy, const void* xhat, co
               const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, float mask_scale);
 
 /* Rows per work-list tile of the attention kernel that serves a problem of
- * this shape (the kernels are chosen by shape: long non-causal problems with
- * 64-wide heads run 256-row workgroups, everything else 128-row ones).
+ * this shape (the kernels are chosen by shape: 128-row workgroups, except
+ * the forward for <= 64 queries against >= 256 keys with 64-wide heads -
+ * the decoder-encoder attention - which runs 32-query workgroups).
  * which: 0 = st_attn_fwd (query tiles), 1 = st_attn_bwd work_q (query tiles),
  * 2 = st_attn_bwd work_k (key tiles). */
 int st_attn_tile_rows(int which, int d_k, int max_q, int max_k, int causal);
@@ -219,6 +220,21 @@ int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
                 int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
                 int H, int d_k, int max_q, int max_k, int q_rows_total, int causal, float scale, const int* work,
                 int n_work, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+
+/* The decoder-encoder attention of Layers.py:41 TOGETHER with what stands between it and the self-attention in front of it:
+ * cur = LN(ctxA Wo^T + bo + R) (the self-attention's output_linear + residual + layernorm, Attention.py:92-94; out0 / xhat0 /
+ * rstd0 as st_row_chain's PRE writes them) and q = cur Wq^T + bq (Attention.py:74; Qout [rows, 256]), then st_attn_fwd on
+ * that q - one launch instead of st_row_chain(PRE + POST) + st_attn_fwd.  wfrag: the two-block fragment stream of that chain
+ * (st_wfrag_build), n_blocks == 2, next_blocks as st_row_chain.  Only for the shapes st_attn_f1_applicable reports
+ * (d_model 256, d_k 64, max_q <= 64, max_k >= 256: the few-queries forward); otherwise -10 - callers then issue the two
+ * launches.  Results are those of the two launches (same arithmetic, same order). */
+int st_attn_f1_applicable(int d_model, int d_k, int max_q, int max_k);
+int st_attn_f1_fwd(st_stream_t stream, const void* ctxA, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
+                   int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
+                   float* rstd0, const float* bq, void* Qout, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                   int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len,
+                   int B, int H, int d_k, int max_q, int max_k, int q_rows_total, float scale, const int* work, int n_work,
+                   const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
 /* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
  * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:

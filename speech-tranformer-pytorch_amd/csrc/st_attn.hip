@@ -33,7 +33,11 @@
 // st_attn64.hip (AttnArgs passed by address: the type is local to each translation unit, the layout is shared)
 extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop);
 // st_attn_xs.hip: few queries against many keys (the decoder-encoder attention), 64-wide heads
-extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop);
+extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop, const void* f1);
+extern "C" void st_attn_xs_f1_args(void* out, const void* A, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
+                                   int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0,
+                                   void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq);
+extern "C" int st_attn_xs_f1_args_size();
 extern "C" int st_attn_xs_tile_rows();
 
 namespace {
@@ -576,7 +580,7 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   }
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
   if (fwd_xs(d_k, max_q, max_k, causal))
-    return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0);
+    return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0, nullptr);
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
 #define ST_FWD(DKK, DR) \
   do { if (ks2 && a.psplit) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2, true>), grid, block, 0, stream, a); \
@@ -592,6 +596,35 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
 #undef ST_FWD
   ST_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int st_attn_f1_applicable(int d_model, int d_k, int max_q, int max_k) {
+  // st_attn_f1_fwd serves the shapes the few-queries forward serves, at d_model 256 (the row chains' width)
+  return (d_model == 256 && fwd_xs(d_k, max_q, max_k, 0)) ? 1 : 0;
+}
+
+extern "C" int st_attn_f1_fwd(hipStream_t stream, const void* ctxA, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
+                              int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0,
+                              void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq, const void* K, int ldk,
+                              const void* V, int ldv, void* O, int ldo, void* Ores, float* lse, const int* q_off,
+                              const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q, int max_k,
+                              int q_rows_total, float scale, const int* work, int n_work, const unsigned* drop_seed,
+                              unsigned drop_salt, int drop_thresh, float drop_scale) {
+  if (B <= 0 || H <= 0 || max_q <= 0 || (work && n_work <= 0)) return 0;
+  if (!st_attn_f1_applicable(H * d_k, d_k, max_q, max_k)) return -10;
+  if (!ctxA || !R || !wfrag || n_blocks != 2 || !bo || !g0 || !be0 || !out0 || !bq || !Qout) return -11;
+  if ((lda & 7) || (ldr & 7) || (ldq & 7) || ldq < 256 || (ldk & 7) || (ldv & 7) || (ldo & 7)) return -2;
+  if (B > 32767) return -4;
+  AttnArgs a = {};
+  a.Q = (const bf16*)Qout; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
+  a.O = (bf16*)O; a.ldo = ldo; a.Ores = (bf16*)Ores; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
+  a.q_rows_total = q_rows_total; a.causal = 0; a.scale = scale;
+  const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
+  a.psplit = (Ores != nullptr && max_q <= 64) ? 1 : 0;
+  alignas(16) char f1[256];
+  if (st_attn_xs_f1_args_size() > (int)sizeof(f1)) return -12;
+  st_attn_xs_f1_args(f1, ctxA, lda, R, ldr, wfrag, n_blocks, next_blocks, eps, bo, g0, be0, out0, xhat0, rstd0, bq, Qout, ldq);
+  return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0, f1);
 }
 
 extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,

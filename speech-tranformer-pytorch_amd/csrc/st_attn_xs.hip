@@ -21,6 +21,7 @@
 // register stage 14.0-14.7 us - prologue 3.1, merge + stores 2.5, first block 3.7, every further block 2.35 us whatever its
 // arithmetic (reduction trees and lockstep query blocks: no change): each block waited for loads issued half a block earlier.
 #include "st_attn_common.cuh"
+#include "st_rowchain_common.cuh"
 
 namespace {
 
@@ -47,8 +48,24 @@ struct XStage {                       // one 32-key block in flight: K fragments
   bf16x8 v[4];
 };
 
-template <bool DROP, bool PS>
-__global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a) {
+// F1: the chain stage in front of the decoder-encoder attention - cur = LN(ctx Wo^T + bo + x) (the self-attention's output_linear +
+// residual + LayerNorm, Attention.py:92-94) and q = cur Wq^T + bq (Attention.py:74) - computed HERE for the workgroup's 32 rows from
+// the same weight-fragment streams st_row_chain reads (csrc/st_rowchain_common.cuh), instead of by a launch of its own: the four
+// heads' workgroups of a row tile repeat it (2 x 128 KB of weights from L2 each; head 0 writes out / xhat / rstd / q for the
+// backward), the K / V requests of the attention are already in flight underneath, and q never leaves the chip on its way to the
+// scores.  A decoder-sized st_row_chain of two blocks is 14 us of launch + prologue + epilogue for 1.2 us of matrix work.
+struct XF1Args {
+  const bf16* A; int lda;            // the self-attention context [rows, 256]
+  const bf16* R; int ldr;            // the residual (the layer input)
+  const bf16x8* wfrag; int wave_frags; int next_frags;
+  float eps;
+  const float* bo; const float* g0; const float* be0;
+  bf16* out0; bf16* xhat0; float* rstd0;
+  const float* bp; bf16* P; int ldp; // q projection: bias, output [rows, 256]
+};
+
+template <bool DROP, bool PS, bool F1>
+__global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args f) {
   constexpr int DK = 64;
   __shared__ __attribute__((aligned(16))) float xch[XW * XSLOTS * 64];          // 69,632 B (the V patches alias its head)
   __shared__ __attribute__((aligned(16))) bf16 patch[2 * 32 * DK];              // O rows (hi), Ores rows (lo)
@@ -67,13 +84,6 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a) {
   const size_t qrow0 = (size_t)a.q_off[b];
   const int q = q0 + r32;
 
-  bf16x8 qf[4];
-  {
-    const size_t row = qrow0 + min(q, lq - 1);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + row * a.ldq + h * DK + t * 16 + hi * 8);
-  }
-
   bf16* vpatch = reinterpret_cast<bf16*>(xch) + wave * 32 * XVS;
   const int nblk = (lk + 31) >> 5;
   auto fetch = [&](XStage& st, int blk) {       // rows past the last key are clamped onto it (finite data; masked below)
@@ -87,6 +97,76 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a) {
       st.v[p] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)min(k0 + (id >> 3), lk - 1) * a.ldv + (id & 7) * 8);
     }
   };
+
+  XStage st0, st1, st2;
+  int blk = wave;
+  if (blk < nblk) fetch(st0, blk);
+  if (blk + XW < nblk) fetch(st1, blk + XW);
+  if (blk + 2 * XW < nblk) fetch(st2, blk + 2 * XW);
+
+  bf16x8 qf[4];
+  if (F1) {
+    constexpr int TE = 32 * AS;
+    bf16* cur = reinterpret_cast<bf16*>(xch);       // three activation tiles + the LayerNorm exchange: 52,736 B of the 69,632
+    bf16* f0 = cur + TE;
+    bf16* f1 = cur + 2 * TE;
+    float (*red)[NW * 32] = reinterpret_cast<float (*)[NW * 32]>(xch + 3 * TE / 2);
+    Ctx<1> c;
+    c.tid = threadIdx.x; c.wave = wave; c.l = l; c.hi = hi; c.r = r32;
+    c.row0 = (int)qrow0 + q0; c.nvalid = min(32, lq - q0);
+    c.ws = f.wfrag + (size_t)wave * f.wave_frags * 64;
+#pragma unroll
+    for (int i = 0; i < Ring<1>::D; ++i) c.ring[i] = c.ws[i * 64 + l];
+    c.ws += Ring<1>::D * 64;
+    // the chain stored behind this one (the layer's feed-forward chain) runs right after this launch: warm its streams as the
+    // st_row_chain launch this stage replaces did (the workgroups of an XCD deal the 128-byte lines among their threads)
+    int touched[TOUCH];
+    {
+      const int nlines = NW * (f.wave_frags + f.next_frags) * 8;
+      const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
+      const char* sb = reinterpret_cast<const char*>(f.wfrag);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TOUCH; ++t) {
+        const int ln = min(((int)blockIdx.x >> 3) * 512 + (int)threadIdx.x + t * nr * 512, nlines - 1);
+        touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      TileRegs<1> ra, rr;
+      tile_load(c, f.A, f.lda, ra);
+      tile_load(c, f.R, f.ldr, rr);
+      tile_store(c, ra, cur);
+      tile_store(c, rr, f0);
+    }
+    const Drop off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
+    const bool writer = h == 0;                     // one of the four heads' workgroups stores the stage's outputs
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    block_mma(c, cur, acc);
+    epi_ln<false>(c, acc, f.bo, f0, f.g0, f.be0, f.eps, off, cur, f1, red, writer ? f.out0 : nullptr, writer ? f.xhat0 : nullptr,
+                  writer ? f.rstd0 : nullptr);
+    zero_acc(acc);
+    block_mma(c, f1, acc);                          // q = cur Wq^T (+ bq): staged in f0 (the residual: last read before epi_ln's barriers)
+    epi_store<false, false>(c, acc, f.bp, f0, off, 0, 0);
+    __syncthreads();
+    if (writer) tile_out(c, f0, f.P, f.ldp);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = frag_nat(f0, AS, r32, h * DK + t * 16 + hi * 8);
+    {
+      int tsum = 0;
+#pragma unroll
+      for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+      if (tsum == 0x5a5a5a5a && lq < 0) red[0][0] = 1.f;      // (never true: keeps the warm-up loads alive)
+    }
+    __syncthreads();                                // the tiles are dead: the waves' V patches take their place
+  } else {
+    const size_t row = qrow0 + min(q, lq - 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + row * a.ldq + h * DK + t * 16 + hi * 8);
+  }
 
   f32x16 o[2];
   o[0] = zero16();
@@ -152,11 +232,6 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a) {
     asm volatile("" ::: "memory");     // the next block's V store stays behind this block's transposing reads
   };
 
-  XStage st0, st1, st2;
-  int blk = wave;
-  if (blk < nblk) fetch(st0, blk);
-  if (blk + XW < nblk) fetch(st1, blk + XW);
-  if (blk + 2 * XW < nblk) fetch(st2, blk + 2 * XW);
   while (blk < nblk) {
     block(st0, blk);
     blk += XW;
@@ -232,12 +307,31 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a) {
 
 extern "C" int st_attn_xs_tile_rows() { return XQ; }
 
-extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args_, int grid_x, int drop) {
+extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args_, int grid_x, int drop, const void* f1_) {
   const AttnArgs& a = *static_cast<const AttnArgs*>(args_);
   dim3 grid(grid_x), block(512);
-  if (drop && a.psplit) hipLaunchKernelGGL((attn_xs_fwd_kernel<true, true>), grid, block, 0, stream, a);
-  else if (drop) hipLaunchKernelGGL((attn_xs_fwd_kernel<true, false>), grid, block, 0, stream, a);
-  else if (a.psplit) hipLaunchKernelGGL((attn_xs_fwd_kernel<false, true>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((attn_xs_fwd_kernel<false, false>), grid, block, 0, stream, a);
+  XF1Args f = {};
+  if (f1_) f = *static_cast<const XF1Args*>(f1_);
+#define ST_XS(DR, PSS) \
+  do { if (f1_) hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, true>), grid, block, 0, stream, a, f); \
+       else hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, false>), grid, block, 0, stream, a, f); } while (0)
+  if (drop && a.psplit) ST_XS(true, true);
+  else if (drop) ST_XS(true, false);
+  else if (a.psplit) ST_XS(false, true);
+  else ST_XS(false, false);
+#undef ST_XS
   return (int)hipGetLastError();
 }
+
+// the F1 stage's arguments as st_attn.hip hands them over (the struct is local to this translation unit)
+extern "C" void st_attn_xs_f1_args(void* out, const void* A, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
+                                   int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0,
+                                   void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq) {
+  XF1Args f;
+  f.A = (const bf16*)A; f.lda = lda; f.R = (const bf16*)R; f.ldr = ldr; f.wfrag = (const bf16x8*)wfrag;
+  f.wave_frags = n_blocks * 16 + DEPTH; f.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0; f.eps = eps;
+  f.bo = bo; f.g0 = g0; f.be0 = be0; f.out0 = (bf16*)out0; f.xhat0 = (bf16*)xhat0; f.rstd0 = rstd0; f.bp = bq; f.P = (bf16*)Qout;
+  f.ldp = ldq;
+  *static_cast<XF1Args*>(out) = f;
+}
+extern "C" int st_attn_xs_f1_args_size() { return (int)sizeof(XF1Args); }

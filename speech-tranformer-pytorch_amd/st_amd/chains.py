@@ -433,13 +433,14 @@ class DecoderChains:
             if need_bwd:
                 a.xhat, a.rstd = E(M, d), E(M, dt=F32)
             b.qkv = E(M, d)
-            nv.row_chain(a.ctx, self.f1[l], pre=(x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
-                         post=(1, ca._st.b_q, b.qkv))
-            # ---- encoder-decoder attention over this layer's column block of kv
+            # ---- and the encoder-decoder attention over this layer's column block of kv: ONE launch where the few-queries
+            #      kernel serves the shape (nv.attn_f1_fwd; the F1 chain + the attention kernel otherwise)
             b.kvbuf, b.drop = kv[:, l * 2 * d:(l + 1) * 2 * d], ca._drop(dev)
             b.ctx, b.lse, b.ores = EZ(M, d, t_rows), E(H * M, dt=F32), (EZ(M, d, t_rows) if need_bwd else None)
-            nv.attn_fwd(b.qkv, b.kvbuf[:, :d], b.kvbuf[:, d:], b.ctx, b.lse, t_rows.off, t_rows.len, in_rows.off, in_rows.len,
-                        H, t_rows.max_len, False, scale, work=work_cross, drop=b.drop, max_k=in_rows.max_len, ores=b.ores)
+            nv.attn_f1_fwd(a.ctx, self.f1[l], (x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
+                           (1, ca._st.b_q, b.qkv), b.kvbuf[:, :d], b.kvbuf[:, d:], b.ctx, b.lse, t_rows.off, t_rows.len,
+                           in_rows.off, in_rows.len, H, t_rows.max_len, scale, work=work_cross, drop=b.drop,
+                           max_k=in_rows.max_len, ores=b.ores)
             # ---- F2: its output_linear + residual + LayerNorm, the feed-forward sublayer, the next layer's q|k|v
             b.out, f.out, f.h = E(M, d), E(M, d), E(M, ff._st.d_ff)
             if need_bwd:

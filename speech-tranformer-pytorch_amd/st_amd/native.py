@@ -62,6 +62,11 @@ SIGNATURES = {
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
+    "st_attn_f1_applicable": [_c_int, _c_int, _c_int, _c_int],
+    "st_attn_f1_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p,
+                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int,
+                       _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                       _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -619,6 +624,48 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
                             k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), rows, int(causal),
                             float(scale), *_work(work), *_drop(drop))
     _check(rc, "st_attn_fwd")
+    return O
+
+
+def attn_f1_fwd(A, chain, pre, post, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, scale, work=None, drop=None,
+                max_k=0, ores=None, eps=1e-6):
+    """The decoder-encoder attention together with the chain stage in front of it, as ONE launch where the few-queries
+    kernel serves the shape (d_model 256, 64-wide heads, <= 64 queries, >= 256 keys; csrc/st_attn_xs.hip), else as the two
+    launches it stands for:
+        row_chain(A, chain, pre=pre, post=post)        cur = LN(A Wo^T + bo + R) -> out / xhat / rstd;  q = cur Wq^T + bq -> post[2]
+        attn_fwd(post[2], K, V, O, lse, ..., causal=False)
+    pre = (R, bo, gamma, beta, out, xhat, rstd), post = (1, bq, Qout) exactly as row_chain takes them."""
+    R, bo, g0, be0, out0, xhat0, rstd0 = pre
+    pb, bq, Qout = post
+    M, d = A.shape
+    d_k = d // n_head
+    if pb != 1 or chain.n_blocks != 2 or not load().st_attn_f1_applicable(int(d), int(d_k), int(max_q), int(max_k)):
+        row_chain(A, chain, pre=pre, post=post, eps=eps)
+        return attn_fwd(Qout, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, False, scale, work=work, drop=drop,
+                        max_k=max_k, ores=ores)
+    for t, nm in ((A, "A"), (R, "R"), (out0, "out0"), (Qout, "Qout"), (K, "K"), (V, "V"), (O, "O")):
+        _mat(t, BF16, nm)
+    _vec(bo, F32, d, "bo"), _vec(g0, F32, d, "g0"), _vec(be0, F32, d, "be0"), _vec(bq, F32, d, "bq")
+    assert out0.stride(0) == d and (xhat0 is None or xhat0.stride(0) == d) and R.shape[0] >= M and Qout.shape == (M, d)
+    assert rstd0 is None or (rstd0.dtype == F32 and rstd0.numel() >= M)
+    if chain.stream.numel() != 8 * (2 * 16 + wfrag_depth()) * 512 or chain.stream.dtype != BF16:
+        raise ValueError("attn_f1_fwd: the fragment stream does not match a two-block chain")
+    if ores is not None:
+        _mat(ores, BF16, "ores")
+        if ores.stride(0) != O.stride(0) or ores.shape != O.shape:
+            raise ValueError("attn_f1_fwd: ores must have O's shape and stride")
+    B = q_off.numel()
+    for t, nm in ((q_off, "q_off"), (q_len, "q_len"), (k_off, "k_off"), (k_len, "k_len")):
+        _vec(t, I32, B, nm)
+    _vec(lse, F32, n_head * M, "lse")
+    _tag("attn_fwd", n_head, d_k, 0, q_len, k_len, io=(A, R, out0, xhat0, rstd0, Qout, K, V, O, ores, lse))
+    rc = load().st_attn_f1_fwd(_stream(), A.data_ptr(), A.stride(0), R.data_ptr(), R.stride(0), chain.stream.data_ptr(), 2,
+                               int(chain.next_blocks), float(eps), bo.data_ptr(), g0.data_ptr(), be0.data_ptr(), out0.data_ptr(),
+                               _p(xhat0), _p(rstd0), bq.data_ptr(), Qout.data_ptr(), Qout.stride(0), K.data_ptr(), K.stride(0),
+                               V.data_ptr(), V.stride(0), O.data_ptr(), O.stride(0), _p(ores), lse.data_ptr(), q_off.data_ptr(),
+                               q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), M,
+                               float(scale), *_work(work), *_drop(drop))
+    _check(rc, "st_attn_f1_fwd")
     return O
 
 

@@ -89,17 +89,20 @@ class Decode(object):
                             scale, max_k=S)
             # -- output_linear + LayerNorm, then the encoder-decoder attention's q projection: separate launches, or ONE
             #    row chain (csrc/st_rowchain.hip) when the layers fit it
-            y, q = E(d), E(d)
+            # -- encoder-decoder attention: keys / values projected once per utterance; the beam's hypotheses of one
+            #    utterance are consecutive rows = ONE attention problem of `beam` queries (one pass over its keys).  With the
+            #    row chains the chain stage and the attention are one launch (nv.attn_f1_fwd) where the shape allows
+            y, q, ctx2 = E(d), E(d), E(d)
             if dc is not None:
-                nv.row_chain(ctx, dc.f1[l], pre=(x, s.b_o, s.gamma, s.beta, y, None, None), post=(1, c.b_q, q))
+                nv.attn_f1_fwd(ctx, dc.f1[l], (x, s.b_o, s.gamma, s.beta, y, None, None), (1, c.b_q, q), st.cross[l][:, :d],
+                               st.cross[l][:, d:], ctx2, st.lse, st.u_off, st.u_len, st.k_off, st.k_len, H, st.beam, scale,
+                               max_k=st.max_k)
             else:
                 nv.gemm_ln(ctx, s.w_o, s.b_o, x, s.gamma, s.beta, y, None, None, eps=LN_EPS)
                 nv.gemm(y, c.w_q, q, bias=c.b_q)
-            # -- encoder-decoder attention: keys / values projected once per utterance; the beam's hypotheses of one
-            #    utterance are consecutive rows = ONE attention problem of `beam` queries (one pass over its keys)
-            ctx = E(d)
-            nv.attn_fwd(q, st.cross[l][:, :d], st.cross[l][:, d:], ctx, st.lse, st.u_off, st.u_len, st.k_off, st.k_len, H,
-                        st.beam, False, scale, max_k=st.max_k)
+                nv.attn_fwd(q, st.cross[l][:, :d], st.cross[l][:, d:], ctx2, st.lse, st.u_off, st.u_len, st.k_off, st.k_len, H,
+                            st.beam, False, scale, max_k=st.max_k)
+            ctx = ctx2
             # -- its output_linear + LayerNorm, the position-wise feed-forward, the next layer's q|k|v projection
             z, h, x_next = E(d), E(f.d_ff), E(d)
             nxt = layers[l + 1].slf_attn._st if l + 1 < len(layers) else None

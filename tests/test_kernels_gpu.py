@@ -810,6 +810,58 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
         _zero_pattern_equal(got["H"], h, "row_chain dropout1 vs st_gemm")
 
 
+@pytest.mark.parametrize("case", ["train", "train+drop", "decode", "short-keys"])
+def test_attn_f1_fwd_equals_row_chain_plus_attn_fwd(case):
+    """st_attn_f1_fwd (the decoder-encoder attention with its chain stage - output_linear + LayerNorm + q projection - in the
+    prologue of the few-queries kernel) against the two launches it replaces: every tensor bit for bit (same arithmetic in
+    the same order; the attention then sees the same q).  'short-keys' does not qualify for the fused kernel: the wrapper must
+    fall back to the two launches."""
+    from st_amd import chains
+    from st_amd.functional import Rows, attn_work
+    d, H = 256, 4
+    gen = torch.Generator().manual_seed(11)
+    if case == "decode":
+        B, beam = 7, 10
+        q_len = torch.full((B,), beam, dtype=torch.int64)
+        k_len = torch.randint(300, 900, (B,), generator=gen)
+    elif case == "short-keys":
+        B = 5
+        q_len, k_len = torch.randint(3, 50, (B,), generator=gen), torch.randint(40, 200, (B,), generator=gen)
+    else:
+        B = 9
+        q_len, k_len = torch.randint(1, 64, (B,), generator=gen), torch.randint(260, 1000, (B,), generator=gen)
+        q_len[0], q_len[1], k_len[0] = 64, 33, 999
+    q_rows, k_rows = Rows.packed(q_len, "cuda"), Rows.packed(k_len, "cuda")
+    M, Mk = int(q_len.sum()), int(k_len.sum())
+    wo, wq = cu(g(d, d, seed=1, scale=d ** -0.5)), cu(g(d, d, seed=2, scale=d ** -0.5))
+    bo, bq = cu(g(d, seed=3, dtype=F32)), cu(g(d, seed=4, dtype=F32))
+    g0, be0 = cu(g(d, seed=5, dtype=F32) * 0.2 + 1), cu(g(d, seed=6, dtype=F32) * 0.1)
+    A, R, kv = cu(g(M, d, seed=7)), cu(g(M, d, seed=8)), cu(g(Mk, 2 * d, seed=9))
+    cs = chains.ChainSet("cuda")
+    cid = cs.add(chains.blocks_of(wo) + chains.blocks_of(wq))
+    cs.finalize().rebuild()
+    ch = cs.chain(cid)
+    drop = _drops(31, 0.1)[0] if "drop" in case else None
+    work = attn_work(q_rows, k_rows, False, d // H, H)[0]
+    scale = (d // H) ** -0.5
+
+    def bufs():
+        E = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device="cuda")
+        return dict(out=E(M, d), xhat=E(M, d), rstd=E(M, dt=F32), q=E(M, d), O=E(M, d), ores=E(M, d), lse=E(H * M, dt=F32))
+
+    a, b = bufs(), bufs()
+    nv.row_chain(A, ch, pre=(R, bo, g0, be0, a["out"], a["xhat"], a["rstd"]), post=(1, bq, a["q"]))
+    nv.attn_fwd(a["q"], kv[:, :d], kv[:, d:], a["O"], a["lse"], q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, int(q_len.max()),
+                False, scale, work=work, drop=drop, max_k=int(k_len.max()), ores=a["ores"])
+    nv.attn_f1_fwd(A, ch, (R, bo, g0, be0, b["out"], b["xhat"], b["rstd"]), (1, bq, b["q"]), kv[:, :d], kv[:, d:], b["O"], b["lse"],
+                   q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, int(q_len.max()), scale, work=work, drop=drop,
+                   max_k=int(k_len.max()), ores=b["ores"])
+    torch.cuda.synchronize()
+    for n in a:
+        assert torch.equal(a[n], b[n]), "attn_f1_fwd %s: %s differs (max |d| %.3e)" % (case, n, (a[n].float() - b[n].float()).abs().max().item())
+    assert float(b["O"].float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail",
                                      "head0+ffn+tail+drop"])
