@@ -1,11 +1,12 @@
 // (dev, NOT built.)  One-pass backward of the few-queries attention (dQ, dK, dV of an (utterance, head) by one workgroup; appended
-// to csrc/st_attn_xs.hip it builds and passes the 35 attention tests).  Measured at config 2's decoder-encoder shape, same box:
-// 41.9 us as written, 15.7 us with its dK / dV stores removed, 10.5 us with one key block per wave, 4.5 us without the loop -
-// against 21.4 us for the merged launch of the general kernels.  The stores are the problem: on gfx9 a store is a vmcnt event
-// like a load, the block loop has conditional fetches / stores and early exits, so the compiler's wait for the NEXT block's
-// fragments becomes vmcnt(0) and every block waits for the write acknowledgement of the previous one.  What would fix it:
-// unconditional (clamped) fetches and stores in a fixed-trip loop so the waits stay counted, or LDS-DMA staging with
-// hand-placed waits.  Not pursued: the floor of this design (15.7 us) buys 6 x 5 us per step.
+// to csrc/st_attn_xs.hip and dispatched from st_attn_bwd's merged-launch branch it builds and passes the 35 attention tests).
+// Measured at config 2's decoder-encoder shape, same box: 42-46 us against 21.4 us for the merged launch of the general kernels
+// (10.5 us with one key block per wave, 4.5 us without the loop: ~6 us per 32-key block and wave).  First reading - the in-loop
+// dK / dV stores drag every counted wait to vmcnt(0) - was wrong: this version has a fixed-trip loop with unconditional (clamped)
+// fetches and stores, its waits are counted (vmcnt(16) .. vmcnt(39) in the ISA) and it still takes 46.0 us; the "15.7 us without
+// the stores" of the first version was the compiler deleting the whole dK / dV half as dead code.  With 4 waves per workgroup (one
+// per SIMD, nothing to overlap with) the ~800 instructions of a block (56 MFMAs in dependent chains of 4, both score layouts, 192
+// accumulator moves between AGPRs and VGPRs) simply run at ~18 clocks each.  Not pursued.
 // =====================================================================================================================
 // Backward of the same shape in ONE pass: dQ, dK and dV of an (utterance, head) by one workgroup.
 //
@@ -72,19 +73,25 @@ __global__ __launch_bounds__(256, 1) void attn_xs_bwd_kernel(AttnArgs a) {
   }
 
   const int nblk = (lk + 31) >> 5;
-  auto fetch = [&](BStage& st, int blk) {       // rows past the last key are clamped onto it (finite data)
-    const size_t krow = (size_t)min(blk * 32 + r32, lk - 1);
+  auto fetch = [&](BStage& st, int blk) {       // blocks past the last one and rows past the last key are clamped (finite data)
+    const size_t krow = (size_t)min(min(blk, nblk - 1) * 32 + r32, lk - 1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       st.k[t] = *reinterpret_cast<const bf16x8*>(kbase + krow * a.ldk + t * 16 + hi * 8);
       st.v[t] = *reinterpret_cast<const bf16x8*>(vbase + krow * a.ldv + t * 16 + hi * 8);
     }
   };
+  // A FIXED-TRIP loop with unconditional (clamped) fetches and stores: on gfx9 a store is a vmcnt event like a load, and only
+  // in straight-line code does the compiler keep the wait for a block's fragments COUNTED - with conditional fetches / stores
+  // and early exits it fell back to vmcnt(0), i.e. every block waited for the write acknowledgement of the one before (41.9 us
+  // instead of ~16).  Slots past a wave's last block repeat the utterance's last block: their dK / dV stores rewrite the same
+  // values, their dQ contribution is zeroed.
   BStage st0, st1, st2;
   int blk = wave;
-  if (blk < nblk) fetch(st0, blk);
-  if (blk + BW < nblk) fetch(st1, blk + BW);
-  if (blk + 2 * BW < nblk) fetch(st2, blk + 2 * BW);
+  fetch(st0, blk);
+  fetch(st1, blk + BW);
+  fetch(st2, blk + 2 * BW);
+  const int n_it = ((nblk + BW - 1) / BW + 2) / 3;
   __syncthreads();                      // the query tiles are in place
 
   float lse_q[2], dl_q[2];              // this lane's query in each query block (lane = query layout)
@@ -103,7 +110,9 @@ __global__ __launch_bounds__(256, 1) void attn_xs_bwd_kernel(AttnArgs a) {
   bf16* op = opatch + wave * 2 * 32 * DK;
   const int nqb = lq > 32 ? 2 : 1;
 
-  auto block = [&](BStage& st, int kblk) {
+  auto block = [&](BStage& st, int slot) {
+    const bool valid = slot < nblk;
+    const int kblk = min(slot, nblk - 1);
     const int k0 = kblk * 32;
     const int key = k0 + r32;
     // this wave's K block -> its patch (row = key, as the fragments hold it), for the transposing read of dQ's product
@@ -140,10 +149,10 @@ __global__ __launch_bounds__(256, 1) void attn_xs_bwd_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, nl)) * (dp[r] - dl);
-        if (partial) {
+        if (partial || !valid) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (k0 + acc_row(r, hi) >= lk) s[r] = 0.f;
+            if (!valid || k0 + acc_row(r, hi) >= lk) s[r] = 0.f;
         }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -215,25 +224,21 @@ __global__ __launch_bounds__(256, 1) void attn_xs_bwd_kernel(AttnArgs a) {
       const int id = l + p * 64, row = id >> 3, c8 = id & 7;
       const bf16x8 rk = *reinterpret_cast<const bf16x8*>(op + row * DK + c8 * 8);
       const bf16x8 rv = *reinterpret_cast<const bf16x8*>(op + 32 * DK + row * DK + c8 * 8);
-      if (k0 + row < lk) {
-        *reinterpret_cast<bf16x8*>(a.dK + (krow0 + k0 + row) * a.lddk + h * DK + c8 * 8) = rk;
-        *reinterpret_cast<bf16x8*>(a.dV + (krow0 + k0 + row) * a.lddv + h * DK + c8 * 8) = rv;
-      }
+      // rows past the last key hold that key's own dK / dV (their K / V rows were clamped onto it): written onto its row
+      const size_t orow = krow0 + min(k0 + row, lk - 1);
+      *reinterpret_cast<bf16x8*>(a.dK + orow * a.lddk + h * DK + c8 * 8) = rk;
+      *reinterpret_cast<bf16x8*>(a.dV + orow * a.lddv + h * DK + c8 * 8) = rv;
     }
     asm volatile("" ::: "memory");
-    if (kblk + 3 * BW < nblk) fetch(st, kblk + 3 * BW);
+    fetch(st, slot + 3 * BW);
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  while (blk < nblk) {
+  for (int it = 0; it < n_it; ++it) {
     block(st0, blk);
-    blk += BW;
-    if (blk >= nblk) break;
-    block(st1, blk);
-    blk += BW;
-    if (blk >= nblk) break;
-    block(st2, blk);
-    blk += BW;
+    block(st1, blk + BW);
+    block(st2, blk + 2 * BW);
+    blk += 3 * BW;
   }
 
   // ---- the four partial dQ -> LDS; wave w adds up registers of (query block w >> 1, column block w & 1) ------------------
