@@ -429,10 +429,14 @@ class DecoderChains:
             nv.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a.ctx, a.lse, t_rows.off, t_rows.len, t_rows.off, t_rows.len,
                         H, t_rows.max_len, True, scale, work=work_self, drop=a.drop, max_k=t_rows.max_len, ores=a.ores)
             # ---- F1: its output_linear + residual + LayerNorm, the next attention's q
-            a.out = E(M, d)
+            # (nv.attn_f1_fwd writes utterance rows only - the chain launch it replaces wrote every row of the matrix: on
+            # padded / bucket layouts the rows outside the utterances must read as zeros, they are operands of the row-wise
+            # chains behind and of the weight-gradient contractions)
+            a.out = EZ(M, d, t_rows)
             if need_bwd:
-                a.xhat, a.rstd = E(M, d), E(M, dt=F32)
-            b.qkv = E(M, d)
+                a.xhat = EZ(M, d, t_rows)
+                a.rstd = E(M, dt=F32) if t_rows.dense else torch.zeros(M, dtype=F32, device=dev)
+            b.qkv = EZ(M, d, t_rows)
             # ---- and the encoder-decoder attention over this layer's column block of kv: ONE launch where the few-queries
             #      kernel serves the shape (nv.attn_f1_fwd; the F1 chain + the attention kernel otherwise)
             b.kvbuf, b.drop = kv[:, l * 2 * d:(l + 1) * 2 * d], ca._drop(dev)

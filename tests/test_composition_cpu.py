@@ -633,7 +633,7 @@ def test_row_chain_step_narrow_heads_composition():
         run_row_chain_step_narrow_heads("cpu")
 
 
-def run_bucket_mode(device, use_graph, bucket_rows=None):
+def run_bucket_mode(device, use_graph, bucket_rows=None, T_cap=96, L_cap=12, t_min=40):
     """TrainStep(bucket=(T_cap, L_cap)): ONE captured step (padded layouts, lengths on the device) must serve batches whose
     lengths never repeat - six seeded batches through it against the eager packed step on a twin model: loss, clip norm
     and the weights after every update.  bucket_rows: the same with the bucket's rows PACKED into a fixed capacity (offsets
@@ -644,7 +644,7 @@ def run_bucket_mode(device, use_graph, bucket_rows=None):
     from st_amd.trainer import TrainStep
     from transformer.Optim import ScheduledOptim
     torch.manual_seed(5)
-    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=96, max_target_length=12, num_enc_layer=2, num_dec_layer=2,
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=T_cap, max_target_length=L_cap, num_enc_layer=2, num_dec_layer=2,
                           n_heads=4, d_k=64, d_v=64, d_model=256, d_inner_hid=512, dropout=0.0, vocab_size=30))
     ma = M.Transformer(cfg)
     U.init_parameters(ma)
@@ -652,13 +652,12 @@ def run_bucket_mode(device, use_graph, bucket_rows=None):
     ma, mb = ma.eval().to(device), mb.eval().to(device)
     oa = ScheduledOptim(ma, 256, U.AttrDict(n_warmup_steps=50))
     ob = ScheduledOptim(mb, 256, U.AttrDict(n_warmup_steps=50))
-    T_cap, L_cap = 96, 12
     sa = TrainStep(ma, oa, 30, 5.0, use_graph=use_graph, graph_warmup=1, bucket=(T_cap, L_cap), bucket_rows=bucket_rows)
     sb = TrainStep(mb, ob, 30, 5.0, use_graph=False)
     for i in range(6):
         # (packed buckets: batch 3 is four full-length utterances - more rows than the capacity: it takes the padded bucket)
         full = bucket_rows is not None and i == 3
-        b = orc.synthetic_batch(4, T_cap, L_cap, 80, 30, seed=20 + i, t_min=T_cap if full else 40, l_min=L_cap if full else 4)
+        b = orc.synthetic_batch(4, T_cap, L_cap, 80, 30, seed=20 + i, t_min=T_cap if full else t_min, l_min=L_cap if full else 4)
         T, L = int(b["in_len"].max()), int(b["tgt_len"].max())
         x, tok, gt = b["x"][:, :T].to(device), b["tokens"][:, :L].to(device), b["gt"][:, :L].to(device)
         la, ga = sa(x, b["in_len"], tok, b["tgt_len"], gt)

@@ -132,6 +132,25 @@ def test_bucket_mode_eager_gpu():
     comp.run_bucket_mode("cuda", use_graph=False)
 
 
+@pytest.mark.parametrize("bucket_rows", [None, (1300, 110)])
+def test_bucket_mode_long_inputs_with_poisoned_allocations_gpu(bucket_rows, monkeypatch):
+    """Bucket layouts (rows that belong to no utterance) at lengths that reach the few-queries attention kernel and its fused
+    chain stage (st_attn_f1_fwd: >= 256 keys) - with every floating-point torch.empty on the GPU filled with NaN first: a
+    kernel that writes utterance rows only must not leave a row any later kernel (row-wise chain, weight-gradient contraction)
+    reads as uninitialised memory.  (st_attn_f1_fwd writes utterance rows only where the st_row_chain launch it replaces wrote
+    every row: its outputs are zero-initialised on such layouts - st_amd/chains.py.)"""
+    import torch
+    real_empty = torch.empty
+
+    def poisoned(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_cuda and t.is_floating_point() and t.numel():
+            t.fill_(float("nan"))
+        return t
+    monkeypatch.setattr(torch, "empty", poisoned)
+    comp.run_bucket_mode("cuda", use_graph=False, bucket_rows=bucket_rows, T_cap=400, L_cap=30, t_min=260)
+
+
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_packed_bucket_mode_one_capture_serves_changing_lengths_gpu(use_graph):
     """The same with the bucket's rows packed into a fixed capacity (offsets on the device, unassigned tail rows): the step
