@@ -132,8 +132,9 @@ def test_bucket_mode_eager_gpu():
     comp.run_bucket_mode("cuda", use_graph=False)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("bucket_rows", [None, (1300, 110)])
-def test_bucket_mode_long_inputs_with_poisoned_allocations_gpu(bucket_rows, monkeypatch):
+def test_bucket_mode_long_inputs_with_poisoned_allocations_gpu(bucket_rows, use_graph, monkeypatch):
     """Bucket layouts (rows that belong to no utterance) at lengths that reach the few-queries attention kernel and its fused
     chain stage (st_attn_f1_fwd: >= 256 keys) - with every floating-point torch.empty on the GPU filled with NaN first: a
     kernel that writes utterance rows only must not leave a row any later kernel (row-wise chain, weight-gradient contraction)
@@ -148,7 +149,7 @@ def test_bucket_mode_long_inputs_with_poisoned_allocations_gpu(bucket_rows, monk
             t.fill_(float("nan"))
         return t
     monkeypatch.setattr(torch, "empty", poisoned)
-    comp.run_bucket_mode("cuda", use_graph=False, bucket_rows=bucket_rows, T_cap=400, L_cap=30, t_min=260)
+    comp.run_bucket_mode("cuda", use_graph=use_graph, bucket_rows=bucket_rows, T_cap=400, L_cap=30, t_min=260)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
