@@ -403,8 +403,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
   auto load = [&](int set, int it) {
     const int qt = q_begin + it * TILE;
     sq[set].load(offq, qbase, a.ldq, qt, lq);
-    so[set].load(offo, dobase, a.lddo, qt, lq);
-    sst[set] = statsrc[min(qt + (int)(threadIdx.x & 63), lq - 1)];
+    so[set].template load<true>(offo, dobase, a.lddo, qt, lq);          // queries past the end: ZERO dO rows and a zero delta -
+    sst[set] = statsrc[min(qt + (int)(threadIdx.x & 63), lq - 1)];    // dP = 0, dS = P (0 - 0) = 0, dV += 0: no mask needed
+    if ((threadIdx.x & 64) && qt + (int)(threadIdx.x & 63) >= lq) sst[set] = 0.f;
   };
   auto store = [&](int set) {
     bf16* base = smem + set * BUF;
@@ -420,7 +421,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
     // wave-uniform: every (query, key) pair of this tile x this wave's 32 keys is unmasked.  Keys past lk need no mask:
     // lane = key here, so such a lane (its K / V rows are clamped, finite) only fills its OWN dK / dV rows, which are never
     // stored - a partial last key block runs the plain path on every tile (it took the masked one on all of them)
-    const bool full = (qt + TILE <= lq) && (!a.causal || k0 + wave * 32 + 31 <= qt);
+    const bool full = !a.causal || k0 + wave * 32 + 31 <= qt;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s = zero16(), dp = zero16();

@@ -71,7 +71,11 @@ struct Stage {
       off[p] = ((uint32_t)(id / G::CPR) * (uint32_t)ld + (id % G::CPR) * 8) * 2u;
     }
   }
-  // rows r0 .. r0+ROWS-1 of the utterance's column slice `base`; rows >= nvalid read row nvalid-1
+  // rows r0 .. r0+ROWS-1 of the utterance's column slice `base`; rows >= nvalid read row nvalid-1 - or, ZERO_TAIL, arrive as
+  // zeros: a zero dO row (with a zero delta) or a zero K row takes a masked pair out of the backward's sums by itself
+  // (dP = 0 and dS = P (0 - 0) = 0 for a query past the end; dQ += dS K with K = 0 for a key past the end), so the tile
+  // that crosses a sequence end runs the unmasked path
+  template <bool ZERO_TAIL = false>
   __device__ __forceinline__ void load(const uint32_t (&off)[G::CH], const bf16* __restrict__ base, int ld, int r0,
                                        int nvalid) {
     if (r0 + ROWS <= nvalid) {
@@ -84,6 +88,7 @@ struct Stage {
         const int id = threadIdx.x + p * 256;
         const int row = min(r0 + id / G::CPR, nvalid - 1);
         v[p] = *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + (id % G::CPR) * 8);
+        if (ZERO_TAIL && r0 + id / G::CPR >= nvalid) v[p] = zero_bf8();
       }
     }
   }
