@@ -141,7 +141,9 @@ int st_gemm_lnbwd(st_stream_t stream, const void* dY, int lddy, const void* W, i
 /* ---- row chains for decoder-sized row counts (csrc/st_rowchain.hip) ---------------------------------------------
  * Everything the decoder does between two attention kernels is row-wise; one launch runs it for blocks of 32 rows:
  *   PRE   cur = LN(A Wo^T + bo + R) * g0 + be0               (Attention.py:92-94)   out0 / xhat0 / rstd0 as st_gemm_ln
+ *                                                                                    (each may be NULL when nothing outside the chain reads it)
  *   FFN   H   = dropout1(relu(cur W1^T + b1))                (SubLayers.py:25)      [M, d_ff], saved for the backward
+ *                                                                                    (H may be NULL: inference - it stays on the chip)
  *         cur = dropout2(LN(H W2^T + b2 + cur) * g1 + be1)   (SubLayers.py:26-27)   out1 / xhat1 / rstd1
  *   POST  P   = cur Wp^T + bp, Wp [256 post_blocks, 256]     (Attention.py:74-76 of the NEXT attention)
  * PRE is present iff R != NULL, FFN iff d_ff > 0, POST iff post_blocks > 0; without PRE the chain input is A.

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
                             a.relu_bits ? a.relu_bits + ((size_t)(blockIdx.x * a.nc + ch) * NW + c.wave) * 64 : nullptr);
       __syncthreads();
       block_mma(c, hc, acc2);
-      tile_out(c, hc, a.H + ch * 256, dff);
+      if (a.H) tile_out(c, hc, a.H + ch * 256, dff);      // (no H: inference - nobody reads the hidden activation back)
     }
     // xhat goes to the tile the LAST chunk did not use (last read one chunk earlier), the output replaces cur in place
     // (its residual reads precede epi_ln's barriers, its MFMA reads too)
@@ -514,8 +514,8 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   if (M <= 0) return 0;
   const bool pre = R != nullptr, ffn = d_ff > 0, post = post_blocks > 0;
   if (!A || !wfrag || (lda & 7) || (!pre && !ffn && !post)) return -1;
-  if (pre && ((ldr & 7) || !bo || !g0 || !be0 || !out0)) return -2;
-  if (ffn && ((d_ff & 255) || !b1 || !b2 || !g1 || !be1 || !H || !out1)) return -3;
+  if (pre && ((ldr & 7) || !bo || !g0 || !be0)) return -2;      // (out0 may be NULL: nobody outside the chain reads it - inference)
+  if (ffn && ((d_ff & 255) || !b1 || !b2 || !g1 || !be1 || !out1)) return -3;
   if (post && (!bp || !P || (ldp & 7) || ldp < 256 * post_blocks)) return -4;
   if (n_blocks != (pre ? 1 : 0) + (ffn ? 2 * (d_ff / 256) : 0) + post_blocks) return -5;
   ChainArgs a;

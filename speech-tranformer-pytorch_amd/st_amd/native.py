@@ -430,6 +430,7 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
     ``chain``: st_amd.chains.Chain (the fragment streams of this chain's weight blocks); A [M, 256] bf16.
     pre  = (R, bo, gamma, beta, out, xhat, rstd):                 cur = LN(A Wo^T + bo + R)
     ffn  = (d_ff, b1, b2, gamma, beta, H, out, xhat, rstd, drop1, drop2[, relu_bits]): cur = drop2(LN(drop1(relu(cur W1^T + b1)) W2^T + b2 + cur));
+           H (the hidden activation, the weight gradient's operand) may be None when no backward follows
            relu_bits (int64 [chain_mask_words(M, d_ff)]) receives the H > 0 mask row_chain_bwd reads
     post = (n_blocks_out, bias, P):                               P = cur Wp^T + bias, Wp [256 n_blocks_out, 256]
     xhat / rstd may be None when no backward follows."""
@@ -449,13 +450,19 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
     d_ff, b1, b2, g1, be1, H, out1, xhat1, rstd1, drop1, drop2 = ffn if ffn else (0,) + z[:10]
     pb, bp, P = post if post else (0, None, None)
     if pre:
-        _mat(R, BF16, "R"), _mat(out0, BF16, "out0"), _vec(bo, F32, d, "bo"), _vec(g0, F32, d, "g0"), _vec(be0, F32, d, "be0")
-        assert out0.stride(0) == d and (xhat0 is None or xhat0.stride(0) == d) and R.shape[0] >= M
+        _mat(R, BF16, "R"), _vec(bo, F32, d, "bo"), _vec(g0, F32, d, "g0"), _vec(be0, F32, d, "be0")
+        if out0 is not None:       # (None: the sublayer's output is only the chain's own running activation - inference)
+            _mat(out0, BF16, "out0")
+            assert out0.stride(0) == d
+        assert (xhat0 is None or xhat0.stride(0) == d) and R.shape[0] >= M
         assert rstd0 is None or (rstd0.dtype == F32 and rstd0.numel() >= M)
     if ffn:
-        _mat(H, BF16, "H"), _mat(out1, BF16, "out1"), _vec(b1, F32, d_ff, "b1"), _vec(b2, F32, d, "b2")
+        _mat(out1, BF16, "out1"), _vec(b1, F32, d_ff, "b1"), _vec(b2, F32, d, "b2")
         _vec(g1, F32, d, "g1"), _vec(be1, F32, d, "be1")
-        assert H.stride(0) == d_ff and H.shape == (M, d_ff) and out1.stride(0) == d and (xhat1 is None or xhat1.stride(0) == d)
+        if H is not None:          # (None: inference - the hidden activation stays on the chip)
+            _mat(H, BF16, "H")
+            assert H.stride(0) == d_ff and H.shape == (M, d_ff)
+        assert out1.stride(0) == d and (xhat1 is None or xhat1.stride(0) == d)
         assert rstd1 is None or (rstd1.dtype == F32 and rstd1.numel() >= M)
         assert relu_bits is None or (relu_bits.dtype == torch.int64 and relu_bits.is_contiguous() and relu_bits.numel() >= chain_mask_words(M, d_ff))
     if post:

@@ -104,7 +104,8 @@ class Decode(object):
                             st.beam, False, scale, max_k=st.max_k)
             ctx = ctx2
             # -- its output_linear + LayerNorm, the position-wise feed-forward, the next layer's q|k|v projection
-            z, h, x_next = E(d), E(f.d_ff), E(d)
+            x_next = E(d)
+            z, h = (None, None) if dc is not None else (E(d), E(f.d_ff))      # (inside the chain neither leaves the chip)
             nxt = layers[l + 1].slf_attn._st if l + 1 < len(layers) else None
             qkv = E(3 * d) if nxt is not None else None
             if dc is not None:

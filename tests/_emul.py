@@ -204,6 +204,8 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
     if pre:
         R, bo, g0, be0, out0, xhat0, rstd0 = pre
         (wo,) = take(1)
+        if out0 is None:
+            out0 = torch.empty(A.shape[0], 256, dtype=BF16, device=A.device)
         gemm_ln(A, wo, bo, R[:A.shape[0]], g0, be0, out0, xhat0, rstd0, eps=eps)
         cur = out0
     if ffn:
@@ -212,6 +214,8 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
         ws = take(2 * (d_ff // 256))
         w1 = torch.cat(ws[0::2], 0)
         w2 = torch.cat(ws[1::2], 1)
+        if H is None:          # inference: the hidden activation is not handed out
+            H = torch.empty(A.shape[0], d_ff, dtype=BF16, device=A.device)
         gemm(cur, w1, H, bias=b1, epi=nv.EPI_BF16_RELU, drop=drop1)
         if relu_bits is not None:
             _pack_bits(H[:A.shape[0]].float() > 0, relu_bits)
