@@ -634,6 +634,17 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     return O
 
 
+_F1_OK = {}
+
+
+def _f1_applicable(d, d_k, max_q, max_k):
+    """Host-only query (not a launch: bypasses the per-launch timer), cached per shape."""
+    key = (d, d_k, max_q, max_k)
+    if key not in _F1_OK:
+        _F1_OK[key] = bool(load()._cdll.st_attn_f1_applicable(d, d_k, max_q, max_k))
+    return _F1_OK[key]
+
+
 def attn_f1_fwd(A, chain, pre, post, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, scale, work=None, drop=None,
                 max_k=0, ores=None, eps=1e-6):
     """The decoder-encoder attention together with the chain stage in front of it, as ONE launch where the few-queries
@@ -646,7 +657,7 @@ def attn_f1_fwd(A, chain, pre, post, K, V, O, lse, q_off, q_len, k_off, k_len, n
     pb, bq, Qout = post
     M, d = A.shape
     d_k = d // n_head
-    if pb != 1 or chain.n_blocks != 2 or not load().st_attn_f1_applicable(int(d), int(d_k), int(max_q), int(max_k)):
+    if pb != 1 or chain.n_blocks != 2 or not _f1_applicable(int(d), int(d_k), int(max_q), int(max_k)):
         row_chain(A, chain, pre=pre, post=post, eps=eps)
         return attn_fwd(Qout, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, False, scale, work=work, drop=drop,
                         max_k=max_k, ores=ores)
