@@ -1,5 +1,8 @@
 """Dev: the merged attention backward (encoder self-attention shape of config 2) with the cheapest FRAC of its dQ items handed over
-as HALF tiles (work-list entry bit 15: 64 query rows through the key-split body) against the plain list: results and time."""
+as HALF tiles (work-list entry bit 15: 64 query rows through the key-split body) against the plain list: results and time.
+NEEDS the experimental kernel (not in the tree: attn_bwd_kernel<64, false, 1, HALF = true> - attn_bwd_dq_body decodes the item and
+sends entries with bit 15 to attn_bwd_dq_item<.., 2>; DESIGN.md section 4, "half tiles"): with the shipped library the flagged
+entries are no-ops and dQ comes out incomplete."""
 import math, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "speech-tranformer-pytorch_amd")): sys.path.insert(0, p)
