@@ -238,6 +238,21 @@ int st_attn_f1_fwd(st_stream_t stream, const void* ctxA, int lda, const void* R,
                    int B, int H, int d_k, int max_q, int max_k, int q_rows_total, float scale, const int* work, int n_work,
                    const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
 
+/* st_attn_f1_fwd with the decoder's causal SELF-attention (Layers.py:39) computed in front of the chain stage, by the same launch:
+ * qkv_q / qkv_k / qkv_v = the layer's q | k | v projection (leading dimension ld_qkv, head h at columns h * 64; queries and keys
+ * are the utterance's own <= 64 target positions: q_off / q_len), Os / Oress / lses = what st_attn_fwd(causal = 1) writes
+ * for it (Os and lses bit for bit, Oress - may be NULL - to its own precision), its dropout (Attention.py:89) with its own salt / threshold / scale on the shared device seed.
+ * The context goes from there straight into output_linear + LayerNorm + q projection and the decoder-encoder attention: the
+ * three launches st_attn_fwd + st_row_chain + st_attn_fwd as one.  Same shapes as st_attn_f1_fwd (-10 otherwise); H <= 8. */
+int st_attn_sf1_fwd(st_stream_t stream, const void* qkv_q, const void* qkv_k, const void* qkv_v, int ld_qkv, void* Os, void* Oress,
+                    int ldos, float* lses, unsigned sdrop_salt, int sdrop_thresh, float sdrop_scale, const void* R, int ldr,
+                    const void* wfrag, int n_blocks, int next_blocks, float eps, const float* bo, const float* g0,
+                    const float* be0, void* out0, void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq, const void* K,
+                    int ldk, const void* V, int ldv, void* O, int ldo, void* Ores, float* lse, const int* q_off,
+                    const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q, int max_k,
+                    int q_rows_total, float scale, const int* work, int n_work, const unsigned* drop_seed, unsigned drop_salt,
+                    int drop_thresh, float drop_scale);
+
 /* Attention backward (autograd of Attention.py:82-90): dQ, dK, dV from
  * Q, K, V, O, dO, lse; `delta` is f32 [H, q_rows_total] scratch.  Two kernels:
  * parts & 1 = dQ (also writes delta), parts & 2 = dK/dV (reads delta); 3 = both.

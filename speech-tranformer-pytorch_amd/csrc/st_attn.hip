@@ -33,7 +33,10 @@
 // st_attn64.hip (AttnArgs passed by address: the type is local to each translation unit, the layout is shared)
 extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop);
 // st_attn_xs.hip: few queries against many keys (the decoder-encoder attention), 64-wide heads
-extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop, const void* f1);
+extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop, const void* f1, const void* self);
+extern "C" void st_attn_xs_self_args(void* out, const void* Q, const void* K, const void* V, int ld, void* O, void* Ores, int ldo,
+                                     float* lse, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+extern "C" int st_attn_xs_self_args_size();
 extern "C" void st_attn_xs_f1_args(void* out, const void* A, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
                                    int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0,
                                    void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq);
@@ -581,7 +584,7 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   }
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
   if (fwd_xs(d_k, max_q, max_k, causal))
-    return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0, nullptr);
+    return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0, nullptr, nullptr);
   dim3 grid(plan(a, work, n_work, B, H, max_q)), block(256);
 #define ST_FWD(DKK, DR) \
   do { if (ks2 && a.psplit) hipLaunchKernelGGL((attn_fwd_kernel<DKK, DR, 2, true>), grid, block, 0, stream, a); \
@@ -604,16 +607,16 @@ extern "C" int st_attn_f1_applicable(int d_model, int d_k, int max_q, int max_k)
   return (d_model == 256 && fwd_xs(d_k, max_q, max_k, 0)) ? 1 : 0;
 }
 
-extern "C" int st_attn_f1_fwd(hipStream_t stream, const void* ctxA, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
-                              int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0,
-                              void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq, const void* K, int ldk,
-                              const void* V, int ldv, void* O, int ldo, void* Ores, float* lse, const int* q_off,
-                              const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q, int max_k,
-                              int q_rows_total, float scale, const int* work, int n_work, const unsigned* drop_seed,
-                              unsigned drop_salt, int drop_thresh, float drop_scale) {
+namespace {
+int attn_f1_impl(hipStream_t stream, const void* ctxA, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
+                 int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
+                 float* rstd0, const float* bq, void* Qout, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                 int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
+                 int H, int d_k, int max_q, int max_k, int q_rows_total, float scale, const int* work, int n_work,
+                 const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, const void* self_args) {
   if (B <= 0 || H <= 0 || max_q <= 0 || (work && n_work <= 0)) return 0;
   if (!st_attn_f1_applicable(H * d_k, d_k, max_q, max_k)) return -10;
-  if (!ctxA || !R || !wfrag || n_blocks != 2 || !bo || !g0 || !be0 || !out0 || !bq || !Qout) return -11;
+  if ((!ctxA && !self_args) || !R || !wfrag || n_blocks != 2 || !bo || !g0 || !be0 || !out0 || !bq || !Qout) return -11;
   if ((lda & 7) || (ldr & 7) || (ldq & 7) || ldq < 256 || (ldk & 7) || (ldv & 7) || (ldo & 7)) return -2;
   if (B > 32767) return -4;
   AttnArgs a = {};
@@ -625,7 +628,43 @@ extern "C" int st_attn_f1_fwd(hipStream_t stream, const void* ctxA, int lda, con
   alignas(16) char f1[256];
   if (st_attn_xs_f1_args_size() > (int)sizeof(f1)) return -12;
   st_attn_xs_f1_args(f1, ctxA, lda, R, ldr, wfrag, n_blocks, next_blocks, eps, bo, g0, be0, out0, xhat0, rstd0, bq, Qout, ldq);
-  return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0, f1);
+  return st_attn_xs_fwd_launch(stream, &a, plan(a, work, n_work, B, H, max_q, st_attn_xs_tile_rows()), drop ? 1 : 0, f1, self_args);
+}
+}  // namespace
+
+extern "C" int st_attn_f1_fwd(hipStream_t stream, const void* ctxA, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,
+                              int next_blocks, float eps, const float* bo, const float* g0, const float* be0, void* out0,
+                              void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq, const void* K, int ldk,
+                              const void* V, int ldv, void* O, int ldo, void* Ores, float* lse, const int* q_off,
+                              const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q, int max_k,
+                              int q_rows_total, float scale, const int* work, int n_work, const unsigned* drop_seed,
+                              unsigned drop_salt, int drop_thresh, float drop_scale) {
+  return attn_f1_impl(stream, ctxA, lda, R, ldr, wfrag, n_blocks, next_blocks, eps, bo, g0, be0, out0, xhat0, rstd0, bq, Qout, ldq, K,
+                      ldk, V, ldv, O, ldo, Ores, lse, q_off, q_len, k_off, k_len, B, H, d_k, max_q, max_k, q_rows_total, scale, work,
+                      n_work, drop_seed, drop_salt, drop_thresh, drop_scale, nullptr);
+}
+
+// st_attn_f1_fwd with the decoder's causal SELF-attention in front of the chain stage (its context never leaves the chip on
+// its way to output_linear): qkv_q / qkv_k / qkv_v = the layer's q | k | v projection (leading dimension ld_qkv, head h at
+// columns h * 64), Os / Oress / lses = what st_attn_fwd(causal) would have written (bit-identical), the self-attention's dropout
+// with its own salt / threshold / scale on the shared device seed.  The self-attention's keys are the utterance's own <= 64
+// target positions (q_off / q_len describe both sides).
+extern "C" int st_attn_sf1_fwd(hipStream_t stream, const void* qkv_q, const void* qkv_k, const void* qkv_v, int ld_qkv, void* Os,
+                               void* Oress, int ldos, float* lses, unsigned sdrop_salt, int sdrop_thresh, float sdrop_scale,
+                               const void* R, int ldr, const void* wfrag, int n_blocks, int next_blocks, float eps,
+                               const float* bo, const float* g0, const float* be0, void* out0, void* xhat0, float* rstd0,
+                               const float* bq, void* Qout, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                               int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off,
+                               const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, float scale,
+                               const int* work, int n_work, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh,
+                               float drop_scale) {
+  if (!qkv_q || !qkv_k || !qkv_v || !Os || !lses || (ld_qkv & 7) || (ldos & 7) || H > 8) return -13;
+  alignas(16) char sa[128];
+  if (st_attn_xs_self_args_size() > (int)sizeof(sa)) return -12;
+  st_attn_xs_self_args(sa, qkv_q, qkv_k, qkv_v, ld_qkv, Os, Oress, ldos, lses, drop_seed, sdrop_salt, sdrop_thresh, sdrop_scale);
+  return attn_f1_impl(stream, nullptr, 8, R, ldr, wfrag, n_blocks, next_blocks, eps, bo, g0, be0, out0, xhat0, rstd0, bq, Qout, ldq, K,
+                      ldk, V, ldv, O, ldo, Ores, lse, q_off, q_len, k_off, k_len, B, H, d_k, max_q, max_k, q_rows_total, scale, work,
+                      n_work, drop_seed, drop_salt, drop_thresh, drop_scale, sa);
 }
 
 extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,

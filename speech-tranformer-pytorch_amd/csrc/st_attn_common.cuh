@@ -198,9 +198,9 @@ __device__ __forceinline__ void store_rows_pair(bf16* patch_hi, bf16* patch_lo, 
       bf16x4 vh, vl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float x = acc[d][4 * g + e] * mul;
-        vh[e] = (bf16)x;
-        vl[e] = (bf16)(x - (float)vh[e]);
+        const float x = __fmul_rn(acc[d][4 * g + e], mul);      // (explicitly rounded product and difference: with the default
+        vh[e] = (bf16)x;                                        // contraction the compiler is free to form fma(acc, mul, -vh) in one
+        vl[e] = (bf16)__fsub_rn(x, (float)vh[e]);               // kernel and not in another - the residual then differs by an ulp)
       }
       const int col = d * 32 + 8 * g + 4 * hi;
       const int at = r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7);

@@ -64,10 +64,22 @@ struct XF1Args {
   const float* bp; bf16* P; int ldp; // q projection: bias, output [rows, 256]
 };
 
-template <bool DROP, bool PS, bool F1>
-__global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args f) {
+// SELF: the decoder's causal self-attention (Layers.py:39, Attention.py:82-90 on <= 64 target positions) in front of that chain
+// stage, for the workgroup's 32 query rows and ALL heads (waves 0 .. H-1 take a head each: <= 64 keys, one tile) - the context goes
+// straight into the stage's LDS tile instead of through a launch of its own and HBM.  The arithmetic is attn_fwd_kernel's
+// (st_attn.hip: one 64-key tile, two-term P, the same order of operations): the saved O and lse are bit-identical, Ores (the
+// bf16 residual of O) agrees to a few 1e-6 of O - inside the 2^-16 the pair promises.
+struct XSelfArgs {
+  const bf16* Q; const bf16* K; const bf16* V; int ld;      // the layer's q | k | v projection [rows, ld], head h at columns h * 64
+  bf16* O; bf16* Ores; int ldo;                              // context and its bf16 residual (Ores may be null: no backward)
+  float* lse;                                                // [H][q_rows_total], log2 domain
+  DropArgs drop;
+};
+
+template <bool DROP, bool PS, bool F1, bool SELF = false, bool SDROP = false>
+__global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args f, XSelfArgs sa) {
   constexpr int DK = 64;
-  __shared__ __attribute__((aligned(16))) float xch[XW * XSLOTS * 64];          // 69,632 B (the V patches alias its head)
+  __shared__ __attribute__((aligned(16))) float xch[XW * XSLOTS * 64 + 1024];   // 73,728 B (the V patches alias its head; SELF: 4 x 64-key V patches behind two tiles)
   __shared__ __attribute__((aligned(16))) bf16 patch[2 * 32 * DK];              // O rows (hi), Ores rows (lo)
 
   int b, h, tile;
@@ -100,9 +112,12 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
 
   XStage st0, st1, st2;
   int blk = wave;
-  if (blk < nblk) fetch(st0, blk);
-  if (blk + XW < nblk) fetch(st1, blk + XW);
-  if (blk + 2 * XW < nblk) fetch(st2, blk + 2 * XW);
+  auto fetch_all = [&]() {
+    if (blk < nblk) fetch(st0, blk);
+    if (blk + XW < nblk) fetch(st1, blk + XW);
+    if (blk + 2 * XW < nblk) fetch(st2, blk + 2 * XW);
+  };
+  if (!SELF) fetch_all();      // (SELF: behind the self-attention - its registers are needed there)
 
   bf16x8 qf[4];
   if (F1) {
@@ -115,13 +130,16 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
     c.tid = threadIdx.x; c.wave = wave; c.l = l; c.hi = hi; c.r = r32;
     c.row0 = (int)qrow0 + q0; c.nvalid = min(32, lq - q0);
     c.ws = f.wfrag + (size_t)wave * f.wave_frags * 64;
+    auto ring_start = [&]() {
 #pragma unroll
-    for (int i = 0; i < Ring<1>::D; ++i) c.ring[i] = c.ws[i * 64 + l];
-    c.ws += Ring<1>::D * 64;
+      for (int i = 0; i < Ring<1>::D; ++i) c.ring[i] = c.ws[i * 64 + l];
+      c.ws += Ring<1>::D * 64;
+    };
+    if (!SELF) ring_start();
     // the chain stored behind this one (the layer's feed-forward chain) runs right after this launch: warm its streams as the
     // st_row_chain launch this stage replaces did (the workgroups of an XCD deal the 128-byte lines among their threads)
     int touched[TOUCH];
-    {
+    auto touch_all = [&]() {
       const int nlines = NW * (f.wave_frags + f.next_frags) * 8;
       const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
       const char* sb = reinterpret_cast<const char*>(f.wfrag);
@@ -132,8 +150,115 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
         touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    {
+    };
+    if (!SELF) touch_all();
+    const bool writer = h == 0;                     // one of the four heads' workgroups stores the stage's outputs
+    if (SELF) {
+      TileRegs<1> rr;
+      tile_load(c, f.R, f.ldr, rr);
+      if (wave < a.H) {      // ---- causal self-attention of head `wave` for the 32 queries: attn_fwd_kernel<64, *, 1, true>'s arithmetic
+        const int hs = wave;
+        const Drop sdr = make_drop(sa.drop);
+        const int sbh = b * a.H + hs;
+        const size_t srow = qrow0 + min(q, lq - 1);
+        bf16x8 sq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sq[t] = *reinterpret_cast<const bf16x8*>(sa.Q + srow * sa.ld + hs * DK + t * 16 + hi * 8);
+        bf16* vp = reinterpret_cast<bf16*>(xch) + 2 * TE + wave * 64 * XVS;        // this wave's 64-key V patch (f1 and behind)
+        f32x16 s2[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const size_t krow = qrow0 + min(kb * 32 + r32, lq - 1);               // keys past the end: clamped (finite), masked below
+          bf16x8 kf[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(sa.K + krow * sa.ld + hs * DK + t * 16 + hi * 8);
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) {
+            const int id = l + p2 * 64;
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(sa.V + (qrow0 + min(kb * 32 + (id >> 3), lq - 1)) * sa.ld + hs * DK + (id & 7) * 8);
+            *reinterpret_cast<bf16x8*>(vp + (kb * 32 + (id >> 3)) * XVS + (id & 7) * 8) = vv;
+          }
+          s2[kb] = zero16();
+#pragma unroll
+          for (int t = 0; t < 4; ++t) s2[kb] = mfma32(kf[t], sq[t], s2[kb]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + acc_row(r, hi);
+            if (key >= lq || key > q) s2[kb][r] = -INFINITY;
+          }
+        }
+        asm volatile("" ::: "memory");
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s2[kb][r]);
+        mx = fmaxf(mx, wave_xor32(mx));
+        const float sm = mx * c2;                     // (key 0 is visible to every query: finite)
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s2[kb][r], c2, -sm));
+            s2[kb][r] = pv;
+            psum += pv;
+          }
+        if (SDROP) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            bool keep[16];
+            keep16<true>(sdr, sbh, q, kb * 32, hi, keep);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2[kb][r] = keep[r] ? s2[kb][r] : 0.f;
+          }
+        }
+        f32x16 so[2];
+        so[0] = zero16();
+        so[1] = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const bf16x8 pf = pack_acc8(s2[kb], 8 * hf);
+            bf16x8 pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pl[j] = (bf16)(s2[kb][8 * hf + j] - (float)pf[j]);
+            const int base = kb * 32 + 16 * hf + 4 * hi;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const bf16x8 vf = frag_tr(vp, XVS, d * 32, base, base + 8);
+              so[d] = mfma32(vf, pf, so[d]);
+              so[d] = mfma32(vf, pl, so[d]);
+            }
+          }
+        const float ltot = psum + wave_xor32(psum);
+        const float inv = ltot > 0.f ? (SDROP ? sdr.scale : 1.f) / ltot : 0.f;
+        if (writer && q < lq && hi == 0) sa.lse[(size_t)hs * a.q_rows_total + qrow0 + q] = sm + log2f(ltot);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xv = __fmul_rn(so[d][4 * g + e], inv);
+              vh[e] = (bf16)xv;
+              vl[e] = (bf16)__fsub_rn(xv, (float)vh[e]);
+            }
+            const int col = hs * DK + d * 32 + 8 * g + 4 * hi;
+            *reinterpret_cast<bf16x4*>(cur + r32 * AS + col) = vh;             // the chain stage's operand tile
+            if (writer && q < lq) {
+              *reinterpret_cast<bf16x4*>(sa.O + (qrow0 + q) * sa.ldo + col) = vh;
+              if (sa.Ores) *reinterpret_cast<bf16x4*>(sa.Ores + (qrow0 + q) * sa.ldo + col) = vl;
+            }
+          }
+      }
+      tile_store(c, rr, f0);
+      fetch_all();
+      ring_start();
+      touch_all();
+    } else {
       TileRegs<1> ra, rr;
       tile_load(c, f.A, f.lda, ra);
       tile_load(c, f.R, f.ldr, rr);
@@ -141,7 +266,6 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
       tile_store(c, rr, f0);
     }
     const Drop off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
-    const bool writer = h == 0;                     // one of the four heads' workgroups stores the stage's outputs
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
@@ -283,9 +407,9 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
     bf16x4 vh, vl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float xv = val[e] * inv;
+      const float xv = __fmul_rn(val[e], inv);
       vh[e] = (bf16)xv;
-      vl[e] = (bf16)(xv - (float)vh[e]);
+      vl[e] = (bf16)__fsub_rn(xv, (float)vh[e]);
     }
     const int col = (wave >> 2) * 32 + 8 * (wave & 3) + 4 * hi;
     *reinterpret_cast<bf16x4*>(patch + r32 * DK + col) = vh;
@@ -307,14 +431,19 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
 
 extern "C" int st_attn_xs_tile_rows() { return XQ; }
 
-extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args_, int grid_x, int drop, const void* f1_) {
+extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args_, int grid_x, int drop, const void* f1_, const void* self_) {
   const AttnArgs& a = *static_cast<const AttnArgs*>(args_);
   dim3 grid(grid_x), block(512);
   XF1Args f = {};
+  XSelfArgs sa = {};
   if (f1_) f = *static_cast<const XF1Args*>(f1_);
+  if (self_) sa = *static_cast<const XSelfArgs*>(self_);
+  const bool sdrop = self_ && sa.drop.seed != nullptr && sa.drop.thresh > 0;
 #define ST_XS(DR, PSS) \
-  do { if (f1_) hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, true>), grid, block, 0, stream, a, f); \
-       else hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, false>), grid, block, 0, stream, a, f); } while (0)
+  do { if (self_ && sdrop) hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, true, true, true>), grid, block, 0, stream, a, f, sa); \
+       else if (self_) hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, true, true, false>), grid, block, 0, stream, a, f, sa); \
+       else if (f1_) hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, true>), grid, block, 0, stream, a, f, sa); \
+       else hipLaunchKernelGGL((attn_xs_fwd_kernel<DR, PSS, false>), grid, block, 0, stream, a, f, sa); } while (0)
   if (drop && a.psplit) ST_XS(true, true);
   else if (drop) ST_XS(true, false);
   else if (a.psplit) ST_XS(false, true);
@@ -322,6 +451,16 @@ extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args_, int 
 #undef ST_XS
   return (int)hipGetLastError();
 }
+
+extern "C" void st_attn_xs_self_args(void* out, const void* Q, const void* K, const void* V, int ld, void* O, void* Ores, int ldo,
+                                     float* lse, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale) {
+  XSelfArgs s;
+  s.Q = (const bf16*)Q; s.K = (const bf16*)K; s.V = (const bf16*)V; s.ld = ld; s.O = (bf16*)O; s.Ores = (bf16*)Ores; s.ldo = ldo; s.lse = lse;
+  const bool on = drop_seed != nullptr && drop_thresh > 0;
+  s.drop.seed = on ? drop_seed : nullptr; s.drop.salt = drop_salt; s.drop.thresh = on ? drop_thresh : 0; s.drop.scale = on ? drop_scale : 1.f;
+  *static_cast<XSelfArgs*>(out) = s;
+}
+extern "C" int st_attn_xs_self_args_size() { return (int)sizeof(XSelfArgs); }
 
 // the F1 stage's arguments as st_attn.hip hands them over (the struct is local to this translation unit)
 extern "C" void st_attn_xs_f1_args(void* out, const void* A, int lda, const void* R, int ldr, const void* wfrag, int n_blocks,

@@ -426,8 +426,7 @@ class DecoderChains:
             # ---- causal self-attention (Attention.py:82-90)
             a.qkv, a.drop = qkv, sa._drop(dev)
             a.ctx, a.lse, a.ores = EZ(M, d, t_rows), E(H * M, dt=F32), (EZ(M, d, t_rows) if need_bwd else None)
-            nv.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a.ctx, a.lse, t_rows.off, t_rows.len, t_rows.off, t_rows.len,
-                        H, t_rows.max_len, True, scale, work=work_self, drop=a.drop, max_k=t_rows.max_len, ores=a.ores)
+            # (launched below, together with the chain stage behind it and the encoder-decoder attention: nv.attn_sf1_fwd)
             # ---- F1: its output_linear + residual + LayerNorm, the next attention's q
             # (nv.attn_f1_fwd writes utterance rows only - the chain launch it replaces wrote every row of the matrix: on
             # padded / bucket layouts the rows outside the utterances must read as zeros, they are operands of the row-wise
@@ -437,14 +436,14 @@ class DecoderChains:
                 a.xhat = EZ(M, d, t_rows)
                 a.rstd = E(M, dt=F32) if t_rows.dense else torch.zeros(M, dtype=F32, device=dev)
             b.qkv = EZ(M, d, t_rows)
-            # ---- and the encoder-decoder attention over this layer's column block of kv: ONE launch where the few-queries
-            #      kernel serves the shape (nv.attn_f1_fwd; the F1 chain + the attention kernel otherwise)
+            # ---- the self-attention, that stage and the encoder-decoder attention over this layer's column block of kv: ONE launch
+            #      where the few-queries kernel serves the shape (nv.attn_sf1_fwd; the three launches otherwise)
             b.kvbuf, b.drop = kv[:, l * 2 * d:(l + 1) * 2 * d], ca._drop(dev)
             b.ctx, b.lse, b.ores = EZ(M, d, t_rows), E(H * M, dt=F32), (EZ(M, d, t_rows) if need_bwd else None)
-            nv.attn_f1_fwd(a.ctx, self.f1[l], (x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
-                           (1, ca._st.b_q, b.qkv), b.kvbuf[:, :d], b.kvbuf[:, d:], b.ctx, b.lse, t_rows.off, t_rows.len,
-                           in_rows.off, in_rows.len, H, t_rows.max_len, scale, work=work_cross, drop=b.drop,
-                           max_k=in_rows.max_len, ores=b.ores)
+            nv.attn_sf1_fwd(qkv, a.ctx, a.lse, (x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
+                            (1, ca._st.b_q, b.qkv), self.f1[l], b.kvbuf[:, :d], b.kvbuf[:, d:], b.ctx, b.lse, t_rows.off, t_rows.len,
+                            in_rows.off, in_rows.len, H, t_rows.max_len, scale, work_self=work_self, work=work_cross,
+                            drop_self=a.drop, drop=b.drop, max_k=in_rows.max_len, ores_self=a.ores, ores=b.ores)
             # ---- F2: its output_linear + residual + LayerNorm, the feed-forward sublayer, the next layer's q|k|v
             b.out, f.out, f.h = E(M, d), E(M, d), E(M, ff._st.d_ff)
             if need_bwd:

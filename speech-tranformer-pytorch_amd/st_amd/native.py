@@ -67,6 +67,11 @@ SIGNATURES = {
                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int,
                        _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                        _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
+    "st_attn_sf1_fwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int,
+                        _c_float, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                        _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -684,6 +689,57 @@ def attn_f1_fwd(A, chain, pre, post, K, V, O, lse, q_off, q_len, k_off, k_len, n
                                q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), M,
                                float(scale), *_work(work), *_drop(drop))
     _check(rc, "st_attn_f1_fwd")
+    return O
+
+
+def attn_sf1_fwd(qkv, Os, lses, pre, post, chain, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, scale, work_self=None,
+                 work=None, drop_self=None, drop=None, max_k=0, ores_self=None, ores=None, eps=1e-6):
+    """A decoder layer's causal self-attention, the chain stage behind it and its decoder-encoder attention as ONE launch where the
+    few-queries kernel serves the shape (st_attn_sf1_fwd), else as the three launches it stands for:
+        attn_fwd(q, k, v of qkv, Os, lses, ..., causal=True)                          (keys = the utterance's own target positions)
+        row_chain(Os, chain, pre=pre, post=post)
+        attn_fwd(post[2], K, V, O, lse, ..., causal=False)
+    qkv [M, 3 d]: the layer's q | k | v projection; pre / post as attn_f1_fwd."""
+    R, bo, g0, be0, out0, xhat0, rstd0 = pre
+    pb, bq, Qout = post
+    M, d3 = qkv.shape
+    d = d3 // 3
+    d_k = d // n_head
+    if (pb != 1 or chain.n_blocks != 2 or n_head > 8 or not _f1_applicable(int(d), int(d_k), int(max_q), int(max_k))
+            or (drop_self is not None and drop is not None and drop_self.thresh and drop.thresh
+                and drop_self.seed.data_ptr() != drop.seed.data_ptr())):
+        attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], Os, lses, q_off, q_len, q_off, q_len, n_head, max_q, True, scale,
+                 work=work_self, drop=drop_self, max_k=max_q, ores=ores_self)
+        return attn_f1_fwd(Os, chain, pre, post, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, scale, work=work, drop=drop,
+                           max_k=max_k, ores=ores, eps=eps)
+    for t, nm in ((qkv, "qkv"), (Os, "Os"), (R, "R"), (out0, "out0"), (Qout, "Qout"), (K, "K"), (V, "V"), (O, "O")):
+        _mat(t, BF16, nm)
+    _vec(bo, F32, d, "bo"), _vec(g0, F32, d, "g0"), _vec(be0, F32, d, "be0"), _vec(bq, F32, d, "bq")
+    assert out0.stride(0) == d and (xhat0 is None or xhat0.stride(0) == d) and R.shape[0] >= M and Qout.shape == (M, d) and Os.shape == (M, d)
+    assert rstd0 is None or (rstd0.dtype == F32 and rstd0.numel() >= M)
+    if chain.stream.numel() != 8 * (2 * 16 + wfrag_depth()) * 512 or chain.stream.dtype != BF16:
+        raise ValueError("attn_sf1_fwd: the fragment stream does not match a two-block chain")
+    for o_, r_, nm in ((O, ores, "ores"), (Os, ores_self, "ores_self")):
+        if r_ is not None:
+            _mat(r_, BF16, nm)
+            if r_.stride(0) != o_.stride(0) or r_.shape != o_.shape:
+                raise ValueError("attn_sf1_fwd: %s must have its output's shape and stride" % nm)
+    B = q_off.numel()
+    for t, nm in ((q_off, "q_off"), (q_len, "q_len"), (k_off, "k_off"), (k_len, "k_len")):
+        _vec(t, I32, B, nm)
+    _vec(lse, F32, n_head * M, "lse"), _vec(lses, F32, n_head * M, "lses")
+    sd, cd = _drop(drop_self), _drop(drop)
+    seed = sd[0] if sd[0] is not None else cd[0]
+    _tag("attn_fwd", n_head, d_k, 0, q_len, k_len, io=(qkv, Os, ores_self, lses, R, out0, xhat0, rstd0, Qout, K, V, O, ores, lse))
+    q_, k_, v_ = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    rc = load().st_attn_sf1_fwd(_stream(), q_.data_ptr(), k_.data_ptr(), v_.data_ptr(), qkv.stride(0), Os.data_ptr(), _p(ores_self),
+                                Os.stride(0), lses.data_ptr(), sd[1], sd[2], sd[3], R.data_ptr(), R.stride(0), chain.stream.data_ptr(), 2,
+                                int(chain.next_blocks), float(eps), bo.data_ptr(), g0.data_ptr(), be0.data_ptr(), out0.data_ptr(),
+                                _p(xhat0), _p(rstd0), bq.data_ptr(), Qout.data_ptr(), Qout.stride(0), K.data_ptr(), K.stride(0),
+                                V.data_ptr(), V.stride(0), O.data_ptr(), O.stride(0), _p(ores), lse.data_ptr(), q_off.data_ptr(),
+                                q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), M,
+                                float(scale), *_work(work), seed, cd[1], cd[2], cd[3])
+    _check(rc, "st_attn_sf1_fwd")
     return O
 
 

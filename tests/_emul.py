@@ -339,6 +339,16 @@ def attn_f1_fwd(A, chain, pre, post, K, V, O, lse, q_off, q_len, k_off, k_len, n
                     max_k=max_k, ores=ores)
 
 
+def attn_sf1_fwd(qkv, Os, lses, pre, post, chain, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, scale, work_self=None,
+                 work=None, drop_self=None, drop=None, max_k=0, ores_self=None, ores=None, eps=1e-6):
+    """st_attn_sf1_fwd = the three launches it stands for."""
+    d = qkv.shape[1] // 3
+    attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], Os, lses, q_off, q_len, q_off, q_len, n_head, max_q, True, scale,
+             work=work_self, drop=drop_self, max_k=max_q, ores=ores_self)
+    return attn_f1_fwd(Os, chain, pre, post, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, scale, work=work, drop=drop,
+                       max_k=max_k, ores=ores, eps=eps)
+
+
 def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
              parts=3, work_q=None, work_k=None, drop=None):
     rows = Q.shape[0]
@@ -520,7 +530,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_bwd", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 

@@ -862,6 +862,64 @@ def test_attn_f1_fwd_equals_row_chain_plus_attn_fwd(case):
     assert float(b["O"].float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize("case", ["train", "train+drop", "short-keys"])
+def test_attn_sf1_fwd_equals_the_three_launches(case):
+    """st_attn_sf1_fwd (a decoder layer's causal self-attention, the chain stage behind it and the decoder-encoder attention as one
+    launch) against st_attn_fwd(causal) + st_row_chain + st_attn_fwd: every tensor bit for bit (the fused self-attention repeats
+    attn_fwd_kernel's arithmetic in its order) except the self-attention's bf16 residual, which agrees to its own precision.  'short-keys' does not qualify: the wrapper falls back to the three launches."""
+    from st_amd import chains
+    from st_amd.functional import Rows, attn_work
+    d, H = 256, 4
+    gen = torch.Generator().manual_seed(12)
+    B = 9
+    if case == "short-keys":
+        q_len, k_len = torch.randint(3, 50, (B,), generator=gen), torch.randint(40, 200, (B,), generator=gen)
+    else:
+        q_len, k_len = torch.randint(1, 64, (B,), generator=gen), torch.randint(260, 1000, (B,), generator=gen)
+        q_len[0], q_len[1], q_len[2], k_len[0] = 64, 33, 32, 999
+    q_rows, k_rows = Rows.packed(q_len, "cuda"), Rows.packed(k_len, "cuda")
+    M, Mk = int(q_len.sum()), int(k_len.sum())
+    wo, wq = cu(g(d, d, seed=1, scale=d ** -0.5)), cu(g(d, d, seed=2, scale=d ** -0.5))
+    bo, bq = cu(g(d, seed=3, dtype=F32)), cu(g(d, seed=4, dtype=F32))
+    g0, be0 = cu(g(d, seed=5, dtype=F32) * 0.2 + 1), cu(g(d, seed=6, dtype=F32) * 0.1)
+    qkv, R, kv = cu(g(M, 3 * d, seed=7)), cu(g(M, d, seed=8)), cu(g(Mk, 2 * d, seed=9))
+    cs = chains.ChainSet("cuda")
+    cid = cs.add(chains.blocks_of(wo) + chains.blocks_of(wq))
+    cs.finalize().rebuild()
+    ch = cs.chain(cid)
+    d_self = _drops(41, 0.1)[0] if "drop" in case else None
+    d_cross = nv.Drop(d_self.seed, 42, 0.1) if "drop" in case else None
+    w_self = attn_work(q_rows, q_rows, True, d // H, H)[0]
+    w_cross = attn_work(q_rows, k_rows, False, d // H, H)[0]
+    scale, mq, mk = (d // H) ** -0.5, int(q_len.max()), int(k_len.max())
+
+    def bufs():
+        E = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device="cuda")
+        return dict(ctx=E(M, d), ores_s=E(M, d), lse_s=E(H * M, dt=F32), out=E(M, d), xhat=E(M, d), rstd=E(M, dt=F32), q=E(M, d),
+                    O=E(M, d), ores=E(M, d), lse=E(H * M, dt=F32))
+
+    a, b = bufs(), bufs()
+    nv.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a["ctx"], a["lse_s"], q_rows.off, q_rows.len, q_rows.off, q_rows.len, H, mq,
+                True, scale, work=w_self, drop=d_self, max_k=mq, ores=a["ores_s"])
+    nv.row_chain(a["ctx"], ch, pre=(R, bo, g0, be0, a["out"], a["xhat"], a["rstd"]), post=(1, bq, a["q"]))
+    nv.attn_fwd(a["q"], kv[:, :d], kv[:, d:], a["O"], a["lse"], q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, mq, False, scale,
+                work=w_cross, drop=d_cross, max_k=mk, ores=a["ores"])
+    nv.attn_sf1_fwd(qkv, b["ctx"], b["lse_s"], (R, bo, g0, be0, b["out"], b["xhat"], b["rstd"]), (1, bq, b["q"]), ch, kv[:, :d], kv[:, d:],
+                    b["O"], b["lse"], q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, mq, scale, work_self=w_self, work=w_cross,
+                    drop_self=d_self, drop=d_cross, max_k=mk, ores_self=b["ores_s"], ores=b["ores"])
+    torch.cuda.synchronize()
+    for n in a:
+        if n == "ores_s":
+            # the self-attention's bf16 RESIDUAL of the context (what bf16 rounding dropped: O + Ores = the fp32 context to ~16 bits):
+            # the fused stage reproduces the context and the LSE bit for bit, its fp32 context agrees to a few 1e-6 relative (it shows
+            # only here) - well inside the 2^-16 the pair promises
+            err = (a[n].float() - b[n].float()).abs()
+            assert bool((err <= 2.0 ** -15 * a["ctx"].float().abs() + 1e-9).all()), "attn_sf1_fwd %s: ores_s off by %.3e" % (case, float(err.max()))
+            continue
+        assert torch.equal(a[n], b[n]), "attn_sf1_fwd %s: %s differs (max |d| %.3e)" % (case, n, (a[n].float() - b[n].float()).abs().max().item())
+    assert float(b["O"].float().abs().sum()) > 0 and float(b["ctx"].float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail",
                                      "head0+ffn+tail+drop"])
