@@ -303,9 +303,12 @@ int st_embed_step(st_stream_t stream, const long long* tokens, const float* emb,
 /* Decode-shaped self-attention of one beam-search step (Decode.py:96-98 with a KV cache): one query per hypothesis.
    qkv bf16 [n, ldq] = this step's q | k | v (3 * H * 64 columns); cache bf16 [n][S][2 * H * 64] of ONE layer; appends k | v
    at position *step (device scalar) and writes ctx [n, ldc] = softmax(q K^T * scale) V over positions 0 .. *step.
-   d_k = 64, S <= 128. */
-int st_decode_self_attn(st_stream_t stream, const void* qkv, int ldq, void* cache, const long long* step, void* ctx, int ldc,
-                        int n, int S, int H, int d_k, float scale);
+   d_k = 64, S <= 128.  `anc`: NULL, or the lineage table int32 [n][S] that st_beam_advance maintains - position p < *step of
+   hypothesis i is then read from cache row anc[i][p] (the slot the ancestor that produced it sat in), the step's own K | V
+   still goes to row i: the cache rows never move and st_cache_reorder is not needed.  Every entry of the table must be a
+   valid row at all times (initialise it to anc[i][p] = i). */
+int st_decode_self_attn(st_stream_t stream, const void* qkv, int ldq, void* cache, const long long* step, const int* anc,
+                        void* ctx, int ldc, int n, int S, int H, int d_k, float scale);
 
 /* Beam.advance (Beam.py:43-74) for all B utterances in one launch, from the raw vocabulary logits f32 [B * beam, ldl] (V
    valid columns): log-softmax per hypothesis (Decode.py:102), the `beam` best of score + log-probability over beam x V
@@ -313,10 +316,16 @@ int st_decode_self_attn(st_stream_t stream, const void* qkv, int ldq, void* cach
    `eos` (Beam.py:70-72; a done utterance is frozen: identity back-pointers, scores / tokens unchanged).  Device state,
    updated in place: scores f32 [B, beam], tokens i64 [B * beam], done u8 [B], lengths i64 [B], the trellis hist_scores f32 /
    back i64 / toks i64 [S, B, beam] at row *step (device scalar), order i64 [B * beam] = the cache rows the hypotheses
-   inherit (input of st_cache_reorder).  beam <= 16. */
+   inherit (input of st_cache_reorder).  beam <= 16.  `work`: NULL, or device scratch of B * beam * beam (+ 1 with `step_next`) 8-byte words - with
+   it (and V <= 5120) the step runs as two launches over B * beam workgroups (the `beam` best of every hypothesis row, then
+   one wave per utterance merges them) instead of one workgroup per utterance; same results.  `anc`: NULL, or the lineage
+   table int32 [B * beam][S] of st_decode_self_attn (needs `work`, S <= 128): the hypothesis placed in slot s takes over
+   positions 0 .. *step - 1 of its origin's row of the table and gets the origin's slot as position *step.  `step_next`:
+   NULL, or `step` itself (needs `work`, which then holds one more word - a ticket counter that is zero before the first
+   call): the launch also advances the device step counter, *step += 1, once every utterance has used the old value. */
 int st_beam_advance(st_stream_t stream, const float* logits, int ldl, int V, int beam, int B, const long long* step, int eos,
                     float* scores, long long* tokens, unsigned char* done, long long* lengths, float* hist_scores,
-                    long long* back, long long* toks, long long* order);
+                    long long* back, long long* toks, long long* order, void* work, int* anc, int S, long long* step_next);
 
 /* Beam-search decode (transformer/Decode.py with a KV cache): cache bf16 [L][n][S][W]; for every layer, position
    t <= *step (device scalar) and utterance (beam consecutive hypothesis rows), row u*beam+s <- row order[u*beam+s]

@@ -667,6 +667,232 @@ __global__ __launch_bounds__(512) void beam_advance_kernel(const float* __restri
   }
 }
 
+// The same step as TWO launches over more of the chip (the kernel above keeps one compute unit per utterance busy for 43 us:
+// ~20 dependent batches of loads that 32 workgroups cannot hide, then ~12 vector instructions per candidate on one CU):
+//   (1) beam_row_best_kernel - one workgroup per HYPOTHESIS row (B * beam of them), the row's V logits in registers with
+//       every load issued before the first use: log-sum-exp, then the row's `beam` best candidates score + log-probability
+//       (the utterance's winners are among them), as 64-bit keys in `work`;
+//   (2) beam_merge_kernel - one wave per utterance: the `beam` best of its beam x beam keys, and the state update.
+// Wave reductions run on DPP (row butterflies + row_bcast), not ds_bpermute.  Across lanes candidates are ordered through
+// one 64-bit key (monotone image of the score in the high word, 0x7fffffff - flat index in the low word: larger score
+// first, lower flat index on ties - the order of beam_before); inside a thread the scan runs in increasing flat index with
+// strict comparisons, which is the same order.
+__device__ __forceinline__ unsigned long long beam_key(float x, int flat) {
+  const unsigned u = __float_as_uint(x);
+  const unsigned m = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)m << 32) | (unsigned)(0x7fffffff - flat);
+}
+__device__ __forceinline__ float beam_key_value(unsigned long long k) {
+  const unsigned m = (unsigned)(k >> 32);
+  return __uint_as_float((m & 0x80000000u) ? (m & 0x7fffffffu) : ~m);
+}
+__device__ __forceinline__ int beam_key_flat(unsigned long long k) { return 0x7fffffff - (int)(unsigned)(k & 0xffffffffu); }
+
+// DPP moves: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140 (after these four a
+// butterfly has every lane of a 16-lane row hold the row's result), row_bcast15 = 0x142 (rows 1, 3 take lane 15 of rows 0, 2),
+// row_bcast31 = 0x143 (rows 2, 3 take lane 31): the wave's result is in lane 63.  Lanes a row mask leaves out keep `old`.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_f(float old, float v) { return __int_as_float(dpp_i<CTRL, ROWS>(__float_as_int(old), __float_as_int(v))); }
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_f<0x141, 0xf>(v, v));
+  return fmaxf(v, dpp_f<0x140, 0xf>(v, v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1, 0xf>(0.f, v);
+  v += dpp_f<0x4E, 0xf>(0.f, v);
+  v += dpp_f<0x141, 0xf>(0.f, v);
+  return v + dpp_f<0x140, 0xf>(0.f, v);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {       // -> lane 63's value, uniform
+  v = row16_max(v);
+  v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum(v);
+  v += dpp_f<0x142, 0xa>(0.f, v);
+  v += dpp_f<0x143, 0xc>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned long long key_max_step(unsigned long long k) {
+  const unsigned lo = (unsigned)dpp_i<CTRL, ROWS>((int)(unsigned)k, (int)(unsigned)k);
+  const unsigned hi = (unsigned)dpp_i<CTRL, ROWS>((int)(unsigned)(k >> 32), (int)(unsigned)(k >> 32));
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {    // uniform
+  k = key_max_step<0xB1, 0xf>(k);
+  k = key_max_step<0x4E, 0xf>(k);
+  k = key_max_step<0x141, 0xf>(k);
+  k = key_max_step<0x140, 0xf>(k);
+  k = key_max_step<0x142, 0xa>(k);
+  k = key_max_step<0x143, 0xc>(k);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int NU>
+__global__ __launch_bounds__(256) void beam_row_best_kernel(const float* __restrict__ logits, int ldl, int V, int beam,
+                                                            const float* __restrict__ scores, unsigned long long* __restrict__ work) {
+  constexpr int NW = 4;
+  __shared__ float s_red[2][NW];
+  __shared__ unsigned long long s_cand[NW * 16];
+  const int row = blockIdx.x, j = row % beam, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* lg = logits + (size_t)row * ldl;
+  float x[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) x[u] = lg[u * 256 + tid < V ? u * 256 + tid : 0];      // (no branch around any load)
+  const float sc = scores[row];
+  if (tid < NW * 16) s_cand[tid] = 0ull;
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    if (u * 256 + tid >= V) x[u] = -INFINITY;
+  // ---- log-sum-exp of the row
+  float m = x[0];
+#pragma unroll
+  for (int u = 1; u < NU; ++u) m = fmaxf(m, x[u]);
+  m = wave_max_dpp(m);
+  if (lane == 0) s_red[0][wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+  float sm = 0.f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) sm += __expf(x[u] - m);
+  sm = wave_sum_dpp(sm);
+  if (lane == 0) s_red[1][wave] = sm;
+  __syncthreads();
+  sm = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+  const float base = sc - (m + __logf(sm));                   // score - lse, as the kernel above forms it
+  // ---- the thread's two best candidates (first) / its two best after `lim` in the result order (refill), as keys (0 = none)
+  unsigned long long k0, k1;
+  auto local_best = [&](unsigned long long lim, bool first) {
+    const float limv = beam_key_value(lim);
+    const int limf = beam_key_flat(lim);
+    const float nan = __int_as_float(0x7fc00000);
+    float v0 = nan, v1 = nan;             // (NaN = empty: !(c <= NaN) holds for every c)
+    int e0 = -1, e1 = -1;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int col = u * 256 + tid;
+      const float c = base + x[u];
+      bool ok = col < V && !(c <= v1);
+      if (!first) ok = ok && (c < limv || (c == limv && j * V + col > limf));
+      const bool top = !(c <= v0);
+      v1 = ok ? (top ? v0 : c) : v1;
+      e1 = ok ? (top ? e0 : col) : e1;
+      v0 = (ok && top) ? c : v0;
+      e0 = (ok && top) ? col : e0;
+    }
+    k0 = e0 >= 0 ? beam_key(v0, j * V + e0) : 0ull;
+    k1 = e1 >= 0 ? beam_key(v1, j * V + e1) : 0ull;
+  };
+  local_best(0ull, true);
+  // ---- every wave: its `beam` best, best first (shuffles only, no barrier)
+  int head = 0;
+  unsigned long long w = wave_max_key(k0);
+  for (int r = 0; r < beam && w != 0ull; ++r) {
+    if (lane == 0) s_cand[wave * 16 + r] = w;
+    const unsigned long long mine = head == 0 ? k0 : k1;
+    if (mine == w && ++head == 2) {        // (keys are distinct: one lane advances; past its second candidate it rescans)
+      local_best(w, false);
+      head = 0;
+    }
+    w = wave_max_key(head == 0 ? k0 : k1);
+  }
+  __syncthreads();
+  // ---- wave 0: the row's `beam` best of the four lists
+  if (wave == 0) {
+    unsigned long long c = s_cand[lane];
+    for (int r = 0; r < beam; ++r) {
+      const unsigned long long best = wave_max_key(c);
+      if (c == best) c = 0ull;
+      if (lane == 0) work[(size_t)row * beam + r] = best;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void beam_merge_kernel(const unsigned long long* __restrict__ work, int V, int beam, int B,
+                                                        const long long* __restrict__ step_p, int eos, float* scores,
+                                                        long long* tokens, unsigned char* done, long long* lengths,
+                                                        float* hist_scores, long long* back, long long* toks, long long* order,
+                                                        int* anc, int S, long long* step_next, unsigned* ticket) {
+  __shared__ int s_anc[16][128];
+  const int b = blockIdx.x, lane = threadIdx.x, n = beam * beam;          // n <= 256
+  const long long step = *step_p;
+  unsigned long long c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = i * 64 + lane < n ? work[(size_t)b * n + i * 64 + lane] : 0ull;
+  const float old = lane < beam ? scores[b * beam + lane] : 0.f;
+  // (the utterance's rows of the lineage table, asked for before the merge rounds: one memory round trip, hidden)
+  const int t = (int)step;
+  int r[16][2];
+  if (anc) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (s < beam && lane + 64 * h < t) r[s][h] = anc[((size_t)b * beam + s) * S + lane + 64 * h];
+  }
+  float bestv = 0.f;
+  int flat = 0;
+  for (int r = 0; r < beam; ++r) {
+    const unsigned long long m01 = c[0] > c[1] ? c[0] : c[1], m23 = c[2] > c[3] ? c[2] : c[3];
+    const unsigned long long best = wave_max_key(m01 > m23 ? m01 : m23);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c[i] == best) c[i] = 0ull;
+    if (lane == r) { bestv = beam_key_value(best); flat = beam_key_flat(best); }
+  }
+  // ---- the lineage table of st_decode_self_attn: the new hypothesis in slot s inherits positions 0 .. step - 1 from its
+  //      origin and finds position `step` in the origin's slot (a done utterance: the identity)
+  if (anc) {
+    const bool live_u = !done[b];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (s < beam && lane + 64 * h < t) s_anc[s][lane + 64 * h] = r[s][h];
+    __syncthreads();
+    for (int s = 0; s < beam; ++s) {
+      const int o = live_u ? __shfl(flat, s, 64) / V : s;
+      for (int p = lane; p < t; p += 64) anc[((size_t)b * beam + s) * S + p] = s_anc[o][p];
+      if (lane == 0) anc[((size_t)b * beam + s) * S + t] = b * beam + o;
+    }
+  }
+  // ---- the state update (one lane per beam slot), as in beam_advance_kernel
+  if (lane < beam) {
+    const int s = lane;
+    const bool live = !done[b];
+    const size_t at = ((size_t)step * B + b) * beam + s;
+    const long long origin = live ? flat / V : s, token = flat % V;
+    hist_scores[at] = old;
+    back[at] = origin;
+    toks[at] = token;
+    order[b * beam + s] = origin + (long long)b * beam;
+    if (live) {
+      scores[b * beam + s] = bestv;
+      tokens[b * beam + s] = token;
+      if (s == 0) {
+        lengths[b] += 1;
+        if (token == eos) done[b] = 1;
+      }
+    }
+  }
+  // ---- the step counter: every workgroup has read it by the time it draws its ticket, the last one to draw advances it
+  if (step_next && lane == 0) {
+    if (atomicAdd(ticket, 1u) == (unsigned)(B - 1)) {
+      *ticket = 0u;
+      *step_next = step + 1;
+    }
+  }
+}
+
 // One beam-search step's decoder input: out[i] = bf16(emb[tokens[i]] + pe[*step])   (Models.py:84,87 with repair R3)
 __global__ __launch_bounds__(256) void embed_step_kernel(const long long* __restrict__ tokens, const float* __restrict__ emb, int V,
                                                          const float* __restrict__ pe, const long long* __restrict__ step_p,
@@ -694,46 +920,85 @@ extern "C" int st_embed_step(hipStream_t stream, const long long* tokens, const 
 }
 
 // Decode-shaped self-attention (Decode.py:96-98 with a KV cache): one wave per (hypothesis, head), ONE query each.
-// Appends the step's K | V (columns [d, 3d) of qkv) to cache [n][S][2d] at position t = *step and attends over positions
-// 0 .. t: scores on the VALU (lane = key, 64 keys per pass), softmax by wave reductions, P V with lane = value column.
-// d_k = 64.  Replaces cache.index_copy_ + st_attn_fwd (whose 128-query tile holds one query per hypothesis here).
+// Appends the step's K | V (columns [d, 3d) of qkv) to cache [n][S][2d] at position t = *step (row = the hypothesis' own
+// slot) and attends over positions 0 .. t: scores on the VALU (lane = key, 64 keys per pass), softmax by wave reductions,
+// P V with lane = value column.  d_k = 64.  Replaces cache.index_copy_ + st_attn_fwd (whose 128-query tile holds one query
+// per hypothesis here).
+// `anc` (optional, int32 [n][S]): the lineage table - position p < t of hypothesis i is read from cache row anc[i][p], the
+// slot the ancestor that produced it sat in (st_beam_advance maintains the table; every entry is a valid row at all times) -
+// so the cache rows never move (without it: own rows, and st_cache_reorder permutes the cache after every step).
+// A launch here is a chain of memory round trips with nothing to hide behind, so everything that can be asked for early
+// is: the step counter, the lineage entries and q first, then the key rows and ALL value rows of the first 64 positions
+// (registers), and only then the arithmetic.
 __global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16* __restrict__ qkv, int ldq, bf16* cache, const long long* __restrict__ step_p,
-                                                               bf16* __restrict__ ctx, int ldc, int n, int S, int H, float scale) {
+                                                               const int* __restrict__ anc, bf16* __restrict__ ctx, int ldc, int n, int S, int H,
+                                                               float scale) {
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wave, i = item / H, h = item % H;
   if (i >= n) return;
   const int d = H * 64, t = (int)*step_p;
   const bf16* row = qkv + (size_t)i * ldq;
-  bf16* cbase = cache + (size_t)i * S * 2 * d;
+  int a0 = i, a1 = i;                     // cache rows of positions l and l + 64
+  if (anc) {
+    a0 = anc[(size_t)i * S + min(l, S - 1)];
+    a1 = anc[(size_t)i * S + min(l + 64, S - 1)];
+  }
   // the step's K | V into the cache (lanes 0-7: K, 8-15: V; 16 bytes each)
   if (l < 16) {
     const int part = l >> 3, c = (l & 7) * 8;
-    *reinterpret_cast<bf16x8*>(cbase + (size_t)t * 2 * d + part * d + h * 64 + c) =
+    *reinterpret_cast<bf16x8*>(cache + ((size_t)i * S + t) * 2 * d + part * d + h * 64 + c) =
         *reinterpret_cast<const bf16x8*>(row + d + part * d + h * 64 + c);
   }
   // q (64 values) in registers of every lane (same address for all lanes: one broadcast load per 16 bytes)
-  float q[64];
+  bf16x8 qraw[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + h * 64 + c * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e] * scale;
-  }
-  // scores: lane = key (keys l and l + 64); the newest key is read from qkv (its cache line was written by other lanes)
-  float sc[2];
+  for (int c = 0; c < 8; ++c) qraw[c] = *reinterpret_cast<const bf16x8*>(row + h * 64 + c * 8);
+  // key rows: lane = key (keys l and l + 64); the newest key is read from qkv (its cache line was written by other lanes)
+  bf16x8 kraw[2][8];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int k = l + 64 * p;
-    float acc = -INFINITY;
     if (k <= t) {
-      const bf16* kr = (k == t) ? row + d + h * 64 : cbase + (size_t)k * 2 * d + h * 64;
+      const bf16* kr = (k == t) ? row + d + h * 64 : cache + ((size_t)(p ? a1 : a0) * S + k) * 2 * d + h * 64;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kraw[p][c] = *reinterpret_cast<const bf16x8*>(kr + c * 8);
+    }
+  }
+  // value rows: lane = (position group g = l / 8, 8-column chunk l % 8) - a load instruction fetches 16 bytes of eight
+  // positions' rows (positions j * 8 + g), so the 64 positions of a pass are 8 load instructions with per-lane addresses
+  // (one instruction per position with a scalar address - 64 of them, each behind a v_readlane and a 64-bit scalar
+  // multiply - made this phase grow by 0.16 us per cached position)
+  const int g = l >> 3, ch = l & 7;
+  bf16x8 vraw[8];
+  auto load_values = [&](int base) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = base + j * 8 + g;
+      bf16x8 v = {};
+      if (k <= t) {
+        const int ak = anc ? anc[(size_t)i * S + k] : i;
+        const bf16* vr = (k == t) ? row + 2 * d + h * 64 : cache + ((size_t)ak * S + k) * 2 * d + d + h * 64;
+        v = *reinterpret_cast<const bf16x8*>(vr + ch * 8);
+      }
+      vraw[j] = v;
+    }
+  };
+  load_values(0);
+  float q[64];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)qraw[c][e] * scale;
+  float sc[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float acc = -INFINITY;
+    if (l + 64 * p <= t) {
       acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(kr + c * 8);
+      for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], (float)v[e], acc);
-      }
+        for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], (float)kraw[p][c][e], acc);
     }
     sc[p] = acc;
   }
@@ -745,32 +1010,38 @@ __global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16* __res
 #pragma unroll
   for (int o = 32; o; o >>= 1) sm += __shfl_xor(sm, o, 64);
   const float inv = 1.f / sm;
-  // context: lane = value column; p[k] broadcast from lane k.  Loads in batches of 16 keys (a load per iteration would be
-  // a chain of L2 latencies: there is one wave per SIMD-slot here and nothing to hide behind)
-  float out = 0.f;
-  for (int k0 = 0; k0 <= t; k0 += 16) {
-    float v[16];
+  // context: every lane sums its positions (p of position k sits in lane k % 64), then the eight groups are added up
+  float out[8] = {};
+  auto accumulate = [&](float prp) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int k = min(k0 + u, t);
-      const bf16* vr = (k == t) ? row + 2 * d + h * 64 : cbase + (size_t)k * 2 * d + d + h * 64;
-      v[u] = (float)vr[l];
-    }
+    for (int j = 0; j < 8; ++j) {
+      const float p = __shfl(prp, j * 8 + g, 64);          // (0 for a position past t)
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int k = k0 + u;
-      const float p = k <= t ? __shfl(k < 64 ? pr[0] : pr[1], k & 63, 64) : 0.f;
-      out = fmaf(p, v[u], out);
+      for (int e = 0; e < 8; ++e) out[e] = fmaf(p, (float)vraw[j][e], out[e]);
     }
+  };
+  accumulate(pr[0]);
+  if (t >= 64) {                       // (S > 64 only)
+    load_values(64);
+    accumulate(pr[1]);
   }
-  ctx[(size_t)i * ldc + h * 64 + l] = (bf16)(out * inv);
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] += __shfl_xor(out[e], o, 64);
+  if (g == 0) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (bf16)(out[e] * inv);
+    *reinterpret_cast<bf16x8*>(ctx + (size_t)i * ldc + h * 64 + ch * 8) = r;
+  }
 }
 
-extern "C" int st_decode_self_attn(hipStream_t stream, const void* qkv, int ldq, void* cache, const long long* step, void* ctx,
-                                   int ldc, int n, int S, int H, int d_k, float scale) {
+extern "C" int st_decode_self_attn(hipStream_t stream, const void* qkv, int ldq, void* cache, const long long* step, const int* anc,
+                                   void* ctx, int ldc, int n, int S, int H, int d_k, float scale) {
   if (n <= 0) return 0;
-  if (d_k != 64 || H <= 0 || S <= 0 || S > 128 || (ldq & 7) || !qkv || !cache || !step || !ctx) return -1;
-  hipLaunchKernelGGL(decode_self_attn_kernel, dim3((n * H + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, ldq, (bf16*)cache, step,
+  if (d_k != 64 || H <= 0 || S <= 0 || S > 128 || (ldq & 7) || (ldc & 7) || !qkv || !cache || !step || !ctx) return -1;
+  hipLaunchKernelGGL(decode_self_attn_kernel, dim3((n * H + 3) / 4), dim3(256), 0, stream, (const bf16*)qkv, ldq, (bf16*)cache, step, anc,
                      (bf16*)ctx, ldc, n, S, H, scale);
   ST_CHECK_LAUNCH();
   return 0;
@@ -778,13 +1049,25 @@ extern "C" int st_decode_self_attn(hipStream_t stream, const void* qkv, int ldq,
 
 extern "C" int st_beam_advance(hipStream_t stream, const float* logits, int ldl, int V, int beam, int B, const long long* step,
                                int eos, float* scores, long long* tokens, unsigned char* done, long long* lengths,
-                               float* hist_scores, long long* back, long long* toks, long long* order) {
+                               float* hist_scores, long long* back, long long* toks, long long* order, void* work, int* anc,
+                               int S, long long* step_next) {
   if (B <= 0) return 0;
   if (beam <= 0 || beam > 16 || V <= 0 || ldl < V || !logits || !step || !scores || !tokens || !done || !lengths || !hist_scores ||
       !back || !toks || !order)
     return -1;
-  hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(512), 0, stream, logits, ldl, V, beam, B, step, eos, scores, tokens, done,
-                     lengths, hist_scores, back, toks, order);
+  const bool pair = work && V <= 20 * 256;
+  if (anc && (!pair || S <= 0 || S > 128)) return -1;       // (the lineage table is maintained by the merge launch)
+  if (step_next && (!pair || step_next != step)) return -1;
+  if (pair) {                           // two launches over B * beam workgroups: see beam_row_best_kernel
+    hipLaunchKernelGGL((beam_row_best_kernel<20>), dim3(B * beam), dim3(256), 0, stream, logits, ldl, V, beam, scores,
+                       (unsigned long long*)work);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, stream, (const unsigned long long*)work, V, beam, B, step, eos,
+                       scores, tokens, done, lengths, hist_scores, back, toks, order, anc, S, step_next,
+                       (unsigned*)((unsigned long long*)work + (size_t)B * beam * beam));
+  } else {
+    hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(512), 0, stream, logits, ldl, V, beam, B, step, eos, scores, tokens, done,
+                       lengths, hist_scores, back, toks, order);
+  }
   ST_CHECK_LAUNCH();
   return 0;
 }

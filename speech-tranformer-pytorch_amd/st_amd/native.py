@@ -88,10 +88,10 @@ SIGNATURES = {
                      _c_void_p, _c_int],
     "st_cast_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_ll],
     "st_embed_step": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int],
-    "st_decode_self_attn": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
-                            _c_float],
+    "st_decode_self_attn": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                            _c_int, _c_float],
     "st_beam_advance": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
-                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "st_ce_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_ce_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                   _c_void_p, _c_int],
@@ -862,10 +862,17 @@ def embed_step(tokens, emb, pe, step, out):
     return out
 
 
-def decode_self_attn(qkv, cache, step, ctx, n_head, scale):
+def _lineage(anc, n, S, name):
+    if anc is not None and not (anc.is_cuda and anc.dtype == I32 and anc.is_contiguous() and tuple(anc.shape) == (n, S)):
+        raise ValueError("%s: anc must be a contiguous int32 [n, S] tensor on the GPU" % name)
+    return anc.data_ptr() if anc is not None else None
+
+
+def decode_self_attn(qkv, cache, step, ctx, n_head, scale, anc=None):
     """One beam-search step's self-attention (one query per hypothesis): appends this step's k | v (columns [d, 3d) of qkv
     [n, 3d]) to ``cache`` [n, S, 2d] (one layer, contiguous) at position ``step`` (i64 [1], device) and writes the context
-    [n, d] over positions 0 .. step.  d / n_head = 64, S <= 128."""
+    [n, d] over positions 0 .. step.  d / n_head = 64, S <= 128.  ``anc``: optional lineage table i32 [n, S] (see
+    st_decode_self_attn): earlier positions are read from the cache rows it names."""
     _mat(qkv, BF16, "qkv"), _mat(ctx, BF16, "ctx")
     n, S, w = cache.shape
     d = w // 2
@@ -875,14 +882,19 @@ def decode_self_attn(qkv, cache, step, ctx, n_head, scale):
         raise ValueError("decode_self_attn: head width 64 and at most 128 cached positions")
     _vec(step, I64, 1, "step")
     _tag("decode_self_attn", n, n_head, S)
-    _check(load().st_decode_self_attn(_stream(), qkv.data_ptr(), qkv.stride(0), cache.data_ptr(), step.data_ptr(), ctx.data_ptr(),
-                                      ctx.stride(0), n, S, int(n_head), d // n_head, float(scale)), "st_decode_self_attn")
+    _check(load().st_decode_self_attn(_stream(), qkv.data_ptr(), qkv.stride(0), cache.data_ptr(), step.data_ptr(),
+                                      _lineage(anc, n, S, "decode_self_attn"), ctx.data_ptr(), ctx.stride(0), n, S, int(n_head),
+                                      d // n_head, float(scale)), "st_decode_self_attn")
 
 
-def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order):
-    """Beam.advance for all utterances in one launch (see st_beam_advance): logits f32 [B * beam, >= V]; the state tensors
+def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order, work=None, anc=None,
+                 advance_step=False):
+    """Beam.advance for all utterances on the device (see st_beam_advance): logits f32 [B * beam, >= V]; the state tensors
     are updated in place (scores f32 [B, beam], tokens i64 [B * beam], done bool [B], lengths i64 [B], hist_scores f32 /
-    back i64 / toks i64 [S, B, beam] at row ``step`` (i64 [1], device)); order i64 [B * beam] receives the cache rows."""
+    back i64 / toks i64 [S, B, beam] at row ``step`` (i64 [1], device)); order i64 [B * beam] receives the cache rows.
+    ``work``: optional i64 [>= B * beam * beam] scratch - with it the step runs as two launches over B * beam workgroups.
+    ``anc``: optional lineage table i32 [B * beam, S'] of decode_self_attn, updated for the new hypotheses (needs ``work``).
+    ``advance_step``: the launch also does ``step += 1`` (needs ``work`` with one more element, zero before the first call)."""
     B = scores.shape[0]
     if not (logits.is_cuda and logits.dtype == F32 and logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == B * beam):
         raise ValueError("beam_advance: logits must be an fp32 [B * beam, >= V] row matrix on the GPU")
@@ -895,10 +907,19 @@ def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist
     for t, dt, name in ((hist_scores, F32, "hist_scores"), (back, I64, "back"), (toks, I64, "toks")):
         if tuple(t.shape) != (S, B, beam) or t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
             raise ValueError("beam_advance: %s must be a contiguous [S, B, beam] tensor" % name)
+    if work is not None and not (work.is_cuda and work.dtype == I64 and work.is_contiguous() and
+                                 work.numel() >= B * beam * beam + (1 if advance_step else 0)):
+        raise ValueError("beam_advance: work must be a contiguous int64 tensor of >= B * beam * beam (+ 1) elements on the GPU")
+    if advance_step and work is None:
+        raise ValueError("beam_advance: advance_step needs the work buffer")
     _tag("beam_advance", B, beam, V)
     _check(load().st_beam_advance(_stream(), logits.data_ptr(), logits.stride(0), int(V), int(beam), B, step.data_ptr(), int(eos),
                                   scores.data_ptr(), tokens.data_ptr(), done.data_ptr(), lengths.data_ptr(),
-                                  hist_scores.data_ptr(), back.data_ptr(), toks.data_ptr(), order.data_ptr()), "st_beam_advance")
+                                  hist_scores.data_ptr(), back.data_ptr(), toks.data_ptr(), order.data_ptr(),
+                                  work.data_ptr() if work is not None else None,
+                                  _lineage(anc, B * beam, anc.shape[1] if anc is not None and anc.dim() == 2 else 0, "beam_advance"),
+                                  int(anc.shape[1]) if anc is not None else 0,
+                                  step.data_ptr() if advance_step else None), "st_beam_advance")
 
 
 def cache_reorder(cache, order, step, beam):

@@ -81,7 +81,7 @@ class Decode(object):
             ctx = E(d)
             if d // H == 64 and S <= 128:
                 # decode-shaped kernel: one wave per (hypothesis, head); it also appends this step's K | V to the cache
-                nv.decode_self_attn(qkv, st.caches[l], st.step, ctx, H, scale)
+                nv.decode_self_attn(qkv, st.caches[l], st.step, ctx, H, scale, anc=st.anc)
             else:
                 st.caches[l].index_copy_(1, st.step, qkv[:, d:].unsqueeze(1))
                 kv = st.caches[l].view(n * S, 2 * d)
@@ -126,16 +126,21 @@ class Decode(object):
 
     @torch.no_grad()
     def _advance(self, st, logits):
-        """Beam.advance (Beam.py:43-74) for every utterance at once, on the device, as ONE launch (``st_beam_advance``):
+        """Beam.advance (Beam.py:43-74) for every utterance at once, on the device (``st_beam_advance``: the best of every
+        hypothesis row, then one wave per utterance merges them):
         log-softmax of the logits, top-k over beam x vocab of score + log-probability, back-pointer = index // vocab,
         token = index % vocab; an utterance is finished once the top of its beam emits EOS - after which its state is
         frozen (the reference removes it from the batch, Decode.py:112-165; here it keeps its rows and is ignored).
-        Step 0 expands slot 0 only (Beam.py:48-51): the other slots start at -inf.  Then the caches follow the
-        back-pointers and the step counters advance."""
+        Step 0 expands slot 0 only (Beam.py:48-51): the other slots start at -inf.  Then the self-attention histories
+        follow the back-pointers - through the lineage table the same launch maintains (``st.anc``: the cache rows stay
+        where they were written), or, on the fall-back attention path, by permuting the caches - and the step counter
+        advances."""
         nv.beam_advance(logits, self.model.vocab_size, st.beam, st.step, Constants.EOS, st.scores, st.tokens, st.done,
-                        st.lengths, st.hist_scores, st.back, st.toks, st.order)
-        nv.cache_reorder(st.caches, st.order, st.step, st.beam)
-        st.step.add_(1)
+                        st.lengths, st.hist_scores, st.back, st.toks, st.order, work=st.beam_work, anc=st.anc,
+                        advance_step=st.anc is not None)
+        if st.anc is None:         # (with the lineage table the cache rows stay where they were written, and the merge
+            nv.cache_reorder(st.caches, st.order, st.step, st.beam)             # launch has advanced the step counter)
+            st.step.add_(1)
         if st.need_c_len:          # (only the fall-back self-attention path reads the cache length vector)
             st.c_len.add_(1)
 
@@ -197,6 +202,11 @@ class Decode(object):
         st.back = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
         st.toks = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
         st.order = torch.zeros(n, dtype=torch.long, device=dev)
+        st.beam_work = torch.zeros(n * beam + 1, dtype=torch.long, device=dev)  # st_beam_advance's candidate keys + ticket
+        # the lineage table of the decode-shaped self-attention (cache row of every earlier position of every hypothesis):
+        # the caches are then never permuted.  The fall-back self-attention reads its own rows: st_cache_reorder stays.
+        st.anc = None if st.need_c_len or model.vocab_size > 5120 else \
+            torch.arange(n, dtype=I32, device=dev).unsqueeze(1).repeat(1, S).contiguous()
         return st
 
     @torch.no_grad()

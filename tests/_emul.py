@@ -447,20 +447,26 @@ def embed_step(tokens, emb, pe, step, out):
     return out
 
 
-def decode_self_attn(qkv, cache, step, ctx, n_head, scale):
+def decode_self_attn(qkv, cache, step, ctx, n_head, scale, anc=None):
     n, S, w = cache.shape
     d = w // 2
     t = int(step)
     cache[:, t] = qkv[:, d:]
-    k = cache[:, :t + 1, :d].float().view(n, t + 1, n_head, d // n_head)
-    v = cache[:, :t + 1, d:].float().view(n, t + 1, n_head, d // n_head)
+    hist = cache[:, :t + 1]
+    if anc is not None:                   # lineage table: position p < t of hypothesis i lives in cache row anc[i][p]
+        rows = anc[:, :t + 1].long().clone()
+        rows[:, t] = torch.arange(n)
+        hist = cache[rows, torch.arange(t + 1).unsqueeze(0).expand(n, t + 1)]
+    k = hist[:, :, :d].float().view(n, t + 1, n_head, d // n_head)
+    v = hist[:, :, d:].float().view(n, t + 1, n_head, d // n_head)
     q = qkv[:, :d].float().view(n, 1, n_head, d // n_head)
     sc = (q * k).sum(-1) * scale                         # [n, t + 1, H]
     p = torch.softmax(sc, dim=1).unsqueeze(-1)
     ctx.copy_((p * v).sum(1).reshape(n, d).to(BF16))
 
 
-def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order):
+def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order, work=None, anc=None,
+                 advance_step=False):
     """Beam.advance for all utterances with torch ops (the formulation transformer/Decode.py used before st_beam_advance)."""
     B = scores.shape[0]
     word_lk = torch.log_softmax(logits[:, :V].float(), dim=-1)
@@ -480,6 +486,12 @@ def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist
     lengths.add_(live.to(lengths.dtype))
     done.logical_or_(live & (token[:, 0] == eos))
     order.copy_((origin + (torch.arange(B) * beam).unsqueeze(1)).view(-1))
+    if anc is not None:
+        t = int(step)
+        anc[:, :t] = anc[order][:, :t].clone()
+        anc[:, t] = order.to(anc.dtype)
+    if advance_step:
+        step.add_(1)
 
 
 def ce_fwd(logits, target, ignore_index, lse, sums, V=None, index=None):

@@ -981,10 +981,17 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
         check(got[n], ref[n], tol, "row_chain_bwd %s M=%d: %s" % (variant, M, n))
 
 
-@pytest.mark.parametrize("B,beam,V", [(5, 4, 30), (32, 10, 4337), (3, 16, 1000)])
-def test_beam_advance_matches_torch_formulation(B, beam, V):
-    """st_beam_advance (log-softmax + top-k over beam x V + Beam.py's bookkeeping, one launch) against the torch
-    formulation (tests/_emul.py) over several steps, with finished utterances (frozen), -inf slots (step 0) and EOS."""
+@pytest.mark.parametrize("two_launch", [False, True])
+@pytest.mark.parametrize("B,beam,V", [(5, 4, 30), (32, 10, 4337), (3, 16, 1000), (7, 10, 5120), (2, 1, 100), (4, 3, 257)])
+def test_beam_advance_matches_torch_formulation(B, beam, V, two_launch):
+    """st_beam_advance (log-softmax + top-k over beam x V + Beam.py's bookkeeping; one launch, or - given scratch - the
+    row-best + merge pair) against the torch formulation (tests/_emul.py) over several steps, with finished utterances
+    (frozen), -inf slots (step 0) and EOS."""
+    work = torch.zeros(B * beam * beam + 1, dtype=torch.long, device="cuda") if two_launch else None     # (+ 1: advance_step's ticket)
+    anc_a = torch.arange(B * beam, dtype=torch.int32).unsqueeze(1).repeat(1, 9).contiguous() if two_launch else None   # lineage table
+    anc_b = anc_a.clone() if two_launch else None
+    if two_launch:
+        anc_a = anc_a.cuda()
     gen = torch.Generator().manual_seed(7)
     S, eos, ld = 6, 2, (V + 7) // 8 * 8
 
@@ -1003,22 +1010,61 @@ def test_beam_advance_matches_torch_formulation(B, beam, V):
             logits[0, eos] += 30.0          # utterance 0 finishes: its best hypothesis emits EOS
         for st, fn, dev in ((a, nv.beam_advance, "cuda"), (b, em.beam_advance, "cpu")):
             fn(logits.to(dev), V, beam, st["step"], eos, st["scores"], st["tokens"], st["done"], st["lengths"], st["hist"],
-               st["back"], st["toks"], st["order"])
-            st["step"] += 1
+               st["back"], st["toks"], st["order"], work=work if dev == "cuda" else None, anc=anc_a if dev == "cuda" else anc_b,
+               advance_step=two_launch)
+            if not two_launch:
+                st["step"] += 1
+        assert int(a["step"]) == t + 1 and int(b["step"]) == t + 1
         assert torch.equal(a["done"].cpu(), b["done"]) and torch.equal(a["lengths"].cpu(), b["lengths"]), t
         live = ~b["done"] | (b["lengths"] == t + 1)        # rows of utterances that advanced in this step
         assert torch.equal(a["back"].cpu()[t], b["back"][t]) and torch.equal(a["order"].cpu(), b["order"]), t
         assert torch.equal(a["toks"].cpu()[t][live], b["toks"][t][live]) and torch.equal(a["tokens"].cpu(), b["tokens"]), t
+        if two_launch:
+            assert torch.equal(anc_a.cpu()[:, :t + 1], anc_b[:, :t + 1]), t
         assert torch.allclose(a["scores"].cpu(), b["scores"], atol=2e-5, rtol=1e-6) and \
             torch.allclose(a["hist"].cpu()[t], b["hist"][t], atol=2e-5, rtol=1e-6), t
     assert bool(b["done"][0]) and not bool(b["done"][1:].all())
 
 
-def test_beam_advance_vs_reference_trellis_golden():
+@pytest.mark.parametrize("two_launch", [False, True])
+def test_beam_advance_vs_reference_trellis_golden(two_launch):
     """st_beam_advance against tests/golden/beam_trellis.npz - the trellis the reference's own Beam class produced
     (tools/make_beam_goldens.py, repair R5): back-pointers and tokens bit-exact, scores to fp32 rounding."""
     from tests.test_decode_cpu import run_beam_advance_vs_trellis
-    run_beam_advance_vs_trellis(nv, "cuda")
+    run_beam_advance_vs_trellis(nv, "cuda", two_launch=two_launch)
+
+
+@pytest.mark.parametrize("B,beam,V", [(3, 5, 3), (6, 10, 4337), (4, 16, 700), (2, 10, 4096)])
+def test_beam_advance_two_launches_equal_one(B, beam, V):
+    """The row-best + merge pair of st_beam_advance against its one-workgroup-per-utterance kernel: the same winners in the
+    same order - including ties (equal logits in every row: lowest flat index first) and fewer finite candidates than beam
+    slots (V = 3 < beam at step 0: -inf candidates fill the beam) - and the same scores to fp32 rounding."""
+    gen = torch.Generator().manual_seed(11)
+    S, eos, ld = 4, 2, (V + 7) // 8 * 8
+
+    def state():
+        sc = torch.full((B, beam), float("-inf"))
+        sc[:, 0] = 0.0
+        return dict(scores=sc.cuda(), tokens=torch.ones(B * beam, dtype=torch.long, device="cuda"), done=torch.zeros(B, dtype=torch.bool, device="cuda"),
+                    lengths=torch.zeros(B, dtype=torch.long, device="cuda"), hist=torch.zeros(S, B, beam, device="cuda"),
+                    back=torch.zeros(S, B, beam, dtype=torch.long, device="cuda"), toks=torch.zeros(S, B, beam, dtype=torch.long, device="cuda"),
+                    order=torch.zeros(B * beam, dtype=torch.long, device="cuda"), step=torch.zeros(1, dtype=torch.long, device="cuda"))
+
+    a, b = state(), state()
+    work = torch.zeros(B * beam * beam, dtype=torch.long, device="cuda")
+    for t in range(S):
+        logits = (torch.randn(B * beam, ld, generator=gen) * 3).cuda()
+        logits[: beam] = 0.0                       # utterance 0: every candidate of a row ties
+        if t == 2:
+            logits[beam: 2 * beam] = logits[beam].clone()      # utterance 1: its rows are copies of each other
+        for st, w in ((a, None), (b, work)):
+            nv.beam_advance(logits, V, beam, st["step"], eos, st["scores"], st["tokens"], st["done"], st["lengths"], st["hist"],
+                            st["back"], st["toks"], st["order"], work=w)
+            st["step"] += 1
+        for k in ("done", "lengths", "back", "toks", "order", "tokens"):
+            assert torch.equal(a[k], b[k]), (k, t)
+        for k in ("scores", "hist"):
+            assert torch.allclose(a[k], b[k], atol=2e-5, rtol=1e-6, equal_nan=True), (k, t)
 
 
 @pytest.mark.parametrize("R,V", [(7, 30), (1206, 4337)])
@@ -1062,18 +1108,21 @@ def test_cross_entropy_rows_matches_torch(R, V):
     assert abs(float(outs[0][1][2]) - ref.item()) < 1e-5 * abs(ref.item())
 
 
-@pytest.mark.parametrize("t", [0, 1, 37, 63, 64, 99])
-def test_decode_self_attention_matches_reference(t):
+@pytest.mark.parametrize("lineage", [False, True])
+@pytest.mark.parametrize("t", [0, 1, 15, 16, 37, 63, 64, 99])
+def test_decode_self_attention_matches_reference(t, lineage):
     """st_decode_self_attn (one query per hypothesis over the KV cache, appending this step's K | V) == the fp32 softmax
-    attention over cache positions 0 .. t, for positions inside and beyond the first 64-key pass."""
+    attention over cache positions 0 .. t, for positions inside and beyond the first 64-key pass; with a lineage table
+    the earlier positions come from the cache rows it names (random rows here), the step's own from the hypothesis' row."""
     n, H, d, S = 37, 4, 256, 100
     qkv = g(n, 3 * d, seed=1)
     cache = g(n, S, 2 * d, seed=2)
     step = torch.tensor([t], dtype=torch.long)
+    anc = torch.randint(0, n, (n, S), generator=torch.Generator().manual_seed(5), dtype=torch.int32) if lineage else None
     cg, ce = cache.clone().cuda(), cache.clone()
     out_g, out_e = torch.zeros(n, d, dtype=BF16, device="cuda"), torch.zeros(n, d, dtype=BF16)
-    nv.decode_self_attn(cu(qkv), cg, step.cuda(), out_g, H, 0.125)
-    em.decode_self_attn(qkv, ce, step, out_e, H, 0.125)
+    nv.decode_self_attn(cu(qkv), cg, step.cuda(), out_g, H, 0.125, anc=anc.cuda() if lineage else None)
+    em.decode_self_attn(qkv, ce, step, out_e, H, 0.125, anc=anc)
     check(out_g, out_e, 1e-2, "decode self-attention t=%d" % t)
     assert torch.equal(cg.cpu()[:, t], qkv[:, d:]) and torch.equal(cg.cpu()[:, t + 1:], cache[:, t + 1:]) and \
         torch.equal(cg.cpu()[:, :t], cache[:, :t])
