@@ -156,7 +156,13 @@ int st_gemm_lnbwd(st_stream_t stream, const void* dY, int lddy, const void* W, i
  * number of chains.  Rebuild after every weight update.
  * next_blocks > 0: another chain of that many blocks is stored right behind this one and runs next - the launch warms the
  * L2 with its streams too (the streams are read once per step, from HBM).
- * Both dropout sites read the device seed *drop_seed (NULL = off) with their own salt / threshold / scale. */
+ * Both dropout sites read the device seed *drop_seed (NULL = off) with their own salt / threshold / scale.
+ * split_work (optional; split_bytes = its size): zero-initialised device scratch of (256 + 256 * 8192) * 4 bytes (256 tickets, then the partial sums; only the tickets need the zeroes).  With it, a
+ * chain that has an FFN part and whose M / 32 row blocks x (d_ff / 256) fit 256 workgroups runs d_ff / 256 workgroups per row
+ * block: each does PRE, ONE 256-wide chunk of the hidden dimension and leaves its partial of the second GEMM in the
+ * scratch; the last of a row block's workgroups adds them (in chunk order: the result does not depend on arrival order, but
+ * differs in rounding from the one-workgroup chain) and finishes the chain.  Launches that share the scratch must be
+ * ordered on one stream. */
 int st_wfrag_depth(void);
 int st_wfrag_build(st_stream_t stream, const long long* table, int n_blocks);
 int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A,
@@ -166,7 +172,7 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
                  unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed,
                  unsigned drop1_salt,
                  int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
-                 int post_blocks, const float* bp, void* P, int ldp);
+                 int post_blocks, const float* bp, void* P, int ldp, void* split_work, long long split_bytes);
 
 /* relu_bits (st_row_chain: optional output, st_row_chain_bwd: input): which hidden values of the feed-forward sublayer are
  * > 0 after ReLU and dropout (the mask of SubLayers.py:25's backward), one bit per value in a layout private to the two

@@ -135,6 +135,132 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
   }
 }
 
+// The same chain with the feed-forward sublayer's hidden dimension cut over nc WORKGROUPS per 32-row block (decoder-sized
+// row counts only: M / 32 x nc workgroups must fit one round of the chip).  A 12-block chain is 12 weight blocks through
+// ONE compute unit at the latency-bound rate of a single requester (~2.2 us per 128 KB block: ten workgroups of a decode
+// step, 38 of a training step, on a 256-CU chip).  Only the hidden dimension can be cut without an exchange per block: the
+// nc chunks of d_ff are independent until their contributions to the second GEMM are added.  So workgroup (block, part)
+// runs PRE (replicated - one block), chunk `part` of the feed-forward (two blocks) and leaves its 32 x 256 fp32 partial in
+// `split_ws` with write-through stores; the LAST of the block's nc workgroups to draw the block's ticket adds the partials
+// in index order (the result does not depend on who is last), and runs the LayerNorm epilogue and POST: 6 blocks + one
+// merge on the critical path instead of 12.  No fence (an agent-scope release writes the whole L2 back: +60-80 us,
+// tools/dev/merge_probe.hip): system-scope relaxed stores, s_waitcnt, a device-scope ticket, device-scope loads.
+// Part 0 writes PRE's saved tensors; every part writes its chunk of H and its ReLU bits.
+template <bool PRE, bool POST, bool DROP>
+__global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
+  constexpr int MT = 1, RB = 32, TE = RB * AS;
+  __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
+  __shared__ float red[2][NW * 32 * MT];
+  __shared__ bool last;
+  Ctx<MT> c;
+  c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
+  const int parts = a.nc, block = blockIdx.x / parts, part = blockIdx.x - block * parts;
+  c.row0 = block * RB; c.nvalid = min(RB, a.M - c.row0);
+  const bf16x8* base = a.wfrag + (size_t)c.wave * a.wave_frags * 64;
+  // stream order: [PRE] [W1_0 W2_0] .. [W1_(nc-1) W2_(nc-1)] [POST blocks]; this workgroup multiplies PRE, its chunk's two
+  // blocks and - if it turns out to be the last - POST.  The ring always holds the block being multiplied and is refilled
+  // from c.ws, so c.ws is pointed at the block that comes NEXT for this workgroup before every block_mma.
+  auto at_block = [&](int b) { return base + (size_t)b * 16 * 64; };
+  const int b_chunk = (PRE ? 1 : 0) + 2 * part, b_post = (PRE ? 1 : 0) + 2 * parts;
+  c.ws = at_block(PRE ? 0 : b_chunk);
+#pragma unroll
+  for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
+  c.ws += Ring<MT>::D * 64;
+  int touched[TOUCH];
+  {
+    const int nlines = NW * (a.wave_frags + a.next_frags) * 8;
+    const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
+    const char* sb = reinterpret_cast<const char*>(a.wfrag);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) {
+      const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
+      touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* cur = tiles;
+  bf16* f0 = tiles + TE;
+  bf16* f1 = tiles + 2 * TE;
+  {
+    TileRegs<MT> ra, rr;
+    tile_load(c, a.A, a.lda, ra);
+    if (PRE) tile_load(c, a.R, a.ldr, rr);
+    tile_store(c, ra, cur);
+    if (PRE) tile_store(c, rr, f0);
+  }
+  const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
+  __syncthreads();
+  if (PRE) {
+    f32x16 acc[MT];
+    zero_acc(acc);
+    c.ws = at_block(b_chunk);
+    block_mma(c, cur, acc);
+    const bool w = part == 0;
+    epi_ln<false>(c, acc, a.bo, f0, a.g0, a.be0, a.eps, off, cur, f1, red, w ? a.out0 : nullptr, w ? a.xhat0 : nullptr,
+                  w ? a.rstd0 : nullptr);
+    bf16* t = cur; cur = f1; f1 = t;
+  }
+  f32x16 acc2[MT];
+  zero_acc(acc2);
+  {
+    const int dff = parts * 256;
+    bf16* hc = f0;       // (free: the residual's last read precedes epi_ln's barriers; without PRE never written)
+    f32x16 acc1[MT];
+    zero_acc(acc1);
+    block_mma(c, cur, acc1);                  // W1 chunk; refills: the W2 chunk right behind it
+    epi_store<true, DROP>(c, acc1, a.b1 + part * 256, hc, d1, part * 256, dff,
+                          a.relu_bits ? a.relu_bits + ((size_t)(block * parts + part) * NW + c.wave) * 64 : nullptr);
+    __syncthreads();
+    c.ws = at_block(b_post);                  // (POST's first block, on the chance that this workgroup is the last)
+    block_mma(c, hc, acc2);
+    if (a.H) tile_out(c, hc, a.H + part * 256, dff);
+  }
+  // ---- the partial leaves through the L2 (write-through), the ticket says who merges
+  float* slot = a.split_ws + (size_t)block * parts * (512 * 16);
+  {
+    float* mine = slot + (size_t)part * (512 * 16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) __hip_atomic_store(mine + i * 512 + c.tid, acc2[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  __syncthreads();
+  if (c.tid == 0)
+    last = __hip_atomic_fetch_add(a.split_tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1);
+  __syncthreads();
+  if (last) {
+    if (c.tid == 0) __hip_atomic_store(a.split_tickets + block, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    zero_acc(acc2);
+    for (int p = 0; p < parts; ++p) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(slot + (size_t)p * (512 * 16) + i * 512 + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc2[0][i] += v[i];
+    }
+    // xhat goes to f1 (the A tile / PRE's xhat staging: last read two barriers ago), the output replaces cur in place
+    epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, f1, cur, red, a.out1, a.xhat1, a.rstd1);
+    if (POST) {
+      for (int u = 0; u < a.nb; ++u) {
+        bf16* st = (u & 1) ? f1 : f0;
+        f32x16 acc[MT];
+        zero_acc(acc);
+        block_mma(c, cur, acc);
+        epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0);
+        __syncthreads();
+        tile_out(c, st, a.P + u * 256, a.ldp);
+      }
+    }
+  }
+  {
+    int tsum = 0;
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+    if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;      // (never true: keeps the warm-up loads alive)
+  }
+}
+
 // =====================================================================================================================
 // Backward chains: the same row blocks, weight blocks read transposed (st_wfrag_build), in the reverse order of the
 // forward chain:
@@ -510,7 +636,7 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
                             float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
                             unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
                             int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
-                            int post_blocks, const float* bp, void* P, int ldp) {
+                            int post_blocks, const float* bp, void* P, int ldp, void* split_work, long long split_bytes) {
   if (M <= 0) return 0;
   const bool pre = R != nullptr, ffn = d_ff > 0, post = post_blocks > 0;
   if (!A || !wfrag || (lda & 7) || (!pre && !ffn && !post)) return -1;
@@ -534,6 +660,29 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   const int mt = row_tiles(M);
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
   const bool drop = on1 || on2;
+  // the feed-forward's hidden dimension over nc workgroups per row block (row_chain_split_kernel): decoder-sized M only
+  a.split_ws = nullptr; a.split_tickets = nullptr;
+  if (split_work && ffn && mt == 1 && a.nc >= 2 && a.nc <= 8 && (int)grid.x * a.nc <= 256) {
+    // layout: 256 tickets (one per row block; at a FIXED place - launches of different M share the scratch, and a ticket
+    // must never lie where another launch leaves partial sums), then the partials
+    const size_t words = (size_t)grid.x * a.nc * 512 * 16;
+    if (split_bytes < (long long)((256 + words) * 4)) return -6;
+    a.split_tickets = (unsigned*)split_work;
+    a.split_ws = (float*)split_work + 256;
+    const dim3 sgrid(grid.x * a.nc);
+#define ST_SPLIT(PRE_, POST_)                                                                                        \
+  do {                                                                                                               \
+    if (drop) hipLaunchKernelGGL((row_chain_split_kernel<PRE_, POST_, true>), sgrid, blk, 0, stream, a);             \
+    else hipLaunchKernelGGL((row_chain_split_kernel<PRE_, POST_, false>), sgrid, blk, 0, stream, a);                 \
+  } while (0)
+    if (pre && post) ST_SPLIT(true, true);
+    else if (pre) ST_SPLIT(true, false);
+    else if (post) ST_SPLIT(false, true);
+    else ST_SPLIT(false, false);
+#undef ST_SPLIT
+    ST_CHECK_LAUNCH();
+    return 0;
+  }
 #define ST_CHAIN(PRE_, FFN_, POST_)                                                                               \
   do {                                                                                                            \
     if (mt == 3) {                                                                                                \

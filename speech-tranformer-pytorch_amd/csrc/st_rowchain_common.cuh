@@ -35,6 +35,8 @@ struct ChainArgs {
   DropArgs drop1, drop2;
   // POST
   int nb; const float* bp; bf16* P; int ldp;
+  // split feed-forward (row_chain_split_kernel): nc partial-sum slots of 32 x 256 fp32 per row block, then one ticket per block
+  float* split_ws; unsigned* split_tickets;
 };
 
 // fragments in flight per wave: with three row tiles a fragment feeds three MFMAs (it is consumed a third as often), and

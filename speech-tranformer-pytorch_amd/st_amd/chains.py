@@ -18,6 +18,7 @@ from __future__ import annotations
 import math
 from typing import List, Sequence, Tuple
 
+import os
 import torch
 
 from . import native as nv
@@ -29,12 +30,16 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 class Chain:
     """One chain's fragment streams (a slice of its ChainSet's buffer) and the weight blocks they were built from."""
-    __slots__ = ("stream", "n_blocks", "blocks", "next_blocks")
+    __slots__ = ("stream", "n_blocks", "blocks", "next_blocks", "split_work")
 
     def __init__(self, stream, n_blocks, blocks, next_blocks=0):
         # next_blocks: size of the chain stored right behind this one IF it is also the one that runs next (the kernel
         # then warms the L2 with it as well), else 0
         self.stream, self.n_blocks, self.blocks, self.next_blocks = stream, n_blocks, blocks, next_blocks
+        # split_work: scratch (zero-initialised int32 tensor, native.split_work_words() elements) that lets st_row_chain cut
+        # the feed-forward's hidden dimension over several workgroups per row block at decoder-sized row counts; chains
+        # that run one after the other on one stream may share it.  None: one workgroup per row block.
+        self.split_work = None
 
 
 def blocks_of(w: torch.Tensor, order: str = "rows") -> List[Tuple[torch.Tensor, int, int]]:
@@ -370,6 +375,10 @@ class DecoderChains:
         self.set.finalize()
         self.f1 = [self.set.chain(c, True) for c in f1]      # stored in running order: F1(0), F2(0), F1(1), ...
         self.f2 = [self.set.chain(c, True) for c in f2]
+        if self.f2 and os.environ.get("ST_CHAIN_SPLIT", "1") != "0":      # (development switch)
+            work = torch.zeros(nv.split_work_words(), dtype=torch.int32, device=self.f2[0].stream.device)
+            for ch in self.f2:
+                ch.split_work = work
         # backward chains in running order (last layer first): B2(l) = [q|k|v projection of layer l + 1] + feed-forward +
         # the encoder-decoder attention's output_linear; B1(l) = its q projection + the self-attention's output_linear
         self.bset = ChainSet(arena.device)

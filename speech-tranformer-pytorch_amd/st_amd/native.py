@@ -47,7 +47,7 @@ SIGNATURES = {
     "st_row_chain": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
-                     _c_int, _c_void_p, _c_void_p, _c_int],
+                     _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_ll],
     "st_row_chain_mask_words": [_c_int, _c_int],
     "st_row_chain_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                          _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
@@ -480,13 +480,23 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
                 raise ValueError("row_chain: both dropout sites must read the same device seed")
             seed = dr.seed
     s1, s2 = _drop(drop1), _drop(drop2)
+    work = getattr(chain, "split_work", None) if ffn else None
+    if work is not None and not (work.is_cuda and work.is_contiguous() and work.dtype == torch.int32):
+        raise ValueError("row_chain: chain.split_work must be a contiguous int32 tensor on the GPU")
     _tag("row_chain", M, n_blocks, d_ff, io=((A, M), (R, M), (out0, M), (xhat0, M), (H, M), relu_bits, (out1, M), (xhat1, M), (P, M),
                                              (rstd0, M), (rstd1, M), 2.0 * 256 * 256 * n_blocks))
     rc = load().st_row_chain(_stream(), M, wfrag.data_ptr(), n_blocks, int(chain.next_blocks), float(eps), A.data_ptr(), A.stride(0), _p(R),
                              0 if R is None else R.stride(0), _p(bo), _p(g0), _p(be0), _p(out0), _p(xhat0), _p(rstd0),
                              int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(relu_bits), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
-                             s1[1], s1[2], s1[3], s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0))
+                             s1[1], s1[2], s1[3], s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0),
+                             _p(work), 0 if work is None else work.numel() * work.element_size())
     _check(rc, "st_row_chain")
+
+
+def split_work_words() -> int:
+    """int32 elements of the scratch a Chain may carry as ``split_work`` (zero-initialised; the kernel leaves it zeroed where
+    it matters): the 32 x 256 fp32 partial sums of up to 256 workgroups, and one ticket per row block."""
+    return 256 * 512 * 16 + 256          # 256 workgroups' partials (the launch never uses more) + tickets
 
 
 def chain_mask_words(M: int, d_ff: int) -> int:

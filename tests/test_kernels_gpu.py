@@ -734,7 +734,8 @@ def test_gemm_ws_stacked_weights():
 
 # ---- row chains (csrc/st_rowchain.hip) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
-@pytest.mark.parametrize("variant", ["pre+post1", "pre+ffn+post3", "pre+ffn", "ffn", "ffn+post1", "pre+ffn+post3+drop"])
+@pytest.mark.parametrize("variant", ["pre+post1", "pre+ffn+post3", "pre+ffn", "ffn", "ffn+post1", "pre+ffn+post3+drop",
+                                     "pre+ffn+post3+split", "pre+ffn+split", "ffn+split", "ffn+post1+split", "pre+ffn+post3+drop+split"])
 def test_row_chain_matches_the_separate_kernels(M, variant):
     """One st_row_chain launch == output_linear + residual + LayerNorm, feed-forward sublayer and the next projection as
     separate kernels (the emulation composes their emulations): every tensor the backward reads, ragged last row block,
@@ -774,6 +775,8 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
             cid = cs.add(blocks("cuda"))
             cs.finalize().rebuild()
             ch = cs.chain(cid)
+            if "split" in parts:        # the feed-forward's hidden dimension over 4 workgroups per row block (M <= 2048; else ignored)
+                ch.split_work = split_work
             Aw = torch.zeros(M, d + 64, dtype=BF16, device="cuda")      # strided operand views
             Aw[:, 32:32 + d] = f(A)
             Rw = torch.zeros(M + 2, d + 8, dtype=BF16, device="cuda")
@@ -790,7 +793,32 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
            post=(nb, f(bp), o["P"]) if nb else None)
         return o
 
+    split_work = torch.zeros(nv.split_work_words(), dtype=torch.int32, device="cuda") if "split" in parts else None
     got, ref = run("cuda", nv.row_chain, dn1, dn2), run("cpu", em.row_chain, de1, de2)
+    if split_work is not None:
+        # the tickets are back at zero, and a second launch on the same scratch gives bit-identical results (the partials are
+        # added in chunk order, whoever arrives last)
+        assert int(split_work[:256].abs().sum()) == 0, "split tickets not reset"
+        again = run("cuda", nv.row_chain, dn1, dn2)
+        for n in got:
+            assert torch.equal(got[n], again[n]), "split row chain not reproducible: %s" % n
+        if M == 5:      # the same scratch after a launch with more row blocks (whose partials lie where nothing else may)
+            M_big = 320
+            chains_mod = chains
+            cs = chains_mod.ChainSet("cuda")
+            cid = cs.add(blocks("cuda"))
+            cs.finalize().rebuild()
+            chb = cs.chain(cid)
+            chb.split_work = split_work
+            Ab, Rb = cu(g(M_big, d, seed=31)), cu(g(M_big, d, seed=32))
+            Eb = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device="cuda")
+            nv.row_chain(Ab, chb,
+                         pre=(Rb, cu(bo), cu(g0), cu(be0), Eb(M_big, d), Eb(M_big, d), Eb(M_big, dt=F32)) if has_pre else None,
+                         ffn=(dff, cu(b1), cu(b2), cu(g1), cu(be1), Eb(M_big, dff), Eb(M_big, d), Eb(M_big, d), Eb(M_big, dt=F32), dn1, dn2),
+                         post=(nb, cu(bp), Eb(M_big, 256 * max(nb, 1))) if nb else None)
+            again = run("cuda", nv.row_chain, dn1, dn2)
+            for n in got:
+                assert torch.equal(got[n], again[n]), "split row chain after a larger launch on the same scratch: %s" % n
     names = (["out0", "xhat0", "rstd0"] if has_pre else []) + (["H", "out1", "xhat1", "rstd1"] if has_ffn else []) + (["P"] if nb else [])
     for n in names:
         check(got[n], ref[n], 2e-3 if n.startswith("rstd") else 1e-2, "row_chain %s M=%d: %s" % (variant, M, n))
