@@ -187,14 +187,17 @@ int st_row_chain_mask_words(int M, int d_ff);
  *         dH W1 + ds; xhat_b, rstd_b, gamma_b) and its column sums
  *   TAIL  (O != NULL)  dctx = ds Wo;  delta[h * M + i] = sum over head h's 64 columns of dctx (O + Ores)   (== ST_EPI_BF16_DELTA)
  * ds = the running gradient: ds_a after HEAD, ds_b after FFN, the input DS [M, 256] without HEAD.  Heads are 64 columns.
- * Reference lines: the backward of Attention.py:74-76,92-94 and SubLayers.py:24-28. */
+ * Reference lines: the backward of Attention.py:74-76,92-94 and SubLayers.py:24-28.
+ * split_work / split_bytes: as st_row_chain - d_ff / 256 workgroups per row block at decoder-sized M (HEAD replicated, one
+ * chunk of the hidden dimension each, the last arriver adds the partial dy in chunk order and runs the second LayerNorm
+ * backward and TAIL). */
 int st_row_chain_bwd(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, int head_blocks,
                      const void* dP, int ldp, const void* G, int ldg, const void* xhat_a, const float* rstd_a,
                      const float* gamma_a, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale,
                      void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a, const void* DS, int d_ff,
                      const unsigned long long* relu_bits, float mask_scale, void* dH, const void* xhat_b, const float* rstd_b, const float* gamma_b, void* ds_b,
                      float* dgamma_b, float* dbeta_b, float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx,
-                     int lddc, float* delta);
+                     int lddc, float* delta, void* split_work, long long split_bytes);
 
 /* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
  * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).

@@ -288,6 +288,8 @@ struct ChainBwdArgs {
   bf16* ds_b; float* dgamma_b; float* dbeta_b; float* dbias_b;
   // TAIL
   const bf16* O; const bf16* Ores; int ldo; bf16* dctx; int lddc; float* delta;
+  // split feed-forward (row_chain_bwd_split_kernel): as ChainArgs
+  float* split_ws; unsigned* split_tickets;
 };
 
 // LayerNorm backward over the 256 columns held by the 8 waves.  acc = the GEMM result; t_aux holds the addend and receives
@@ -359,7 +361,7 @@ __device__ __forceinline__ void epi_lnbwd(const Ctx<MT>& c, f32x16 (&acc)[MT], b
     }
   }
   __syncthreads();
-  tile_out(c, t_dx, g_dx, DM);
+  if (g_dx) tile_out(c, t_dx, g_dx, DM);
   // column sums: thread = (column, half of the rows); the upper half hands its sums over through LDS (red is free: the row
   // sums were consumed before the barrier above), so a workgroup issues ONE atomic per column and quantity - the adds of
   // all workgroups to one address serialise in the L2 (measured at 251 workgroups: 17 us of a 94 us launch with two)
@@ -605,6 +607,185 @@ extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_
 }
 
 namespace {
+// The backward chain with the feed-forward's hidden dimension over nc workgroups per 32-row block - the mirror image of
+// row_chain_split_kernel: workgroup (block, part) runs HEAD (replicated; part 0 writes ds_a and adds the column sums),
+// chunk `part` (dH chunk = (ds W2[:, chunk]) masked; its contribution dH W1[chunk, :] to dy), leaves the 32 x 256 fp32
+// partial in the scratch and draws the block's ticket; the last one adds the partials in chunk order and runs the second
+// LayerNorm backward (+ its column sums) and TAIL.
+template <bool HEAD, bool TAIL, bool DROP>
+__global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArgs a) {
+  constexpr int MT = 1, RB = 32, TE = RB * AS;
+  __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
+  __shared__ float red[2][NW * 32 * MT];
+  __shared__ bool last;
+  Ctx<MT> c;
+  c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
+  const int parts = a.nc, block = blockIdx.x / parts, part = blockIdx.x - block * parts;
+  c.row0 = block * RB; c.nvalid = min(RB, a.M - c.row0);
+  const bf16x8* base = a.wfrag + (size_t)c.wave * a.wave_frags * 64;
+  auto at_block = [&](int b) { return base + (size_t)b * 16 * 64; };
+  const int nbh = HEAD ? a.nb : 0, b_chunk = nbh + 2 * part, b_tail = nbh + 2 * parts;
+  c.ws = at_block(nbh > 0 ? 0 : b_chunk);
+#pragma unroll
+  for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
+  c.ws += Ring<MT>::D * 64;
+  int touched[TOUCH];
+  {
+    const int nlines = NW * (a.wave_frags + a.next_frags) * 8;
+    const int xcd = blockIdx.x & 7, nr = ((int)gridDim.x - xcd + 7) >> 3;
+    const char* sb = reinterpret_cast<const char*>(a.wfrag);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) {
+      const int ln = min(((int)blockIdx.x >> 3) * 512 + c.tid + t * nr * 512, nlines - 1);
+      touched[t] = *reinterpret_cast<const int*>(sb + (size_t)ln * 128);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf16* t0 = tiles; bf16* t1 = tiles + TE; bf16* t2 = tiles + 2 * TE;
+  const Drop da = make_drop(a.drop_a), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
+  bf16* cur;
+  bf16 *fa, *fb;
+  if (HEAD) {
+    TileRegs<MT> nxt;
+    {
+      TileRegs<MT> rg, rx;
+      if (a.G) tile_load(c, a.G, a.ldg, rg);
+      tile_load(c, a.xhat_a, DM, rx);
+      if (a.nb > 0) tile_load(c, a.dP, a.ldp, nxt);
+      if (a.G) tile_store(c, rg, t1);
+      else {
+#pragma unroll
+        for (int p = 0; p < 2 * MT; ++p) *reinterpret_cast<bf16x8*>(t1 + ((c.tid + p * 512) >> 5) * AS + ((c.tid + p * 512) & 31) * 8) = zero_bf8();
+      }
+      tile_store(c, rx, t2);
+    }
+    f32x16 acc[MT];
+    zero_acc(acc);
+    for (int u = 0; u < a.nb; ++u) {
+      tile_store(c, nxt, t0);
+      __syncthreads();
+      if (u + 1 < a.nb) tile_load(c, a.dP + (u + 1) * 256, a.ldp, nxt);
+      if (u + 1 == a.nb) c.ws = at_block(b_chunk);          // (the block after HEAD's last: this workgroup's chunk)
+      block_mma(c, t0, acc);
+      __syncthreads();
+    }
+    if (a.nb == 0) __syncthreads();
+    const bool w = part == 0;
+    epi_lnbwd<DROP>(c, acc, t1, t2, t0, a.rstd_a, a.gamma_a, da, red, w ? a.ds_a : nullptr, w ? a.dgamma_a : nullptr,
+                    w ? a.dbeta_a : nullptr, w ? a.dbias_a : nullptr);
+    cur = t0; fa = t1; fb = t2;
+    __syncthreads();
+  } else {
+    tile_in(c, a.DS, DM, t0);
+    cur = t0; fa = t1; fb = t2;
+    __syncthreads();
+  }
+  f32x16 acc2[MT];
+  zero_acc(acc2);
+  TileRegs<MT> xr;
+  {
+    const int dff = parts * 256;
+    bf16* hc = fa;
+    const unsigned long long relu = a.relu_bits[((size_t)(block * parts + part) * NW + c.wave) * 64 + c.l];
+    f32x16 acc1[MT];
+    zero_acc(acc1);
+    block_mma(c, cur, acc1);                   // ds x W2[:, chunk]; refills: W1[chunk, :] right behind
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bf16 v = (bf16)(acc1[0][4 * g + e] * a.mask_scale);
+        const int b = 4 * g + e;
+        o[e] = (((uint32_t)relu >> b) & 1u) ? v : (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x4*>(hc + c.r * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
+    }
+    __syncthreads();
+    tile_load(c, a.xhat_b, DM, xr);            // (used by the last arriver only; asked for by all: nobody knows yet)
+    c.ws = at_block(b_tail);
+    block_mma(c, hc, acc2);                    // dH chunk x W1[chunk, :]
+    tile_out(c, hc, a.dH + part * 256, dff);
+  }
+  float* slot = a.split_ws + (size_t)block * parts * (512 * 16);
+  {
+    float* mine = slot + (size_t)part * (512 * 16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) __hip_atomic_store(mine + i * 512 + c.tid, acc2[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  __syncthreads();
+  if (c.tid == 0)
+    last = __hip_atomic_fetch_add(a.split_tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1);
+  __syncthreads();
+  if (last) {
+    if (c.tid == 0) __hip_atomic_store(a.split_tickets + block, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    zero_acc(acc2);
+    for (int p = 0; p < parts; ++p) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(slot + (size_t)p * (512 * 16) + i * 512 + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc2[0][i] += v[i];
+    }
+    // dy = acc2 + ds (in place over the ds tile), xhat_b into fb (free since HEAD's last barrier), ds_b into the chunk's tile
+    bf16* tx = fb;
+    bf16* td = fa;
+    tile_store(c, xr, tx);
+    __syncthreads();
+    epi_lnbwd<false>(c, acc2, cur, tx, td, a.rstd_b, a.gamma_b, off, red, a.ds_b, a.dgamma_b, a.dbeta_b, a.dbias_b);
+    fa = cur; fb = tx; cur = td;
+    __syncthreads();
+    if (TAIL) {
+      TileRegs<MT> ro, rr_;
+      tile_load(c, a.O, a.ldo, ro);
+      if (a.Ores) tile_load(c, a.Ores, a.ldo, rr_);
+      f32x16 acc[MT];
+      zero_acc(acc);
+      block_mma(c, cur, acc);
+      tile_store(c, ro, fa);
+      if (a.Ores) tile_store(c, rr_, fb);
+      __syncthreads();
+      {
+        const int row = c.r;
+        float part_ = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int at = row * AS + c.wave * 32 + 8 * g + 4 * c.hi;
+          const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(fa + at);
+          bf16x4 r4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+          if (a.Ores) r4 = *reinterpret_cast<const bf16x4*>(fb + at);
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (bf16)acc[0][4 * g + e];
+            part_ += (float)o[e] * ((float)o4[e] + (float)r4[e]);
+          }
+          *reinterpret_cast<bf16x4*>(cur + at) = o;
+        }
+        part_ += wave_xor32(part_);
+        if (c.hi == 0) red[0][c.wave * 32 + c.r] = part_;
+      }
+      __syncthreads();
+      tile_out(c, cur, a.dctx, a.lddc);
+      for (int i = c.tid; i < 4 * RB; i += 512) {
+        const int h = i / RB, row = i % RB;
+        if (row < c.nvalid) a.delta[(size_t)h * a.M + c.row0 + row] = red[0][(2 * h) * 32 + row] + red[0][(2 * h + 1) * 32 + row];
+      }
+    }
+  }
+  {
+    int tsum = 0;
+#pragma unroll
+    for (int t = 0; t < TOUCH; ++t) tsum ^= touched[t];
+    if (tsum == 0x5a5a5a5a && a.M < 0) red[0][0] = 1.f;
+  }
+}
+}  // namespace
+
+namespace {
 // row tiles per workgroup: the smallest of 1, 2, 3 that gives at most one round of workgroups (256 CUs)
 // row tiles of 32 per workgroup (1, 2 or 3): the choice that needs the least time for M rows at one workgroup per CU -
 // rounds of 256 workgroups x the time a workgroup of that height takes (forward chain, measured: 27 / 41 / 59 us; the
@@ -715,7 +896,8 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
                                 const void* DS, int d_ff, const unsigned long long* relu_bits, float mask_scale, void* dH,
                                 const void* xhat_b,
                                 const float* rstd_b, const float* gamma_b, void* ds_b, float* dgamma_b, float* dbeta_b,
-                                float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta) {
+                                float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta,
+                                void* split_work, long long split_bytes) {
   if (M <= 0) return 0;
   // HEAD is present iff xhat_a is given; with head_blocks == 0 it is the bare LayerNorm backward of G (the gradient that
   // reaches the LAST sublayer of a stack from outside)
@@ -744,6 +926,26 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
   const int mt = row_tiles(M);
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
+  a.split_ws = nullptr; a.split_tickets = nullptr;
+  if (split_work && ffn && mt == 1 && a.nc >= 2 && a.nc <= 8 && (int)grid.x * a.nc <= 256) {      // see st_row_chain
+    const size_t words = (size_t)grid.x * a.nc * 512 * 16;
+    if (split_bytes < (long long)((256 + words) * 4)) return -6;
+    a.split_tickets = (unsigned*)split_work;
+    a.split_ws = (float*)split_work + 256;
+    const dim3 sgrid(grid.x * a.nc);
+#define ST_BSPLIT(HEAD_, TAIL_)                                                                                        \
+  do {                                                                                                                 \
+    if (drop) hipLaunchKernelGGL((row_chain_bwd_split_kernel<HEAD_, TAIL_, true>), sgrid, blk, 0, stream, a);          \
+    else hipLaunchKernelGGL((row_chain_bwd_split_kernel<HEAD_, TAIL_, false>), sgrid, blk, 0, stream, a);              \
+  } while (0)
+    if (head && tail) ST_BSPLIT(true, true);
+    else if (head) ST_BSPLIT(true, false);
+    else if (tail) ST_BSPLIT(false, true);
+    else ST_BSPLIT(false, false);
+#undef ST_BSPLIT
+    ST_CHECK_LAUNCH();
+    return 0;
+  }
 #define ST_BWD(HEAD_, FFN_, TAIL_)                                                                                     \
   do {                                                                                                                 \
     if (mt == 3) {                                                                                                     \

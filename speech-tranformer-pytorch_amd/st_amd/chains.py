@@ -390,6 +390,9 @@ class DecoderChains:
             b1[l] = self.bset.add(t_blocks(blocks_of(ca.w_q)) + t_blocks(blocks_of(sa.w_o)))
         self.bset.finalize()
         self.bwd2 = [self.bset.chain(b2[l], True) for l in range(n)]
+        if self.f2 and self.f2[0].split_work is not None and os.environ.get("ST_CHAIN_SPLIT", "1") != "f":      # ("f": forward only)
+            for ch in self.bwd2:
+                ch.split_work = self.f2[0].split_work       # (forward and backward launches are ordered on one stream)
         self.bwd1 = [self.bset.chain(b1[l], True) for l in range(n)]
         self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
         ChainHub.of(arena).add(self.set, self.bset)

@@ -52,7 +52,7 @@ SIGNATURES = {
     "st_row_chain_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                          _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p],
+                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_ll],
     "st_gemm_lnbwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                       _c_void_p, _c_uint, _c_int, _c_float],
@@ -560,13 +560,17 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     if head is None and ds_in is None:
         raise ValueError("row_chain_bwd: without head the chain needs ds_in")
     sd = _drop(drop)
+    work = getattr(chain, "split_work", None) if ffn else None
+    if work is not None and not (work.is_cuda and work.is_contiguous() and work.dtype == torch.int32):
+        raise ValueError("row_chain_bwd: chain.split_work must be a contiguous int32 tensor on the GPU")
     _tag("row_chain_bwd", M, n_blocks, d_ff, io=((dP, M), (G, M), (xa, M), (dsa, M), (ds_in, M), bits, (dH, M), (xb, M), (dsb, M), (O, M),
                                                  (Ores, M), (dctx, M), (delta, 4 * M), (ra, M), (rb, M), 2.0 * 256 * 256 * n_blocks))
     rc = load().st_row_chain_bwd(
         _stream(), M, chain.stream.data_ptr(), n_blocks, int(chain.next_blocks), int(nb), _p(dP), 0 if dP is None else dP.stride(0),
         _p(G), 0 if G is None else G.stride(0), _p(xa), _p(ra), _p(ga), sd[0], sd[1], sd[2], sd[3], _p(dsa), _p(dga), _p(dba),
         _p(dbia), _p(ds_in), int(d_ff), _p(bits), float(msc), _p(dH), _p(xb), _p(rb), _p(gb), _p(dsb), _p(dgb), _p(dbb), _p(dbib),
-        _p(O), _p(Ores), 0 if O is None else O.stride(0), _p(dctx), 0 if dctx is None else dctx.stride(0), _p(delta))
+        _p(O), _p(Ores), 0 if O is None else O.stride(0), _p(dctx), 0 if dctx is None else dctx.stride(0), _p(delta),
+        _p(work), 0 if work is None else work.numel() * work.element_size())
     _check(rc, "st_row_chain_bwd")
 
 

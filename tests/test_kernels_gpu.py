@@ -950,7 +950,8 @@ def test_attn_sf1_fwd_equals_the_three_launches(case):
 
 @pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail",
-                                     "head0+ffn+tail+drop"])
+                                     "head0+ffn+tail+drop", "head3+ffn+tail+split", "ffn+tail+split", "head3+ffn+tail+drop+split",
+                                     "head3+ffn+split", "head0+ffn+tail+drop+split", "ffn+split"])
 def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
     """One st_row_chain_bwd launch == st_gemm_lnbwd, st_gemm (mask epilogue), st_gemm_lnbwd and st_gemm (delta epilogue) as
     separate kernels (the emulation composes their emulations): every gradient tensor, the atomically accumulated
@@ -991,6 +992,8 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
             cid = cs.add(blocks(f))
             cs.finalize().rebuild()
             ch = cs.chain(cid)
+            if "split" in parts:        # the hidden dimension over 4 workgroups per row block (M <= 2048; else ignored)
+                ch.split_work = split_work
         else:
             ch = chains.Chain(None, len(blocks(f)), blocks(f))
         fn(ch, M,
@@ -1001,7 +1004,13 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
            tail=(f(O), f(Ores), o["dctx"], o["delta"]) if has_tail else None)
         return o
 
+    split_work = torch.zeros(nv.split_work_words(), dtype=torch.int32, device="cuda") if "split" in parts else None
     got, ref = run("cuda", nv.row_chain_bwd, dn), run("cpu", em.row_chain_bwd, de)
+    if split_work is not None:
+        assert int(split_work[:256].abs().sum()) == 0, "split tickets not reset"
+        again = run("cuda", nv.row_chain_bwd, dn)
+        for n in ("ds_a", "dH", "ds_b", "dctx", "delta"):       # (the column sums are atomic adds: order-dependent rounding)
+            assert torch.equal(got[n], again[n]), "split backward row chain not reproducible: %s" % n
     names = (["ds_a", "dga", "dba", "dbia"] if has_head else []) + (["dH", "ds_b", "dgb", "dbb", "dbib"] if has_ffn else []) + \
         (["dctx", "delta"] if has_tail else [])
     for n in names:
