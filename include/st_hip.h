@@ -325,16 +325,20 @@ int st_decode_self_attn(st_stream_t stream, const void* qkv, int ldq, void* cach
    `eos` (Beam.py:70-72; a done utterance is frozen: identity back-pointers, scores / tokens unchanged).  Device state,
    updated in place: scores f32 [B, beam], tokens i64 [B * beam], done u8 [B], lengths i64 [B], the trellis hist_scores f32 /
    back i64 / toks i64 [S, B, beam] at row *step (device scalar), order i64 [B * beam] = the cache rows the hypotheses
-   inherit (input of st_cache_reorder).  beam <= 16.  `work`: NULL, or device scratch of B * beam * beam (+ 1 with `step_next`) 8-byte words - with
-   it (and V <= 5120) the step runs as two launches over B * beam workgroups (the `beam` best of every hypothesis row, then
-   one wave per utterance merges them) instead of one workgroup per utterance; same results.  `anc`: NULL, or the lineage
-   table int32 [B * beam][S] of st_decode_self_attn (needs `work`, S <= 128): the hypothesis placed in slot s takes over
-   positions 0 .. *step - 1 of its origin's row of the table and gets the origin's slot as position *step.  `step_next`:
-   NULL, or `step` itself (needs `work`, which then holds one more word - a ticket counter that is zero before the first
-   call): the launch also advances the device step counter, *step += 1, once every utterance has used the old value. */
+   inherit (input of st_cache_reorder).  beam <= 16.  `work`: NULL, or ZEROED device scratch of B * beam * beam + 1 + B 8-byte words - with
+   it (and V <= 5120) the step runs over B * beam workgroups instead of one per utterance (the `beam` best of every hypothesis
+   row; the wave of an utterance's row that finishes last merges them - a ticket per utterance, no second launch); same
+   results.  Only with `work`:
+   `anc`: NULL, or the lineage table int32 [B * beam][S] of st_decode_self_attn (S <= 128): the hypothesis placed in slot s
+   takes over positions 0 .. *step - 1 of its origin's row of the table and gets the origin's slot as position *step.
+   `step_next`: NULL, or `step` itself: the launch also advances the device step counter, *step += 1, once every utterance
+   has used the old value.
+   `x_next`: NULL, or bf16 [B * beam, D]: the NEXT step's decoder input, bf16(emb[token] + pe[*step + 1]) for the tokens
+   just chosen (st_embed_step's arithmetic; emb f32 [emb_rows, D], pe f32 [pe_rows, D]; skipped when *step + 1 == pe_rows). */
 int st_beam_advance(st_stream_t stream, const float* logits, int ldl, int V, int beam, int B, const long long* step, int eos,
                     float* scores, long long* tokens, unsigned char* done, long long* lengths, float* hist_scores,
-                    long long* back, long long* toks, long long* order, void* work, int* anc, int S, long long* step_next);
+                    long long* back, long long* toks, long long* order, void* work, int* anc, int S, long long* step_next,
+                    const float* emb, int emb_rows, const float* pe, int pe_rows, void* x_next, int D);
 
 /* Beam-search decode (transformer/Decode.py with a KV cache): cache bf16 [L][n][S][W]; for every layer, position
    t <= *step (device scalar) and utterance (beam consecutive hypothesis rows), row u*beam+s <- row order[u*beam+s]

@@ -667,12 +667,13 @@ __global__ __launch_bounds__(512) void beam_advance_kernel(const float* __restri
   }
 }
 
-// The same step as TWO launches over more of the chip (the kernel above keeps one compute unit per utterance busy for 43 us:
+// The same step over more of the chip (the kernel above keeps one compute unit per utterance busy for 43 us:
 // ~20 dependent batches of loads that 32 workgroups cannot hide, then ~12 vector instructions per candidate on one CU):
 //   (1) beam_row_best_kernel - one workgroup per HYPOTHESIS row (B * beam of them), the row's V logits in registers with
 //       every load issued before the first use: log-sum-exp, then the row's `beam` best candidates score + log-probability
 //       (the utterance's winners are among them), as 64-bit keys in `work`;
-//   (2) beam_merge_kernel - one wave per utterance: the `beam` best of its beam x beam keys, and the state update.
+//   (2) the merge - by the wave of the utterance's row that finishes last (a ticket per utterance): the `beam` best of its
+//       beam x beam keys, and the state update (beam_merge_wave).  One launch.
 // Wave reductions run on DPP (row butterflies + row_bcast), not ds_bpermute.  Across lanes candidates are ordered through
 // one 64-bit key (monotone image of the score in the high word, 0x7fffffff - flat index in the low word: larger score
 // first, lower flat index on ties - the order of beam_before); inside a thread the scan runs in increasing flat index with
@@ -737,12 +738,117 @@ __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k)
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The merge, run by ONE wave (the wave of the utterance's hypothesis rows that drew the last ticket): the `beam` best of the
+// utterance's beam x beam keys, the lineage table, the state update, the NEXT step's decoder input (embedding + positional
+// encoding of the tokens just chosen: st_embed_step's arithmetic) and the step counter.
+__device__ __forceinline__ void beam_merge_wave(int (*s_anc)[128], const unsigned long long* work, int b, int lane, int V, int beam, int B,
+                                                const long long* __restrict__ step_p, int eos, float* scores, long long* tokens,
+                                                unsigned char* done, long long* lengths, float* hist_scores, long long* back,
+                                                long long* toks, long long* order, int* anc, int S, long long* step_next,
+                                                unsigned* ticket, const float* __restrict__ emb, int emb_rows,
+                                                const float* __restrict__ pe, int pe_rows, bf16* x_next, int D) {
+  const int n = beam * beam;          // n <= 256
+  const long long step = *step_p;
+  unsigned long long c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    c[i] = i * 64 + lane < n ? __hip_atomic_load(work + (size_t)b * n + i * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  const float old = lane < beam ? scores[b * beam + lane] : 0.f;
+  const long long old_tok = lane < beam ? tokens[b * beam + lane] : 0;
+  // (the utterance's rows of the lineage table, asked for before the merge rounds: one memory round trip, hidden)
+  const int t = (int)step;
+  int r[16][2];
+  if (anc) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (s < beam && lane + 64 * h < t) r[s][h] = anc[((size_t)b * beam + s) * S + lane + 64 * h];
+  }
+  float bestv = 0.f;
+  int flat = 0;
+  for (int r = 0; r < beam; ++r) {
+    const unsigned long long m01 = c[0] > c[1] ? c[0] : c[1], m23 = c[2] > c[3] ? c[2] : c[3];
+    const unsigned long long best = wave_max_key(m01 > m23 ? m01 : m23);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c[i] == best) c[i] = 0ull;
+    if (lane == r) { bestv = beam_key_value(best); flat = beam_key_flat(best); }
+  }
+  const bool live_u = !done[b];
+  // ---- the lineage table of st_decode_self_attn: the new hypothesis in slot s inherits positions 0 .. step - 1 from its
+  //      origin and finds position `step` in the origin's slot (a done utterance: the identity)
+  if (anc) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (s < beam && lane + 64 * h < t) s_anc[s][lane + 64 * h] = r[s][h];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (one wave writes and reads the staging rows: no barrier)
+    for (int s = 0; s < beam; ++s) {
+      const int o = live_u ? __shfl(flat, s, 64) / V : s;
+      for (int p = lane; p < t; p += 64) anc[((size_t)b * beam + s) * S + p] = s_anc[o][p];
+      if (lane == 0) anc[((size_t)b * beam + s) * S + t] = b * beam + o;
+    }
+  }
+  // ---- the state update (one lane per beam slot), as in beam_advance_kernel
+  long long token = old_tok;
+  if (lane < beam) {
+    const int s = lane;
+    const size_t at = ((size_t)step * B + b) * beam + s;
+    const long long origin = live_u ? flat / V : s, tk = flat % V;
+    hist_scores[at] = old;
+    back[at] = origin;
+    toks[at] = tk;
+    order[b * beam + s] = origin + (long long)b * beam;
+    if (live_u) {
+      token = tk;
+      scores[b * beam + s] = bestv;
+      tokens[b * beam + s] = tk;
+      if (s == 0) {
+        lengths[b] += 1;
+        if (tk == eos) done[b] = 1;
+      }
+    }
+  }
+  // ---- the next step's decoder input for this utterance's hypotheses: bf16(emb[token] + pe[step + 1])
+  if (x_next && step + 1 < pe_rows) {
+    for (int s = 0; s < beam; ++s) {
+      const long long tk = __shfl(token, s, 64);
+      if (tk < 0 || tk >= emb_rows) __builtin_trap();
+      for (int ch = lane; ch < D / 4; ch += 64) {
+        const f32x4 e = *reinterpret_cast<const f32x4*>(emb + (size_t)tk * D + ch * 4);
+        const f32x4 pp = *reinterpret_cast<const f32x4*>(pe + (size_t)(step + 1) * D + ch * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (bf16)(e[k] + pp[k]);
+        *reinterpret_cast<bf16x4*>(x_next + ((size_t)b * beam + s) * D + ch * 4) = o;
+      }
+    }
+  }
+  // ---- the step counter: every utterance's wave has read it by the time it draws its ticket, the last one advances it
+  if (step_next && lane == 0) {
+    if (atomicAdd(ticket, 1u) == (unsigned)(B - 1)) {
+      *ticket = 0u;
+      *step_next = step + 1;
+    }
+  }
+}
+
+struct BeamState {       // what the merge updates (see st_beam_advance)
+  const long long* step; int eos, B; float* scores; long long* tokens; unsigned char* done; long long* lengths;
+  float* hist_scores; long long* back; long long* toks; long long* order; int* anc; int S; long long* step_next;
+  unsigned* ticket; unsigned* row_tickets; const float* emb; int emb_rows; const float* pe; int pe_rows; bf16* x_next; int D;
+};
+
 template <int NU>
 __global__ __launch_bounds__(256) void beam_row_best_kernel(const float* __restrict__ logits, int ldl, int V, int beam,
-                                                            const float* __restrict__ scores, unsigned long long* __restrict__ work) {
+                                                            unsigned long long* work, BeamState st) {
   constexpr int NW = 4;
   __shared__ float s_red[2][NW];
   __shared__ unsigned long long s_cand[NW * 16];
+  __shared__ int s_anc[16][128];
+  const float* __restrict__ scores = st.scores;
   const int row = blockIdx.x, j = row % beam, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* lg = logits + (size_t)row * ldl;
   float x[NU];
@@ -806,92 +912,29 @@ __global__ __launch_bounds__(256) void beam_row_best_kernel(const float* __restr
     w = wave_max_key(head == 0 ? k0 : k1);
   }
   __syncthreads();
-  // ---- wave 0: the row's `beam` best of the four lists
-  if (wave == 0) {
-    unsigned long long c = s_cand[lane];
-    for (int r = 0; r < beam; ++r) {
-      const unsigned long long best = wave_max_key(c);
-      if (c == best) c = 0ull;
-      if (lane == 0) work[(size_t)row * beam + r] = best;
-    }
+  // ---- wave 0: the row's `beam` best of the four lists; they leave through the L2 (write-through), then the utterance's
+  //      ticket: the wave of the LAST of its `beam` rows merges them (no fence: see row_chain_split_kernel)
+  if (wave != 0) return;
+  unsigned long long c = s_cand[lane];
+  for (int r = 0; r < beam; ++r) {
+    const unsigned long long best = wave_max_key(c);
+    if (c == best) c = 0ull;
+    if (lane == 0) __hip_atomic_store(work + (size_t)row * beam + r, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0);
+  const int b = row / beam;
+  int last = 0;
+  if (lane == 0) {
+    last = __hip_atomic_fetch_add(st.row_tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(beam - 1);
+    if (last) __hip_atomic_store(st.row_tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!__builtin_amdgcn_readfirstlane(last)) return;
+  beam_merge_wave(s_anc, work, b, lane, V, beam, st.B, st.step, st.eos, st.scores, st.tokens, st.done, st.lengths, st.hist_scores,
+                  st.back, st.toks, st.order, st.anc, st.S, st.step_next, st.ticket, st.emb, st.emb_rows, st.pe, st.pe_rows,
+                  st.x_next, st.D);
 }
 
-__global__ __launch_bounds__(64) void beam_merge_kernel(const unsigned long long* __restrict__ work, int V, int beam, int B,
-                                                        const long long* __restrict__ step_p, int eos, float* scores,
-                                                        long long* tokens, unsigned char* done, long long* lengths,
-                                                        float* hist_scores, long long* back, long long* toks, long long* order,
-                                                        int* anc, int S, long long* step_next, unsigned* ticket) {
-  __shared__ int s_anc[16][128];
-  const int b = blockIdx.x, lane = threadIdx.x, n = beam * beam;          // n <= 256
-  const long long step = *step_p;
-  unsigned long long c[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) c[i] = i * 64 + lane < n ? work[(size_t)b * n + i * 64 + lane] : 0ull;
-  const float old = lane < beam ? scores[b * beam + lane] : 0.f;
-  // (the utterance's rows of the lineage table, asked for before the merge rounds: one memory round trip, hidden)
-  const int t = (int)step;
-  int r[16][2];
-  if (anc) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (s < beam && lane + 64 * h < t) r[s][h] = anc[((size_t)b * beam + s) * S + lane + 64 * h];
-  }
-  float bestv = 0.f;
-  int flat = 0;
-  for (int r = 0; r < beam; ++r) {
-    const unsigned long long m01 = c[0] > c[1] ? c[0] : c[1], m23 = c[2] > c[3] ? c[2] : c[3];
-    const unsigned long long best = wave_max_key(m01 > m23 ? m01 : m23);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (c[i] == best) c[i] = 0ull;
-    if (lane == r) { bestv = beam_key_value(best); flat = beam_key_flat(best); }
-  }
-  // ---- the lineage table of st_decode_self_attn: the new hypothesis in slot s inherits positions 0 .. step - 1 from its
-  //      origin and finds position `step` in the origin's slot (a done utterance: the identity)
-  if (anc) {
-    const bool live_u = !done[b];
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (s < beam && lane + 64 * h < t) s_anc[s][lane + 64 * h] = r[s][h];
-    __syncthreads();
-    for (int s = 0; s < beam; ++s) {
-      const int o = live_u ? __shfl(flat, s, 64) / V : s;
-      for (int p = lane; p < t; p += 64) anc[((size_t)b * beam + s) * S + p] = s_anc[o][p];
-      if (lane == 0) anc[((size_t)b * beam + s) * S + t] = b * beam + o;
-    }
-  }
-  // ---- the state update (one lane per beam slot), as in beam_advance_kernel
-  if (lane < beam) {
-    const int s = lane;
-    const bool live = !done[b];
-    const size_t at = ((size_t)step * B + b) * beam + s;
-    const long long origin = live ? flat / V : s, token = flat % V;
-    hist_scores[at] = old;
-    back[at] = origin;
-    toks[at] = token;
-    order[b * beam + s] = origin + (long long)b * beam;
-    if (live) {
-      scores[b * beam + s] = bestv;
-      tokens[b * beam + s] = token;
-      if (s == 0) {
-        lengths[b] += 1;
-        if (token == eos) done[b] = 1;
-      }
-    }
-  }
-  // ---- the step counter: every workgroup has read it by the time it draws its ticket, the last one to draw advances it
-  if (step_next && lane == 0) {
-    if (atomicAdd(ticket, 1u) == (unsigned)(B - 1)) {
-      *ticket = 0u;
-      *step_next = step + 1;
-    }
-  }
-}
 
 // One beam-search step's decoder input: out[i] = bf16(emb[tokens[i]] + pe[*step])   (Models.py:84,87 with repair R3)
 __global__ __launch_bounds__(256) void embed_step_kernel(const long long* __restrict__ tokens, const float* __restrict__ emb, int V,
@@ -1050,20 +1093,22 @@ extern "C" int st_decode_self_attn(hipStream_t stream, const void* qkv, int ldq,
 extern "C" int st_beam_advance(hipStream_t stream, const float* logits, int ldl, int V, int beam, int B, const long long* step,
                                int eos, float* scores, long long* tokens, unsigned char* done, long long* lengths,
                                float* hist_scores, long long* back, long long* toks, long long* order, void* work, int* anc,
-                               int S, long long* step_next) {
+                               int S, long long* step_next, const float* emb, int emb_rows, const float* pe, int pe_rows,
+                               void* x_next, int D) {
   if (B <= 0) return 0;
   if (beam <= 0 || beam > 16 || V <= 0 || ldl < V || !logits || !step || !scores || !tokens || !done || !lengths || !hist_scores ||
       !back || !toks || !order)
     return -1;
-  const bool pair = work && V <= 20 * 256;
-  if (anc && (!pair || S <= 0 || S > 128)) return -1;       // (the lineage table is maintained by the merge launch)
-  if (step_next && (!pair || step_next != step)) return -1;
-  if (pair) {                           // two launches over B * beam workgroups: see beam_row_best_kernel
-    hipLaunchKernelGGL((beam_row_best_kernel<20>), dim3(B * beam), dim3(256), 0, stream, logits, ldl, V, beam, scores,
-                       (unsigned long long*)work);
-    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, stream, (const unsigned long long*)work, V, beam, B, step, eos,
-                       scores, tokens, done, lengths, hist_scores, back, toks, order, anc, S, step_next,
-                       (unsigned*)((unsigned long long*)work + (size_t)B * beam * beam));
+  const bool wide = work && V <= 20 * 256;
+  if (anc && (!wide || S <= 0 || S > 128)) return -1;       // (the lineage table is maintained by the merging wave)
+  if (step_next && (!wide || step_next != step)) return -1;
+  if (x_next && (!wide || !emb || !pe || emb_rows <= 0 || pe_rows <= 0 || D <= 0 || (D & 3))) return -1;
+  if (wide) {                           // B * beam workgroups: see beam_row_best_kernel
+    unsigned long long* w = (unsigned long long*)work;
+    BeamState st{step, eos, B, scores, tokens, done, lengths, hist_scores, back, toks, order, anc, S, step_next,
+                 (unsigned*)(w + (size_t)B * beam * beam), (unsigned*)(w + (size_t)B * beam * beam + 1), emb, emb_rows, pe, pe_rows,
+                 (bf16*)x_next, D};
+    hipLaunchKernelGGL((beam_row_best_kernel<20>), dim3(B * beam), dim3(256), 0, stream, logits, ldl, V, beam, w, st);
   } else {
     hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(512), 0, stream, logits, ldl, V, beam, B, step, eos, scores, tokens, done,
                        lengths, hist_scores, back, toks, order);

@@ -91,7 +91,8 @@ SIGNATURES = {
     "st_decode_self_attn": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                             _c_int, _c_float],
     "st_beam_advance": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
-                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                        _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int],
     "st_ce_fwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_ce_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                   _c_void_p, _c_int],
@@ -902,13 +903,15 @@ def decode_self_attn(qkv, cache, step, ctx, n_head, scale, anc=None):
 
 
 def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order, work=None, anc=None,
-                 advance_step=False):
+                 advance_step=False, embed=None):
     """Beam.advance for all utterances on the device (see st_beam_advance): logits f32 [B * beam, >= V]; the state tensors
     are updated in place (scores f32 [B, beam], tokens i64 [B * beam], done bool [B], lengths i64 [B], hist_scores f32 /
     back i64 / toks i64 [S, B, beam] at row ``step`` (i64 [1], device)); order i64 [B * beam] receives the cache rows.
-    ``work``: optional i64 [>= B * beam * beam] scratch - with it the step runs as two launches over B * beam workgroups.
+    ``work``: optional zeroed i64 [>= beam_work_words(B, beam)] scratch - with it the step runs over B * beam workgroups.
     ``anc``: optional lineage table i32 [B * beam, S'] of decode_self_attn, updated for the new hypotheses (needs ``work``).
-    ``advance_step``: the launch also does ``step += 1`` (needs ``work`` with one more element, zero before the first call)."""
+    ``advance_step``: the launch also does ``step += 1`` (needs ``work``).
+    ``embed`` = (emb f32 [V', D], pe f32 [P, D], x_next bf16 [B * beam, D]): the launch also writes the next step's decoder
+    input for the chosen tokens (embed_step's arithmetic at position step + 1; needs ``work``)."""
     B = scores.shape[0]
     if not (logits.is_cuda and logits.dtype == F32 and logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == B * beam):
         raise ValueError("beam_advance: logits must be an fp32 [B * beam, >= V] row matrix on the GPU")
@@ -921,11 +924,17 @@ def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist
     for t, dt, name in ((hist_scores, F32, "hist_scores"), (back, I64, "back"), (toks, I64, "toks")):
         if tuple(t.shape) != (S, B, beam) or t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
             raise ValueError("beam_advance: %s must be a contiguous [S, B, beam] tensor" % name)
-    if work is not None and not (work.is_cuda and work.dtype == I64 and work.is_contiguous() and
-                                 work.numel() >= B * beam * beam + (1 if advance_step else 0)):
-        raise ValueError("beam_advance: work must be a contiguous int64 tensor of >= B * beam * beam (+ 1) elements on the GPU")
-    if advance_step and work is None:
-        raise ValueError("beam_advance: advance_step needs the work buffer")
+    if work is not None and not (work.is_cuda and work.dtype == I64 and work.is_contiguous() and work.numel() >= beam_work_words(B, beam)):
+        raise ValueError("beam_advance: work must be a contiguous int64 tensor of >= beam_work_words(B, beam) elements on the GPU")
+    if (advance_step or embed is not None) and work is None:
+        raise ValueError("beam_advance: advance_step / embed need the work buffer")
+    emb = pe = x_next = None
+    if embed is not None:
+        emb, pe, x_next = embed
+        if not (emb.is_cuda and emb.dtype == F32 and emb.is_contiguous() and pe.is_cuda and pe.dtype == F32 and pe.is_contiguous()
+                and emb.dim() == 2 and pe.dim() == 2 and emb.shape[1] == pe.shape[1] and x_next.is_cuda and x_next.dtype == BF16
+                and x_next.is_contiguous() and tuple(x_next.shape) == (B * beam, emb.shape[1])):
+            raise ValueError("beam_advance: embed = (emb f32 [V', D], pe f32 [P, D], x_next bf16 [B * beam, D]), contiguous, on the GPU")
     _tag("beam_advance", B, beam, V)
     _check(load().st_beam_advance(_stream(), logits.data_ptr(), logits.stride(0), int(V), int(beam), B, step.data_ptr(), int(eos),
                                   scores.data_ptr(), tokens.data_ptr(), done.data_ptr(), lengths.data_ptr(),
@@ -933,7 +942,14 @@ def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist
                                   work.data_ptr() if work is not None else None,
                                   _lineage(anc, B * beam, anc.shape[1] if anc is not None and anc.dim() == 2 else 0, "beam_advance"),
                                   int(anc.shape[1]) if anc is not None else 0,
-                                  step.data_ptr() if advance_step else None), "st_beam_advance")
+                                  step.data_ptr() if advance_step else None, _p(emb), 0 if emb is None else emb.shape[0], _p(pe),
+                                  0 if pe is None else pe.shape[0], _p(x_next), 0 if emb is None else emb.shape[1]), "st_beam_advance")
+
+
+def beam_work_words(B: int, beam: int) -> int:
+    """int64 elements of beam_advance's ``work`` scratch (zero-initialised): beam keys per hypothesis row, the step ticket, a
+    ticket per utterance."""
+    return B * beam * beam + 1 + B
 
 
 def cache_reorder(cache, order, step, beam):

@@ -60,7 +60,10 @@ class Decode(object):
         dec = self.model.decoder
         n, d, S = st.n, dec.d_model, self.max_steps
         dst = dec._st
-        x = nv.embed_step(st.tokens, dst.emb, dst.pe, st.step, torch.empty(n, d, dtype=BF16, device=st.tokens.device))  # Models.py:84,87
+        if st.x_in is not None:    # (search: st_beam_advance left the decoder input of the tokens it chose; step 0: _init_state)
+            x = st.x_in
+        else:
+            x = nv.embed_step(st.tokens, dst.emb, dst.pe, st.step, torch.empty(n, d, dtype=BF16, device=st.tokens.device))  # Models.py:84,87
         dc = st.chains
         layers = list(dec.layer_stack)
 
@@ -137,7 +140,8 @@ class Decode(object):
         advances."""
         nv.beam_advance(logits, self.model.vocab_size, st.beam, st.step, Constants.EOS, st.scores, st.tokens, st.done,
                         st.lengths, st.hist_scores, st.back, st.toks, st.order, work=st.beam_work, anc=st.anc,
-                        advance_step=st.anc is not None)
+                        advance_step=st.anc is not None,
+                        embed=(self.model.decoder._st.emb, self.model.decoder._st.pe, st.x_in) if st.x_in is not None else None)
         if st.anc is None:         # (with the lineage table the cache rows stay where they were written, and the merge
             nv.cache_reorder(st.caches, st.order, st.step, st.beam)             # launch has advanced the step counter)
             st.step.add_(1)
@@ -161,7 +165,7 @@ class Decode(object):
         cur.wait_stream(self._side)
         return out
 
-    def _init_state(self, src_batch, beam, arena):
+    def _init_state(self, src_batch, beam, arena, search=True):
         """Encoder pass + the device state of a search over ``beam`` hypotheses per utterance (call inside ``arena.scope()``)."""
         inputs, in_len = src_batch
         model, dev = self.model, self.device
@@ -202,11 +206,16 @@ class Decode(object):
         st.back = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
         st.toks = torch.zeros(S, B, beam, dtype=torch.long, device=dev)
         st.order = torch.zeros(n, dtype=torch.long, device=dev)
-        st.beam_work = torch.zeros(n * beam + 1, dtype=torch.long, device=dev)  # st_beam_advance's candidate keys + ticket
+        st.beam_work = torch.zeros(nv.beam_work_words(B, beam), dtype=torch.long, device=dev)  # st_beam_advance's keys + tickets
         # the lineage table of the decode-shaped self-attention (cache row of every earlier position of every hypothesis):
         # the caches are then never permuted.  The fall-back self-attention reads its own rows: st_cache_reorder stays.
         st.anc = None if st.need_c_len or model.vocab_size > 5120 else \
             torch.arange(n, dtype=I32, device=dev).unsqueeze(1).repeat(1, S).contiguous()
+        # the decoder input of the current step: written by st_beam_advance for the tokens it chose (no st_embed_step launch per
+        # step); step 0's is made here.  Only a search advances that way (search=False: the caller feeds the tokens).
+        st.x_in = None
+        if search and st.anc is not None:
+            st.x_in = nv.embed_step(st.tokens, dec._st.emb, dec._st.pe, st.step, torch.empty(n, d, dtype=BF16, device=dev))
         return st
 
     @torch.no_grad()
@@ -222,7 +231,7 @@ class Decode(object):
         arena = arena_of(self.model)
         total = torch.zeros(B, dtype=torch.float64, device=dev)
         with arena.scope():
-            st = self._init_state(src_batch, 1, arena)
+            st = self._init_state(src_batch, 1, arena, search=False)
             steps = max(len(h) for h in hyps)
             fed = torch.full((steps, B), Constants.PAD, dtype=torch.long)
             live = torch.zeros(steps, B, dtype=torch.float64)

@@ -465,8 +465,12 @@ def decode_self_attn(qkv, cache, step, ctx, n_head, scale, anc=None):
     ctx.copy_((p * v).sum(1).reshape(n, d).to(BF16))
 
 
+def beam_work_words(B, beam):
+    return B * beam * beam + 1 + B
+
+
 def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist_scores, back, toks, order, work=None, anc=None,
-                 advance_step=False):
+                 advance_step=False, embed=None):
     """Beam.advance for all utterances with torch ops (the formulation transformer/Decode.py used before st_beam_advance)."""
     B = scores.shape[0]
     word_lk = torch.log_softmax(logits[:, :V].float(), dim=-1)
@@ -490,6 +494,10 @@ def beam_advance(logits, V, beam, step, eos, scores, tokens, done, lengths, hist
         t = int(step)
         anc[:, :t] = anc[order][:, :t].clone()
         anc[:, t] = order.to(anc.dtype)
+    if embed is not None:
+        emb, pe, x_next = embed
+        if int(step) + 1 < pe.shape[0]:
+            x_next.copy_((emb.index_select(0, tokens) + pe.index_select(0, step + 1)).to(BF16))
     if advance_step:
         step.add_(1)
 
@@ -543,7 +551,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "beam_work_words", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 
 @contextlib.contextmanager

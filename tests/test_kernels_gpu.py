@@ -1024,7 +1024,7 @@ def test_beam_advance_matches_torch_formulation(B, beam, V, two_launch):
     """st_beam_advance (log-softmax + top-k over beam x V + Beam.py's bookkeeping; one launch, or - given scratch - the
     row-best + merge pair) against the torch formulation (tests/_emul.py) over several steps, with finished utterances
     (frozen), -inf slots (step 0) and EOS."""
-    work = torch.zeros(B * beam * beam + 1, dtype=torch.long, device="cuda") if two_launch else None     # (+ 1: advance_step's ticket)
+    work = torch.zeros(nv.beam_work_words(B, beam), dtype=torch.long, device="cuda") if two_launch else None
     anc_a = torch.arange(B * beam, dtype=torch.int32).unsqueeze(1).repeat(1, 9).contiguous() if two_launch else None   # lineage table
     anc_b = anc_a.clone() if two_launch else None
     if two_launch:
@@ -1041,6 +1041,8 @@ def test_beam_advance_matches_torch_formulation(B, beam, V, two_launch):
                     order=torch.zeros(B * beam, dtype=torch.long, device=dev), step=torch.zeros(1, dtype=torch.long, device=dev))
 
     a, b = state("cuda"), state("cpu")
+    emb, pe = torch.randn(V, 64, generator=gen), torch.randn(S + 1, 64, generator=gen)
+    a["x"], b["x"] = torch.zeros(B * beam, 64, dtype=BF16, device="cuda"), torch.zeros(B * beam, 64, dtype=BF16)
     for t in range(S):
         logits = torch.randn(B * beam, ld, generator=gen) * 4
         if t >= 2:
@@ -1048,7 +1050,7 @@ def test_beam_advance_matches_torch_formulation(B, beam, V, two_launch):
         for st, fn, dev in ((a, nv.beam_advance, "cuda"), (b, em.beam_advance, "cpu")):
             fn(logits.to(dev), V, beam, st["step"], eos, st["scores"], st["tokens"], st["done"], st["lengths"], st["hist"],
                st["back"], st["toks"], st["order"], work=work if dev == "cuda" else None, anc=anc_a if dev == "cuda" else anc_b,
-               advance_step=two_launch)
+               advance_step=two_launch, embed=(emb.to(dev), pe.to(dev), st["x"]) if two_launch else None)
             if not two_launch:
                 st["step"] += 1
         assert int(a["step"]) == t + 1 and int(b["step"]) == t + 1
@@ -1058,6 +1060,7 @@ def test_beam_advance_matches_torch_formulation(B, beam, V, two_launch):
         assert torch.equal(a["toks"].cpu()[t][live], b["toks"][t][live]) and torch.equal(a["tokens"].cpu(), b["tokens"]), t
         if two_launch:
             assert torch.equal(anc_a.cpu()[:, :t + 1], anc_b[:, :t + 1]), t
+            assert torch.equal(a["x"].cpu(), b["x"]), t          # the next step's decoder input (embedding + PE, one rounding)
         assert torch.allclose(a["scores"].cpu(), b["scores"], atol=2e-5, rtol=1e-6) and \
             torch.allclose(a["hist"].cpu()[t], b["hist"][t], atol=2e-5, rtol=1e-6), t
     assert bool(b["done"][0]) and not bool(b["done"][1:].all())
@@ -1088,7 +1091,7 @@ def test_beam_advance_two_launches_equal_one(B, beam, V):
                     order=torch.zeros(B * beam, dtype=torch.long, device="cuda"), step=torch.zeros(1, dtype=torch.long, device="cuda"))
 
     a, b = state(), state()
-    work = torch.zeros(B * beam * beam, dtype=torch.long, device="cuda")
+    work = torch.zeros(nv.beam_work_words(B, beam), dtype=torch.long, device="cuda")
     for t in range(S):
         logits = (torch.randn(B * beam, ld, generator=gen) * 3).cuda()
         logits[: beam] = 0.0                       # utterance 0: every candidate of a row ties

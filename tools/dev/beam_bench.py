@@ -13,8 +13,8 @@ def state():
                 lengths=torch.zeros(B, dtype=torch.long, device="cuda"), hist=torch.zeros(S, B, beam, device="cuda"),
                 back=torch.zeros(S, B, beam, dtype=torch.long, device="cuda"), toks=torch.zeros(S, B, beam, dtype=torch.long, device="cuda"),
                 order=torch.zeros(B * beam, dtype=torch.long, device="cuda"), step=torch.zeros(1, dtype=torch.long, device="cuda"))
-work = torch.zeros(B * beam * beam, dtype=torch.long, device="cuda")
-for name, w in (("one launch", None), ("two launches", work), ("one launch", None), ("two launches", work)):
+work = torch.zeros(nv.beam_work_words(B, beam), dtype=torch.long, device="cuda")
+for name, w in (("one launch", None), ("B x beam workgroups", work), ("one launch", None), ("B x beam workgroups", work)):
     st = state()
     def call():
         st["scores"].zero_()
