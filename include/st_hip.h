@@ -76,6 +76,15 @@ int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int l
             int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits,
             const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, const void* aux2);
 
+/* D (bf16 [M, N]) = X Y^T (y_cmajor as st_gemm) for FEW output tiles and a LONG contraction (the vocabulary projection's input
+ * gradient, Models.py:151 backward: 1,206 x 256 over 4,344): the contraction is cut `splits` ways over workgroups, every
+ * split leaves its fp32 partial tile in `work` (write-through) and the last one to finish a tile adds them in split order
+ * and rounds once - no atomic adds; the result does not depend on arrival order (it differs from st_gemm's in fp32
+ * summation order only).  work: device scratch of 4096 + tiles * splits * 65536 bytes (tiles = ceil(M / 128) *
+ * ceil(N / 128) <= 1024) whose first 4096 bytes are zero before the first call (tickets; the launch leaves them zero). */
+int st_gemm_splitk(st_stream_t stream, int y_cmajor, const void* X, int ldx, const void* Y, int ldy, void* D, int ldd, int M,
+                   int N, int Kc, int splits, void* work, long long work_bytes);
+
 /* st_gemm whose Y operand (and bias) is a stack of equally shaped blocks lying y_block_stride (bias_block_stride)
  * elements apart in memory - the same nn.Linear weight of consecutive identical layers as the parameter arena
  * lays them out.  Forward (0,0): N = blocks * y_block_rows output columns, block b = rows [b * y_block_rows, ..);

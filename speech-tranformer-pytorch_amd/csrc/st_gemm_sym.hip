@@ -55,6 +55,8 @@ struct GemmArgs {
   // yseg_extra + 2^yseg_shift * ldy elements apart (bias blocks: bias_extra + 2^yseg_shift).  yseg_shift = 31: one block.
   int yseg_shift; long yseg_extra, bias_extra;
   DropArgs drop;   // EPI_BF16_RELU: dropout after the ReLU (SubLayers.py:25); EPI_BF16_MASK: .scale on the survivors
+  // EPI_BF16 with splits > 1 (st_gemm_splitk): fp32 partial tiles of the contraction splits and one ticket per output tile
+  float* split_ws; unsigned* split_tickets;
 };
 
 // Column of a contraction-major tile element after the swizzle: bits 5-6 of the column are XORed with (c-row & 3).
@@ -300,6 +302,56 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int ts, int ti, int
     // the bf16 epilogues stage the tile in the same LDS: every wave must have read its hand-over block first
     if (EPI != EPI_F32_ATOMIC_T) __syncthreads();
   }
+  if constexpr (EPI == EPI_BF16 && !DROP) {
+    if (a.splits > 1) {
+      // split-K with a bf16 result (st_gemm_splitk: few output tiles, a long contraction): every split leaves its fp32
+      // partial tile in the scratch with write-through stores and draws the tile's ticket; the last one adds the partials
+      // in split order (the result does not depend on who is last) and runs the epilogue.  No fence, no atomic adds: see
+      // row_chain_split_kernel (st_rowchain.hip) for the protocol, DESIGN.md for what fp32 atomics cost here.
+      __shared__ bool last;
+      float* slot = a.split_ws + (size_t)(tj * a.tiles_i + ti) * a.splits * (256 * 64);
+      float* mine = slot + (size_t)ts * (256 * 64);
+      // (two floats per 8-byte access: half the memory instructions of the exchange)
+      auto pack2 = [](float lo, float hi_) { return ((unsigned long long)__float_as_uint(hi_) << 32) | __float_as_uint(lo); };
+      unsigned long long* mine8 = reinterpret_cast<unsigned long long*>(mine);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int t = 0; t < 16; t += 2)
+            __hip_atomic_store(mine8 + ((x * 2 + y) * 8 + t / 2) * 256 + tid, pack2(acc[x][y][t], acc[x][y][t + 1]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0) {
+        unsigned* tk = a.split_tickets + (tj * a.tiles_i + ti);
+        last = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.splits - 1);
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (!last) return;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = zero16();
+      for (int p = 0; p < a.splits; ++p) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(slot + (size_t)p * (256 * 64));
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+              const unsigned long long v = __hip_atomic_load(src + ((x * 2 + y) * 8 + t / 2) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              acc[x][y][t] += __uint_as_float((unsigned)v);
+              acc[x][y][t + 1] += __uint_as_float((unsigned)(v >> 32));
+            }
+      }
+      __syncthreads();      // (the bf16 epilogue stages the tile in LDS)
+    }
+  }
   if (EPI == EPI_F32_ATOMIC_T) {
     // D^T[j][i] += acc: the lane index i is the contiguous axis of dW -> coalesced fp32 atomics
     float* D = reinterpret_cast<float*>(a.D);
@@ -543,7 +595,7 @@ int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int
               int ldy, void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux,
               int ldaux, int epi, int splits, const unsigned* drop_seed, unsigned drop_salt,
               int drop_thresh, float drop_scale, int y_block_rows, long y_block_stride,
-              long bias_block_stride, const void* aux2) {
+              long bias_block_stride, const void* aux2, void* split_work = nullptr, long long split_bytes = 0) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
   int yseg_shift = 31;
   if (y_block_rows > 0) {   // power-of-two multiple of 128 rows per block; forward and dgrad operands only
@@ -563,7 +615,8 @@ int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int
   GemmArgs a;
   a.head_dim = epi == EPI_BF16_DELTA ? splits : 0;   // this epilogue takes the head width in the `splits` slot
   if (splits < 1) splits = 1;
-  if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T) splits = 1;
+  if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && !(epi == EPI_BF16 && split_work)) splits = 1;
+  a.split_ws = nullptr; a.split_tickets = nullptr;
   a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
   a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux;
   a.aux2 = epi == EPI_BF16_DELTA ? (const bf16*)aux2 : nullptr;
@@ -575,6 +628,12 @@ int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int
   a.drop.seed = drop ? drop_seed : nullptr; a.drop.salt = drop_salt; a.drop.thresh = drop ? drop_thresh : 0;
   a.drop.scale = (drop || epi == EPI_BF16_MASK) && drop_scale > 0.f ? drop_scale : 1.f;
   dim3 grid(plan_splits(a, splits));
+  if (epi == EPI_BF16 && a.splits > 1) {      // scratch: 1024 tickets (fixed place), then splits x 64 KB per output tile
+    const long long tiles = (long long)a.tiles_i * a.tiles_j;
+    if (tiles > 1024 || split_bytes < 4096 + tiles * a.splits * (256 * 64 * 4)) return -8;
+    a.split_tickets = (unsigned*)split_work;
+    a.split_ws = (float*)split_work + 1024;
+  }
   int rc;
   if (!x_cmajor && !y_cmajor) rc = launch<false, false>(stream, a, epi, grid);
   else if (!x_cmajor && y_cmajor) rc = launch<false, true>(stream, a, epi, grid);
@@ -585,6 +644,14 @@ int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int
 }
 
 }  // namespace
+
+// D (bf16) = X Y^T with the contraction cut `splits` ways over workgroups (few output tiles, long Kc): see gemm_body
+extern "C" int st_gemm_splitk(hipStream_t stream, int y_cmajor, const void* X, int ldx, const void* Y, int ldy, void* D, int ldd,
+                              int M, int N, int Kc, int splits, void* work, long long work_bytes) {
+  if (!work || splits < 1) return -1;
+  return gemm_impl(stream, 0, y_cmajor, X, ldx, Y, ldy, D, ldd, M, N, Kc, nullptr, nullptr, 0, EPI_BF16, splits, nullptr, 0u, 0, 1.f,
+                   0, 0, 0, nullptr, work, work_bytes);
+}
 
 extern "C" int st_gemm_stacked(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y,
                                int ldy, void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux,

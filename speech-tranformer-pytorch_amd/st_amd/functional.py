@@ -393,6 +393,18 @@ def dgrad(dY, W, out, epi=nv.EPI_BF16, aux=None, kc=None, drop=None):
     return nv.gemm(dY, W, out, epi=epi, aux=aux, y_cmajor=True, kc=kc, drop=drop)
 
 
+def dgrad_long_k(dY, W, out):
+    """dgrad for FEW output tiles and a LONG contraction (the vocabulary projection's input gradient: 1,206 target rows x 256
+    columns over 4,344 vocabulary entries = 20 output tiles that each walk the whole contraction: 45 us on 20 compute
+    units): the contraction cut 6 ways over workgroups, merged by the last one per tile (st_gemm_splitk: 40 -> 23 us; 2 / 4 / 8 /
+    12 splits: 29 / 24 / 26 / 36 us - the exchange costs what the shorter loop saves).  Elsewhere: dgrad."""
+    M, K = dY.shape
+    tiles = ((M + 127) // 128) * ((out.shape[1] + 127) // 128)
+    if tiles > 32 or K < 2048:
+        return dgrad(dY, W, out)
+    return nv.gemm_splitk(dY, W, out, max(2, min(6, 128 // tiles)), y_cmajor=True)
+
+
 def _empty(rows, cols, like, dtype=BF16):
     return torch.empty(rows, cols, dtype=dtype, device=like.device)
 
@@ -884,7 +896,7 @@ class VocabFn(torch.autograd.Function):
         dl = dlogits if dlogits.dtype == BF16 else dlogits.to(BF16)      # (CeFn hands over bf16 directly)
         wgrad(dl, x, s.g_w_vocab)
         dx = _empty(x.shape[0], x.shape[1], x)
-        dgrad(dl, s.w_vocab, dx)
+        dgrad_long_k(dl, s.w_vocab, dx)
         arena.grads_ready(s.vocab_lo, s.vocab_hi)
         return dx, None, None, None
 
@@ -917,7 +929,7 @@ class VocabCeFn(torch.autograd.Function):
         nv.ce_bwd(logits, target, ctx.ignore_index, lse, sums, go.reshape(1).float(), dl, index=index)
         wgrad(dl, x, s.g_w_vocab)
         dx = _empty(x.shape[0], x.shape[1], x)
-        dgrad(dl, s.w_vocab, dx)
+        dgrad_long_k(dl, s.w_vocab, dx)
         arena.grads_ready(s.vocab_lo, s.vocab_hi)
         return dx, None, None, None, None, None
 

@@ -49,6 +49,8 @@ SIGNATURES = {
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
                      _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_ll],
     "st_row_chain_mask_words": [_c_int, _c_int],
+    "st_gemm_splitk": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                       _c_void_p, _c_ll],
     "st_row_chain_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                          _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
@@ -498,6 +500,29 @@ def split_work_words() -> int:
     """int32 elements of the scratch a Chain may carry as ``split_work`` (zero-initialised; the kernel leaves it zeroed where
     it matters): the 32 x 256 fp32 partial sums of up to 256 workgroups, and one ticket per row block."""
     return 256 * 512 * 16 + 256          # 256 workgroups' partials (the launch never uses more) + tickets
+
+
+_splitk_work = {}
+
+
+def gemm_splitk(X, Y, out, splits, y_cmajor=False):
+    """out (bf16 [M, N]) = X Y^T with the contraction cut ``splits`` ways over workgroups and merged by the last one to finish
+    each output tile (st_gemm_splitk: few output tiles, long contraction).  Y: [N, Kc], or [Kc, N] with y_cmajor."""
+    _mat(X, BF16, "X"), _mat(Y, BF16, "Y"), _mat(out, BF16, "out")
+    M, Kc = X.shape
+    N = Y.shape[1] if y_cmajor else Y.shape[0]
+    if (Y.shape[0] if y_cmajor else Y.shape[1]) != Kc or tuple(out.shape) != (M, N):
+        raise ValueError("gemm_splitk: shapes")
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    need = 4096 + tiles * int(splits) * 65536
+    key = (X.device, need)
+    work = _splitk_work.get(key)
+    if work is None:
+        work = _splitk_work[key] = torch.zeros(need // 4, dtype=torch.int32, device=X.device)
+    _tag("gemm", 0, int(y_cmajor), M, N, Kc, 0, io=(X, Y, out, 2.0 * tiles * int(splits) * 65536))
+    _check(load().st_gemm_splitk(_stream(), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), out.data_ptr(),
+                                 out.stride(0), M, N, Kc, int(splits), work.data_ptr(), need), "st_gemm_splitk")
+    return out
 
 
 def chain_mask_words(M: int, d_ff: int) -> int:

@@ -732,6 +732,26 @@ def test_gemm_ws_stacked_weights():
     check(out, tiled, 5e-3, "gemm_ws vs st_gemm_stacked")
 
 
+@pytest.mark.parametrize("M,N,K,splits,ycm", [(1206, 256, 4344, 8, True), (5, 256, 2104, 3, True), (300, 384, 4096, 5, False),
+                                              (129, 128, 96, 2, True)])
+def test_gemm_splitk_matches_gemm(M, N, K, splits, ycm):
+    """st_gemm_splitk (contraction cut over workgroups, fp32 partial tiles merged by the last arriver of each output tile, in
+    split order) == st_gemm's product (fp32 summation order differs: bf16 results within one rounding of each other and of
+    the fp32 reference), bit-reproducible from launch to launch, tickets back at zero; ragged M, K not a multiple of the
+    k-tile, more splits than k-tiles allow."""
+    x = g(M, K, seed=1)
+    w = g(K, N, seed=2, scale=K ** -0.5) if ycm else g(N, K, seed=2, scale=K ** -0.5)
+    ref = em.gemm(x, w, torch.zeros(M, N, dtype=BF16), y_cmajor=ycm)
+    plain = nv.gemm(cu(x), cu(w), torch.zeros(M, N, dtype=BF16, device="cuda"), y_cmajor=ycm)
+    a = nv.gemm_splitk(cu(x), cu(w), torch.full((M, N), float("nan"), dtype=BF16, device="cuda"), splits, y_cmajor=ycm)
+    b = nv.gemm_splitk(cu(x), cu(w), torch.full((M, N), float("nan"), dtype=BF16, device="cuda"), splits, y_cmajor=ycm)
+    check(a, ref, 1e-2, "gemm_splitk vs fp32 reference")
+    check(a, plain, 1e-2, "gemm_splitk vs st_gemm")
+    assert torch.equal(a, b), "gemm_splitk not reproducible"
+    for wk in nv._splitk_work.values():
+        assert int(wk[:1024].abs().sum()) == 0, "split-K tickets not reset"
+
+
 # ---- row chains (csrc/st_rowchain.hip) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["pre+post1", "pre+ffn+post3", "pre+ffn", "ffn", "ffn+post1", "pre+ffn+post3+drop",
