@@ -281,14 +281,15 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, f
 // index order: the result does not depend on the arrival order), writes *gnorm, advances the optimiser's step counter
 // (*step += 1, optional) and resets the ticket for the next launch.  Replaces torch.linalg.vector_norm (52 MB at 2.6 TB/s
 // plus a memset) and the separate step increment: three graph nodes -> one.
-__global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict__ g, size_t n4, float* partial, unsigned* ticket,
+__global__ __launch_bounds__(1024) void grad_norm_kernel(const float* __restrict__ g, size_t n4, float* partial, unsigned* ticket,
                                                         float* __restrict__ gnorm, float* step) {
-  __shared__ float red[4];
+  __shared__ float red[16];      // 1024 threads x four 16-byte loads in flight = 64 KB per workgroup, 16 MB over the chip
+                                 // (256 threads: 4 MB in flight = ~2 TB/s at ~2 us memory latency: 18 us for 52 MB)
   __shared__ bool last;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = blockIdx.x * (size_t)256 + tid;
+  const size_t stride = (size_t)gridDim.x * 1024;
+  size_t i = blockIdx.x * (size_t)1024 + tid;
   for (; i + 3 * stride < n4; i += 4 * stride) {      // four 16-byte loads in flight per thread
     f32x4 v[4];
 #pragma unroll
@@ -311,7 +312,10 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict_
   if (tid == 0) {
     // write-through store, acknowledged before the ticket is drawn; the last workgroup reads with device-scope loads.  No
     // fence: an agent-scope release writes the whole L2 back (tools/dev/merge_probe.hip: +60-80 us on 512 workgroups)
-    __hip_atomic_store(partial + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    float bs = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) bs += red[w];
+    __hip_atomic_store(partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0);
     last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
@@ -319,9 +323,10 @@ __global__ __launch_bounds__(256) void grad_norm_kernel(const float* __restrict_
   __syncthreads();
   if (!last) return;
   double t = 0.0;
-  for (int i = tid; i < (int)gridDim.x; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 256)
+    for (int i = tid; i < (int)gridDim.x; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __shared__ double redd[256];
-  redd[tid] = t;
+  if (tid < 256) redd[tid] = t;
   __syncthreads();
   for (int o = 128; o; o >>= 1) {
     if (tid < o) redd[tid] += redd[tid + o];
@@ -1265,9 +1270,9 @@ extern "C" int st_grad_norm(hipStream_t stream, const float* g, long long n, flo
   const size_t n4 = (size_t)n / 4;
   // one workgroup per CU: the tickets are same-address atomics, which serialise (~15 ns each: 1024 workgroups spent 15 us on
   // them, ce_fwd's 1,200 once 43 us)
-  int blocks = (int)((n4 + 255) / 256);
+  int blocks = (int)((n4 + 1023) / 1024);
   if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(grad_norm_kernel, dim3(blocks), dim3(256), 0, stream, g, n4, scratch, reinterpret_cast<unsigned*>(scratch + 1024),
+  hipLaunchKernelGGL(grad_norm_kernel, dim3(blocks), dim3(1024), 0, stream, g, n4, scratch, reinterpret_cast<unsigned*>(scratch + 1024),
                      gnorm, step);
   ST_CHECK_LAUNCH();
   return 0;
