@@ -514,11 +514,14 @@ def gemm_splitk(X, Y, out, splits, y_cmajor=False):
     if (Y.shape[0] if y_cmajor else Y.shape[1]) != Kc or tuple(out.shape) != (M, N):
         raise ValueError("gemm_splitk: shapes")
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    need = 4096 + tiles * int(splits) * 65536
-    key = (X.device, need)
-    work = _splitk_work.get(key)
+    if tiles * int(splits) > 256:
+        raise ValueError("gemm_splitk: at most 256 (output tile, split) pairs")
+    # ONE scratch per device, sized for the largest launch (16.8 MB): a size that followed the shape would be allocated anew -
+    # possibly inside a graph capture, from the graph's private pool - whenever a batch brings another row count
+    need = 4096 + 256 * 65536
+    work = _splitk_work.get(X.device)
     if work is None:
-        work = _splitk_work[key] = torch.zeros(need // 4, dtype=torch.int32, device=X.device)
+        work = _splitk_work[X.device] = torch.zeros(need // 4, dtype=torch.int32, device=X.device)
     _tag("gemm", 0, int(y_cmajor), M, N, Kc, 0, io=(X, Y, out, 2.0 * tiles * int(splits) * 65536))
     _check(load().st_gemm_splitk(_stream(), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), out.data_ptr(),
                                  out.stride(0), M, N, Kc, int(splits), work.data_ptr(), need), "st_gemm_splitk")
