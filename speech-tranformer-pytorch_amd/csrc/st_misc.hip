@@ -976,7 +976,7 @@ extern "C" int st_embed_step(hipStream_t stream, const long long* tokens, const 
 // slot the ancestor that produced it sat in (st_beam_advance maintains the table; every entry is a valid row at all times) -
 // so the cache rows never move (without it: own rows, and st_cache_reorder permutes the cache after every step).
 // A launch here is a chain of memory round trips with nothing to hide behind, so everything that can be asked for early
-// is: the step counter, the lineage entries and q first, then the key rows and ALL value rows of the first 64 positions
+// is: the step counter, the lineage entries and q first, then the key AND value chunks of the first 64 positions
 // (registers), and only then the arithmetic.
 __global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16* __restrict__ qkv, int ldq, bf16* cache, const long long* __restrict__ step_p,
                                                                const int* __restrict__ anc, bf16* __restrict__ ctx, int ldc, int n, int S, int H,
@@ -986,92 +986,91 @@ __global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16* __res
   if (i >= n) return;
   const int d = H * 64, t = (int)*step_p;
   const bf16* row = qkv + (size_t)i * ldq;
-  int a0 = i, a1 = i;                     // cache rows of positions l and l + 64
-  if (anc) {
-    a0 = anc[(size_t)i * S + min(l, S - 1)];
-    a1 = anc[(size_t)i * S + min(l + 64, S - 1)];
-  }
+  // lane = (position group g = l / 8, 8-column chunk ch = l % 8): one load instruction fetches 16 bytes of the rows of eight
+  // positions (positions j * 8 + g, j = 0 .. 7 per 64-position pass) - whole 128-byte head segments, for keys and values alike;
+  // a score is the sum of the eight chunk lanes' partial dot products, and the probability of position (j, g) then sits in
+  // exactly the lanes that hold that position's value chunks (no broadcasts in P V)
+  const int g = l >> 3, ch = l & 7;
+  int ak[2][8];                     // cache rows of this lane's positions
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ak[p][j] = anc ? anc[(size_t)i * S + min(p * 64 + j * 8 + g, S - 1)] : i;
   // the step's K | V into the cache (lanes 0-7: K, 8-15: V; 16 bytes each)
   if (l < 16) {
     const int part = l >> 3, c = (l & 7) * 8;
     *reinterpret_cast<bf16x8*>(cache + ((size_t)i * S + t) * 2 * d + part * d + h * 64 + c) =
         *reinterpret_cast<const bf16x8*>(row + d + part * d + h * 64 + c);
   }
-  // q (64 values) in registers of every lane (same address for all lanes: one broadcast load per 16 bytes)
-  bf16x8 qraw[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) qraw[c] = *reinterpret_cast<const bf16x8*>(row + h * 64 + c * 8);
-  // key rows: lane = key (keys l and l + 64); the newest key is read from qkv (its cache line was written by other lanes)
-  bf16x8 kraw[2][8];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int k = l + 64 * p;
-    if (k <= t) {
-      const bf16* kr = (k == t) ? row + d + h * 64 : cache + ((size_t)(p ? a1 : a0) * S + k) * 2 * d + h * 64;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) kraw[p][c] = *reinterpret_cast<const bf16x8*>(kr + c * 8);
-    }
-  }
-  // value rows: lane = (position group g = l / 8, 8-column chunk l % 8) - a load instruction fetches 16 bytes of eight
-  // positions' rows (positions j * 8 + g), so the 64 positions of a pass are 8 load instructions with per-lane addresses
-  // (one instruction per position with a scalar address - 64 of them, each behind a v_readlane and a 64-bit scalar
-  // multiply - made this phase grow by 0.16 us per cached position)
-  const int g = l >> 3, ch = l & 7;
-  bf16x8 vraw[8];
-  auto load_values = [&](int base) {
+  const bf16x8 qraw = *reinterpret_cast<const bf16x8*>(row + h * 64 + ch * 8);
+  bf16x8 kraw[8], vraw[8];
+  auto fetch = [&](int p, int off, bf16x8 (&dst)[8]) {      // off: 0 = keys, d = values (the newest position is read from qkv)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int k = base + j * 8 + g;
+      const int k = p * 64 + j * 8 + g;
       bf16x8 v = {};
       if (k <= t) {
-        const int ak = anc ? anc[(size_t)i * S + k] : i;
-        const bf16* vr = (k == t) ? row + 2 * d + h * 64 : cache + ((size_t)ak * S + k) * 2 * d + d + h * 64;
-        v = *reinterpret_cast<const bf16x8*>(vr + ch * 8);
+        const bf16* r = (k == t) ? row + d + off + h * 64 : cache + ((size_t)ak[p][j] * S + k) * 2 * d + off + h * 64;
+        v = *reinterpret_cast<const bf16x8*>(r + ch * 8);
       }
-      vraw[j] = v;
+      dst[j] = v;
     }
   };
-  load_values(0);
-  float q[64];
+  fetch(0, 0, kraw);
+  fetch(0, d, vraw);
+  float q[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)qraw[c][e] * scale;
-  float sc[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    float acc = -INFINITY;
-    if (l + 64 * p <= t) {
-      acc = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], (float)kraw[p][c][e], acc);
-    }
-    sc[p] = acc;
-  }
-  float mx = fmaxf(sc[0], sc[1]);
-#pragma unroll
-  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  float pr[2] = {sc[0] > -INFINITY ? __expf(sc[0] - mx) : 0.f, sc[1] > -INFINITY ? __expf(sc[1] - mx) : 0.f};
-  float sm = pr[0] + pr[1];
-#pragma unroll
-  for (int o = 32; o; o >>= 1) sm += __shfl_xor(sm, o, 64);
-  const float inv = 1.f / sm;
-  // context: every lane sums its positions (p of position k sits in lane k % 64), then the eight groups are added up
-  float out[8] = {};
-  auto accumulate = [&](float prp) {
+  for (int e = 0; e < 8; ++e) q[e] = (float)qraw[e] * scale;
+  float sc[2][8];
+  auto scores = [&](int p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float p = __shfl(prp, j * 8 + g, 64);          // (0 for a position past t)
+      float acc = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) out[e] = fmaf(p, (float)vraw[j][e], out[e]);
+      for (int e = 0; e < 8; ++e) acc = fmaf(q[e], (float)kraw[j][e], acc);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      sc[p][j] = (p * 64 + j * 8 + g <= t) ? acc : -INFINITY;
     }
   };
-  accumulate(pr[0]);
-  if (t >= 64) {                       // (S > 64 only)
-    load_values(64);
-    accumulate(pr[1]);
+  scores(0);
+  if (t >= 64) {                    // (S > 64 only)
+    fetch(1, 0, kraw);
+    scores(1);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sc[1][j] = -INFINITY;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, sc[p][j]);
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float pr[2][8], sm = 0.f;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pr[p][j] = sc[p][j] > -INFINITY ? __expf(sc[p][j] - mx) : 0.f;
+      sm += pr[p][j];
+    }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) sm += __shfl_xor(sm, o, 64);
+  const float inv = 1.f / sm;
+  float out[8] = {};
+  auto accumulate = [&](int p) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] = fmaf(pr[p][j], (float)vraw[j][e], out[e]);
+  };
+  accumulate(0);
+  if (t >= 64) {
+    fetch(1, d, vraw);
+    accumulate(1);
   }
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1)
