@@ -73,10 +73,13 @@ class TrainStep:
         self.bucket = None if bucket is None else (int(bucket[0]), int(bucket[1]))
         # bucket_rows = (input rows, target rows): the bucket's layouts are PACKED into that many rows (Rows.bucket(rows=...)) -
         # offsets on the device as well - so the captured step runs over about the batch's real row count instead of
-        # B * T_cap.  A batch with more rows than the capacity takes the padded bucket (a second capture).  Pick the
-        # capacities from the loader's length statistics AND the kernels' tile rounds: the encoder-sized row chains run one
-        # 96-row workgroup per CU, so 256 x 96 = 24,576 rows are one round and 24,577 are two.
-        self.bucket_rows = None if bucket_rows is None else (int(bucket_rows[0]), int(bucket_rows[1]))
+        # B * T_cap.  Several capacities may be given, [(rows, rows), ...] in ascending order: a batch takes the first one it
+        # fits (one capture each); a batch with more rows than the largest takes the padded bucket.  Pick the capacities
+        # from the loader's length statistics AND the kernels' tile rounds: the encoder-sized row chains run one 96-row
+        # workgroup per CU, so 256 x 96 = 24,576 rows are one round and 24,577 are two (of 64-row workgroups: up to 32,768).
+        if bucket_rows is not None and not isinstance(bucket_rows[0], (tuple, list)):
+            bucket_rows = [bucket_rows]
+        self.bucket_rows = None if bucket_rows is None else [(int(a), int(b)) for a, b in bucket_rows]
         if self.bucket_rows is not None and self.bucket is None:
             raise ValueError("TrainStep: bucket_rows needs bucket=(T_cap, L_cap)")
         self._buckets = {}
@@ -211,9 +214,12 @@ class TrainStep:
         L = targets.shape[1]
         if T > T_cap or L > L_cap or ground_truth.shape[1] > L_cap:
             raise ValueError("TrainStep(bucket=%r): batch of %d frames / %d tokens does not fit" % (self.bucket, T, L))
-        packed = self.bucket_rows is not None and int(input_lengths.sum()) <= self.bucket_rows[0] and \
-            int(target_lengths.sum()) <= self.bucket_rows[1]
-        key = (B, Fd, inputs.dtype, str(inputs.device), packed)
+        caps = None                   # the first packed capacity the batch fits (None: the padded bucket)
+        if self.bucket_rows is not None:
+            n_in, n_tgt = int(input_lengths.sum()), int(target_lengths.sum())
+            caps = next((c for c in self.bucket_rows if n_in <= c[0] and n_tgt <= c[1]), None)
+        packed = caps is not None
+        key = (B, Fd, inputs.dtype, str(inputs.device), caps)
         st = self._buckets.get(key)
         if st is None:
             from .functional import Rows
@@ -225,7 +231,7 @@ class TrainStep:
             # it stays 0 = ignore_index)
             st.gt_flat = torch.zeros(B * L_cap + 1, dtype=ground_truth.dtype, device=dev)
             st.gt = st.gt_flat[:B * L_cap].view(B, L_cap)
-            in_cap, tgt_cap = self.bucket_rows if packed else (None, None)
+            in_cap, tgt_cap = caps if packed else (None, None)
             st.layouts = (Rows.bucket(B, T_cap, dev, rows=in_cap), Rows.bucket(B, L_cap, dev, rows=tgt_cap))
             if hasattr(self.model, "prepare_layouts"):          # chain plans, work lists: before any capture
                 from .functional import attn_work

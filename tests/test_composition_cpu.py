@@ -671,7 +671,8 @@ def run_bucket_mode(device, use_graph, bucket_rows=None, T_cap=96, L_cap=12, t_m
         db = torch.cat([p.detach().reshape(-1) for p in mb.parameters()]).double()
         assert float((da - db).norm() / db.norm()) < 2e-3, (i, float((da - db).norm() / db.norm()))
     if use_graph:
-        assert len(sa._buckets) == (1 if bucket_rows is None else 2)
+        n_caps = 0 if bucket_rows is None else len(bucket_rows) if isinstance(bucket_rows[0], (tuple, list)) else 1
+        assert 1 <= len(sa._buckets) <= 1 + n_caps and (n_caps == 0 or len(sa._buckets) >= 2)
         assert sum(st.cap is not None for st in sa._buckets.values()) >= 1
 
 
@@ -683,3 +684,9 @@ def test_bucket_mode_composition():
 def test_packed_bucket_mode_composition():
     with emulated_kernels():
         run_bucket_mode("cpu", use_graph=False, bucket_rows=(340, 44))
+
+
+def test_packed_bucket_two_capacities_composition():
+    """Two packed capacities: a batch takes the first it fits, the full-length batch the padded bucket."""
+    with emulated_kernels():
+        run_bucket_mode("cpu", use_graph=False, bucket_rows=[(250, 44), (340, 44)])

@@ -157,6 +157,7 @@ def test_packed_bucket_mode_one_capture_serves_changing_lengths_gpu(use_graph):
     """The same with the bucket's rows packed into a fixed capacity (offsets on the device, unassigned tail rows): the step
     costs the capacity's rows, not B x T_cap."""
     comp.run_bucket_mode("cuda", use_graph=use_graph, bucket_rows=(340, 44))
+    comp.run_bucket_mode("cuda", use_graph=use_graph, bucket_rows=[(250, 44), (340, 44)])      # two capacities
 
 
 def test_row_chain_step_narrow_heads_gpu():

@@ -18,7 +18,8 @@ bs = []
 for sd in range(6):
     bx, bt, bil, btl, bgt = synthetic.make_batch(32, 1000, 50, 80, 4337, seed=100 + sd, t_min=500, l_min=25)
     bs.append((bx.cuda(), bil, bt.cuda(), btl, bgt.cuda()))
-caps = (256 * 96, int(32 * (25 + 50) / 2 * 1.2) // 32 * 32)
+tc = int(32 * (25 + 50) / 2 * 1.2) // 32 * 32
+caps = [(256 * 96, tc), (420 * 64, tc)]
 mode = sys.argv[1] if len(sys.argv) > 1 else "packed"
 kw = dict(use_graph=True, graph_warmup=1, bucket=(1000, 50), bucket_rows=caps) if mode == "packed" else dict(use_graph=True, graph_warmup=1)
 st = TrainStep(model, optim, 4337, max_grad_norm=5.0, **kw)
