@@ -220,8 +220,12 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
   float* slot = a.split_ws + (size_t)block * parts * (512 * 16);
   {
     float* mine = slot + (size_t)part * (512 * 16);
+    unsigned long long* mine8 = reinterpret_cast<unsigned long long*>(mine);      // (two floats per 8-byte access)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) __hip_atomic_store(mine + i * 512 + c.tid, acc2[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = 0; i < 16; i += 2)
+      __hip_atomic_store(mine8 + (i / 2) * 512 + c.tid,
+                         ((unsigned long long)__float_as_uint(acc2[0][i + 1]) << 32) | __float_as_uint(acc2[0][i]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0);
   }
@@ -233,11 +237,15 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
     if (c.tid == 0) __hip_atomic_store(a.split_tickets + block, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     zero_acc(acc2);
     for (int p = 0; p < parts; ++p) {
-      float v[16];
+      const unsigned long long* src8 = reinterpret_cast<const unsigned long long*>(slot + (size_t)p * (512 * 16));
+      unsigned long long v[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(slot + (size_t)p * (512 * 16) + i * 512 + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < 8; ++i) v[i] = __hip_atomic_load(src8 + i * 512 + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc2[0][i] += v[i];
+      for (int i = 0; i < 8; ++i) {
+        acc2[0][2 * i] += __uint_as_float((unsigned)v[i]);
+        acc2[0][2 * i + 1] += __uint_as_float((unsigned)(v[i] >> 32));
+      }
     }
     // xhat goes to f1 (the A tile / PRE's xhat staging: last read two barriers ago), the output replaces cur in place
     epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, f1, cur, red, a.out1, a.xhat1, a.rstd1);
@@ -711,8 +719,12 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArg
   float* slot = a.split_ws + (size_t)block * parts * (512 * 16);
   {
     float* mine = slot + (size_t)part * (512 * 16);
+    unsigned long long* mine8 = reinterpret_cast<unsigned long long*>(mine);      // (two floats per 8-byte access)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) __hip_atomic_store(mine + i * 512 + c.tid, acc2[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = 0; i < 16; i += 2)
+      __hip_atomic_store(mine8 + (i / 2) * 512 + c.tid,
+                         ((unsigned long long)__float_as_uint(acc2[0][i + 1]) << 32) | __float_as_uint(acc2[0][i]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0);
   }
@@ -724,11 +736,15 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArg
     if (c.tid == 0) __hip_atomic_store(a.split_tickets + block, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     zero_acc(acc2);
     for (int p = 0; p < parts; ++p) {
-      float v[16];
+      const unsigned long long* src8 = reinterpret_cast<const unsigned long long*>(slot + (size_t)p * (512 * 16));
+      unsigned long long v[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(slot + (size_t)p * (512 * 16) + i * 512 + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < 8; ++i) v[i] = __hip_atomic_load(src8 + i * 512 + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc2[0][i] += v[i];
+      for (int i = 0; i < 8; ++i) {
+        acc2[0][2 * i] += __uint_as_float((unsigned)v[i]);
+        acc2[0][2 * i + 1] += __uint_as_float((unsigned)(v[i] >> 32));
+      }
     }
     // dy = acc2 + ds (in place over the ds tile), xhat_b into fb (free since HEAD's last barrier), ds_b into the chunk's tile
     bf16* tx = fb;
