@@ -42,6 +42,8 @@ extern "C" void st_attn_xs_f1_args(void* out, const void* A, int lda, const void
                                    void* xhat0, float* rstd0, const float* bq, void* Qout, int ldq);
 extern "C" int st_attn_xs_f1_args_size();
 extern "C" int st_attn_xs_tile_rows();
+// st_attn_bwd64.hip: the hand-scheduled backward for long non-causal problems with 64-wide heads
+extern "C" int st_attn_bwd64_launch(hipStream_t stream, const void* a, const void* ak, int n_q, int n_k);
 
 namespace {
 
@@ -549,6 +551,14 @@ bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
   return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1;
 }
 
+// ... and the hand-scheduled backward of st_attn_bwd64.hip (no dropout, delta supplied by the producer of dO).  ST_ATTN_BWD64=0
+// (read at every call: a development switch for same-process A/B runs) keeps the general kernels
+bool bwd_long64(int d_k, int max_q, int max_k, int causal, bool drop) {
+  if (!(d_k == 64 && !causal && !drop && max_q > 128 && max_k > 128 && attn_impl() != 1)) return false;
+  const char* e = getenv("ST_ATTN_BWD64");
+  return !(e && e[0] == '0');
+}
+
 // few queries against many keys with 64-wide heads (the decoder-encoder attention) take the forward of st_attn_xs.hip
 bool fwd_xs(int d_k, int max_q, int max_k, int causal) { return d_k == 64 && key_split(max_q, max_k, causal) && attn_impl() != 1; }
 
@@ -689,6 +699,11 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   dim3 block(256);
   const bool ks2 = key_split(max_q, max_k, causal);
   const bool run_q = (parts & 1) && !(work_q && n_work_q <= 0), run_k = (parts & 2) && !(work_k && n_work_k <= 0);
+  if (O == nullptr && (run_q || run_k) && !ks2 && bwd_long64(d_k, max_q, max_k, causal, drop) && lddq % 8 == 0) {
+    AttnArgs ak = a;
+    const int nq = run_q ? plan(a, work_q, n_work_q, B, H, max_q) : 0, nk = run_k ? plan(ak, work_k, n_work_k, B, H, max_k) : 0;
+    return st_attn_bwd64_launch(stream, &a, &ak, nq, nk);
+  }
   if (run_q && run_k && O == nullptr) {
     // delta was produced together with dO (st_gemm, ST_EPI_BF16_DELTA): the two kernels are independent -> one launch
     AttnArgs ak = a;
