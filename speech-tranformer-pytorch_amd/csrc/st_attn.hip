@@ -702,6 +702,7 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   if (O == nullptr && (run_q || run_k) && !ks2 && bwd_long64(d_k, max_q, max_k, causal, drop) && lddq % 8 == 0) {
     AttnArgs ak = a;
     const int nq = run_q ? plan(a, work_q, n_work_q, B, H, max_q) : 0, nk = run_k ? plan(ak, work_k, n_work_k, B, H, max_k) : 0;
+    if (const char* tp = getenv("ST_ATTN_TRACE_PTR")) a.Ores = (bf16*)strtoull(tp, nullptr, 0);      // development: per-workgroup clock stamps
     return st_attn_bwd64_launch(stream, &a, &ak, nq, nk);
   }
   if (run_q && run_k && O == nullptr) {

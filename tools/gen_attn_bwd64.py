@@ -47,8 +47,8 @@ NBUF = 3
 # ---- physical scratch registers (v128..v255 are declared clobbered by the asm statement) ----------------------------
 SET_A, SET_B = 128, 160          # each: s[16] then dp[16]
 FRAG = 192                       # 8 slots x 4 registers
-G = 224                          # staging: 4 x 4 registers
-GST = 240                        # staging: one statistic
+# (v224..v240 free: the staging registers are asm operands - the C++ prologue fetches tile 0 into them while the
+# register-resident fragments are on their way)
 A_G0, A_G1, A_H0, A_H1, A_ST = 241, 242, 243, 244, 245    # global byte offsets of this lane's chunks (matrix 0 / 1, stats)
 W_T, W_ST = 246, 247             # LDS write addresses (tile chunk 0, statistic)
 R_NAT, R_TR, R_STAT = 248, 249, 250
@@ -454,8 +454,8 @@ class Body:
         """per-lane byte offsets: staging chunk (row = tid >> 3 and row + 32, 16-byte chunk tid & 7) of the two streamed
         matrices, LDS write address of that chunk, LDS read bases of the row fragments / transposing fragments"""
         e = self.e
-        e.valu("v_lshrrev_b32", T0, ["=3", "%12"])
-        e.valu("v_and_b32", T1, ["=7", "%12"])
+        e.valu("v_lshrrev_b32", T0, ["=3", self.TID])
+        e.valu("v_and_b32", T1, ["=7", self.TID])
         e.valu("v_lshlrev_b32", T1, ["=4", T1])
         e.valu("v_mad_u32_u24", A_G0, [T0, "=" + ld0, T1])
         e.valu("v_mad_u32_u24", A_H0, [T0, "=" + ld1, T1])
@@ -465,7 +465,7 @@ class Body:
         e.valu("v_mov_b32", T3, ["=%d" % STR])
         e.valu("v_mad_u32_u24", W_T, [T0, T3, T1])
         e.valu("v_add_u32", W_T, ["=" + lds, W_T])
-        e.valu("v_and_b32", T2, ["=63", "%12"])                               # lane
+        e.valu("v_and_b32", T2, ["=63", self.TID])                            # lane
         e.valu("v_lshrrev_b32", T0, ["=5", T2])                               # hi
         e.valu("v_and_b32", T1, ["=31", T2])
         e.valu("v_mul_u32_u24", R_NAT, [T1, T3])
@@ -505,12 +505,18 @@ class Body:
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# dK / dV body.  operands: %0 %1 = dk[0..1], %2 %3 = dv[0..1] (f32x16, in/out); %4..%7 = K fragments * scale * log2 e,
-# %8..%11 = V fragments; %12 = threadIdx.x; %13 = Q base (utterance row 0, head column 0), %14 = dO base, %15 = the
-# wave's statistic base (lse for even waves, delta for odd ones); %16 = ldq * 2, %17 = lddo * 2 (bytes); %18 = lq;
-# %19 = tiles (64 queries each); %20 = LDS byte address of the ring
+# dK / dV body.  operands (in / out): %0 %1 = dk[0..1], %2 %3 = dv[0..1] (f32x16); %4..%7 = the staging registers of the
+# streamed tiles (Q rows 0-31 / 32-63, dO likewise: this thread's 16-byte chunks; the C++ prologue has loaded tile 0 into them),
+# %8 = the staging register of the statistics; (in): %9..%12 = K fragments * scale * log2 e, %13..%16 = V fragments;
+# %17 = threadIdx.x; %18 = Q base (utterance row 0, head column 0), %19 = dO base, %20 = the wave's statistic base (lse for
+# even waves, delta for odd ones); %21 = ldq * 2, %22 = lddo * 2 (bytes); %23 = lq; %24 = tiles (64 queries each); %25 = LDS
+# byte address of the ring
 # ------------------------------------------------------------------------------------------------------------------
 class DKV(Body):
+    G = ["%4", "%5", "%6", "%7"]
+    GST = "%8"
+    TID = "%17"
+
     def m2(self, buf, blk, Y):
         out = []
         for mat, acc0, yoff, tag in ((1, 2, 0, "dV"), (0, 0, 16, "dK")):
@@ -521,7 +527,7 @@ class DKV(Body):
 
     def m1(self, buf, blk, Y):
         out = []
-        for mat, yoff, b0, which, after in ((0, 0, 4, 0, 4), (1, 16, 8, 1, 8)):
+        for mat, yoff, b0, which, after in ((0, 0, 9, 0, 4), (1, 16, 13, 1, 8)):
             for t in range(4):
                 out.append(Mf(Y + yoff, "%%%d" % (b0 + t), Y + yoff, nat_read(buf, mat, blk, t),
                               init=stat_reads(buf, blk, which, Y + yoff) if t == 0 else None, init_after=after,
@@ -540,50 +546,52 @@ class DKV(Body):
 
     def loads(self):
         e = self.e
-        return [lambda: e.buffer_load(G + 0, 4, A_G0, S_SRD0), lambda: e.buffer_load(G + 4, 4, A_G1, S_SRD0),
-                lambda: e.buffer_load(G + 8, 4, A_H0, S_SRD1), lambda: e.buffer_load(G + 12, 4, A_H1, S_SRD1),
+        G, GST = self.G, self.GST
+        return [lambda: e.buffer_load(G[0], 4, A_G0, S_SRD0), lambda: e.buffer_load(G[1], 4, A_G1, S_SRD0),
+                lambda: e.buffer_load(G[2], 4, A_H0, S_SRD1), lambda: e.buffer_load(G[3], 4, A_H1, S_SRD1),
                 lambda: e.buffer_load(GST, 1, A_ST, S_SRD2),
                 lambda: self.advance_srd(S_SRD0, "s%d" % S_STEP0), lambda: self.advance_srd(S_SRD1, "s%d" % S_STEP1),
                 lambda: self.advance_srd(S_SRD2, "256")]
 
     def writes(self, buf):
         e = self.e
+        G, GST = self.G, self.GST
         return [lambda: e.valu("v_xor_b32", GST, ["=0x80000000", GST]),
-                lambda: e.ds_write("ds_write_b128", W_T, G + 0, 4, buf * BUF),
-                lambda: e.ds_write("ds_write_b128", W_T, G + 4, 4, buf * BUF + 32 * STR),
-                lambda: e.ds_write("ds_write_b128", W_T, G + 8, 4, buf * BUF + MAT),
-                lambda: e.ds_write("ds_write_b128", W_T, G + 12, 4, buf * BUF + MAT + 32 * STR),
+                lambda: e.ds_write("ds_write_b128", W_T, G[0], 4, buf * BUF),
+                lambda: e.ds_write("ds_write_b128", W_T, G[1], 4, buf * BUF + 32 * STR),
+                lambda: e.ds_write("ds_write_b128", W_T, G[2], 4, buf * BUF + MAT),
+                lambda: e.ds_write("ds_write_b128", W_T, G[3], 4, buf * BUF + MAT + 32 * STR),
                 lambda: e.ds_write("ds_write_b32", W_ST, GST, 1, buf * BUF)]
 
     def prologue(self):
         e = self.e
         e.comment("dK/dV body: descriptors, lane offsets")
         e.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        self.descriptor(S_SRD0, "%13", "%16", "%18")
-        self.descriptor(S_SRD1, "%14", "%17", "%18")
-        e.salu("s_mov_b64 s[%d:%d], %%15" % (S_SRD2, S_SRD2 + 1))
-        e.salu("s_lshl_b32 s%d, %%18, 2" % (S_SRD2 + 2))                     # lq * 4 bytes of statistics
+        self.descriptor(S_SRD0, "%18", "%21", "%23")
+        self.descriptor(S_SRD1, "%19", "%22", "%23")
+        e.salu("s_mov_b64 s[%d:%d], %%20" % (S_SRD2, S_SRD2 + 1))
+        e.salu("s_lshl_b32 s%d, %%23, 2" % (S_SRD2 + 2))                     # lq * 4 bytes of statistics
         e.salu("s_mov_b32 s%d, 0x00020000" % (S_SRD2 + 3))
-        e.salu("s_lshl_b32 s%d, %%16, 6" % S_STEP0)                          # bytes per 64-row tile
-        e.salu("s_lshl_b32 s%d, %%17, 6" % S_STEP1)
-        e.salu("s_sub_u32 s%d, %%19, 1" % S_CNT)                             # tiles after the current one
-        self.lane_addresses("%16", "%17", "%20")
+        e.salu("s_lshl_b32 s%d, %%21, 6" % S_STEP0)                          # bytes per 64-row tile
+        e.salu("s_lshl_b32 s%d, %%22, 6" % S_STEP1)
+        e.salu("s_sub_u32 s%d, %%24, 1" % S_CNT)                             # tiles after the current one
+        for f in self.loads()[5:]:                                            # tile 0 is in the staging registers: on to tile 1
+            f()
+        self.lane_addresses("%21", "%22", "%25")
         e.valu("v_lshlrev_b32", A_ST, ["=2", T2])                             # statistic of query `lane` of the tile
-        e.valu("v_and_b32", W_ST, ["=127", "%12"])
+        e.valu("v_and_b32", W_ST, ["=127", self.TID])
         e.valu("v_lshlrev_b32", W_ST, ["=2", W_ST])
-        e.valu("v_add_u32", W_ST, ["=%20", W_ST])
+        e.valu("v_add_u32", W_ST, ["=%25", W_ST])
         e.valu("v_add_u32", W_ST, ["=%d" % STAT, W_ST])
         e.valu("v_lshlrev_b32", R_STAT, ["=4", T0])
-        e.valu("v_add_u32", R_STAT, ["=%20", R_STAT])
+        e.valu("v_add_u32", R_STAT, ["=%25", R_STAT])
         e._nop(5)                                                             # SALU write -> VMEM descriptor read
 
     def build(self):
         e = self.e
         A, B = SET_A, SET_B
         self.prologue()
-        for f in self.loads():         # tile 0 -> buffer 0; tile 1 -> staging registers
-            f()
-        for f in self.writes(0):
+        for f in self.writes(0):       # tile 0 (loaded by the C++ prologue) -> buffer 0; tile 1 -> staging registers
             f()
         for f in self.loads():
             f()
@@ -634,17 +642,21 @@ class DKV(Body):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# dQ body.  operands: %0 %1 = dq[0..1] (in/out); %2..%5 = Q fragments * scale * log2 e, %6..%9 = dO fragments;
-# %10 = -lse (16 equal registers), %11 = -delta; %12 = threadIdx.x; %13 = K base, %14 = V base; %15 = ldk * 2,
-# %16 = ldv * 2; %17 = lk; %18 = tiles (64 keys each); %19 = LDS byte address of the ring
+# dQ body.  operands (in / out): %0 %1 = dq[0..1]; %2..%5 = the staging registers of the streamed tiles (K rows 0-31 / 32-63, V
+# likewise; tile 0 loaded by the C++ prologue); (in): %6..%9 = Q fragments * scale * log2 e, %10..%13 = dO fragments; %14 = -lse
+# (16 equal registers), %15 = -delta; %16 = threadIdx.x; %17 = K base, %18 = V base; %19 = ldk * 2, %20 = ldv * 2; %21 = lk;
+# %22 = tiles (64 keys each); %23 = LDS byte address of the ring
 # ------------------------------------------------------------------------------------------------------------------
 class DQ(Body):
+    G = ["%2", "%3", "%4", "%5"]
+    TID = "%16"
+
     def m2(self, buf, blk, Y):
         return [Mf("%%%d" % d, Y + 16 + 4 * hf, "%%%d" % d, tr_reads(buf, 0, blk, hf, d), tag="dQ") for hf in range(2) for d in range(2)]
 
     def m1(self, buf, blk, Y):
         out = []
-        for mat, yoff, b0, c0 in ((0, 0, 2, "%10"), (1, 16, 6, "%11")):
+        for mat, yoff, b0, c0 in ((0, 0, 6, "%14"), (1, 16, 10, "%15")):
             for t in range(4):
                 out.append(Mf(Y + yoff, "%%%d" % (b0 + t), c0 if t == 0 else Y + yoff, nat_read(buf, mat, blk, t), tag="S" if mat == 0 else "dP"))
         if knob("DQ_CHAIN_IL", 0):       # (switch) the two accumulation chains interleaved
@@ -667,29 +679,33 @@ class DQ(Body):
 
     def loads(self):
         e = self.e
-        return [lambda: e.buffer_load(G + 0, 4, A_G0, S_SRD0), lambda: e.buffer_load(G + 4, 4, A_G1, S_SRD0),
-                lambda: e.buffer_load(G + 8, 4, A_H0, S_SRD1), lambda: e.buffer_load(G + 12, 4, A_H1, S_SRD1),
+        G = self.G
+        return [lambda: e.buffer_load(G[0], 4, A_G0, S_SRD0), lambda: e.buffer_load(G[1], 4, A_G1, S_SRD0),
+                lambda: e.buffer_load(G[2], 4, A_H0, S_SRD1), lambda: e.buffer_load(G[3], 4, A_H1, S_SRD1),
                 lambda: self.advance_srd(S_SRD0, "s%d" % S_STEP0), lambda: self.advance_srd(S_SRD1, "s%d" % S_STEP1)]
 
     def writes(self, buf):
         e = self.e
-        return [lambda: e.ds_write("ds_write_b128", W_T, G + 0, 4, buf * BUF),
-                lambda: e.ds_write("ds_write_b128", W_T, G + 4, 4, buf * BUF + 32 * STR),
-                lambda: e.ds_write("ds_write_b128", W_T, G + 8, 4, buf * BUF + MAT),
-                lambda: e.ds_write("ds_write_b128", W_T, G + 12, 4, buf * BUF + MAT + 32 * STR)]
+        G = self.G
+        return [lambda: e.ds_write("ds_write_b128", W_T, G[0], 4, buf * BUF),
+                lambda: e.ds_write("ds_write_b128", W_T, G[1], 4, buf * BUF + 32 * STR),
+                lambda: e.ds_write("ds_write_b128", W_T, G[2], 4, buf * BUF + MAT),
+                lambda: e.ds_write("ds_write_b128", W_T, G[3], 4, buf * BUF + MAT + 32 * STR)]
 
     def prologue(self):
         e = self.e
         e.comment("dQ body: descriptors, lane offsets")
         e.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        self.descriptor(S_SRD0, "%13", "%15", "%17")
-        self.descriptor(S_SRD1, "%14", "%16", "%17")
-        e.salu("s_lshl_b32 s%d, %%15, 6" % S_STEP0)
-        e.salu("s_lshl_b32 s%d, %%16, 6" % S_STEP1)
-        e.salu("s_sub_u32 s%d, %%18, 1" % S_CNT)
+        self.descriptor(S_SRD0, "%17", "%19", "%21")
+        self.descriptor(S_SRD1, "%18", "%20", "%21")
+        e.salu("s_lshl_b32 s%d, %%19, 6" % S_STEP0)
+        e.salu("s_lshl_b32 s%d, %%20, 6" % S_STEP1)
+        e.salu("s_sub_u32 s%d, %%22, 1" % S_CNT)
         e.salu("s_lshl_b32 s%d, s%d, 6" % (S_T1, S_CNT))                     # first key of the last tile
-        e.salu("s_sub_u32 s%d, %%17, s%d" % (S_T1, S_T1))                    # keys of the last tile that exist
-        self.lane_addresses("%15", "%16", "%19")
+        e.salu("s_sub_u32 s%d, %%21, s%d" % (S_T1, S_T1))                    # keys of the last tile that exist
+        for f in self.loads()[4:]:                                            # tile 0 is in the staging registers: on to tile 1
+            f()
+        self.lane_addresses("%19", "%20", "%23")
         e.valu("v_lshlrev_b32", T1, ["=2", T0])                               # 4 hi
         e.valu("v_sub_u32", V_M, ["=s%d" % S_T1, T1])                         # key row r of block blk exists iff 32 blk + row(r) < V_M
         e._nop(5)
@@ -711,8 +727,6 @@ class DQ(Body):
         e = self.e
         A, B = SET_A, SET_B
         self.prologue()
-        for f in self.loads():
-            f()
         for f in self.writes(0):
             f()
         for f in self.loads():
