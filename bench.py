@@ -200,6 +200,12 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the extra beam-search decode measurement")
     ap.add_argument("--force-dp", action="store_true", help="N = 1 only: run the data-parallel code path (split backward "
                     "graphs, bucketed RCCL all-reduce) on a one-rank group - its overhead without a second GPU")
+    ap.add_argument("--bucket-mb", type=int, default=32, help="gradient all-reduce bucket size (MiB of fp32 gradients; a ring on "
+                    "point-to-point xGMI is bound by one ~153 GB/s link, so buckets are large)")
+    ap.add_argument("--nccl-algo", type=str, default=None, help="sets NCCL_ALGO for RCCL (Ring / Tree / ...); recorded in config")
+    ap.add_argument("--nccl-proto", type=str, default=None, help="sets NCCL_PROTO for RCCL (Simple / LL / LL128); recorded in config")
+    ap.add_argument("--no-dp-probe", action="store_true", help="N = 1: skip the extra pass that runs the data-parallel code path "
+                    "on a one-rank RCCL group to report what the exchange machinery itself costs (allreduce_exposed_ms)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
                                                             "the captured HIP graph of the step")
     args = ap.parse_args()
@@ -221,6 +227,10 @@ def main():
     from st_amd.arena import arena_of
     from st_amd.trainer import TrainStep
 
+    if args.nccl_algo:
+        os.environ["NCCL_ALGO"] = args.nccl_algo
+    if args.nccl_proto:
+        os.environ["NCCL_PROTO"] = args.nccl_proto
     rank, local, world = dp.init_from_env()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
@@ -236,7 +246,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=0, world_size=1)
-    reducer = dp.GradReducer(arena, wire_dtype=torch.bfloat16 if args.wire_bf16 else None,
+    reducer = dp.GradReducer(arena, bucket_bytes=args.bucket_mb << 20, wire_dtype=torch.bfloat16 if args.wire_bf16 else None,
                              force=args.force_dp) if (world > 1 or args.force_dp) else None
     optim = ScheduledOptim(model, CFG["d_model"], U.AttrDict(n_warmup_steps=12000))
     step = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, reducer=reducer, use_graph=not args.no_graph)
@@ -322,6 +332,32 @@ def main():
             dist.all_reduce(t_plain, op=dist.ReduceOp.MAX)
         exposed_ms = round(ms_step - t_plain.item(), 3)
         dp.broadcast_parameters(arena)            # the un-exchanged steps let the replicas drift: re-align them
+    dp_probe = None
+    if reducer is None and world == 1 and not args.no_dp_probe and not args.no_graph:
+        # N = 1: what the data-parallel machinery itself costs - the same step with a GradReducer on a ONE-rank RCCL group
+        # (bucketed all-reduces captured inside the step graph); with no second GPU nothing is exchanged, so this is the
+        # floor of `allreduce_exposed_ms` that the driver's N > 1 runs add their wire time to
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+            red1 = dp.GradReducer(arena, bucket_bytes=args.bucket_mb << 20, wire_dtype=torch.bfloat16 if args.wire_bf16 else None, force=True)
+            step1 = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, reducer=red1, use_graph=True)
+            for _ in range(4):
+                step1(xg, in_len, tg, tgt_len, gg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step1(xg, in_len, tg, tgt_len, gg)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t1) / args.steps * 1e3
+            exposed_ms = round(ms1 - ms_step, 3)
+            dp_probe = {"ms_per_step": round(ms1, 3), "dp_mode": getattr(step1, "dp_mode", None), "buckets": len(red1.buckets),
+                        "note": "one-rank RCCL group: the bucketed all-reduces run (captured in the step graph) but exchange nothing"}
+            red1.detach()
+            del step1
+        except Exception as e:  # noqa: BLE001 - the headline must still be printed
+            dp_probe = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- roofline pass: per-launch HIP events on the launch stream (outside the timed region) ----
     step.use_graph = False                      # per-launch events need real launches, not a graph replay
@@ -597,7 +633,8 @@ def main():
                                       if args.global_batch else "B=32 per GPU (weak scaling, train_multi.py:136-139)", int(in_len.sum())),
                        "global_batch": args.global_batch or BATCH * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay of the whole step",
-                       "wire": "bf16" if args.wire_bf16 else "fp32"},
+                       "wire": "bf16" if args.wire_bf16 else "fp32", "dp_bucket_mb": args.bucket_mb,
+                       "nccl_algo": os.environ.get("NCCL_ALGO", "default"), "nccl_proto": os.environ.get("NCCL_PROTO", "default")},
             "loss": round(loss.item(), 4), "grad_norm": round(gnorm.item(), 4),
             "step_tflops_valid": round(flops / (ms_step * 1e-3) / 1e12, 2),
             "step_frac_of_bf16_peak": round(flops / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -605,6 +642,10 @@ def main():
             "roofline": roofline, "kernels": kernels,
             "hbm_bytes_source": "per launch: the launch's own operands, each counted once (st_amd.native._tag io lists)",
         }
+        if dp_probe is not None:
+            out["dp_probe"] = dp_probe
+            if out["dp_mode"] is None:
+                out["dp_mode"] = dp_probe.get("dp_mode")
         if strong is not None:
             out["strong_scaling"] = strong
         if weak is not None:

@@ -391,6 +391,16 @@ int st_ce_bwd(st_stream_t stream, const float* logits, int ldl, int R, int V, co
               const long long* target_index, int ignore_index, const float* lse, const float* sums, const float* grad_out,
               void* dlogits, int ldd);
 
+/* Attention probabilities of ONE attention sublayer, materialised (reference transformer/Attention.py:89,96: the `attns`
+ * MultiHeadAttention.forward returns; Models.py:53-54,107-109 collect them under return_attns): P (f32 [B, H, Lq, Lk],
+ * dense) = softmax over keys of scale * Q K^T with keys >= k_len[b] (and, when causal, keys > the query) masked out -
+ * zeros there and in the rows of query positions >= q_len[b].  Q, K: bf16 row matrices (utterance b owns rows
+ * off[b] .. off[b] + len[b] - 1, head h columns h * d_k ..), d_k % 8 == 0.  A diagnostic path: the fused attention kernels
+ * never write these maps. */
+int st_attn_probs(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, float* P, const int* q_off,
+                  const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int Lq, int Lk, int causal,
+                  float scale);
+
 /* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
 int st_probe_tr16(st_stream_t stream, const void* in, void* out);
 int st_probe_mfma(st_stream_t stream, const void* A, const void* Bt, float* D);

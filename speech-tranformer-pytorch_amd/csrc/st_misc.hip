@@ -1290,6 +1290,76 @@ extern "C" int st_adam_clip(hipStream_t stream, long long n, float* p, float* g,
   return 0;
 }
 
+// ---- attention maps (return_attns: reference transformer/Attention.py:89,96, Models.py:53-54,107-109) ------------------------
+// The fused attention kernels never materialise the [B, h, Lq, Lk] probabilities; when a caller asks for them
+// (Encoder / Decoder / Transformer.forward(return_attns=True)) this kernel recomputes ONE sublayer's map from its projected
+// queries and keys: one workgroup per (utterance, head, query), scores in LDS, max / sum by block reductions.  A
+// diagnostic path (every head width that is a multiple of 8; nothing here is on the training step).
+namespace {
+__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict__ Q, int ldq, const bf16* __restrict__ K, int ldk,
+                                                         float* __restrict__ P, const int* __restrict__ q_off,
+                                                         const int* __restrict__ q_len, const int* __restrict__ k_off,
+                                                         const int* __restrict__ k_len, int H, int d_k, int Lq, int Lk, int causal,
+                                                         float scale) {
+  extern __shared__ float sm_probs[];      // [Lk] scores, then [d_k] the query, then [8] reduction slots
+  float* sc = sm_probs;
+  float* qv = sm_probs + Lk;
+  float* red = qv + d_k;
+  const int q = blockIdx.x % Lq, h = (blockIdx.x / Lq) % H, b = blockIdx.x / (Lq * H);
+  float* out = P + ((size_t)(b * H + h) * Lq + q) * Lk;
+  const int lq = q_len[b], lk = k_len[b];
+  const int kend = q >= lq ? 0 : (causal ? min(lk, q + 1) : lk);      // rows of padding positions: all zeros
+  if (kend > 0) {
+    const bf16* qr = Q + (size_t)(q_off[b] + q) * ldq + h * d_k;
+    for (int i = threadIdx.x; i < d_k; i += 256) qv[i] = (float)qr[i];
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = threadIdx.x; k < kend; k += 256) {
+      const bf16* kr = K + (size_t)(k_off[b] + k) * ldk + h * d_k;
+      float acc = 0.f;
+      for (int i = 0; i < d_k; i += 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(kr + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(qv[i + e], (float)v[e], acc);
+      }
+      acc *= scale;
+      sc[k] = acc;
+      mx = fmaxf(mx, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int k = threadIdx.x; k < kend; k += 256) {
+      const float e = __expf(sc[k] - mx);
+      sc[k] = e;
+      sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    for (int k = threadIdx.x; k < kend; k += 256) out[k] = sc[k] * inv;
+  }
+  for (int k = kend + threadIdx.x; k < Lk; k += 256) out[k] = 0.f;
+}
+}  // namespace
+
+extern "C" int st_attn_probs(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, float* P, const int* q_off,
+                             const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int Lq, int Lk,
+                             int causal, float scale) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  if (!Q || !K || !P || !q_off || !q_len || !k_off || !k_len) return -1;
+  if (d_k <= 0 || (d_k & 7) || (ldq & 7) || (ldk & 7)) return -2;
+  const size_t smem = (size_t)(Lk + d_k + 8) * sizeof(float);
+  if (smem > 64 * 1024 || (long long)B * H * Lq > 0x7fffffffLL) return -3;
+  hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H * Lq), dim3(256), smem, stream, (const bf16*)Q, ldq, (const bf16*)K, ldk, P, q_off,
+                     q_len, k_off, k_len, H, d_k, Lq, Lk, causal, scale);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int st_probe_tr16(hipStream_t stream, const void* in, void* out) {
   hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, stream, (const bf16*)in, (bf16*)out);
   ST_CHECK_LAUNCH();

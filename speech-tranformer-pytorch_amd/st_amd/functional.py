@@ -589,6 +589,31 @@ def _input_grad(link, dY, W, aux):
     return dx
 
 
+class AttnTap:
+    """``with AttnTap() as tap:`` - every attention sublayer whose forward runs inside materialises its probabilities
+    (native.attn_probs: f32 [B, h, max q_len, max k_len], dropout not applied) and appends (module, map) to ``tap.maps``
+    in call order.  The return_attns path of transformer.Models (reference Models.py:53-54,107-109); the fused kernels
+    themselves never write these tensors."""
+    active = None
+
+    def __enter__(self):
+        self.maps, self._prev = [], AttnTap.active
+        AttnTap.active = self
+        return self
+
+    def __exit__(self, *exc):
+        AttnTap.active = self._prev
+        return False
+
+    def of(self, module, Lq, Lk):
+        """the maps of `module`'s calls, zero-padded to [B, h, Lq, Lk] (the padded batch layout of the reference)"""
+        out = []
+        for m, P in self.maps:
+            if m is module:
+                out.append(torch.nn.functional.pad(P, (0, Lk - P.shape[3], 0, Lq - P.shape[2])) if (P.shape[2] != Lq or P.shape[3] != Lk) else P)
+        return out
+
+
 class MhaFn(torch.autograd.Function):
     """out = LN(attn(x_q W_q, x_kv W_k, x_kv W_v) W_o + b_o + x_q)   (Attention.py:64-96, R2)."""
 
@@ -607,6 +632,10 @@ class MhaFn(torch.autograd.Function):
         else:
             qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd = MhaFn.compute(
                 x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, any(ctx.needs_input_grad), scale)
+        if AttnTap.active is not None:
+            Qm, Km = (qkv[:, :d], qkv[:, d:2 * d]) if x_kv is None else (qkv, kvbuf[:, :d])
+            AttnTap.active.maps.append((mod, nv.attn_probs(Qm, Km, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len,
+                                                           k_rows.max_len, causal, scale)))
         ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask

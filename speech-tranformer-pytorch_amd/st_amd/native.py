@@ -80,6 +80,8 @@ SIGNATURES = {
                     _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "st_attn_probs": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                      _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float],
     "st_feat_stack": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                       _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int],
     "st_unpack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
@@ -811,6 +813,22 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
                             int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),
                             *_work(work_k), *_drop(drop))
     _check(rc, "st_attn_bwd")
+
+
+def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):
+    """The attention probabilities of one sublayer, materialised: f32 [B, n_head, Lq, Lk] (zeros at masked keys and in the
+    rows of padding positions).  Q, K: bf16 row matrices (column slices of the q | k | v projection are fine)."""
+    for t, nm in ((Q, "Q"), (K, "K")):
+        _mat(t, BF16, nm)
+    B = q_off.numel()
+    d_k = Q.shape[1] // n_head
+    P = torch.empty(B, n_head, int(Lq), int(Lk), dtype=F32, device=Q.device)
+    _tag("attn_probs", B, n_head, d_k, int(Lq), int(Lk))
+    rc = load().st_attn_probs(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), P.data_ptr(), q_off.data_ptr(),
+                              q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(Lq), int(Lk), int(causal),
+                              float(scale))
+    _check(rc, "st_attn_probs")
+    return P
 
 
 def feat_stack(x, in_len, stats, left, right, interval, out_off, out_len, max_out_len, out):

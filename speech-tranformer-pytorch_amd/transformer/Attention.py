@@ -106,20 +106,10 @@ class MultiHeadAttention(nn.Module):
         k_rows = F_.Rows.padded(B, Lk, dev, k_len)
         xq = q.reshape(B * Lq, d).to(torch.bfloat16)
         xkv = None if k is q else k.reshape(B * Lk, d).to(torch.bfloat16)
-        out = self.forward_rows(xq, xkv, q_rows, k_rows, causal)
-        attns = self._dense_attn(q, k, k_rows, causal) if self.return_attn else None
+        if self.return_attn:       # Attention.py:96: the probabilities, materialised by st_attn_probs (dropout not applied)
+            with F_.AttnTap() as tap:
+                out = self.forward_rows(xq, xkv, q_rows, k_rows, causal)
+            attns = tap.of(self, Lq, Lk)[0]
+        else:
+            out, attns = self.forward_rows(xq, xkv, q_rows, k_rows, causal), None
         return out.to(q.dtype).view(B, Lq, d), attns
-
-    @torch.no_grad()
-    def _dense_attn(self, q, k, k_rows, causal):
-        """Materialise the attention probabilities with plain torch ops on the GPU
-        (debug / visualisation only; not used by the training step)."""
-        B, Lq, _ = q.shape
-        Lk = k.shape[1]
-        qh = self.linear_q(q.float()).view(B, Lq, self.n_head, self.d_k).transpose(1, 2)
-        kh = self.linear_k(k.float()).view(B, Lk, self.n_head, self.d_k).transpose(1, 2)
-        s = torch.matmul(qh, kh.transpose(2, 3)) / self.scaled
-        dead = torch.arange(Lk, device=q.device).view(1, 1, 1, -1) >= k_rows.len.view(-1, 1, 1, 1)
-        if causal:
-            dead = dead | torch.ones(Lq, Lk, dtype=torch.bool, device=q.device).triu(1)
-        return torch.softmax(s.masked_fill(dead, float('-inf')), dim=-1)

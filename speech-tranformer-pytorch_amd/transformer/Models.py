@@ -98,10 +98,16 @@ class Encoder(nn.Module):
         return hit[1] if self.use_row_chains else None
 
     def forward(self, inputs, inputs_length, return_attns=False):
-        if return_attns:
-            raise NotImplementedError("HIP path: attention maps are not materialised (return_attns must be falsy)")
-        e, rows = self.forward_rows(inputs, inputs_length)
-        return F_.UnpackFn.apply(e, rows, inputs.shape[1]), []
+        """-> (enc_output [B, T, d], enc_slf_attns): with return_attns (Models.py:53-54) one f32 [B, h, T, T] map per layer
+        (st_attn_probs recomputes it from the layer's projected queries and keys; zeros at masked keys and in the rows of
+        padding frames; training-mode dropout is not applied to the returned maps), else []."""
+        if not return_attns:
+            e, rows = self.forward_rows(inputs, inputs_length)
+            return F_.UnpackFn.apply(e, rows, inputs.shape[1]), []
+        T = inputs.shape[1]
+        with F_.AttnTap() as tap:
+            e, rows = self.forward_rows(inputs, inputs_length)
+        return F_.UnpackFn.apply(e, rows, T), [tap.of(layer.slf_attn, T, T)[0] for layer in self.layer_stack]
 
 
 class Decoder(nn.Module):
@@ -170,12 +176,17 @@ class Decoder(nn.Module):
     def forward(self, outputs_data, outputs_pos, input_pos, enc_output, return_attns=False):
         """outputs_data [B, L] tokens, outputs_pos [B] target lengths, input_pos [B]
         input lengths, enc_output [B, T, d] -> (dec_output [B, L, d], [], [])."""
-        if return_attns:
-            raise NotImplementedError("HIP path: attention maps are not materialised (return_attns must be falsy)")
         in_rows = F_.Rows.packed(input_pos, enc_output.device)
         enc = F_.PackFn.apply(enc_output.float(), in_rows)
-        y, t_rows = self.forward_rows(outputs_data, outputs_pos, enc, in_rows)
-        return F_.UnpackFn.apply(y, t_rows, outputs_data.shape[1]), [], []
+        if not return_attns:
+            y, t_rows = self.forward_rows(outputs_data, outputs_pos, enc, in_rows)
+            return F_.UnpackFn.apply(y, t_rows, outputs_data.shape[1]), [], []
+        # Models.py:107-109: per layer the causal self-attention map [B, h, L, L] and the encoder-decoder map [B, h, L, T]
+        L, T = outputs_data.shape[1], enc_output.shape[1]
+        with F_.AttnTap() as tap:
+            y, t_rows = self.forward_rows(outputs_data, outputs_pos, enc, in_rows)
+        return (F_.UnpackFn.apply(y, t_rows, L), [tap.of(layer.slf_attn, L, L)[0] for layer in self.layer_stack],
+                [tap.of(layer.enc_attn, L, T)[0] for layer in self.layer_stack])
 
 
 class Transformer(nn.Module):
@@ -269,8 +280,6 @@ class Transformer(nn.Module):
         -> (logits [sum(targets_pos), V] fp32 (a column slice of a [*, v_pad] buffer), Rows of the target side).
         ``Rows.scatter_index(L)`` maps row r to its position b*L + t in the padded layout; trainer.TrainStep uses
         this form so that the loss runs over valid tokens only and nothing is scattered back to [B, L, V]."""
-        if self.return_attns:
-            raise NotImplementedError("HIP path: attention maps are not materialised (config.return_attns must be falsy)")
         arena = arena_of(self)
         # layouts = (input Rows, target Rows): given by the caller (trainer.TrainStep's bucket mode: padded layouts whose
         # lengths live on the device), else the packed layouts of this batch
@@ -306,9 +315,19 @@ class Transformer(nn.Module):
     def forward(self, inputs, inputs_pos, targets=None, targets_pos=None):
         """inputs [B, T, F]; inputs_pos [B] input lengths; targets [B, L] tokens;
         targets_pos [B] target lengths (the current train.py:39 calling convention)
-        -> (seq_logit [B, L, V] fp32, ([], [], []))."""
+        -> (seq_logit [B, L, V] fp32, (enc_slf_attn, dec_slf_attn, dec_enc_attn)): three empty lists unless
+        config.return_attns (Models.py:147-153), then one f32 map per layer each ([B, h, T, T], [B, h, L, L], [B, h, L, T])."""
         B, L = targets.shape
-        logits, t_rows = self.forward_packed(inputs, inputs_pos, targets, targets_pos)
+        T = inputs.shape[1]
+        if self.return_attns:
+            with F_.AttnTap() as tap:
+                logits, t_rows = self.forward_packed(inputs, inputs_pos, targets, targets_pos)
+            attns = ([tap.of(l.slf_attn, T, T)[0] for l in self.encoder.layer_stack],
+                     [tap.of(l.slf_attn, L, L)[0] for l in self.decoder.layer_stack],
+                     [tap.of(l.enc_attn, L, T)[0] for l in self.decoder.layer_stack])
+        else:
+            logits, t_rows = self.forward_packed(inputs, inputs_pos, targets, targets_pos)
+            attns = ([], [], [])
         # scatter the ragged rows back to the padded [B, L, V] layout train.py:40 expects
         padded = logits.new_zeros(B * L, logits.shape[1]).index_copy(0, t_rows.scatter_index(L), logits)
-        return padded.view(B, L, -1), ([], [], [])
+        return padded.view(B, L, -1), attns

@@ -377,6 +377,22 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
             dV[ks, cs] = (pv.to(BF16).float().t() @ do).to(BF16)
 
 
+def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):
+    B = q_off.numel()
+    d_k = Q.shape[1] // n_head
+    P = torch.zeros(B, n_head, int(Lq), int(Lk))
+    for b in range(B):
+        lq, lk, qo, ko = int(q_len[b]), int(k_len[b]), int(q_off[b]), int(k_off[b])
+        for h in range(n_head):
+            q = Q[qo:qo + lq, h * d_k:(h + 1) * d_k].float()
+            k = K[ko:ko + lk, h * d_k:(h + 1) * d_k].float()
+            s = q @ k.t() * scale
+            if causal:
+                s = s.masked_fill(torch.ones(lq, lk, dtype=torch.bool).triu(1), float("-inf"))
+            P[b, h, :lq, :lk] = torch.softmax(s, -1)
+    return P
+
+
 def feat_stack(x, in_len, stats, left, right, interval, out_off, out_len, max_out_len, out):
     B, T, F = x.shape
     for b in range(B):
@@ -554,7 +570,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "beam_work_words", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 

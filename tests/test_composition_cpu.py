@@ -276,6 +276,87 @@ def test_encoder_padded_api_composition(golden_dir):
         run_encoder_padded_api(golden_dir, "cpu")
 
 
+def run_return_attns(golden_dir, device):
+    """return_attns (reference Models.py:53-54,107-109,147-153; Attention.py:96): the maps st_attn_probs materialises.
+    (1) Encoder.forward(return_attns=True) against the reference's own first-layer map of fixture encoder_2l (sampled
+    entries + sum, fp64); (2) MultiHeadAttention.forward with return_attn against the medium fixtures' maps; (3) the
+    Transformer with config.return_attns: one map per layer and attention, rows sum to one over the visible keys, zeros at
+    masked keys and in padding rows, causal structure in the decoder's self-attention."""
+    import transformer.Attention as A
+    import transformer.Models as M
+    import transformer.Utils as U
+    fx = dict(np.load(os.path.join(golden_dir, "encoder_2l.npz")))
+    enc = M.Encoder(80, 64, n_layers=2, n_head=4, d_k=32, d_v=32, d_model=128, d_inner_hid=256, dropout=0.0).eval()
+    enc.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("w/")})
+    enc = enc.to(device)
+    lens = torch.from_numpy(fx["in_len"])
+    with torch.no_grad():
+        y, attns = enc(torch.from_numpy(fx["x"]).to(device), lens, return_attns=True)
+        y0, none = enc(torch.from_numpy(fx["x"]).to(device), lens)
+    assert none == [] and torch.equal(y, y0)                      # asking for the maps changes nothing else
+    assert len(attns) == 2 and tuple(attns[0].shape) == tuple(int(v) for v in fx["f64/attn0_shape"])
+    a0 = attns[0].double().cpu()
+    # the reference computes a (meaningless) distribution for padding FRAMES too; the product leaves those rows zero
+    B, H, T, _ = a0.shape
+    rows_valid = (torch.arange(T).view(1, 1, T, 1) < lens.view(B, 1, 1, 1)).expand(B, H, T, T)
+    idx = torch.from_numpy(fx["f64/attn0_idx"])
+    keep = rows_valid.reshape(-1)[idx]
+    assert keep.sum() > 50
+    assert rel(a0.reshape(-1)[idx][keep], torch.from_numpy(fx["f64/attn0_val"])[keep]) < 2e-2
+    assert abs(a0.sum().item() - float(lens.sum()) * H) < 1e-3 * float(lens.sum()) * H        # every valid row sums to one
+    assert a0[~rows_valid].abs().max().item() == 0
+    for name in ("mha_self_medium", "mha_cross_medium", "mha_self_causal_c2"):
+        fm = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+        d, h, cross = fm["q"].shape[-1], int(fm["n_head"]), "kv" in fm
+        mha = A.MultiHeadAttention(h, d, d // h, d // h).eval()
+        mha.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in fm.items() if k.startswith("w/")})
+        mha = mha.to(device)
+        mha.return_attn = True
+        q = torch.from_numpy(fm["q"]).to(device)
+        kv = torch.from_numpy(fm["kv"]).to(device) if cross else q
+        with torch.no_grad():
+            _, attn = mha(q, kv, kv, torch.from_numpy(fm["mask"]).to(device))
+        if "f64/attn_idx" in fm:
+            assert tuple(attn.shape) == tuple(int(v) for v in fm["f64/attn_shape"]), name
+            flat = attn.double().cpu().reshape(-1)
+            assert rel(flat[torch.from_numpy(fm["f64/attn_idx"])], torch.from_numpy(fm["f64/attn_val"])) < 2e-2, name
+            assert abs(flat.sum().item() - float(fm["f64/attn_sum"])) < 2e-3 * abs(float(fm["f64/attn_sum"])), name
+        else:             # (the fixture carries no map: structure only - rows are distributions over the visible keys)
+            a = attn.double().cpu()
+            assert (a.sum(-1) - 1).abs().max().item() < 1e-4 and torch.triu(a, 1).abs().max().item() == 0, name
+    # the whole model
+    fx1, w, batch = _load_c1(golden_dir)
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=20, num_enc_layer=2, num_dec_layer=2, n_heads=4,
+                          d_k=32, d_v=32, d_model=128, d_inner_hid=256, dropout=0.0, vocab_size=30, return_attns=True))
+    m = M.Transformer(cfg)
+    m.load_state_dict(w)
+    m = m.eval().to(device)
+    with torch.no_grad():
+        logits, (ea, sa, ca) = m(batch["x"].to(device), batch["in_len"], batch["tokens"].to(device), batch["tgt_len"])
+        m.return_attns = None
+        logits0, empty = m(batch["x"].to(device), batch["in_len"], batch["tokens"].to(device), batch["tgt_len"])
+    assert empty == ([], [], []) and torch.equal(logits, logits0)
+    Bm, T, L = batch["x"].shape[0], batch["x"].shape[1], batch["tokens"].shape[1]
+    assert [tuple(a.shape) for a in ea] == [(Bm, 4, T, T)] * 2 and [tuple(a.shape) for a in sa] == [(Bm, 4, L, L)] * 2
+    assert [tuple(a.shape) for a in ca] == [(Bm, 4, L, T)] * 2
+    il, tl = batch["in_len"], batch["tgt_len"]
+    for maps, ql, kl in ((ea, il, il), (sa, tl, tl), (ca, tl, il)):
+        for a in maps:
+            a = a.double().cpu()
+            for b in range(Bm):
+                nq, nk = int(ql[b]), int(kl[b])
+                assert (a[b, :, :nq].sum(-1) - 1).abs().max().item() < 1e-4
+                assert a[b, :, nq:].abs().max().item() == 0 if nq < a.shape[2] else True
+                assert a[b, :, :, nk:].abs().max().item() == 0 if nk < a.shape[3] else True
+    for a in sa:          # feature_info_mask: no probability above the diagonal
+        assert torch.triu(a.double().cpu(), 1).abs().max().item() == 0
+
+
+def test_return_attns_composition(golden_dir):
+    with emulated_kernels():
+        run_return_attns(golden_dir, "cpu")
+
+
 def run_wide_step(device, d_model=512, n_head=8, d_ff=1024, n_enc=2, n_dec=1):
     """The BASELINE config 3 layer shape (d_model 512, 8 heads, d_k 64) on a small batch: loss, logits and every
     gradient against the fp64 oracle.  Exercises the N = 512 LayerNorm-GEMM geometry and 8-head attention."""

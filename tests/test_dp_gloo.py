@@ -182,17 +182,18 @@ def _model_worker(rank, world, port, mode, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["hooks", "explicit"])
-def test_product_dp_path_matches_oracle_shard_average(mode):
-    """Transformer + ParamArena + GradReducer on world 2 (gloo) == the oracle's ``dp_average_grads`` (pinned to
-    fixture F8 by tests/test_oracle_golden.py::test_dp8_average) on the same 8-utterance batch split 4 + 4."""
+@pytest.mark.parametrize("mode,world", [("hooks", 2), ("explicit", 2), ("hooks", 8)])
+def test_product_dp_path_matches_oracle_shard_average(mode, world):
+    """Transformer + ParamArena + GradReducer on world 2 (gloo; 4 + 4 utterances) and on world 8 (one utterance per rank -
+    the rank count of BASELINE's DP = 8 configuration, contiguous shards as bench.shard_batch cuts them) == the oracle's
+    ``dp_average_grads`` (pinned to fixture F8 by tests/test_oracle_golden.py::test_dp8_average) on the same 8-utterance batch."""
     import sys
     import numpy as np
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(here, "speech-tranformer-pytorch_amd"))
     import oracle as orc
     from tests import test_composition_cpu as comp
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_model_worker, args=(r, world, port, mode, q)) for r in range(world)]

@@ -147,8 +147,8 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
     assert glob < max(GRAD_TOL_GLOBAL, 1.5 * floor_glob) and med < max(GRAD_TOL_MEDIAN, 1.5 * floor_med), head
     bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 1.5 * r[1])]
     assert not bad, "\n".join([head, "outside max(8e-2, 1.5 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
-    for g, q, n in kbias:
-        assert g < 2.5e-1 * q + 1e-6, (n, g, q)
+    for g, q, n in kbias:      # analytically zero: 1e-2 of the query bias' gradient (measured: 5e-4 .. 4e-2 of it where that gradient
+        assert g < 1e-2 * q + 1e-7, (n, g, q)     # itself is ~1e-6 - the absolute term is the fp32 noise floor of those sums)
     assert dev_sum / n_el < 0.08, head          # a sign flip of an Adam first-step update costs 2
     return report
 
@@ -166,6 +166,68 @@ def test_config2_trainstep_graph_full_size_vs_fp64_oracle():
 def test_config3_depth_trainstep_vs_fp64_oracle():
     """BASELINE config 3's depth and width (12+6 layers, d_model 512, 8 heads) on its per-GPU shard (4 utterances)."""
     run_step_parity(C3, 4, "c3_b4")
+
+
+def test_config2_trainstep_trajectory_vs_fp64_oracle():
+    """TWENTY optimisation steps, not one: the captured step (HIP-graph replay, as bench.py times it) against
+    ``oracle.train_step`` in float64 carrying its own Adam state, on one 8-utterance batch of config 2 with a short warm-up
+    (warmup 400: the learning rate reaches 1.6e-4 at step 20 and the loss falls by about half a nat - a trajectory that goes
+    somewhere, inside the smooth regime: this model's loss surface turns sharp near loss 7.4 - the ORACLE's own clip norm jumps
+    0.85 -> 0.92 -> 1.42 there (tools/dev/traj_probe.py, which also shows the HIP gradients agreeing with the oracle's at
+    IDENTICAL weights all the way through, global rel-L2 1e-2 .. 4e-2) - and two roundings of the recursion reach that region a
+    step apart; with warmup 100 / 200 that happens at step 11 / 15).
+    Per step: the loss, the clip norm, and the accumulated weight change w_k - w_0 against the oracle's (rel-L2 over the whole
+    parameter vector).  Early Adam steps are sign-like (update ~ lr * g / |g|), so elements whose gradient is bf16 noise can
+    move the other way: the weight change agrees to a few per cent, not to rounding - what must NOT happen is drift (the error
+    growing step over step) or a loss curve that separates."""
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import synthetic
+    from st_amd.arena import arena_of
+    from st_amd.trainer import TrainStep
+    from transformer.Optim import ScheduledOptim
+
+    cfg, n_utts, n_steps, warmup = C2, 8, 20, 400
+    torch.manual_seed(0)
+    model = M.Transformer(U.AttrDict(cfg))
+    U.init_parameters(model)
+    w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.eval().cuda()
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(32, 1000, 50, cfg["feature_dim"], cfg["vocab_size"], seed=0, t_min=500, l_min=25)
+    x, tokens, in_len, tgt_len, gt = x[:n_utts], tokens[:n_utts], in_len[:n_utts], tgt_len[:n_utts], gt[:n_utts]
+    xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()
+    opt = ScheduledOptim(model, cfg["d_model"], U.AttrDict(n_warmup_steps=warmup))
+    step = TrainStep(model, opt, cfg["vocab_size"], 5.0, use_graph=True, graph_warmup=1)
+    names = [n for n, _ in model.named_parameters()]
+    p64 = {k: v.double().cuda() for k, v in w0.items()}
+    b64 = {"x": xg.double(), "in_len": in_len, "tokens": tg, "tgt_len": tgt_len, "gt": gg}
+    flat0 = torch.cat([p64[n].reshape(-1) for n in names])
+    adam, lines, worst_loss, worst_w = None, ["# 20 steps of TrainStep(use_graph=True) vs oracle.train_step (fp64, own Adam state); config 2, 8 utterances, warmup 400",
+                                              "step  loss(HIP)  loss(oracle)  rel       gnorm(HIP)  gnorm(oracle)  |dw - dw_ref| / |dw_ref|   lr"], 0.0, 0.0
+    for k in range(1, n_steps + 1):
+        loss, gnorm = step(xg, in_len, tg, tgt_len, gg)
+        loss, gnorm = float(loss), float(gnorm)
+        truth = orc.train_step(p64, b64, cfg["n_heads"], cfg["d_model"], warmup, k, 5.0, adam_state=adam)
+        adam, p64 = truth["adam"], truth["params"]
+        sd = model.state_dict()
+        flat = torch.cat([sd[n].detach().double().reshape(-1) for n in names])
+        ref = torch.cat([p64[n].reshape(-1) for n in names])
+        wrel = ((flat - ref).norm() / (ref - flat0).norm()).item()
+        lrel = abs(loss - truth["loss"].item()) / truth["loss"].item()
+        worst_loss, worst_w = max(worst_loss, lrel), max(worst_w, wrel)
+        lines.append("%3d   %.5f    %.5f       %.2e  %.5f     %.5f        %.3e                  %.3e"
+                     % (k, loss, truth["loss"].item(), lrel, gnorm, truth["grad_norm"].item(), wrel, truth["lr"]))
+        assert abs(gnorm - truth["grad_norm"].item()) < 3e-2 * truth["grad_norm"].item(), "\n".join(lines)
+    first, last = float(lines[2].split()[2]), truth["loss"].item()
+    lines.append("loss of the oracle: %.4f -> %.4f; worst loss rel %.2e, worst weight-change rel-L2 %.3e" % (first, last, worst_loss, worst_w))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "trajectory_c2_b8.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    report = "\n".join(lines)
+    assert first - last > 0.4, report                       # the trajectory goes somewhere
+    assert worst_loss < 1e-3 and worst_w < 0.3, report
+    wrels = [float(l.split()[6]) for l in lines[2:2 + n_steps]]
+    assert wrels[-1] < 1.5 * min(wrels), report            # no drift: the disagreement does not grow along the trajectory
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@ sides, so differences come from accumulation order and one bf16 rounding of the
 result: rel-L2 <= 1e-2 for bf16 outputs, <= 2e-3 for fp32 outputs / reductions.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -292,6 +293,32 @@ def test_attention_bwd_delta_supplied(case, use_work):
         rows = torch.cat([torch.arange(int(o), int(o) + int(n)) for o, n in zip(c[off], c[ln])])      # utterance rows (padded layout: the rest is untouched)
         assert torch.isfinite(g_.float().cpu()[rows]).all(), "non-finite %s %s" % (nm, case)
         check(g_.cpu()[rows], r_[rows], tol, "attention (delta supplied) %s %s" % (case, nm))
+
+
+@pytest.mark.parametrize("name", ["mha_self_small", "mha_self_small_causal", "mha_cross_small"])
+def test_attn_probs_kernel_vs_reference_maps(name, golden_dir):
+    """st_attn_probs against the reference's own `attns` (Attention.py:89,96; fixtures generated by importing the reference:
+    d_model 16, two heads of width 8 - a head width only this diagnostic kernel serves): projections in fp32 on the host,
+    rounded to bf16 as the kernels keep them."""
+    import numpy as np
+    fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+    H = int(fx["n_head"])
+    q = torch.from_numpy(fx["q"]).float()
+    kv = torch.from_numpy(fx["kv"]).float() if "kv" in fx else q
+    B, Lq, d = q.shape
+    Lk = kv.shape[1]
+    w = lambda n: torch.from_numpy(fx["w/" + n]).float()
+    Q = (q.reshape(-1, d) @ w("linear_q.weight").t() + w("linear_q.bias")).to(BF16)
+    K = (kv.reshape(-1, d) @ w("linear_k.weight").t() + w("linear_k.bias")).to(BF16)
+    ti = lambda v: torch.tensor(v, dtype=I32)
+    q_off, k_off = ti([b * Lq for b in range(B)]), ti([b * Lk for b in range(B)])
+    q_len, k_len = ti([Lq] * B), torch.from_numpy(fx["k_len"]).to(I32)       # the reference fills every query row (padding_info_mask masks keys)
+    causal = bool(fx["causal"])
+    P = nv.attn_probs(cu(Q), cu(K), cu(q_off), cu(q_len), cu(k_off), cu(k_len), H, Lq, Lk, causal, 1 / math.sqrt(d // H))
+    ref = torch.from_numpy(fx["f64/attn"])
+    assert tuple(P.shape) == tuple(ref.shape)
+    check(P, ref, 1.5e-2, "attn_probs %s" % name)
+    check(P, em.attn_probs(Q, K, q_off, q_len, k_off, k_len, H, Lq, Lk, causal, 1 / math.sqrt(d // H)), 1e-5, "attn_probs vs emulation %s" % name)
 
 
 def test_attention_work_lists_match_plain_enumeration():
@@ -766,6 +793,40 @@ def test_gemm_ws_relu_dropout_mask(p):
     _zero_pattern_equal(out, ref, "gemm_ws relu+dropout p=%g" % p)
     tiled = nv.gemm(cu(x), cu(W), torch.zeros(M, N, dtype=BF16, device="cuda"), bias=cu(b), epi=nv.EPI_BF16_RELU, drop=dn)
     _zero_pattern_equal(out, tiled, "gemm_ws vs st_gemm dropout mask")
+
+
+def test_last_arriver_merges_under_uneven_load():
+    """The in-launch merges (st_gemm_splitk: fp32 partial tiles of the K splits; st_grad_norm: per-workgroup partial sums) publish
+    with write-through stores + a drained vmcnt + a device-scope ticket and read with device-scope loads (the `sc1` store / `sc1`
+    load form of MI355X_MICROARCH.md, "Valid forms") - no L2 write-back fence.  A stale partial would be SILENT, and idle chips
+    hide such races: run both 300 times while a second stream streams 1 GiB copies through every XCD's L2, with inputs that
+    change every iteration (a merge that picked up the previous iteration's partial is then wrong, not accidentally right),
+    and require every result to equal the reference computed WITHOUT an in-launch merge (st_gemm's own product for the
+    split-K GEMM, bit for bit reproducible between two runs; a float64 norm for st_grad_norm)."""
+    M, N, K, splits = 1206, 256, 4344, 6
+    side = torch.cuda.Stream()
+    a, b = torch.empty(1 << 28, dtype=torch.float32, device="cuda"), torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    stop = torch.zeros(1, device="cuda")
+    scratch, out = nv.grad_norm_scratch("cuda"), torch.zeros((), device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    bad = []
+    for it in range(300):
+        if it % 4 == 0:                                    # keep the memory system busy and the load uneven
+            with torch.cuda.stream(side):
+                b.copy_(a)
+        x = (torch.randn(M, K, device="cuda", generator=gen) * 0.5).to(BF16)
+        w = (torch.randn(K, N, device="cuda", generator=gen) * K ** -0.5).to(BF16)
+        o1 = nv.gemm_splitk(x, w, torch.full((M, N), float("nan"), dtype=BF16, device="cuda"), splits, y_cmajor=True)
+        o2 = nv.gemm_splitk(x, w, torch.full((M, N), float("nan"), dtype=BF16, device="cuda"), splits, y_cmajor=True)
+        ref = (x.float() @ w.float())
+        gbuf = torch.randn(3_000_000 + 4 * it, device="cuda", generator=gen)
+        nrm = float(nv.grad_norm(gbuf, scratch, out))
+        if not torch.equal(o1, o2) or rel(o1, ref) > 1e-2 or abs(nrm - float(gbuf.double().norm())) > 1e-5 * nrm:
+            bad.append(it)
+    torch.cuda.synchronize()
+    assert not bad, "stale or torn partials in iterations %s" % bad[:10]
+    for wk in nv._splitk_work.values():
+        assert int(wk[:1024].abs().sum()) == 0, "split-K tickets not reset"
 
 
 def test_gemm_ws_stacked_weights():

@@ -30,6 +30,10 @@ def test_encoder_padded_api_gpu(golden_dir):
     comp.run_encoder_padded_api(golden_dir, "cuda")
 
 
+def test_return_attns_gpu(golden_dir):
+    comp.run_return_attns(golden_dir, "cuda")
+
+
 def test_graph_step_matches_eager_step():
     """TrainStep(use_graph=True) - HIP-graph replay of the step - must reproduce the eager step (same kernels,
     fp32 atomics up to reassociation): loss, gradient norm and the updated parameters."""
