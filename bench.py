@@ -540,40 +540,34 @@ def main():
             shard4 = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- BASELINE config 4 (N = 1, config 2's model): the joint 0.3 CTC + 0.7 attention objective of train_attn_and_ctc.py -
-    # Transformer.forward_joint + transformer/Loss.py:CTCAttentionLoss (PyTorch-ROCm CTC, as the north star prescribes) +
-    # backward + clip + Adam, launched eagerly (the CTC head is not part of the captured step)
+    # st_amd.trainer.JointTrainStep: two captured graphs around an eager torch ctc_loss (PyTorch-ROCm CTC, as the north star
+    # prescribes) on the few log-probabilities it reads
     ctc_joint = None
     if world == 1 and args.config == 2 and not args.no_decode:
         try:
             from transformer.Loss import CTCAttentionLoss
-            from st_amd import functional as F_
+            from st_amd.trainer import JointTrainStep
             torch.manual_seed(0)
             head = CTCAttentionLoss(CFG["d_model"], CFG["vocab_size"], ctc_weight=0.3).cuda()
-            Lm = int(tgt_len.max())
-
-            def joint_step():
-                arena.zero_grads()
-                head.zero_grad(set_to_none=True)
-                lg_j, enc_j = model.forward_joint(xg, in_len, tg[:, :Lm], tgt_len)
-                l_j, _, _ = head(enc_j, in_len, lg_j, gg[:, :Lm], tgt_len, gg[:, :Lm])
-                with F_.deferred_wgrads(True):
-                    l_j.backward()
-                optim.step_captured(grad_norm=torch.linalg.vector_norm(arena.grad), max_norm=5.0)     # clip + Adam (st_adam_clip)
-                return l_j
-            for _ in range(3):
-                lj = joint_step()
+            head._st_prepare("cuda")
+            head_opt = torch.optim.Adam(head.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, capturable=True)
+            jstep = JointTrainStep(model, optim, head, max_grad_norm=5.0, head_optimizer=head_opt, use_graph=not args.no_graph)
+            for _ in range(4):
+                lj = jstep(xg, in_len, tg, tgt_len, gg)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            nj = max(args.steps // 2, 5)
+            nj = max(args.steps, 5)
             for _ in range(nj):
-                lj = joint_step()
+                lj = jstep(xg, in_len, tg, tgt_len, gg)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             ctc_joint = {"ms_per_step": round(dt / nj * 1e3, 3), "value": round(float(in_len.sum()) * nj / dt, 1), "unit": "frames/s",
-                         "loss": round(float(lj), 4),
-                         "note": "BASELINE config 4: forward_joint + 0.3 CTC (torch ctc_loss over [T, B, V] log-probs) + 0.7 CE + backward + "
-                                 "Adam, eager launches (host-bound like eager_ms_per_step); parity: tests/test_fullsize_gpu.py::"
-                                 "test_config4_joint_ctc_attention_at_stated_shape_vs_fp64_oracle"}
+                         "loss": round(float(lj[0]), 4), "ctc": round(float(lj[2]), 4), "att": round(float(lj[1]), 4),
+                         "note": "BASELINE config 4 (st_amd.trainer.JointTrainStep): graph A = forward + CE + the CTC head's projection over the "
+                                 "ragged encoder rows + st_ctc_gather (no [T, B, V] log-softmax), eager torch ctc_loss on the [B, T, L+1] "
+                                 "log-probabilities it reads, graph B = backward from both roots (st_ctc_dlogits, the head's backward "
+                                 "GEMMs) + clip + Adam (model arena; torch Adam for the head's 1.1 M parameters); parity: tests/"
+                                 "test_fullsize_gpu.py::test_config4_joint_trainstep_b32_graph_vs_fp64_oracle"}
         except Exception as e:  # noqa: BLE001
             ctc_joint = {"error": "%s: %s" % (type(e).__name__, e)}
 

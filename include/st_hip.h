@@ -391,6 +391,23 @@ int st_ce_bwd(st_stream_t stream, const float* logits, int ldl, int R, int V, co
               const long long* target_index, int ignore_index, const float* lse, const float* sums, const float* grad_out,
               void* dlogits, int ldd);
 
+/* CTC head of the joint CTC + attention objective (BASELINE config 4; transformer/Loss.py:CTCAttentionLoss - the reference's
+ * train_attn_and_ctc.py is empty, the head is the standard hybrid one).  ctc_loss itself stays in PyTorch-ROCm; these two
+ * kernels stand where the [T, B, V] log-softmax tensor and its gradient would be.  logits f32 [R, ldl]: the ragged rows of
+ * the encoder-side vocabulary projection (V valid columns; padding columns at -1e30 may be counted); rowmap i64 [R]: row r is
+ * frame t of utterance b with rowmap[r] = b * T + t (negative: the row belongs to nobody); cols i32 [B, C]: the vocabulary
+ * column of class k of utterance b (class 0 = blank, classes 1.. = the utterance's labels as ctc_loss is given them).
+ * st_ctc_gather: lse[r] = logsumexp(logits[r, :V]); lp (f32 [B, T, C]) [b][t][k] = logits[r][cols[b][k]] - lse[r] on the
+ * rows that exist (the rest of lp is left untouched: ctc_loss does not read frames past an input length).
+ * st_ctc_dlogits: dlogits (bf16 [R, ldd], ldd % 8 == 0) = *grad_out * (roww[b] * softmax(logits[r]) everywhere, columns >= V
+ * zero; then column scat[b][k] (i32 [B, C], -1 = none) overwritten with gsmall[b][t][k]) - gsmall (f32 [B, T, C]) being
+ * ctc_loss's gradient with respect to lp (which already contains the softmax term at those columns, Graves eq. 16) and
+ * roww[b] the weight of utterance b's loss in the reduction (0 for an utterance whose loss is infinite: zero_infinity). */
+int st_ctc_gather(st_stream_t stream, const float* logits, int ldl, int R, int V, const long long* rowmap, int T, const int* cols,
+                  int C, float* lse, float* lp);
+int st_ctc_dlogits(st_stream_t stream, const float* logits, int ldl, int R, int V, const float* lse, const long long* rowmap, int T,
+                   const float* roww, const int* scat, int C, const float* gsmall, const float* grad_out, void* dlogits, int ldd);
+
 /* Attention probabilities of ONE attention sublayer, materialised (reference transformer/Attention.py:89,96: the `attns`
  * MultiHeadAttention.forward returns; Models.py:53-54,107-109 collect them under return_attns): P (f32 [B, H, Lq, Lk],
  * dense) = softmax over keys of scale * Q K^T with keys >= k_len[b] (and, when causal, keys > the query) masked out -

@@ -1290,6 +1290,112 @@ extern "C" int st_adam_clip(hipStream_t stream, long long n, float* p, float* g,
   return 0;
 }
 
+// ---- CTC head (BASELINE config 4: joint CTC + attention objective, transformer/Loss.py:CTCAttentionLoss) ----------------------
+// torch's ctc_loss (PyTorch-ROCm, as the task prescribes for the loss heads) reads, of the [T, B, V] log-probabilities, only
+// the blank column and the columns of the utterance's own labels; its gradient with respect to normalised log-probabilities
+// (Graves eq. 16) is softmax - occupancy, dense in V only through the softmax term.  So the [T, B, V] log-softmax tensor
+// (555 MB fp32 at config 2) is never built: st_ctc_gather takes the ragged logits rows of the encoder-side projection,
+// writes each row's log-sum-exp and the <= C log-probabilities ctc_loss will read (lp[b][t][k] = logits[row(b, t)][cols[b][k]] -
+// lse), and st_ctc_dlogits turns ctc_loss's small gradient back into the bf16 logits gradient the projection's backward GEMMs
+// read: w[b] * softmax everywhere, the small gradient's entries at the label columns.
+namespace {
+__global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict__ logits, int ldl, int V, const long long* __restrict__ rowmap,
+                                                         int T, const int* __restrict__ cols, int C, float* __restrict__ lse,
+                                                         float* __restrict__ lp) {
+  __shared__ float red[8];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const long long bt = rowmap[r];
+  const float* row = logits + (size_t)r * ldl;
+  // ONE pass over the row: per-thread running (max, sum of exp) pairs, merged across the workgroup (16-byte loads where the
+  // row is aligned for them)
+  float mx = -INFINITY, sum = 0.f;
+  auto take = [&](float x) {
+    if (x > mx) { sum = sum * __expf(mx - x) + 1.f; mx = x; }
+    else sum += __expf(x - mx);
+  };
+  if ((ldl & 3) == 0) {
+    const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+    for (int v = tid; v < (V >> 2); v += 256) {
+      const f32x4 x = row4[v];
+      take(x[0]); take(x[1]); take(x[2]); take(x[3]);
+    }
+    for (int v = (V & ~3) + tid; v < V; v += 256) take(row[v]);
+  } else {
+    for (int v = tid; v < V; v += 256) take(row[v]);
+  }
+  float wmx = mx;
+  for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = wmx;
+  __syncthreads();
+  const float gmx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  sum = (mx == -INFINITY) ? 0.f : sum * __expf(mx - gmx);
+  mx = gmx;
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  const float l = mx + __logf(red[4] + red[5] + red[6] + red[7]);
+  if (tid == 0) lse[r] = l;
+  if (bt < 0) return;                  // (a row that belongs to no utterance: packed bucket tails)
+  const int b = (int)(bt / T);
+  for (int k = tid; k < C; k += 256) lp[(size_t)bt * C + k] = row[cols[b * C + k]] - l;
+}
+
+__global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restrict__ logits, int ldl, int V, const float* __restrict__ lse,
+                                                          const long long* __restrict__ rowmap, int T, const float* __restrict__ roww,
+                                                          const int* __restrict__ scat, int C, const float* __restrict__ gsmall,
+                                                          const float* __restrict__ go, bf16* __restrict__ dl, int ldd) {
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const long long bt = rowmap[r];
+  const float* row = logits + (size_t)r * ldl;
+  bf16* out = dl + (size_t)r * ldd;
+  const int b = bt < 0 ? 0 : (int)(bt / T);
+  const float g = *go, w = bt < 0 ? 0.f : roww[b] * g, l = lse[r];
+  const bool al = (ldl & 3) == 0;
+  for (int v = tid * 8; v < ldd; v += 256 * 8) {      // ldd % 8 == 0; columns >= V get zeros
+    bf16x8 o;
+    if (al && v + 8 <= V && w != 0.f) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + v), x1 = *reinterpret_cast<const f32x4*>(row + v + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = (bf16)(__expf(x0[e] - l) * w); o[4 + e] = (bf16)(__expf(x1[e] - l) * w); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((v + e < V && w != 0.f) ? __expf(row[v + e] - l) * w : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(out + v) = o;
+  }
+  if (bt < 0) return;
+  // the label columns: written by the SAME thread that wrote the dense 16-byte group they lie in (program order then decides;
+  // a second thread's 2-byte store could reach the L2 before the first thread's 16-byte one - a barrier orders execution,
+  // not the arrival of global stores)
+  for (int k = 0; k < C; ++k) {
+    const int c = scat[b * C + k];
+    if (c >= 0 && ((c >> 3) & 255) == tid) out[c] = (bf16)(gsmall[(size_t)bt * C + k] * g);
+  }
+}
+}  // namespace
+
+extern "C" int st_ctc_gather(hipStream_t stream, const float* logits, int ldl, int R, int V, const long long* rowmap, int T,
+                             const int* cols, int C, float* lse, float* lp) {
+  if (R <= 0) return 0;
+  if (!logits || !rowmap || !cols || !lse || !lp || V <= 0 || ldl < V || T <= 0 || C <= 0) return -1;
+  hipLaunchKernelGGL(ctc_gather_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, rowmap, T, cols, C, lse, lp);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_ctc_dlogits(hipStream_t stream, const float* logits, int ldl, int R, int V, const float* lse, const long long* rowmap,
+                              int T, const float* roww, const int* scat, int C, const float* gsmall, const float* grad_out,
+                              void* dlogits, int ldd) {
+  if (R <= 0) return 0;
+  if (!logits || !lse || !rowmap || !roww || !scat || !gsmall || !grad_out || !dlogits || V <= 0 || ldl < V || ldd < V || (ldd & 7) ||
+      T <= 0 || C <= 0)
+    return -1;
+  hipLaunchKernelGGL(ctc_dlogits_kernel, dim3(R), dim3(256), 0, stream, logits, ldl, V, lse, rowmap, T, roww, scat, C, gsmall, grad_out,
+                     (bf16*)dlogits, ldd);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- attention maps (return_attns: reference transformer/Attention.py:89,96, Models.py:53-54,107-109) ------------------------
 // The fused attention kernels never materialise the [B, h, Lq, Lk] probabilities; when a caller asks for them
 // (Encoder / Decoder / Transformer.forward(return_attns=True)) this kernel recomputes ONE sublayer's map from its projected

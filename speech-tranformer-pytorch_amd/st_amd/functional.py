@@ -589,6 +589,77 @@ def _input_grad(link, dY, W, aux):
     return dx
 
 
+class CtcPlan:
+    """What the CTC head needs to know about a batch, computed once per batch signature (tiny eager torch ops; a captured
+    step reads these tensors by address): ctc_loss is fed a SMALL alphabet per utterance - class 0 = blank, class 1 + j = the
+    label first seen at target position j (equal labels share a class, so the repeated-label rule of CTC is untouched) -
+    and only those columns of the [rows, V] logits are ever turned into log-probabilities."""
+
+    def __init__(self, targets, target_lengths, input_lengths, in_rows: Rows, blank: int, v_pad: int):
+        dev = targets.device
+        B, L = targets.shape
+        self.B, self.L, self.C, self.T = B, L, L + 1, in_rows.max_len
+        tl = target_lengths.to(device=dev, dtype=torch.int64)
+        il = input_lengths.to(device=dev, dtype=torch.int64)
+        pos = torch.arange(L, device=dev)
+        valid = pos.view(1, -1) < tl.view(-1, 1)
+        # ext = [blank, label 0, label 1, ...]: the class of an entry is the index of the FIRST entry with the same vocabulary
+        # id (a label equal to the blank id - this repository's synthetic ground truth ends every utterance with id 0 - is the
+        # blank's class 0, exactly as ctc_loss treats it on the dense alphabet)
+        ext = torch.cat([torch.full((B, 1), int(blank), dtype=torch.int64, device=dev), targets.to(torch.int64)], 1)      # [B, L + 1]
+        first = (ext.unsqueeze(2) == ext.unsqueeze(1)).to(torch.int8).argmax(dim=2)                                      # [B, L + 1]
+        self.classes = first[:, 1:].contiguous()                                      # the targets ctc_loss is given
+        self.cols = ext.to(I32).contiguous()                                          # class -> vocabulary column
+        idx = torch.arange(L + 1, device=dev).view(1, -1)
+        keep = (first == idx) & torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), valid], 1)
+        self.scat = torch.where(keep, ext, torch.full_like(ext, -1)).to(I32).contiguous()   # gradients return through first occurrences only
+        # an utterance whose frames cannot spell its labels has an infinite loss: zero_infinity drops it from the objective
+        rep = ((targets[:, 1:] == targets[:, :-1]) & valid[:, 1:]).sum(1) if L > 1 else torch.zeros(B, dtype=torch.int64, device=dev)
+        self.finite = (il >= tl + rep)
+        self.tl = tl.clamp_min(1)
+        self.in_len_host = [int(v) for v in input_lengths.tolist()]
+        self.tgt_len_host = [int(v) for v in target_lengths.tolist()]
+        self.rowmap = in_rows.scatter_index(self.T)
+        self.lp = torch.zeros(B, self.T, self.C, dtype=F32, device=dev)              # frames past a length stay 0 (never read)
+        self.g_lp = torch.zeros(B, self.T, self.C, dtype=F32, device=dev)            # ctc_loss's gradient, staged for the backward graph
+        self.roww = torch.zeros(B, dtype=F32, device=dev)                            # weight of utterance b's softmax term
+        self.one = torch.ones(1, dtype=F32, device=dev)
+        self.v_pad = v_pad
+
+
+class CtcProjFn(torch.autograd.Function):
+    """lp = log_softmax(enc W^T + b)[the columns ctc_loss reads]  (transformer/Loss.py:CTCAttentionLoss, BASELINE config 4): the
+    encoder-side vocabulary projection as an st_gemm over the ragged encoder rows, st_ctc_gather instead of the [T, B, V]
+    log-softmax; backward: st_ctc_dlogits (softmax term + ctc_loss's small gradient -> bf16 logits gradient), then the
+    projection's two backward GEMMs.  The head's parameters live outside the model's arena: their bf16 / padded copies and
+    fp32 gradient buffers belong to the head (`head._st_*`), W.grad / b.grad are views of those buffers."""
+
+    @staticmethod
+    def forward(ctx, enc, W, b, head, plan: CtcPlan):
+        V, d = W.shape
+        wb, bias = head._st_wb, head._st_bias
+        wb[:V].copy_(W)
+        bias[:V].copy_(b)
+        logits = torch.empty(enc.shape[0], plan.v_pad, dtype=F32, device=enc.device)
+        nv.gemm(enc, wb, logits, epi=nv.EPI_F32, bias=bias)          # padding columns at -1e30: probability 0
+        lse = torch.empty(enc.shape[0], dtype=F32, device=enc.device)
+        nv.ctc_gather(logits, plan.rowmap, plan.T, plan.cols, lse, plan.lp)
+        ctx.save_for_backward(enc, logits, lse)
+        ctx.head, ctx.plan, ctx.V = head, plan, V
+        return plan.lp.view_as(plan.lp)
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        enc, logits, lse = ctx.saved_tensors
+        head, plan, V = ctx.head, ctx.plan, ctx.V
+        dl = torch.empty(logits.shape, dtype=BF16, device=logits.device)
+        nv.ctc_dlogits(logits, lse, plan.rowmap, plan.T, plan.roww, plan.scat, g_lp.contiguous(), plan.one, dl, V=V)
+        wgrad(dl, enc, head._st_gw, gB=head._st_gb)
+        dx = _empty(enc.shape[0], enc.shape[1], enc)
+        dgrad(dl, head._st_wb, dx)
+        return dx, None, None, None, None
+
+
 class AttnTap:
     """``with AttnTap() as tap:`` - every attention sublayer whose forward runs inside materialises its probabilities
     (native.attn_probs: f32 [B, h, max q_len, max k_len], dropout not applied) and appends (module, map) to ``tap.maps``

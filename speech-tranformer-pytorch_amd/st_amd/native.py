@@ -80,6 +80,9 @@ SIGNATURES = {
                     _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
+    "st_ctc_gather": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p],
+    "st_ctc_dlogits": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
+                       _c_void_p, _c_void_p, _c_void_p, _c_int],
     "st_attn_probs": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                       _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float],
     "st_feat_stack": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
@@ -813,6 +816,40 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
                             int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),
                             *_work(work_k), *_drop(drop))
     _check(rc, "st_attn_bwd")
+
+
+def ctc_gather(logits, rowmap, T, cols, lse, lp, V=None):
+    """lse[r] = logsumexp(logits[r, :V]); lp[b][t][k] = logits[row(b, t)][cols[b][k]] - lse - see st_ctc_gather."""
+    if not (logits.is_cuda and logits.dtype == F32 and logits.dim() == 2 and logits.stride(1) == 1):
+        raise ValueError("ctc_gather: logits must be an fp32 row matrix on the GPU")
+    R = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    B, C = cols.shape
+    if not (rowmap.dtype == torch.int64 and rowmap.numel() == R and cols.dtype == I32 and cols.is_contiguous()
+            and lp.dtype == F32 and lp.is_contiguous() and tuple(lp.shape) == (B, int(T), C)):
+        raise ValueError("ctc_gather: rowmap i64 [R], cols i32 [B, C], lp f32 [B, T, C] expected")
+    _vec(lse, F32, R, "lse")
+    _tag("ctc_gather", R, V, C, io=(4.0 * R * V, 4.0 * R * C))
+    _check(load().st_ctc_gather(_stream(), logits.data_ptr(), logits.stride(0), R, V, rowmap.data_ptr(), int(T), cols.data_ptr(), C,
+                                lse.data_ptr(), lp.data_ptr()), "st_ctc_gather")
+
+
+def ctc_dlogits(logits, lse, rowmap, T, roww, scat, gsmall, grad_out, dlogits, V=None):
+    """dlogits (bf16) = grad_out * (roww[b] * softmax(logits), label columns overwritten with gsmall) - see st_ctc_dlogits."""
+    R = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    B, C = scat.shape
+    _mat(dlogits, BF16, "dlogits")
+    if dlogits.shape[0] != R or dlogits.shape[1] < V or dlogits.stride(0) % 8 or dlogits.shape[1] != dlogits.stride(0):
+        raise ValueError("ctc_dlogits: dlogits must be a contiguous bf16 [R, >= V] matrix with a row length that is a multiple of 8")
+    if not (scat.dtype == I32 and scat.is_contiguous() and gsmall.dtype == F32 and gsmall.is_contiguous()
+            and tuple(gsmall.shape) == (B, int(T), C) and roww.dtype == F32 and roww.numel() == B):
+        raise ValueError("ctc_dlogits: scat i32 [B, C], gsmall f32 [B, T, C], roww f32 [B] expected")
+    _vec(grad_out, F32, 1, "grad_out")
+    _tag("ctc_dlogits", R, V, C, io=(4.0 * R * V, 2.0 * R * dlogits.shape[1]))
+    _check(load().st_ctc_dlogits(_stream(), logits.data_ptr(), logits.stride(0), R, V, lse.data_ptr(), rowmap.data_ptr(), int(T),
+                                 roww.data_ptr(), scat.data_ptr(), C, gsmall.data_ptr(), grad_out.data_ptr(), dlogits.data_ptr(),
+                                 dlogits.stride(0)), "st_ctc_dlogits")
 
 
 def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):

@@ -382,3 +382,148 @@ class _Captured:
     def __init__(self):
         self.g_fb = self.g_enc = self.g_opt = self.loss = self.gnorm = self.keep = None
         self.dec_lo = 0
+
+
+class JointTrainStep:
+    """One optimisation step of the joint CTC + attention objective (BASELINE config 4; the reference's
+    train_attn_and_ctc.py is an empty file - the step is train.py:25-46 with transformer/Loss.py:CTCAttentionLoss as the
+    criterion):  loss = w * CTC(encoder output) + (1 - w) * CE(decoder logits).
+
+    Everything except ``ctc_loss`` itself runs as HIP kernels and, in graph mode, inside three captured graphs that share a
+    memory pool:
+      graph A1  zero_grad, encoder forward, the CTC head's projection over the ragged encoder rows and st_ctc_gather (the
+                <= L + 1 log-probabilities per frame ctc_loss reads - the [T, B, V] log-softmax tensor of the module-level
+                path is never built);
+      eager     ``torch.nn.functional.ctc_loss`` on that small tensor + its gradient, ON A SIDE STREAM (PyTorch-ROCm, as the
+                task prescribes for the loss heads; torch's CTC kernels build their length tables from pageable host memory,
+                which a stream capture refuses).  Its three kernels walk the 1,000 frames sequentially on 32 workgroups -
+                3.1 ms at config 2 with the chip idle beside them - so meanwhile the main stream replays
+      graph A2  decoder forward, vocabulary projection + cross-entropy (one node), and the backward of that branch down to the
+                encoder output (the decoder never sees the CTC branch);
+      graph B   (after the side stream's event) backward from BOTH roots into the encoder - the encoder output with the
+                decoder's gradient, the log-probabilities with w * ctc_loss's gradient (st_ctc_dlogits -> the head's backward
+                GEMMs) -, the deferred weight gradients, clip + Adam over the model's arena, the head's own Adam.
+    One batch signature at a time (a new signature re-captures)."""
+
+    def __init__(self, model: nn.Module, optimizer, head, max_grad_norm: float, head_optimizer=None, use_graph: bool = True,
+                 graph_warmup: int = 2):
+        self.model, self.optimizer, self.head, self.head_optimizer = model, optimizer, head, head_optimizer
+        self.max_grad_norm, self.use_graph, self.graph_warmup = max_grad_norm, use_graph, graph_warmup
+        self.global_step = 0
+        self._sig, self._seen, self._cap, self._plan = None, 0, None, None
+        self._seed = None
+        self._side = None
+
+    # ---- the parts ------------------------------------------------------------------------------------------------------
+    def _part_a1(self, batch, plan, layouts):
+        inputs, in_len, targets, tgt_len, gt = batch
+        in_rows, t_rows = layouts
+        self.optimizer.zero_grad()
+        self.head.zero_grad_buffers()
+        rng.advance()
+        arena = arena_of(self.model)
+        with arena.scope():
+            enc, _ = self.model.encoder.forward_rows(inputs, in_len, in_rows)
+        lp = self.head.project_rows(enc, plan)
+        return enc, lp
+
+    def _part_a2(self, batch, enc, layouts):
+        from . import functional as F_
+        inputs, in_len, targets, tgt_len, gt = batch
+        in_rows, t_rows = layouts
+        arena = arena_of(self.model)
+        enc_in = enc.detach().requires_grad_(True)
+        arena._depth += 1                     # the bf16 shadow of this step's weights exists (graph A1 refreshed it)
+        try:
+            dec, _ = self.model.decoder.forward_rows(targets, tgt_len, enc_in, in_rows, t_rows)
+            att = F_.VocabCeFn.apply(dec, self.model.tgt_word_proj.weight, self.model, gt.contiguous().view(-1), 0,
+                                     t_rows.scatter_index(gt.shape[1]))
+        finally:
+            arena._depth -= 1
+        if self._seed is None or self._seed.device != att.device:
+            self._seed = torch.empty((), dtype=att.dtype, device=att.device)
+        self._seed.fill_(1.0 - float(self.head.ctc_weight))
+        with deferred_wgrads(True):
+            torch.autograd.backward(att, self._seed)
+        return att.detach(), enc_in
+
+    def _ctc(self, lp, plan):
+        w = float(self.head.ctc_weight)
+        ctc, g = self.head.ctc_rows(lp, plan)
+        plan.g_lp.copy_(g)
+        plan.g_lp.mul_(w)
+        torch.mul(plan.finite.to(plan.roww.dtype), w / plan.B, out=plan.roww)
+        plan.roww.div_(plan.tl.to(plan.roww.dtype))
+        return ctc
+
+    def _part_b(self, enc, enc_in, lp, plan):
+        with deferred_wgrads(True):
+            torch.autograd.backward([enc, lp], [enc_in.grad, plan.g_lp])
+        gnorm = self.optimizer.step_captured(grad_norm=True, max_norm=self.max_grad_norm) \
+            if getattr(self.optimizer, "arena", None) is not None else None
+        if self.head_optimizer is not None:
+            self.head_optimizer.step()
+        return gnorm
+
+    def _joint(self, att, ctc):
+        w = float(self.head.ctc_weight)
+        return w * ctc + (1.0 - w) * att
+
+    def _side_ctc(self, lp, plan):
+        """ctc_loss + its gradient on the side stream, behind everything the main stream has queued so far; -> (loss, event)"""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            ctc = self._ctc(lp, plan)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return ctc, done
+
+    def __call__(self, inputs, input_lengths, targets, target_lengths, ground_truth):
+        """-> (joint loss, attention CE, CTC loss, clip norm): device tensors."""
+        t_max, l_max = int(input_lengths.max()), int(target_lengths.max())
+        self.global_step += 1
+        batch = (inputs[:, :t_max], input_lengths, targets[:, :l_max], target_lengths, ground_truth[:, :l_max])
+        sig = (inputs.data_ptr(), targets.data_ptr(), ground_truth.data_ptr(), tuple(inputs.shape), tuple(targets.shape),
+               input_lengths.cpu().numpy().tobytes(), target_lengths.cpu().numpy().tobytes())
+        if sig != self._sig:
+            self._sig, self._seen, self._cap = sig, 0, None
+            self._layouts = self.model.prepare_layouts(batch[1], batch[3], l_max, inputs.device)
+            # the CTC labels are the ground truth of train.py:40 (label ids, PAD = blank = 0 past each length)
+            self._plan = self.head.plan(batch[4], batch[3], batch[1], self._layouts[0])
+            self._keep = batch
+        plan, layouts = self._plan, self._layouts
+        self.optimizer.update_learning_rate(self.global_step)
+        main = torch.cuda.current_stream()
+        if not self.use_graph or self._seen < self.graph_warmup:
+            self._seen += 1
+            enc, lp = self._part_a1(batch, plan, layouts)
+            ctc, done = self._side_ctc(lp, plan)
+            att, enc_in = self._part_a2(batch, enc, layouts)
+            main.wait_event(done)
+            gnorm = self._part_b(enc, enc_in, lp, plan)
+            return self._joint(att, ctc), att, ctc, gnorm
+        if self._cap is None:
+            if hasattr(self.optimizer, "_flat_state") and getattr(self.optimizer, "arena", None) is not None:
+                self.optimizer._flat_state()
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            ga1, ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga1, pool=pool):
+                enc, lp = self._part_a1(batch, plan, layouts)
+            with torch.cuda.graph(ga2, pool=pool):
+                att, enc_in = self._part_a2(batch, enc, layouts)
+            with torch.cuda.graph(gb, pool=pool):
+                gnorm = self._part_b(enc, enc_in, lp, plan)
+            self._cap = (ga1, ga2, gb, att, lp, gnorm)
+        ga1, ga2, gb, att, lp, gnorm = self._cap
+        ga1.replay()
+        ctc, done = self._side_ctc(lp, plan)
+        ga2.replay()
+        main.wait_event(done)
+        gb.replay()
+        return self._joint(att, ctc), att, ctc, gnorm

@@ -377,6 +377,31 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
             dV[ks, cs] = (pv.to(BF16).float().t() @ do).to(BF16)
 
 
+def ctc_gather(logits, rowmap, T, cols, lse, lp, V=None):
+    V = logits.shape[1] if V is None else V
+    l = torch.logsumexp(logits[:, :V].float(), dim=1)
+    lse.copy_(l)
+    ok = rowmap >= 0
+    b = torch.div(rowmap[ok], T, rounding_mode="floor")
+    rows = torch.nonzero(ok).flatten()
+    lp.view(-1, lp.shape[2])[rowmap[ok]] = logits[rows.view(-1, 1), cols[b].long()] - l[rows].view(-1, 1)
+
+
+def ctc_dlogits(logits, lse, rowmap, T, roww, scat, gsmall, grad_out, dlogits, V=None):
+    V = logits.shape[1] if V is None else V
+    ok = rowmap >= 0
+    b = torch.div(rowmap.clamp_min(0), T, rounding_mode="floor")
+    w = torch.where(ok, roww[b], torch.zeros_like(lse)) * grad_out.reshape(())
+    dense = torch.exp(logits[:, :V].float() - lse.view(-1, 1)) * w.view(-1, 1)
+    dlogits.zero_()
+    dlogits[:, :V] = dense.to(BF16)
+    g = gsmall.view(-1, gsmall.shape[2])
+    for r in torch.nonzero(ok).flatten().tolist():
+        sc = scat[int(b[r])]
+        keep = sc >= 0
+        dlogits[r, sc[keep].long()] = (g[int(rowmap[r])][keep] * grad_out.reshape(())).to(BF16)
+
+
 def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):
     B = q_off.numel()
     d_k = Q.shape[1] // n_head
@@ -570,7 +595,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "ctc_gather", "ctc_dlogits", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "beam_work_words", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 
