@@ -222,6 +222,55 @@ __device__ __forceinline__ void store_rows_pair(bf16* patch_hi, bf16* patch_lo, 
   }
 }
 
+// ---- pieces of the hand-scheduled streams' kernels (st_attn_bwd64.hip, st_attn64.hip) ------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const int __attribute__((address_space(4)))* sptr_t;      // constant address space: uniform addresses load on the scalar unit
+
+template <typename T> __device__ __forceinline__ const T* uniform_ptr(const T* p) {
+  const uint64_t u = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return (const T*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int sload(const int* p, int i) { return reinterpret_cast<sptr_t>((__UINTPTR_TYPE__)p)[i]; }
+
+// blockIdx -> (utterance, head, tile) and the utterance's lengths / offsets, all through SCALAR loads: the general kernels'
+// decode_item goes through three dependent vector-memory round trips (work list, lengths, offsets) before the first useful
+// load can be asked for - 1.7 us of every item's ~20 (tools/dev/attn_bwd64_trace.py)
+struct Item { int b, h, tile, lq, lk, qo, ko; };
+__device__ __forceinline__ Item decode_scalar(const AttnArgs& a, int bid) {
+  Item it;
+  const int idx = bid / a.H;
+  it.h = bid % a.H;
+  if (a.work) {
+    const int w = sload(a.work, idx);
+    it.b = w >> 16;
+    it.tile = w & 0xffff;
+  } else {
+    it.b = idx / a.tiles_max;
+    it.tile = idx % a.tiles_max;
+  }
+  it.lq = sload(a.q_len, it.b); it.lk = sload(a.k_len, it.b); it.qo = sload(a.q_off, it.b); it.ko = sload(a.k_off, it.b);
+  return it;
+}
+
+__device__ __forceinline__ bf16x8 scaled8(const bf16x8 v, float c) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (bf16)((float)v[e] * c);
+  return r;
+}
+
+// this thread's two 16-byte chunks (rows tid >> 3 and 32 + (tid >> 3), chunk tid & 7) of the first 64-row tile of a streamed
+// matrix whose range ends with row `rows - 1` (rows past it read as zeros): asked for BEFORE the register-resident fragments,
+// so that one memory round trip serves both (the streams' own loads start at tile 1)
+__device__ __forceinline__ void tile0(const bf16* base, int ld2, int rows, u32x4& c0, u32x4& c1) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (rows - 1) * ld2 + 128, 0x00020000);
+  const unsigned off = (threadIdx.x >> 3) * (unsigned)ld2 + (threadIdx.x & 7) * 16u;
+  c0 = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  c1 = __builtin_amdgcn_raw_buffer_load_b128(r, off + 32u * (unsigned)ld2, 0, 0);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Forward.  Each wave owns 32 query rows (lane & 31); key / value tiles are streamed.
 // ---------------------------------------------------------------------------------------------

@@ -311,8 +311,9 @@ class Mf:
     """One MFMA of a step with the LDS reads that produce its A operand (and, for the first MFMA of a score chain of the
     dK/dV body, the reads that fill the accumulator with -lse / -delta: `init`, not before MFMA `init_after` of the step)."""
 
-    def __init__(self, d, b, c, reads, init=None, init_after=0, tag=""):
+    def __init__(self, d, b, c, reads, init=None, init_after=0, tag="", a=None):
         self.d, self.b, self.c, self.reads, self.init, self.init_after, self.tag = d, b, c, reads, init, init_after, tag
+        self.a = a        # a register-resident A operand (no LDS read, no fragment slot)
 
 
 def tr_reads(buf, mat, blk, hf, dcol):
@@ -363,15 +364,19 @@ class Body:
             out[name] = (Emit.merge([st for st, _ in lst]), lst[0][1])
         return out
 
-    def run(self, mfs, nxt, valu, extras=None, valu_from=1, valu_to=None, defer_from=None):
-        """mfs: this block's MFMAs; nxt: the MFMAs that follow (their A reads are issued 8 MFMAs ahead, i.e. behind this
-        block's last ones; entries of nxt from index defer_from on are returned as closures instead - data that becomes
-        visible only after the block's barrier); valu: closures emitting one VALU each, spread evenly behind MFMAs
-        valu_from..; extras: {k: [closures]} emitted behind MFMA k (1-based)."""
+    def run(self, mfs, nxt, valu, extras=None, valu_from=1, valu_to=None, defer_from=None, barrier_after=None, pre_deferred=None):
+        """mfs: this block's MFMAs; nxt: the MFMAs that follow (the A reads of every MFMA that has one are issued 8 such MFMAs
+        ahead, i.e. behind this block's last ones; reads of nxt entries from index defer_from on are held back - data that
+        becomes visible only after the block's barrier - and returned as closures, or, with barrier_after = k, emitted right
+        behind the barrier this function then places behind MFMA k); valu: closures emitting one VALU each, spread evenly
+        behind MFMAs valu_from..valu_to; extras: {k: [closures]} emitted behind MFMA k (1-based).
+        self.gidx counts the MFMAs that consume a fragment slot."""
         e = self.e
         extras = extras or {}
         K = len(mfs)
         allm = mfs + nxt
+        ring = [i for i, m in enumerate(allm) if m.a is None]          # indices (in allm) of the slot consumers
+        rpos = {i: j for j, i in enumerate(ring)}
         g0 = self.gidx
         done_v = 0
         inits = {}
@@ -379,27 +384,43 @@ class Body:
             if m.init:
                 inits.setdefault(m.init_after, []).extend(m.init)
         pending_inits = []
-        deferred = []
+        deferred = list(pre_deferred or [])      # reads a predecessor block could not issue yet (same rule)
+        holding = defer_from is not None
+        held = defer_from if callable(defer_from) else (lambda i: i >= defer_from)      # by index in nxt
         vf = max(1, valu_from)
         vt = K if valu_to is None else valu_to
+
+        def slot_of(i):
+            return FRAG + 4 * ((g0 + rpos[i]) % 8)
+
+        def do_valu(k):
+            nonlocal done_v
+            if k >= vf and valu:
+                target = len(valu) if k >= vt else -(-len(valu) * (k - vf + 1) // (vt - vf + 1))
+                while done_v < min(target, len(valu)):
+                    valu[done_v]()
+                    done_v += 1
+
         for k in range(0, K + 1):
             if k >= 1:
                 m = mfs[k - 1]
-                slot = FRAG + 4 * ((g0 + k - 1) % 8)
                 if (k - 1) % self.WAIT_GROUP == 0:      # one wait for the A operands of the next few MFMAs
                     cover = []
-                    for j in range(k, min(K, k + self.WAIT_GROUP - 1) + 1):
-                        cover += regs_of(FRAG + 4 * ((g0 + j - 1) % 8), 4)
+                    for j in range(k - 1, min(K, k - 1 + self.WAIT_GROUP)):
+                        if mfs[j].a is None:
+                            cover += regs_of(slot_of(j), 4)
                     e._wait_regs(cover)
-                e.mfma(m.d, slot, m.b, m.c)
-                if knob("VALU_FIRST", 0) and k >= vf and valu:      # (switch) vector instructions in front of the LDS reads
-                    target = len(valu) if k >= vt else -(-len(valu) * (k - vf + 1) // (vt - vf + 1))
-                    while done_v < min(target, len(valu)):
-                        valu[done_v]()
-                        done_v += 1
-                if k - 1 + 8 < len(allm):               # the slot is free: read the A operand of the MFMA 8 ahead
-                    for (op, sub, n, addr, off) in allm[k - 1 + 8].reads:
-                        if defer_from is not None and k - 1 + 8 >= K + defer_from:
+                if m.a is None:
+                    slot = slot_of(k - 1)
+                    e.mfma(m.d, slot, m.b, m.c)
+                else:
+                    e.mfma(m.d, m.a, m.b, m.c)
+                if knob("VALU_FIRST", 0):                # (switch) vector instructions in front of the LDS reads
+                    do_valu(k)
+                if m.a is None and rpos[k - 1] + 8 < len(ring):      # the slot is free: read the A operand of the consumer 8 ahead
+                    tgt = ring[rpos[k - 1] + 8]
+                    for (op, sub, n, addr, off) in allm[tgt].reads:
+                        if holding and tgt >= K and held(tgt - K):
                             deferred.append(lambda op=op, d=slot + sub, n=n, addr=addr, off=off: e.ds_read(op, d, n, addr, off))
                         else:
                             e.ds_read(op, slot + sub, n, addr, off)
@@ -410,14 +431,16 @@ class Body:
             pending_inits = pending_inits[2:]
             for f in extras.get(k, []):
                 f()
-            if k >= vf and valu:
-                target = len(valu) if k >= vt else -(-len(valu) * (k - vf + 1) // (vt - vf + 1))
-                while done_v < min(target, len(valu)):
-                    valu[done_v]()
-                    done_v += 1
+            if barrier_after is not None and k == barrier_after:
+                e.wait_lds_writes()
+                e.barrier()
+                for f in deferred:
+                    f()
+                deferred, holding = [], False
+            do_valu(k)
         assert not pending_inits
         assert done_v == len(valu), (done_v, len(valu))
-        self.gidx = g0 + K
+        self.gidx = g0 + sum(1 for m in mfs if m.a is None)
         return deferred
 
     def muls(self, L, S, D, i):
@@ -433,7 +456,7 @@ class Body:
     def prime(self, mfs):
         """pipeline fill: the A reads of the first 8 MFMAs and their accumulator-start reads"""
         e = self.e
-        for k, m in enumerate(mfs[:8]):
+        for k, m in enumerate([m for m in mfs if m.a is None][:8]):
             slot = FRAG + 4 * ((self.gidx + k) % 8)
             for (op, sub, n, addr, off) in m.reads:
                 e.ds_read(op, slot + sub, n, addr, off)
@@ -780,6 +803,13 @@ class DQ(Body):
         self.finish()
         return e
 
+
+# (A forward stream in the same style - class FWD: scores of block n + 1 first in the step, exponentials of block n, P V and
+# the row-sum MFMAs of block n - 1; bit-identical to st_attn64.hip's kernel - was generated and measured in round 4: 32.8 us
+# against 33.3 us at the config-2 encoder shape, 86.5 against 81.7 us on 16 x 2048 uniform utterances.  With ten MFMAs and 24
+# vector instructions per 32 x 32 block the compiler-scheduled kernel at three workgroups per CU is already at ~57 % of the
+# matrix rate the chip sustains at the 1.5-1.7 GHz it clocks to under this load, and what is left of the launch is per-item
+# prologue / epilogue and the granularity of 816 items on 512 or 768 slots - nothing an instruction order fixes.  Not kept.)
 
 def generate(cls):
     joins = None
