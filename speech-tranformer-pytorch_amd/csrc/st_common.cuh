@@ -15,6 +15,23 @@
 //     with ds_read_b64_tr_b16 (frag_tr below), so no tile is ever transposed in
 //     registers or re-written transposed to HBM.
 #pragma once
+
+// ---- last-arriver merges (st_grad_norm, the split row chains, st_gemm_splitk, the beam step) ---------------------------------
+// Every contributing workgroup publishes its partial with system-scope (write-through) stores, waits until the memory system
+// has acknowledged them (s_waitcnt 0), then draws a ticket with an agent-scope atomic; the workgroup that draws the last one
+// reads the partials with agent-scope loads (which miss the non-coherent L2 lines) and merges.  This is the sequence gfx950's
+// agent-scope release / acquire lower to, minus the whole-L2 write-back and invalidate that the language-level fences add
+// (measured: +60-80 us per merge launch, tools/dev/merge_probe.hip) - the HIP memory model does not promise it, the hardware
+// does (MI355X_MICROARCH.md, "cross-XCD visibility"), and tests/test_kernels_gpu.py::test_last_arriver_merges_under_uneven_load
+// checks every merge under load against a fenced reference.  ONE switch turns all of them into the language-level form:
+// build with ST_MERGE_FENCE=1 in the environment (st_amd/build.py adds -DST_MERGE_FENCE=1; a separately stamped library).
+#ifdef ST_MERGE_FENCE
+#define ST_PUBLISH_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define ST_MERGER_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define ST_PUBLISH_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront")
+#define ST_MERGER_FENCE() ((void)0)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

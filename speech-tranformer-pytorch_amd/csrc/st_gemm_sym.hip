@@ -322,7 +322,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int ts, int ti, int
           for (int t = 0; t < 16; t += 2)
             __hip_atomic_store(mine8 + ((x * 2 + y) * 8 + t / 2) * 256 + tid, pack2(acc[x][y][t], acc[x][y][t + 1]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      ST_PUBLISH_FENCE();
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid == 0) {
@@ -332,6 +332,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int ts, int ti, int
       }
       __syncthreads();
       if (!last) return;
+      ST_MERGER_FENCE();
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll

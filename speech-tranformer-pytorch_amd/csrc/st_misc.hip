@@ -316,12 +316,13 @@ __global__ __launch_bounds__(1024) void grad_norm_kernel(const float* __restrict
 #pragma unroll
     for (int w = 0; w < 16; ++w) bs += red[w];
     __hip_atomic_store(partial + blockIdx.x, bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    ST_PUBLISH_FENCE();
     __builtin_amdgcn_s_waitcnt(0);
     last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
+  ST_MERGER_FENCE();
   double t = 0.0;
   if (tid < 256)
     for (int i = tid; i < (int)gridDim.x; i += 256) t += (double)__hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -926,7 +927,7 @@ __global__ __launch_bounds__(256) void beam_row_best_kernel(const float* __restr
     if (c == best) c = 0ull;
     if (lane == 0) __hip_atomic_store(work + (size_t)row * beam + r, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  ST_PUBLISH_FENCE();
   __builtin_amdgcn_s_waitcnt(0);
   const int b = row / beam;
   int last = 0;
@@ -935,6 +936,7 @@ __global__ __launch_bounds__(256) void beam_row_best_kernel(const float* __restr
     if (last) __hip_atomic_store(st.row_tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!__builtin_amdgcn_readfirstlane(last)) return;
+  ST_MERGER_FENCE();
   beam_merge_wave(s_anc, work, b, lane, V, beam, st.B, st.step, st.eos, st.scores, st.tokens, st.done, st.lengths, st.hist_scores,
                   st.back, st.toks, st.order, st.anc, st.S, st.step_next, st.ticket, st.emb, st.emb_rows, st.pe, st.pe_rows,
                   st.x_next, st.D);

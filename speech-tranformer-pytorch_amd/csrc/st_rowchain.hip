@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
       __hip_atomic_store(mine8 + (i / 2) * 512 + c.tid,
                          ((unsigned long long)__float_as_uint(acc2[0][i + 1]) << 32) | __float_as_uint(acc2[0][i]), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    ST_PUBLISH_FENCE();
     __builtin_amdgcn_s_waitcnt(0);
   }
   __syncthreads();
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
     last = __hip_atomic_fetch_add(a.split_tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1);
   __syncthreads();
   if (last) {
+    ST_MERGER_FENCE();
     if (c.tid == 0) __hip_atomic_store(a.split_tickets + block, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     zero_acc(acc2);
     for (int p = 0; p < parts; ++p) {
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArg
       __hip_atomic_store(mine8 + (i / 2) * 512 + c.tid,
                          ((unsigned long long)__float_as_uint(acc2[0][i + 1]) << 32) | __float_as_uint(acc2[0][i]), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    ST_PUBLISH_FENCE();
     __builtin_amdgcn_s_waitcnt(0);
   }
   __syncthreads();
@@ -733,6 +734,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArg
     last = __hip_atomic_fetch_add(a.split_tickets + block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1);
   __syncthreads();
   if (last) {
+    ST_MERGER_FENCE();
     if (c.tid == 0) __hip_atomic_store(a.split_tickets + block, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     zero_acc(acc2);
     for (int p = 0; p < parts; ++p) {

@@ -25,6 +25,10 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-
 # per-file additions (none today; a kernel that owns all 512 registers per lane would want "-mllvm -amdgpu-mfma-vgpr-form":
 # left to its heuristics the compiler then puts score accumulators into AGPRs and pays a v_accvgpr_read per score)
 EXTRA = {}
+if os.environ.get("ST_MERGE_FENCE") == "1":
+    # the last-arriver merges with language-level agent-scope release / acquire fences (csrc/st_common.cuh): the documented
+    # conservative build; the flag is part of the source hash, so the library is rebuilt when the switch changes
+    FLAGS = FLAGS + ["-DST_MERGE_FENCE=1"]
 
 
 def _headers() -> bytes:

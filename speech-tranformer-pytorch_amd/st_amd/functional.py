@@ -117,6 +117,8 @@ class Rows:
         return r
 
     _PIN = {}      # device -> ring of (pinned int32 staging buffer, event of the copy that last read it)
+    _PIN_SLOTS = 32    # a packed-bucket step stages 9 vectors (two layouts x off / valid_rows / len + 3 work lists): the ring
+                       # holds three steps' worth, so a slot's previous copy belongs to a step that finished long ago
 
     @staticmethod
     def _h2d(dst: torch.Tensor, src: torch.Tensor) -> None:
@@ -129,7 +131,7 @@ class Rows:
         key = str(dst.device)
         ring = Rows._PIN.setdefault(key, {"slots": [], "next": 0})
         n = src.numel()
-        if len(ring["slots"]) < 8:
+        if len(ring["slots"]) < Rows._PIN_SLOTS:
             ring["slots"].append([torch.empty(max(n, 1024), dtype=I32).pin_memory(), None])
         i = ring["next"] % len(ring["slots"])
         ring["next"] += 1

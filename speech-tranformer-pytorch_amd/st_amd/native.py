@@ -508,6 +508,21 @@ def split_work_words() -> int:
 
 
 _splitk_work = {}
+_SPLITK_BYTES = 4096 + 256 * 65536
+
+
+def splitk_scratch(device):
+    """The per-device scratch of st_gemm_splitk (tickets + 256 fp32 tile partials), zeroed once; the kernel restores its
+    tickets.  TrainStep creates it before a capture (a tensor born inside one belongs to that graph's pool)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    work = _splitk_work.get(device)
+    if work is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("splitk_scratch: first use inside a stream capture; call st_amd.native.splitk_scratch(device) before it")
+        work = _splitk_work[device] = torch.zeros(_SPLITK_BYTES // 4, dtype=torch.int32, device=device)
+    return work
 
 
 def gemm_splitk(X, Y, out, splits, y_cmajor=False):
@@ -523,10 +538,8 @@ def gemm_splitk(X, Y, out, splits, y_cmajor=False):
         raise ValueError("gemm_splitk: at most 256 (output tile, split) pairs")
     # ONE scratch per device, sized for the largest launch (16.8 MB): a size that followed the shape would be allocated anew -
     # possibly inside a graph capture, from the graph's private pool - whenever a batch brings another row count
-    need = 4096 + 256 * 65536
-    work = _splitk_work.get(X.device)
-    if work is None:
-        work = _splitk_work[X.device] = torch.zeros(need // 4, dtype=torch.int32, device=X.device)
+    need = _SPLITK_BYTES
+    work = splitk_scratch(X.device)
     _tag("gemm", 0, int(y_cmajor), M, N, Kc, 0, io=(X, Y, out, 2.0 * tiles * int(splits) * 65536))
     _check(load().st_gemm_splitk(_stream(), int(y_cmajor), X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), out.data_ptr(),
                                  out.stride(0), M, N, Kc, int(splits), work.data_ptr(), need), "st_gemm_splitk")

@@ -300,6 +300,15 @@ class TrainStep:
         if hasattr(self.optimizer, "_flat_state") and getattr(self.optimizer, "arena", None) is not None:
             self.optimizer._flat_state()      # Adam's lazily created state must exist BEFORE the capture (a captured
                                               # zero-fill would reset it on every replay)
+        # ... and so must the process-wide scratch the step's kernels share (split-K partials and tickets, the norm's block
+        # partials, the backward seed): created inside a capture they would live in that graph's private pool while later
+        # captures and eager calls keep using them
+        dev = batch[0].device
+        nv.splitk_scratch(dev)
+        if hasattr(self.optimizer, "norm_scratch"):
+            self.optimizer.norm_scratch(dev)
+        if self._seed is None or self._seed.device != dev:
+            self._seed = torch.ones((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         cap = _Captured()
         # the captured kernels read the ragged layouts (offsets, lengths, positions, attention work lists, scatter
@@ -325,6 +334,7 @@ class TrainStep:
         if split and self.dp_in_graph:
             # ONE graph: forward + loss + decoder backward | decoder-side buckets start on RCCL's stream (a forked branch
             # of the graph) | encoder backward runs beside them | remaining buckets | join | clip + Adam
+            failure = None
             try:
                 g_all = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_all, pool=pool, **mode):
@@ -333,17 +343,36 @@ class TrainStep:
                     self._encoder_backward()
                     self.reducer.synchronize()
                     cap.gnorm = self._clip_and_update()
+            except Exception as e:  # noqa: BLE001 - a process group / RCCL build that cannot be captured: eager collectives
+                failure = e
+            # every rank must take the same mode (a rank replaying captured collectives beside one that issues them from the
+            # host would deadlock): the ranks agree before anything else is exchanged - capture only records, so this is
+            # the next collective on every rank either way
+            if self.reducer.world > 1:
+                ok = torch.tensor([0.0 if failure is not None else 1.0], device=batch[0].device)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.reducer.group)
+                if float(ok) == 0.0 and failure is None:
+                    failure = RuntimeError("another rank could not capture its collectives")
+            if failure is None:
                 cap.g_fb, cap.g_enc, cap.g_opt = g_all, None, None
                 self.dp_mode = "in-graph"
                 return cap
-            except Exception as e:  # noqa: BLE001 - a process group / RCCL build that cannot be captured: eager collectives
-                import warnings
-                warnings.warn("TrainStep: capturing the gradient all-reduces failed (%s: %s); using eager collectives "
-                              "between three graphs" % (type(e).__name__, e))
-                self.reducer._work, self.reducer._fired = [], [False] * len(self.reducer.buckets)
-                torch.cuda.synchronize()
-                pool = torch.cuda.graph_pool_handle()
-                cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            import warnings
+            warnings.warn("TrainStep: capturing the gradient all-reduces failed (%s: %s); using eager collectives "
+                          "between three graphs" % (type(failure).__name__, failure))
+            # the failed capture may have stopped anywhere: collectives noted as fired, tail buffers handed out, the
+            # encoder cut stored, weight gradients still deferred - the recapture starts from a clean slate
+            from .functional import _Deferred
+            self.reducer._work, self.reducer._fired = [], [False] * len(self.reducer.buckets)
+            self._cut = None
+            _Deferred.pending.clear()
+            _Deferred.active = False
+            if TailBuffers.active is not None:
+                TailBuffers.active.i = 0
+            del g_all
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if split:
             self.dp_mode = "split"
             cap.g_enc, cap.dec_lo = torch.cuda.CUDAGraph(), self._decoder_grad_start()

@@ -55,6 +55,13 @@ class ScheduledOptim(object):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return p, st
 
+    def norm_scratch(self, device):
+        """st_grad_norm's zeroed block partials + ticket, one per optimizer; TrainStep asks for it before a graph capture."""
+        if self._norm_scratch is None or self._norm_scratch.device != torch.device(device):
+            from st_amd import native as nv
+            self._norm_scratch = nv.grad_norm_scratch(device)
+        return self._norm_scratch
+
     def step_captured(self, grad_norm=None, max_norm=None):
         """The update alone (rate already set with update_learning_rate) - what a HIP graph captures.
         With ``grad_norm`` and ``max_norm`` on the flat-arena path, gradient clipping (train.py:45) and the Adam update are
@@ -63,14 +70,23 @@ class ScheduledOptim(object):
         grad_norm: True = compute it here (returned as a device scalar), or a device scalar already computed."""
         group = self.optimizer.param_groups[0]
         plain = not (group["weight_decay"] or group["amsgrad"] or group["maximize"])
-        if self.arena is None or grad_norm is None or not plain:
+        if self.arena is None or grad_norm is None:
             self.optimizer.step()
             return None
+        if not plain:
+            # weight decay / amsgrad / maximize: torch's own Adam does the update, the clipping still happens here (train.py:45
+            # clips whatever optimizer follows) - the norm over the flat gradient, the gradient scaled in place, no host sync
+            g = self._flat_state()[0].grad
+            if grad_norm is True:
+                grad_norm = torch.linalg.vector_norm(g.float())
+            if max_norm is not None:
+                g.mul_(torch.clamp(float(max_norm) / (grad_norm + 1e-6), max=1.0))
+            self.optimizer.step()
+            return grad_norm
         from st_amd import native as nv
         p, st = self._flat_state()
         if grad_norm is True:
-            if self._norm_scratch is None or self._norm_scratch.device != p.device:
-                self._norm_scratch = nv.grad_norm_scratch(p.device)
+            self.norm_scratch(p.device)
             grad_norm = nv.grad_norm(p.grad, self._norm_scratch, torch.empty((), dtype=torch.float32, device=p.device), step=st["step"])
         else:
             st["step"].add_(1)

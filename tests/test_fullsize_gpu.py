@@ -529,3 +529,62 @@ def test_config4_joint_trainstep_b32_graph_vs_fp64_oracle():
     assert not bad, "\n".join(lines[:2] + ["outside the bound:"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
     med, fmed = sorted(r[0] for r in rows)[len(rows) // 2], sorted(r[1] for r in rows)[len(rows) // 2]
     assert med < max(7e-2, 1.5 * fmed), "\n".join(lines[:12])      # (half the tensors are the decoder's: the c2 tests' median is 5.5e-2)
+
+
+def test_decode_scoring_at_the_benchmarked_shape_vs_fp64_oracle():
+    """The decode path (transformer/Decode.py: KV cache, shared encoder keys, step row chains) at the shape ``bench.py`` times
+    it on - config 2's model, the seed-0 batch of 32 utterances of 500..1000 frames, vocabulary 4337, up to 50 steps - with the
+    search switched off (``Decode.score_hypotheses``: the tokens are fed, not chosen, so there is no selection among noisy
+    scores): the teacher-forced log-probability of one 25..50-token hypothesis per utterance against the oracle's encoder /
+    decoder evaluated in float64 on the GPU, and against the same oracle arithmetic under bf16 autocast as the noise floor.
+    Bound: every score within 0.3 (scores are ~ -300: 1e-3 relative) and the batch rms within 2x the bf16 reference's."""
+    import transformer.Models as M
+    import transformer.Utils as U
+    from oracle import beam_oracle as bo
+    from st_amd import synthetic
+    from transformer.Decode import Decode
+
+    cfg = C2
+    torch.manual_seed(0)
+    model = M.Transformer(U.AttrDict(cfg))
+    U.init_parameters(model)
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.eval().cuda()
+    x, _, in_len, tgt_len, _ = synthetic.make_batch(32, 1000, 50, cfg["feature_dim"], cfg["vocab_size"], seed=0, t_min=500, l_min=25)
+    g = torch.Generator().manual_seed(11)
+    hyps = [torch.randint(4, cfg["vocab_size"], (int(n),), generator=g).tolist() for n in tgt_len]
+    xg = x.cuda()
+    dec = Decode(U.AttrDict(beam_size=10, n_best=1, max_steps=50), "cuda", model=model)
+    got = dec.score_hypotheses((xg, in_len), hyps).double().cpu()
+
+    L = max(len(h) for h in hyps)
+    prefix = torch.zeros(32, L, dtype=torch.long)
+    for b, h in enumerate(hyps):
+        prefix[b, :len(h)] = torch.tensor([bo.BOS] + h[:-1])
+    lens = torch.tensor([len(h) for h in hyps])
+    fed = torch.zeros(32, L, dtype=torch.long)
+    for b, h in enumerate(hyps):
+        fed[b, :len(h)] = torch.tensor(h)
+    live = (torch.arange(L).view(1, -1) < lens.view(-1, 1)).cuda()
+
+    def score(p, xin):
+        enc, _ = orc.encoder(p, xin, in_len, cfg["n_heads"])
+        out, _, _ = orc.decoder(p, prefix.cuda(), lens, in_len, enc, cfg["n_heads"])
+        lp = torch.log_softmax(torch.nn.functional.linear(out, p["tgt_word_proj.weight"]).double(), -1)
+        return (lp.gather(2, fed.cuda().unsqueeze(2)).squeeze(2) * live).sum(1).cpu()
+
+    with torch.no_grad():
+        truth = score({k: v.double().cuda() for k, v in w.items()}, xg.double())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            floor = score({k: v.float().cuda() for k, v in w.items()}, xg.float())
+    err, ferr = got - truth, floor - truth
+    rms = lambda v: float((v * v).mean().sqrt())
+    report = ["# Decode.score_hypotheses at B = 32, T <= 1000, V = 4337, 25..50 fed tokens per utterance, vs the fp64 oracle on the GPU",
+              "scores %.1f .. %.1f   product error: rms %.4f max %.4f   reference under bf16 autocast: rms %.4f max %.4f"
+              % (float(truth.min()), float(truth.max()), rms(err), float(err.abs().max()), rms(ferr), float(ferr.abs().max())),
+              "per utterance (product | bf16 reference): " + " ".join("%+.3f|%+.3f" % (float(a), float(b)) for a, b in zip(err, ferr))]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_decode_score_b32.txt"), "w") as f:
+        f.write("\n".join(report) + "\n")
+    assert float(err.abs().max()) < 0.3, report
+    assert rms(err) <= max(0.08, 2.0 * rms(ferr)), report

@@ -288,26 +288,43 @@ def test_split_backward_graphs_with_reducer_match_single_graph():
         results = []
         # (no reducer) | eager collectives between three graphs | the same over the loader-proof bucket capture | the
         # collectives CAPTURED inside the one step graph (the default: a DP step is one replay)
-        for with_reducer, bucket, in_graph in ((False, None, False), (True, None, False), (True, (160, 20), False), (True, None, True)):
+        # | the in-graph capture FAILING half-way (a collective that cannot be captured): the step must come back as the three-graph one
+        for with_reducer, bucket, in_graph in ((False, None, False), (True, None, False), (True, (160, 20), False), (True, None, True),
+                                               (True, None, "fails")):
             torch.manual_seed(0)
             model = Transformer(cfg).cuda()
             init_parameters(model)
             model.eval()
             opt = ScheduledOptim(model, 128, AttrDict(n_warmup_steps=4000))
             red = dp.GradReducer(arena_of(model), bucket_bytes=64 << 10, force=True) if with_reducer else None
-            step = TrainStep(model, opt, 30, 5.0, reducer=red, use_graph=True, graph_warmup=1, bucket=bucket, dp_in_graph=in_graph)
+            step = TrainStep(model, opt, 30, 5.0, reducer=red, use_graph=True, graph_warmup=1, bucket=bucket, dp_in_graph=bool(in_graph))
+            if in_graph == "fails":
+                real_fire, tripped = red.fire_from, []
+
+                def fire_once(lo, real_fire=real_fire, tripped=tripped):
+                    if torch.cuda.is_current_stream_capturing() and not tripped:
+                        tripped.append(1)
+                        raise RuntimeError("collective not capturable (forced by the test)")
+                    return real_fire(lo)
+                red.fire_from = fire_once
             x, t, gt = inputs.cuda(), targets.cuda(), truth.cuda()
             out = []
             for _ in range(4):
                 loss, gnorm = step(x, in_len, t, tgt_len, gt)
                 out.append((float(loss), float(gnorm)))
+            if in_graph == "fails":
+                assert tripped and step.dp_mode == "split" and step._g_enc is not None and step._cut is None, step.dp_mode
             if with_reducer and not in_graph:
                 assert step.dp_mode == "split" and step._g_enc is not None and 0 < step._dec_lo < arena_of(model).total
                 assert len(red.buckets) > 4
-            if in_graph:
+            if in_graph is True:
                 assert step.dp_mode == "in-graph" and step._g_enc is None and step._g_opt is None, step.dp_mode
             results.append(([l for l, _ in out], [g for _, g in out], arena_of(model).flat.detach().float().cpu().clone()))
-        (l0, g0, p0), (l1, g1, p1), (l2, g2, p2), (l3, g3, p3) = results
+        (l0, g0, p0), (l1, g1, p1), (l2, g2, p2), (l3, g3, p3), (l4, g4, p4) = results
+        # the fallback after a failed in-graph capture IS the three-graph step
+        for a, b in zip(l1 + g1, l4 + g4):
+            assert abs(a - b) <= 1e-3 * abs(a), (l1, l4, g1, g4)
+        assert float((p1 - p4).norm() / p1.norm()) < 5e-3
         # the captured collectives execute the split-graph step's kernels in the same order: same numbers
         assert abs(l1[0] - l3[0]) <= 1e-5 * abs(l1[0]) and abs(g1[0] - g3[0]) <= 1e-4 * g1[0], (l1, l3, g1, g3)
         for a, b in zip(l1, l3):

@@ -106,3 +106,30 @@ def test_cpu_path_checkpoint_loads_on_the_arena_path_and_back(golden_dir):
         assert torch.allclose(a, b, rtol=0, atol=2e-7), n
     opt_cpu.load_state_dict(back)                          # and the arena path's checkpoint goes back into the per-tensor Adam
     assert float(opt_cpu.optimizer.state[list(m_cpu.parameters())[0]]["step"]) == 3.0
+
+
+def test_step_captured_clips_when_torch_adam_does_the_update(golden_dir):
+    """with weight decay (or amsgrad / maximize) the update is torch's own Adam - the clipping of train.py:45 must
+    still happen and the norm must still be returned (it used to fall through to optimizer.step() and return None)."""
+    from transformer.Optim import ScheduledOptim
+    _, w, _ = _load_c1(golden_dir)
+    with emulated_kernels():
+        m = _build(w)
+        opt = ScheduledOptim(m, 128, _cfg())
+        opt.optimizer.param_groups[0]["weight_decay"] = 1e-2
+        opt.update_learning_rate(1)
+        flat = opt._flat_state()[0]          # the flat parameter over the arena; .grad is the arena's gradient buffer
+        g = torch.Generator().manual_seed(3)
+        flat.grad.copy_(torch.randn(flat.shape, generator=g))
+        norm_before = float(flat.grad.norm())
+        assert norm_before > 5.0
+        before = flat.detach().clone()
+        gnorm = opt.step_captured(grad_norm=True, max_norm=5.0)
+        assert gnorm is not None and abs(float(gnorm) - norm_before) < 1e-3 * norm_before
+        assert abs(float(flat.grad.norm()) - 5.0) < 1e-3          # clipped in place
+        assert float((flat.detach() - before).abs().max()) > 0     # and the update ran
+        # below the bound nothing is scaled
+        flat.grad.copy_(torch.randn(flat.shape, generator=g) * 1e-4)
+        small = flat.grad.detach().clone()
+        opt.step_captured(grad_norm=True, max_norm=5.0)
+        assert torch.equal(flat.grad, small)
