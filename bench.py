@@ -517,10 +517,10 @@ def main():
         except Exception as e:  # noqa: BLE001 - the headline line must still be printed
             loader_proof = {"error": "%s: %s" % (type(e).__name__, e)}
 
-    # ---- config 3 (N = 1): its per-GPU shard of the DP = 8 run (the first 4 utterances of the global batch) on one GPU -
-    # what every rank of the specified partition executes between two all-reduces
+    # ---- the per-GPU shard of the DP = 8 run (the first 4 utterances of the global batch) on one GPU - what every rank of the
+    # specified partition executes between two all-reduces: the floor the strong-scaling curve runs into (both configs)
     shard4 = None
-    if world == 1 and args.config == 3:
+    if world == 1 and not args.no_graph and not args.no_decode or world == 1 and args.config == 3:
         try:
             full = synthetic.make_batch(BATCH, T_MAX, L_MAX, CFG["feature_dim"], CFG["vocab_size"], seed=0, t_min=T_MIN, l_min=L_MIN)
             xs, ts, ils, tls, gs = (t[:4] for t in full)

@@ -537,7 +537,8 @@ def test_decode_scoring_at_the_benchmarked_shape_vs_fp64_oracle():
     search switched off (``Decode.score_hypotheses``: the tokens are fed, not chosen, so there is no selection among noisy
     scores): the teacher-forced log-probability of one 25..50-token hypothesis per utterance against the oracle's encoder /
     decoder evaluated in float64 on the GPU, and against the same oracle arithmetic under bf16 autocast as the noise floor.
-    Bound: every score within 0.3 (scores are ~ -300: 1e-3 relative) and the batch rms within 2x the bf16 reference's."""
+    Bound: every score within 0.1 (scores are ~ -300; measured: rms 0.014, max 0.032 - the bf16 reference shows 0.013 / 0.033)
+    and the batch rms within 2x the bf16 reference's."""
     import transformer.Models as M
     import transformer.Utils as U
     from oracle import beam_oracle as bo
@@ -586,5 +587,5 @@ def test_decode_scoring_at_the_benchmarked_shape_vs_fp64_oracle():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_decode_score_b32.txt"), "w") as f:
         f.write("\n".join(report) + "\n")
-    assert float(err.abs().max()) < 0.3, report
+    assert float(err.abs().max()) < 0.1, report
     assert rms(err) <= max(0.08, 2.0 * rms(ferr)), report
