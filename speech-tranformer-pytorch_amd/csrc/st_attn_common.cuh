@@ -308,4 +308,41 @@ __device__ __forceinline__ void keep16(const Drop& dr, int bh, int fixed, int va
 }
 
 
+// two accumulator tiles (lane = row) -> coalesced rows through two wave-private LDS patches: ONE wait for both images
+template <int DK>
+__device__ __forceinline__ void store_rows_2(bf16* pa, bf16* pb, const f32x16* acca, const f32x16* accb, float mula, float mulb,
+                                             bf16* ga, int lda, bf16* gb, int ldb, int row0, int nvalid_rows) {
+  constexpr int ND = DK / 32, CPR = DK / 8;
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 va, vb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        va[e] = (bf16)(acca[d][4 * g + e] * mula);
+        vb[e] = (bf16)(accb[d][4 * g + e] * mulb);
+      }
+      const int col = d * 32 + 8 * g + 4 * hi;
+      const int at = r * DK + (((col >> 3) ^ (r & (CPR - 1))) << 3) + (col & 7);
+      *reinterpret_cast<bf16x4*>(pa + at) = va;
+      *reinterpret_cast<bf16x4*>(pb + at) = vb;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 32 * CPR / 64; ++p) {
+    const int id = p * 64 + l, rr = id / CPR, c = id % CPR;
+    const int at = rr * DK + ((c ^ (rr & (CPR - 1))) << 3);
+    const bf16x8 va = *reinterpret_cast<const bf16x8*>(pa + at);
+    const bf16x8 vb = *reinterpret_cast<const bf16x8*>(pb + at);
+    if (rr < nvalid_rows) {
+      *reinterpret_cast<bf16x8*>(ga + (size_t)(row0 + rr) * lda + c * 8) = va;
+      *reinterpret_cast<bf16x8*>(gb + (size_t)(row0 + rr) * ldb + c * 8) = vb;
+    }
+  }
+}
+
+
 }  // namespace
