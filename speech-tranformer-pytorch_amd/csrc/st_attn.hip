@@ -43,7 +43,7 @@ extern "C" void st_attn_xs_f1_args(void* out, const void* A, int lda, const void
 extern "C" int st_attn_xs_f1_args_size();
 extern "C" int st_attn_xs_tile_rows();
 // st_attn_bwd64.hip: the hand-scheduled backward for long non-causal problems with 64-wide heads
-extern "C" int st_attn_bwd64_launch(hipStream_t stream, const void* a, const void* ak, int n_q, int n_k);
+extern "C" int st_attn_bwd64_launch(hipStream_t stream, const void* a, const void* ak, int n_q, int n_k, int drop);
 
 namespace {
 
@@ -554,9 +554,10 @@ bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
 // ... and the hand-scheduled backward of st_attn_bwd64.hip (no dropout, delta supplied by the producer of dO).  ST_ATTN_BWD64=0
 // (read at every call: a development switch for same-process A/B runs) keeps the general kernels
 bool bwd_long64(int d_k, int max_q, int max_k, int causal, bool drop) {
-  if (!(d_k == 64 && !causal && !drop && max_q > 128 && max_k > 128 && attn_impl() != 1)) return false;
-  const char* e = getenv("ST_ATTN_BWD64");
-  return !(e && e[0] == '0');
+  if (!(d_k == 64 && !causal && max_q > 128 && max_k > 128 && attn_impl() != 1)) return false;
+  const char* e = getenv("ST_ATTN_BWD64");      // "0": the general kernels; "e": the streams in eval mode only (no dropout variant)
+  if (e && e[0] == '0') return false;
+  return !(drop && e && e[0] == 'e');
 }
 
 // few queries against many keys with 64-wide heads (the decoder-encoder attention) take the forward of st_attn_xs.hip
@@ -703,7 +704,7 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
     AttnArgs ak = a;
     const int nq = run_q ? plan(a, work_q, n_work_q, B, H, max_q) : 0, nk = run_k ? plan(ak, work_k, n_work_k, B, H, max_k) : 0;
     if (const char* tp = getenv("ST_ATTN_TRACE_PTR")) a.Ores = (bf16*)strtoull(tp, nullptr, 0);      // development: per-workgroup clock stamps
-    return st_attn_bwd64_launch(stream, &a, &ak, nq, nk);
+    return st_attn_bwd64_launch(stream, &a, &ak, nq, nk, drop ? 1 : 0);
   }
   if (run_q && run_k && O == nullptr) {
     // delta was produced together with dO (st_gemm, ST_EPI_BF16_DELTA): the two kernels are independent -> one launch

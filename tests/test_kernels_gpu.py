@@ -629,6 +629,49 @@ def test_attention_backward_single_launch(case):
             assert torch.equal(a, b), "single-launch backward changed %s" % nm
 
 
+@pytest.mark.parametrize("lens,p", [([200, 131], 0.1), ([129, 130, 257], 0.1), ([1000, 640], 0.1), ([65, 63, 64, 128, 192], 0.1),
+                                    ([300, 257], 0.5), ([520, 191, 333], 0.25)])
+def test_attention_backward_streams_with_dropout(lens, p, monkeypatch):
+    """Training mode (Attention.py:89): the dropout variant of the hand-scheduled backward streams (csrc/st_attn_bwd64.hip,
+    *_drop.inc) regenerates the forward's keep decisions inside the instruction stream (SDWA byte compares on the lowbias32
+    words of st_attn_common.cuh keep16, one DPP exchange per 2 x 2 block pair).  Against the general kernels with the SAME
+    Drop (ST_ATTN_BWD64=e keeps the streams for eval mode only): a single wrong keep decision is an O(1 / sqrt(n)) error, the
+    two agree to the bf16 rounding of the pre-scaled operand (measured 2.8e-3)."""
+    from st_amd.functional import Rows, attn_work
+    H, dk = 4, 64
+    d, scale = H * dk, 1 / math.sqrt(dk)
+    lens_t = torch.tensor(lens)
+    M = int(lens_t.sum())
+    qkv, dO = cu(g(M, 3 * d, seed=5, scale=0.7)), cu(g(M, d, seed=6, scale=0.5))
+    Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    rows = Rows.packed(lens_t, "cuda")
+    wf, wq, wk = attn_work(rows, rows, False, dk, H)
+    off = torch.zeros_like(lens_t)
+    off[1:] = torch.cumsum(lens_t, 0)[:-1]
+    q_off, q_len = off.to("cuda", torch.int32), lens_t.to("cuda", torch.int32)
+    drop = nv.Drop(torch.tensor([4321], dtype=torch.int32, device="cuda"), 55, p)
+    O = torch.empty(M, d, dtype=BF16, device="cuda")
+    lse = torch.empty(H * M, dtype=F32, device="cuda")
+    nv.attn_fwd(Q, K, V, O, lse, q_off, q_len, q_off, q_len, H, max(lens), False, scale, work=wf, max_k=max(lens), drop=drop)
+    delta = (dO.float() * O.float()).view(M, H, dk).sum(-1).t().contiguous().view(-1)
+    outs = {}
+    for mode in ("e", "1"):
+        monkeypatch.setenv("ST_ATTN_BWD64", mode)
+        got = [torch.full((M, d), float("nan"), dtype=BF16, device="cuda") for _ in range(3)]
+        nv.attn_bwd(Q, K, V, None, dO, lse, delta, *got, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False, scale,
+                    work_q=wq, work_k=wk, drop=drop)
+        torch.cuda.synchronize()
+        outs[mode] = got
+    for a, b, nm in zip(outs["e"], outs["1"], ("dQ", "dK", "dV")):
+        assert torch.isfinite(b.float()).all(), nm
+        check(b, a, 6e-3, "backward streams with dropout p = %s: %s" % (p, nm))
+    # and the masks matter: without them the result is far away (guards against a variant that silently ignores the Drop)
+    monkeypatch.setenv("ST_ATTN_BWD64", "1")
+    plain = [torch.zeros(M, d, dtype=BF16, device="cuda") for _ in range(3)]
+    nv.attn_bwd(Q, K, V, None, dO, lse, delta, *plain, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False, scale, work_q=wq, work_k=wk)
+    assert float((plain[2].float() - outs["1"][2].float()).norm() / outs["1"][2].float().norm()) > 0.1
+
+
 @pytest.mark.parametrize("M,N,K,with_aux,p", [(300, 128, 128, True, 0), (1000, 256, 1024, True, 0), (130, 256, 768, False, 0),
                                                (70, 512, 512, True, 0), (999, 256, 256, True, 0),
                                                (999, 256, 768, True, 0.1), (130, 128, 256, True, 0.3), (200, 512, 512, False, 0.2),

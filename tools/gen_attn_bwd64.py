@@ -57,6 +57,10 @@ T0, T1, T2, T3 = 252, 253, 254, 255
 # scalar scratch (declared clobbered)
 S_SRD0, S_SRD1, S_SRD2 = 36, 40, 44
 S_CNT, S_STEP0, S_STEP1, S_T0, S_T1 = 48, 49, 50, 51, 52
+# dropout variants only: hash key, keep threshold, the two multipliers of lowbias32, the odd-lane mask (pair), statistic transform
+S_KEY, S_THR, S_C1, S_C2, S_NT, S_PAR = 53, 54, 55, 56, 57, 58
+DR_CTR, DR_W, DR_T = 224, 225, 233      # lane counter; 8 hash words; two temporaries (v224..v234 of the free v224..v240)
+DR_ND = 236                             # dK/dV body: four -delta/k values of the register group in work (v236..v239)
 
 
 def v(base, n=1):
@@ -227,12 +231,16 @@ class Emit:
         self.t += 1
         self.stats["mfma"] += 1
 
-    def valu(self, op, d, srcs, trans=False, dn=1, extra_reads=()):
-        """generic VALU: `op d, srcs...`; srcs are registers (int), operand strings or literal text (prefixed '=')"""
+    def valu(self, op, d, srcs, trans=False, dn=1, extra_reads=(), sdwa=False, dpp=False):
+        """generic VALU: `op d, srcs...`; srcs are registers (int), operand strings or literal text (prefixed '='; a literal
+        that starts with a blank is a modifier suffix, appended without a comma)"""
         rr = []
         txt = []
+        suffix = ""
         for s in srcs:
-            if isinstance(s, str) and s.startswith("="):
+            if isinstance(s, str) and s.startswith("= "):
+                suffix += s[1:]
+            elif isinstance(s, str) and s.startswith("="):
                 txt.append(s[1:])
             else:
                 rr += regs_of(s)
@@ -241,10 +249,17 @@ class Emit:
         rd = regs_of(d, dn) if d is not None else []
         self._wait_regs(rr + rd)
         self._hazard_read(rr, by_mfma=False)
+        if sdwa or dpp:      # VALU write -> DPP / SDWA read of the same register: 2 wait states
+            need = 0
+            for r in rr:
+                if r in self.valu_w:
+                    need = max(need, 2 - (self.t - self.valu_w[r][0] - 1))
+            if need > 0:
+                self._nop(need)
         for r in rd:      # WAW behind an MFMA
             if r in self.mfma_w and self.t - self.mfma_w[r] - 1 < self.MFMA_TO_VALU:
                 self._nop(self.MFMA_TO_VALU - (self.t - self.mfma_w[r] - 1))
-        self.lines.append("%s %s" % (op, ", ".join(([v(d, dn)] if d is not None else []) + txt)))
+        self.lines.append("%s %s%s" % (op, ", ".join(([v(d, dn)] if d is not None else []) + txt), suffix))
         for r in rd:
             self.valu_w[r] = (self.t, trans)
             self.mfma_w.pop(r, None)
@@ -443,6 +458,61 @@ class Body:
         self.gidx = g0 + sum(1 for m in mfs if m.a is None)
         return deferred
 
+    # ---- dropout (training mode): the keep decisions of one 32 x 32 block, as csrc/st_attn_common.cuh keep16 makes them -------
+    # One lowbias32 hash of the 2 x 2 block counter yields four keep bytes.  A lane's 16 elements lie in 8 such blocks, each shared
+    # with the neighbouring lane (its fixed index differs in bit 0): the lane hashes four counters (register groups g = 2 par,
+    # 2 par + 1) and takes the other four from lane ^ 1 with a DPP move.  DR_W[0..3] end up as the words of groups 0 / 1
+    # (index (g & 1) * 2 + hb), DR_W[4..7] as those of groups 2 / 3, pre-shifted so that the element's byte is BYTE_0 (e = 0)
+    # or BYTE_<DR_E1> (e = 1) whatever the lane's parity.  DR_CTR = the lane's counter of (register group 2 par, hb 0) of the
+    # current block; it advances by DR_STEP per block.
+    def drop_words(self, L):
+        e = self.e
+        W, T = DR_W, DR_T
+        for j, cj in enumerate(self.DR_CJ):                                  # counters -> hashes (own[j])
+            L.append(lambda j=j, cj=cj: e.valu("v_add_u32", W + j, ["=0x%x" % cj, DR_CTR]))
+            L.append(lambda j=j: e.valu("v_xor_b32", W + j, ["=s%d" % S_KEY, W + j]))
+        for j in range(4):
+            L.append(lambda j=j: e.valu("v_xor_b32_sdwa", W + j, [W + j, W + j, "= dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"], sdwa=True))
+        for j in range(4):
+            L.append(lambda j=j: e.valu("v_mul_lo_u32", W + j, [W + j, "=s%d" % S_C1]))
+        for j in range(4):
+            L.append(lambda j=j: e.valu("v_lshrrev_b32", T, ["=15", W + j]))
+            L.append(lambda j=j: e.valu("v_xor_b32", W + j, [T, W + j]))
+        for j in range(4):
+            L.append(lambda j=j: e.valu("v_mul_lo_u32", W + j, [W + j, "=s%d" % S_C2]))
+        for j in range(4):
+            L.append(lambda j=j: e.valu("v_xor_b32_sdwa", W + j, [W + j, W + j, "= dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"], sdwa=True))
+        for j in range(4):                                                    # nb[j] = own[j] of lane ^ 1
+            L.append(lambda j=j: e.valu("v_mov_b32_dpp", W + 4 + j, [W + j, "= quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"], dpp=True))
+        sh = self.DR_PRESHIFT
+        for j in range(4):
+            # groups 0 / 1: even lanes own them (own[j]), odd lanes got them from the neighbour and read them shifted;
+            # groups 2 / 3: odd lanes own them and read them shifted, even lanes got them from the neighbour
+            L.append(lambda j=j: e.valu("v_lshrrev_b32", T, ["=%d" % sh, W + 4 + j]))
+            L.append(lambda j=j: e.valu("v_lshrrev_b32", T + 1, ["=%d" % sh, W + j]))
+            L.append(lambda j=j: e.valu("v_cndmask_b32_e64", W + j, [W + j, T, "=s[%d:%d]" % (S_PAR, S_PAR + 1)]))
+            L.append(lambda j=j: e.valu("v_cndmask_b32_e64", W + 4 + j, [W + 4 + j, T + 1, "=s[%d:%d]" % (S_PAR, S_PAR + 1)]))
+        L.append(lambda: e.valu("v_add_u32", DR_CTR, ["=0x%x" % self.DR_STEP, DR_CTR]))
+
+    def drop_keep(self, L, r):
+        """vcc = keep decision of accumulator register r (r = 4 g + 2 hb + e)"""
+        e = self.e
+        g, hb, el = r >> 2, (r >> 1) & 1, r & 1
+        w = DR_W + (4 if g >= 2 else 0) + (g & 1) * 2 + hb
+        sel = "BYTE_0" if el == 0 else "BYTE_%d" % self.DR_E1
+        L.append(lambda: e.valu("v_cmp_ge_u32_sdwa", None, ["=vcc", w, "=s%d src0_sel:%s src1_sel:DWORD" % (S_THR, sel)], sdwa=True))
+
+    def drop_setup(self, key_op, lane_base_op, packed_nt_op):
+        """scalar constants of the hash; the lane's counter base; thresh rides in the tile-count operand's upper half"""
+        e = self.e
+        e.salu("s_mov_b32 s%d, %s" % (S_KEY, key_op))
+        e.salu("s_lshr_b32 s%d, %s, 16" % (S_THR, packed_nt_op))
+        e.salu("s_mov_b32 s%d, 0x7feb352d" % S_C1)
+        e.salu("s_mov_b32 s%d, 0x846ca68b" % S_C2)
+        e.salu("s_mov_b32 s%d, 0xaaaaaaaa" % S_PAR)
+        e.salu("s_mov_b32 s%d, 0xaaaaaaaa" % (S_PAR + 1))
+        e.valu("v_mov_b32", DR_CTR, [lane_base_op])
+
     def muls(self, L, S, D, i):
         """dS = P * dP' for the register pair (2i, 2i + 1)"""
         e = self.e
@@ -539,6 +609,12 @@ class DKV(Body):
     G = ["%4", "%5", "%6", "%7"]
     GST = "%8"
     TID = "%17"
+    DROP = False
+    # dropout variant (class DKVDrop): %24 = tiles | thresh << 16, %26 = hash key (s), %27 = the lane's counter base
+    # ((8 (lane & 1) + 2 hi) << 15) + (key >> 1) + (b H + h) * 0x85ebca6b (v), %28 / %29 = multiplier / addend that turn this wave's
+    # raw statistic into the accumulator start value (s): (-1, log2 keep-scale) for the lse waves, (-1 / keep-scale, 0) for the
+    # delta waves
+    DR_CJ, DR_STEP, DR_PRESHIFT, DR_E1 = [0, 1 << 15, 4 << 15, 5 << 15], 1 << 19, 8, 2
 
     def m2(self, buf, blk, Y):
         out = []
@@ -557,10 +633,31 @@ class DKV(Body):
                               tag="S" if mat == 0 else "dP"))
         return out
 
-    def vlist(self, X):
+    def vlist(self, X, stat=None):
+        """stat = (buffer, block) of the statistics the step's scores used (dropout variant: the -delta / k values are read again
+        for the dropped pairs, four at a time)"""
         e = self.e
         S, D = X, X + 16
         L = [(lambda r=r: e.valu("v_exp_f32", S + r, [S + r], trans=True)) for r in range(16)]
+        if self.DROP:
+            # P k = exp2(.) (the keep-scale k rides in the accumulator start value), dS = P k (M ? dP - delta / k : -delta / k),
+            # and dV takes M ? P k : 0
+            H = []
+            self.drop_words(H)
+            L = H + L
+            nd = stat_reads(stat[0], stat[1], 1, DR_ND)
+            for g in range(4):
+                op, dst, n, addr, off = nd[g]
+                L.append(lambda op=op, n=n, addr=addr, off=off: e.ds_read(op, DR_ND, n, addr, off))
+                for r in range(4 * g, 4 * g + 4):
+                    self.drop_keep(L, r)
+                    L.append(lambda r=r: e.valu("v_cndmask_b32", D + r, [DR_ND + (r & 3), D + r, "=vcc"]))
+                    L.append(lambda r=r: e.valu("v_mul_f32", D + r, [S + r, D + r]))
+                    L.append(lambda r=r: e.valu("v_cndmask_b32", S + r, ["=0", S + r, "=vcc"]))
+                for i in (2 * g, 2 * g + 1):
+                    L.append(lambda i=i: e.valu("v_cvt_pk_bf16_f32", S + i, [S + 2 * i, S + 2 * i + 1]))
+                    L.append(lambda i=i: e.valu("v_cvt_pk_bf16_f32", D + i, [D + 2 * i, D + 2 * i + 1]))
+            return L
         for i in range(8):
             self.muls(L, S, D, i)
             L.append(lambda i=i: e.valu("v_cvt_pk_bf16_f32", S + i, [S + 2 * i, S + 2 * i + 1]))
@@ -579,7 +676,9 @@ class DKV(Body):
     def writes(self, buf):
         e = self.e
         G, GST = self.G, self.GST
-        return [lambda: e.valu("v_xor_b32", GST, ["=0x80000000", GST]),
+        neg = ([lambda: e.valu("v_mul_f32", GST, ["=%28", GST]), lambda: e.valu("v_add_f32", GST, ["=%29", GST])] if self.DROP
+               else [lambda: e.valu("v_xor_b32", GST, ["=0x80000000", GST])])
+        return neg + [
                 lambda: e.ds_write("ds_write_b128", W_T, G[0], 4, buf * BUF),
                 lambda: e.ds_write("ds_write_b128", W_T, G[1], 4, buf * BUF + 32 * STR),
                 lambda: e.ds_write("ds_write_b128", W_T, G[2], 4, buf * BUF + MAT),
@@ -597,7 +696,12 @@ class DKV(Body):
         e.salu("s_mov_b32 s%d, 0x00020000" % (S_SRD2 + 3))
         e.salu("s_lshl_b32 s%d, %%21, 6" % S_STEP0)                          # bytes per 64-row tile
         e.salu("s_lshl_b32 s%d, %%22, 6" % S_STEP1)
-        e.salu("s_sub_u32 s%d, %%24, 1" % S_CNT)                             # tiles after the current one
+        nt = "%24"
+        if self.DROP:
+            self.drop_setup("%26", "%27", "%24")
+            e.salu("s_and_b32 s%d, %%24, 0xffff" % S_NT)
+            nt = "s%d" % S_NT
+        e.salu("s_sub_u32 s%d, %s, 1" % (S_CNT, nt))                          # tiles after the current one
         for f in self.loads()[5:]:                                            # tile 0 is in the staging registers: on to tile 1
             f()
         self.lane_addresses("%21", "%22", "%25")
@@ -626,7 +730,7 @@ class DKV(Body):
         self.prime(m10)
         self.run(m10, m11, [])
         self.inits_now(m11)
-        self.run(m11, self.m2(0, 0, A), self.vlist(A), extras=self.spread(self.writes(1)))
+        self.run(m11, self.m2(0, 0, A), self.vlist(A, (0, 0)), extras=self.spread(self.writes(1)))
         e.wait_lds_writes()
         e.barrier()
         e.salu("s_cmp_eq_u32 s%d, 0" % S_CNT)
@@ -637,12 +741,12 @@ class DKV(Body):
             q = (p + 1) % 3
             # odd step of tile t (t % 3 == p): X = B, Y = A.  M2(2t): buffer p block 0; M1(2t + 2): buffer q block 0
             self.enter("ODD%d" % p)
-            self.run(self.m2(p, 0, A) + self.m1(q, 0, A), self.m2(p, 1, B), self.vlist(B), extras=self.spread(self.loads()))
+            self.run(self.m2(p, 0, A) + self.m1(q, 0, A), self.m2(p, 1, B), self.vlist(B, (p, 1)), extras=self.spread(self.loads()))
             e.salu("s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT))
             self.leave("EVEN%d" % q)
             # even step of tile t + 1 (buffer q): X = A, Y = B.  M2(2t + 1): buffer p block 1; M1(2t + 3): buffer q block 1
             self.enter("EVEN%d" % q)
-            self.run(self.m2(p, 1, B) + self.m1(q, 1, B), self.m2(q, 0, A), self.vlist(A), extras=self.spread(self.writes((q + 1) % 3)))
+            self.run(self.m2(p, 1, B) + self.m1(q, 1, B), self.m2(q, 0, A), self.vlist(A, (q, 0)), extras=self.spread(self.writes((q + 1) % 3)))
             e.wait_lds_writes()
             e.barrier()
             e.salu("s_cmp_eq_u32 s%d, 0" % S_CNT)
@@ -654,7 +758,7 @@ class DKV(Body):
         for p in range(3):             # the last tile's odd step (no M1) and the final M2
             self.enter("LASTODD%d" % p)
             nxt = self.m2(p, 1, B)
-            self.run(self.m2(p, 0, A), nxt, self.vlist(B))
+            self.run(self.m2(p, 0, A), nxt, self.vlist(B, (p, 1)))
             self.run(nxt, [], [])
             self.leave("END")
             if p < 2:
@@ -673,6 +777,12 @@ class DKV(Body):
 class DQ(Body):
     G = ["%2", "%3", "%4", "%5"]
     TID = "%16"
+    DROP = False
+    NT = "%22"
+    # dropout variant (class DQDrop): %22 = tiles | thresh << 16, %24 = hash key (s), %25 = the lane's counter base
+    # ((q >> 1) << 15) + 8 (lane & 1) + 2 hi + (b H + h) * 0x85ebca6b (v), %26 = -delta / keep-scale of the lane's query (v);
+    # %14 then holds -lse + log2(keep-scale), %15 = -delta / keep-scale (the C++ prologue folds the scale in)
+    DR_CJ, DR_STEP, DR_PRESHIFT, DR_E1 = [0, 1, 4, 5], 16, 16, 1
 
     def m2(self, buf, blk, Y):
         return [Mf("%%%d" % d, Y + 16 + 4 * hf, "%%%d" % d, tr_reads(buf, 0, blk, hf, d), tag="dQ") for hf in range(2) for d in range(2)]
@@ -695,6 +805,19 @@ class DQ(Body):
                 row = 32 * mask_blk + (r & 3) + 8 * (r >> 2)
                 L.append(lambda row=row: e.valu("v_cmp_lt_i32", None, ["=vcc", "=%d" % row, V_M]))
                 L.append(lambda r=r: e.valu("v_cndmask_b32", S + r, ["=0", S + r, "=vcc"]))
+        if self.DROP:
+            # dS = P k (M ? dP - delta / k : -delta / k): the exponential already carries the keep-scale k (folded into -lse),
+            # the gradient accumulator started at -delta / k; a dropped pair keeps that start value
+            H = []
+            self.drop_words(H)
+            L = H + L          # the hashes need no matrix result: first
+            for i in range(8):
+                for r in (2 * i, 2 * i + 1):
+                    self.drop_keep(L, r)
+                    L.append(lambda r=r: e.valu("v_cndmask_b32", D + r, ["=%26", D + r, "=vcc"]))
+                self.muls(L, S, D, i)
+                L.append(lambda i=i: e.valu("v_cvt_pk_bf16_f32", D + i, [D + 2 * i, D + 2 * i + 1]))
+            return L
         for i in range(8):
             self.muls(L, S, D, i)
             L.append(lambda i=i: e.valu("v_cvt_pk_bf16_f32", D + i, [D + 2 * i, D + 2 * i + 1]))
@@ -723,7 +846,12 @@ class DQ(Body):
         self.descriptor(S_SRD1, "%18", "%20", "%21")
         e.salu("s_lshl_b32 s%d, %%19, 6" % S_STEP0)
         e.salu("s_lshl_b32 s%d, %%20, 6" % S_STEP1)
-        e.salu("s_sub_u32 s%d, %%22, 1" % S_CNT)
+        nt = self.NT
+        if self.DROP:
+            self.drop_setup("%24", "%25", "%22")
+            e.salu("s_and_b32 s%d, %%22, 0xffff" % S_NT)
+            nt = "s%d" % S_NT
+        e.salu("s_sub_u32 s%d, %s, 1" % (S_CNT, nt))
         e.salu("s_lshl_b32 s%d, s%d, 6" % (S_T1, S_CNT))                     # first key of the last tile
         e.salu("s_sub_u32 s%d, %%21, s%d" % (S_T1, S_T1))                    # keys of the last tile that exist
         for f in self.loads()[4:]:                                            # tile 0 is in the staging registers: on to tile 1
@@ -811,6 +939,14 @@ class DQ(Body):
 # matrix rate the chip sustains at the 1.5-1.7 GHz it clocks to under this load, and what is left of the launch is per-item
 # prologue / epilogue and the granularity of 816 items on 512 or 768 slots - nothing an instruction order fixes.  Not kept.)
 
+class DQDrop(DQ):
+    DROP = True
+
+
+class DKVDrop(DKV):
+    DROP = True
+
+
 def generate(cls):
     joins = None
     text = None
@@ -828,7 +964,7 @@ def generate(cls):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     csrc = os.path.join(os.path.dirname(here), "speech-tranformer-pytorch_amd", "csrc")
-    for name, cls in (("dkv", DKV), ("dq", DQ)):
+    for name, cls in (("dkv", DKV), ("dq", DQ), ("dkv_drop", DKVDrop), ("dq_drop", DQDrop)):
         e = generate(cls)
         head = ("// GENERATED by tools/gen_attn_bwd64.py - do not edit.  Instruction stream of the %s body of csrc/st_attn_bwd64.hip\n"
                 "// (in the text: %d MFMA, %d VALU, %d LDS, %d VMEM, %d SALU, %d waits, %d hazard wait states)\n"
@@ -838,14 +974,15 @@ def main():
         with open(path, "w") as f:
             f.write(head + e.text())
         print(path, e.stats, "lines", len(e.lines))
-    # the registers the streams own (clobber list of the asm statements)
-    with open(os.path.join(csrc, "st_attn_bwd64_clobbers.inc"), "w") as f:
-        f.write("// GENERATED by tools/gen_attn_bwd64.py - do not edit.  Registers the hand-scheduled streams use as scratch.\n")
-        f.write('"memory", "scc", "vcc",\n')
-        f.write(", ".join('"s%d"' % r for r in range(36, 53)) + ",\n")
-        regs = ['"v%d"' % r for r in range(128, 256)]
-        for i in range(0, len(regs), 16):
-            f.write(", ".join(regs[i:i + 16]) + ("," if i + 16 < len(regs) else "") + "\n")
+    # the registers the streams own (clobber lists of the asm statements; the dropout variants own seven more scalar registers)
+    for fname, s_hi in (("st_attn_bwd64_clobbers.inc", 53), ("st_attn_bwd64_clobbers_drop.inc", 60)):
+        with open(os.path.join(csrc, fname), "w") as f:
+            f.write("// GENERATED by tools/gen_attn_bwd64.py - do not edit.  Registers the hand-scheduled streams use as scratch.\n")
+            f.write('"memory", "scc", "vcc",\n')
+            f.write(", ".join('"s%d"' % r for r in range(36, s_hi)) + ",\n")
+            regs = ['"v%d"' % r for r in range(128, 256)]
+            for i in range(0, len(regs), 16):
+                f.write(", ".join(regs[i:i + 16]) + ("," if i + 16 < len(regs) else "") + "\n")
 
 
 if __name__ == "__main__":
