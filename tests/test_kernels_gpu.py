@@ -1345,3 +1345,42 @@ def test_decode_self_attention_matches_reference(t, lineage):
     check(out_g, out_e, 1e-2, "decode self-attention t=%d" % t)
     assert torch.equal(cg.cpu()[:, t], qkv[:, d:]) and torch.equal(cg.cpu()[:, t + 1:], cache[:, t + 1:]) and \
         torch.equal(cg.cpu()[:, :t], cache[:, :t])
+
+
+@pytest.mark.parametrize("V,lens,C", [(23, [30, 17, 25], 8), (4337, [300, 211], 41), (1000, [64, 1, 33, 128], 12)])
+def test_ctc_gather_and_dlogits_kernels(V, lens, C):
+    """st_ctc_gather / st_ctc_dlogits (BASELINE config 4's CTC branch around torch's ctc_loss) against their emulation: the
+    row log-sum-exp, the gathered log-probabilities of the columns the loss reads, and the dense bf16 logits gradient with
+    the scattered label columns (duplicates and -1 entries in the scatter list, rows of a padded layout that belong to no
+    utterance)."""
+    from st_amd.functional import Rows
+    gen = torch.Generator().manual_seed(V)
+    lens_t = torch.tensor(lens)
+    B, T, R = len(lens), int(max(lens)), int(sum(lens))
+    v_pad = (V + 1 + 7) // 8 * 8
+    logits = torch.randn(R, v_pad, generator=gen) * 3
+    logits[:, V:] = -1e30
+    cols = torch.randint(0, V, (B, C), generator=gen, dtype=torch.int32)
+    cols[:, 0] = 0
+    cols[0, 3] = cols[0, 1]                                   # a duplicate column: only its first occurrence scatters
+    scat = cols.clone()
+    scat[0, 3] = -1
+    scat[:, C - 1] = -1                                       # a padded target position
+    rowmap = Rows.packed(lens_t, "cpu").scatter_index(T)
+    roww = torch.rand(B, generator=gen) * 0.1
+    gsmall = torch.randn(B, T, C, generator=gen) * 0.05
+    gout = torch.tensor([0.7])
+    outs = []
+    for dev, mod in (("cpu", em), ("cuda", nv)):
+        mv = lambda t: t.to(dev)
+        lse = torch.zeros(R, dtype=F32, device=dev)
+        lp = torch.zeros(B, T, C, dtype=F32, device=dev)
+        mod.ctc_gather(mv(logits), mv(rowmap), T, mv(cols), lse, lp, V=V)
+        dl = torch.full((R, v_pad), 7.0, dtype=BF16, device=dev)
+        mod.ctc_dlogits(mv(logits), lse, mv(rowmap), T, mv(roww), mv(scat), mv(gsmall), mv(gout), dl, V=V)
+        outs.append((lse.cpu(), lp.cpu(), dl.float().cpu()))
+    (l0, p0, d0), (l1, p1, d1) = outs
+    assert torch.allclose(l0, l1, rtol=0, atol=2e-5), float((l0 - l1).abs().max())
+    assert torch.allclose(p0, p1, rtol=0, atol=3e-5), float((p0 - p1).abs().max())
+    assert float((d0[:, :V] - d1[:, :V]).abs().max()) <= 1e-2 * float(d0[:, :V].abs().max()) + 1e-6
+    assert float(d1[:, V:].abs().max()) == 0.0                # the padding columns carry no gradient

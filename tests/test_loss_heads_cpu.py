@@ -59,3 +59,70 @@ def test_joint_ctc_attention_head():
     assert torch.isfinite(loss) and abs(loss.item() - (0.3 * ctc.item() + 0.7 * att.item())) < 1e-5
     loss.backward()
     assert enc.grad.abs().sum() > 0 and dec.grad.abs().sum() > 0 and head.ctc_proj.weight.grad.abs().sum() > 0
+
+
+def test_ctc_head_over_ragged_rows_small_alphabet_vs_dense_reference():
+    """The config-4 fast path (CTCAttentionLoss.plan / project_rows / ctc_rows, functional.CtcPlan / CtcProjFn: the projection
+    over the ragged encoder rows, ctc_loss on a per-utterance alphabet of blank + own labels, the dense logits gradient rebuilt
+    from the small one) under the kernel emulation, against the module's own dense form (Loss.py forward: [T, B, V] log-softmax +
+    ctc_loss): value, and the gradients with respect to the encoder rows and the projection's weight / bias.  The batch holds
+    what the class mapping has to get right: repeated labels, adjacent repeats, a label equal to the blank id inside a target,
+    padded target positions, and an utterance whose frames cannot spell its labels (zero_infinity drops it)."""
+    import torch.nn.functional as func
+    from tests._emul import emulated_kernels
+    from st_amd import functional as F_
+    torch.manual_seed(0)
+    d, V, blank = 32, 23, 0
+    in_len = torch.tensor([30, 17, 25, 6, 22])
+    tgt_len = torch.tensor([7, 5, 9, 6, 4])
+    L = int(tgt_len.max())
+    tgt = torch.tensor([[3, 5, 5, 9, 3, 0, 11, 0, 0],          # adjacent repeat, a repeat further on, the blank id as a label
+                        [8, 8, 8, 2, 1, 0, 0, 0, 0],           # a run of three
+                        [4, 7, 4, 7, 4, 7, 22, 1, 1],          # alternation; the last two equal
+                        [1, 2, 3, 4, 5, 6, 0, 0, 0],           # 6 labels on 6 frames: feasible, no slack
+                        [9, 9, 9, 9, 0, 0, 0, 0, 0]])          # 4 equal labels need 7 frames of 22: fine
+    tgt_len[3] = 6
+    in_len[3] = 6
+    tgt2 = tgt.clone()
+    tgt2[1, :5] = torch.tensor([8, 8, 8, 8, 8])                 # ... and 5 equal labels need 9 frames of 17: fine; make one infeasible:
+    in_len2 = in_len.clone()
+    in_len2[1] = 8                                              # 5 equal labels on 8 frames: infinite loss
+    for targets, ilen in ((tgt, in_len), (tgt2, in_len2)):
+        R = int(ilen.sum())
+        enc0 = (torch.randn(R, d) * 0.7).to(torch.bfloat16)
+        with emulated_kernels():
+            head = CTCAttentionLoss(d, V, ctc_weight=0.3, blank=blank)
+            rows = F_.Rows.packed(ilen, "cpu")
+            plan = head.plan(targets, tgt_len, ilen, rows)
+            head.zero_grad_buffers()
+            enc = enc0.clone().requires_grad_(True)
+            lp = head.project_rows(enc, plan)
+            ctc, g = head.ctc_rows(lp, plan)
+            # what JointTrainStep does with the small gradient: stage it, weight the softmax term per utterance
+            plan.g_lp.copy_(g)
+            torch.mul(plan.finite.to(plan.roww.dtype), 1.0 / plan.B, out=plan.roww)
+            plan.roww.div_(plan.tl.to(plan.roww.dtype))
+            torch.autograd.backward([lp], [plan.g_lp])
+            got = (float(ctc), enc.grad.float().clone(), head.ctc_proj.weight.grad.clone(), head.ctc_proj.bias.grad.clone())
+        # dense reference on the same bf16-rounded operands (padded [B, T, d] layout, fp32)
+        W = head.ctc_proj.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+        b = head.ctc_proj.bias.detach().clone().requires_grad_(True)
+        x = enc0.float().requires_grad_(True)
+        T = int(ilen.max())
+        pad = torch.zeros(len(ilen), T, d)
+        off = 0
+        segs = []
+        for i, n in enumerate(ilen.tolist()):
+            segs.append((i, off, n))
+            off += n
+        xp = torch.stack([torch.cat([x[o:o + n], torch.zeros(T - n, d)]) for _, o, n in segs])
+        logp = func.log_softmax(func.linear(xp, W, b), dim=-1).transpose(0, 1)
+        want = func.ctc_loss(logp, targets, ilen, tgt_len, blank=blank, reduction='mean', zero_infinity=True)
+        want.backward()
+        assert abs(got[0] - want.item()) <= 2e-3 * max(1.0, abs(want.item())), (got[0], want.item())
+        for name, a_, r_ in (("d enc", got[1], x.grad), ("dW", got[2], W.grad), ("db", got[3], b.grad)):
+            err = float((a_ - r_).norm() / r_.norm().clamp_min(1e-12))
+            assert err < 2e-2, (name, err)         # bf16 logits gradient (the kernels' dl is bf16)
+        if ilen is in_len2:                         # the infeasible utterance contributes nothing, to the value or to any gradient
+            o, n = segs[1][1], segs[1][2]
+            assert float(got[1][o:o + n].abs().max()) == 0.0
