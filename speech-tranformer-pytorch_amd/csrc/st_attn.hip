@@ -547,8 +547,12 @@ int attn_impl() {
 }
 
 // long non-causal problems with 64-wide heads take the plain-exponential forward of st_attn64.hip
+bool env_off(const char* name) {      // development switches read at every call (same-process A/B runs): NAME=0 turns a path off
+  const char* e = getenv(name);
+  return e && e[0] == '0';
+}
 bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
-  return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1;
+  return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1 && !env_off("ST_ATTN_FWD64");
 }
 
 // ... and the hand-scheduled backward of st_attn_bwd64.hip (no dropout, delta supplied by the producer of dO).  ST_ATTN_BWD64=0
@@ -561,7 +565,9 @@ bool bwd_long64(int d_k, int max_q, int max_k, int causal, bool drop) {
 }
 
 // few queries against many keys with 64-wide heads (the decoder-encoder attention) take the forward of st_attn_xs.hip
-bool fwd_xs(int d_k, int max_q, int max_k, int causal) { return d_k == 64 && key_split(max_q, max_k, causal) && attn_impl() != 1; }
+bool fwd_xs(int d_k, int max_q, int max_k, int causal) {
+  return d_k == 64 && key_split(max_q, max_k, causal) && attn_impl() != 1 && !env_off("ST_ATTN_XS");
+}
 
 }  // namespace
 

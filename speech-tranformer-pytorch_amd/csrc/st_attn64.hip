@@ -7,7 +7,13 @@
 // mix).  At d_k = 64 a 32 x 32 score block is 8 MFMAs against 16 scores per lane, so the general kernel of st_attn.hip
 // (scale + running maximum + rescale test + exp + sum + convert: 12.6 VALU per MFMA by PMC) is bound by instruction
 // issue at 2.5x its MFMA time.  Here the softmax is cut to what cannot be avoided:
-//   * Q is multiplied by scale * log2(e) once, so the scores leave the matrix pipe in the log2 domain;
+//   * (rounds 3-4) the scores are multiplied by scale * log2(e) in fp32, one multiply per score.  Round 3 pre-multiplied Q and
+//     rounded it to bf16 once more (the scores then left the matrix pipe in the log2 domain: 1.5 us per launch cheaper) - round 4's
+//     bisection of the full-size parity table (tests/test_fullsize_gpu.py, ST_ATTN_FWD64=0 against the general kernel) showed
+//     what that costs: the logits do not notice (rel-L2 7.4e-3 either way), the GRADIENTS do - global rel-L2 against the fp64
+//     oracle 4.28e-2 with the re-rounded Q, 3.86e-2 without (the reference arithmetic under bf16 autocast: 4.01e-2), per-tensor
+//     median 5.48e-2 -> 4.84e-2 (5.24e-2).  The second rounding perturbs every score by ~2^-9 of |q||k|, i.e. the forward then
+//     differentiates a slightly different function than the oracle's;
 //   * NO maximum is subtracted.  softmax(s) = exp2(s) / sum exp2(s) whatever constant is subtracted from s; the
 //     subtraction only keeps fp32 in range, and |s| < ~100 (69 nats) needs no help there.  The row sum l tells whether
 //     that held: a workgroup that finds an l outside [1e-30, 1e30] (or inf / nan) repeats its item with the classical
@@ -52,7 +58,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // one 64-key tile, plain exponentials (EXACT = false) or the classical running-maximum update (EXACT = true)
 template <bool DROP, bool MASK, bool EXACT>
 __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], float& m, float& lsum,
-                                          f32x16& lacc, const bf16x8& ones, int kt, int lk, int q, const Drop& dr, int bh) {
+                                          f32x16& lacc, const bf16x8& ones, int kt, int lk, int q, const Drop& dr, int bh, float c2) {
   constexpr bool MSUM = !DROP && !EXACT;   // row sums on the matrix pipe (see the kernel's header)
   constexpr int DK = 64;
   const int l = threadIdx.x & 63, hi = l >> 5;
@@ -61,6 +67,8 @@ __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const 
     f32x16 s = zero16();
 #pragma unroll
     for (int t = 0; t < 4; ++t) s = mfma32(rd_nat<DK>(ks, kb * 32 + (l & 31), t), qf[t], s);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] *= c2;      // log2 domain, in fp32 (a pre-scaled, re-rounded Q costs gradient accuracy: see the header)
     if (MASK) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -120,7 +128,7 @@ __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const 
 // not), every group fenced with sched_barrier(0) so the order below is the order in the binary.
 #define SB() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], f32x16& lacc,
-                                               const bf16x8& ones) {
+                                               const bf16x8& ones, float c2) {
   constexpr int DK = 64;
   const int l = threadIdx.x & 63, hi = l >> 5;
   bf16x8 kf[4];
@@ -141,7 +149,7 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
   for (int t = 0; t < 4; ++t) {      // S1 = Q K1^T under exp(S0)
     s1 = mfma32(kf[t], qf[t], s1);
 #pragma unroll
-    for (int r = 4 * t; r < 4 * t + 4; ++r) s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+    for (int r = 4 * t; r < 4 * t + 4; ++r) s0[r] = __builtin_amdgcn_exp2f(s0[r] * c2);
     SB();
   }
   bf16x8 pa = pack_acc8(s0, 0), pb = pack_acc8(s0, 8);
@@ -149,31 +157,31 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
   // P0 V0 (+ row sums) under exp(S1)
   o[0] = mfma32(va0, pa, o[0]);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  for (int r = 0; r < 3; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
   o[1] = mfma32(va1, pa, o[1]);
 #pragma unroll
-  for (int r = 3; r < 6; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  for (int r = 3; r < 6; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
   lacc = mfma32(ones, pa, lacc);
   va0 = rd_tr<DK>(vs, 0, 32 + 4 * hi);
   va1 = rd_tr<DK>(vs, 32, 32 + 4 * hi);
 #pragma unroll
-  for (int r = 6; r < 8; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  for (int r = 6; r < 8; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
   o[0] = mfma32(vb0, pb, o[0]);
 #pragma unroll
-  for (int r = 8; r < 11; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  for (int r = 8; r < 11; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
   o[1] = mfma32(vb1, pb, o[1]);
 #pragma unroll
-  for (int r = 11; r < 14; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  for (int r = 11; r < 14; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
   lacc = mfma32(ones, pb, lacc);
   vb0 = rd_tr<DK>(vs, 0, 48 + 4 * hi);
   vb1 = rd_tr<DK>(vs, 32, 48 + 4 * hi);
 #pragma unroll
-  for (int r = 14; r < 16; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+  for (int r = 14; r < 16; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
   pa = pack_acc8(s1, 0);
   pb = pack_acc8(s1, 8);
@@ -208,13 +216,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
   const char* kbase = reinterpret_cast<const char*>(a.K + (size_t)a.k_off[b] * a.ldk + h * DK);
   const char* vbase = reinterpret_cast<const char*>(a.V + (size_t)a.k_off[b] * a.ldv + h * DK);
 
-  bf16x8 qf[NT];     // log2 domain: q * scale * log2(e), rounded to bf16 once more (the scores then need no multiply)
+  bf16x8 qf[NT];     // q as it is: the scores are scaled by scale * log2(e) in fp32 where they are exponentiated
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qf[t][e] = (bf16)((float)v[e] * c2);
-  }
+  for (int t = 0; t < NT; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(a.Q + qrow * a.ldq + h * DK + t * 16 + hi * 8);
   // staging: thread -> two 16-byte chunks of the K tile and two of the V tile (chunk id = tid + p * 256: row id / 8)
   uint32_t vk[2], vv[2];
   int lds_at[2];
@@ -265,15 +269,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
       store(ks);
       load(it + 1);
       __syncthreads();
-      if constexpr (!DROP && !EXACT) lean_tile_pipe(ks, ks + G::E, qf, o, lacc, ones);
-      else lean_tile<DROP, false, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh);
+      if constexpr (!DROP && !EXACT) lean_tile_pipe(ks, ks + G::E, qf, o, lacc, ones, c2);
+      else lean_tile<DROP, false, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
     }
     {
       const int it = ntiles - 1;
       bf16* ks = smem + (it & 1) * 2 * G::E;
       store(ks);
       __syncthreads();
-      lean_tile<DROP, true, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh);
+      lean_tile<DROP, true, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
     }
     __syncthreads();           // the tile buffers are free (epilogue patches, or the second attempt)
     // matrix-pipe sums: every accumulator row of lane q holds the whole row sum (both key halves: the contraction spans them)
