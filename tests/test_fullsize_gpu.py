@@ -17,7 +17,7 @@ ill-conditioned for ANY bf16 implementation (near-uniform attention makes the de
 stream - on the same batch and prints its per-tensor error next to the HIP path's: a tensor passes when it is within
 8e-2 OR within 1.5x what the bf16 reference itself shows on that tensor (round 3: was 2x; the worst ratio among the
 tensors above 8e-2 is 1.42, profiles/r03_parity_c2_b32.txt); the global and median figures must be within
-3e-2 / 4e-2 OR 1.5x the bf16 reference's.  The table is written to ``gpurun_out/parity_<config>.txt`` (and shown
+3e-2 / 4e-2 OR 1.15x the bf16 reference's (round 4; it was 1.5x).  The table is written to ``gpurun_out/parity_<config>.txt`` (and shown
 when an assertion fails); a copy per round lives under ``profiles/``.
 """
 import os
@@ -144,7 +144,9 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
     assert logit_rel < LOGIT_TOL, head
     assert abs(loss - truth["loss"].item()) < 2e-2 * truth["loss"].item(), head
     assert abs(gnorm - truth["grad_norm"].item()) < 2e-2 * truth["grad_norm"].item(), head
-    assert glob < max(GRAD_TOL_GLOBAL, 1.5 * floor_glob) and med < max(GRAD_TOL_MEDIAN, 1.5 * floor_med), head
+    # (round 4: with the long forward's scores scaled in fp32 both figures lie BELOW the bf16 reference's - 0.96x / 0.92x on
+    # config 2, 0.84x / 0.85x on config 3's shard; 1.15x leaves room for another box's rounding realisation)
+    assert glob < max(GRAD_TOL_GLOBAL, 1.15 * floor_glob) and med < max(GRAD_TOL_MEDIAN, 1.15 * floor_med), head
     bad = [r for r in rows if r[0] > max(GRAD_TOL_TENSOR, 1.5 * r[1])]
     assert not bad, "\n".join([head, "outside max(8e-2, 1.5 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
     for g, q, n in kbias:      # analytically zero: 1e-2 of the query bias' gradient (measured: 5e-4 .. 4e-2 of it where that gradient
