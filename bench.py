@@ -200,8 +200,11 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the extra beam-search decode measurement")
     ap.add_argument("--force-dp", action="store_true", help="N = 1 only: run the data-parallel code path (split backward "
                     "graphs, bucketed RCCL all-reduce) on a one-rank group - its overhead without a second GPU")
-    ap.add_argument("--bucket-mb", type=int, default=32, help="gradient all-reduce bucket size (MiB of fp32 gradients; a ring on "
-                    "point-to-point xGMI is bound by one ~153 GB/s link, so buckets are large)")
+    ap.add_argument("--bucket-mb", type=int, default=8, help="gradient all-reduce bucket size (MiB of fp32 gradients).  8 MiB = seven "
+                    "buckets on config 2: with the collectives captured in the step graph a bucket costs no host time, and the "
+                    "encoder's 19 MB must be more than one bucket for its upper layers to be exchanged under the backward of the "
+                    "lower ones (TrainStep._encoder_backward(fire_layers=True)); a ring on point-to-point xGMI is bound by one "
+                    "~153 GB/s link, so far smaller buckets would be latency-bound")
     ap.add_argument("--nccl-algo", type=str, default=None, help="sets NCCL_ALGO for RCCL (Ring / Tree / ...); recorded in config")
     ap.add_argument("--nccl-proto", type=str, default=None, help="sets NCCL_PROTO for RCCL (Simple / LL / LL128); recorded in config")
     ap.add_argument("--no-dp-probe", action="store_true", help="N = 1: skip the extra pass that runs the data-parallel code path "

@@ -222,6 +222,10 @@ class ChainBackward:
 class EncoderBackward(ChainBackward):
     def input_grad(self, key, dproj, ds):
         kind, l = key
+        if kind == "self" and self.owner.layer_hook is not None:
+            # the backward of every layer above l has returned: its weight gradients are all registered (deferred) and its
+            # LayerNorm / bias gradients are enqueued - a data-parallel step flushes and starts exchanging them here
+            self.owner.layer_hook(l + 1)
         if kind != "self" or l == 0:
             return None
         ds_f, head = self._ffn_head(l - 1, dproj, ds)
@@ -294,6 +298,7 @@ class EncoderChains:
         self.bset.finalize()
         self.bwd = [self.bset.chain(ids[l], True) for l in range(n)]
         self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
+        self.layer_hook = None      # optional callable(first_finished_layer): EncoderBackward.input_grad / trainer.TrainStep
         ChainHub.of(arena).add(self.set, self.bset)
 
     @staticmethod
@@ -395,6 +400,7 @@ class DecoderChains:
                 ch.split_work = self.f2[0].split_work       # (forward and backward launches are ordered on one stream)
         self.bwd1 = [self.bset.chain(b1[l], True) for l in range(n)]
         self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
+        self.layer_hook = None      # optional callable(first_finished_layer): EncoderBackward.input_grad / trainer.TrainStep
         ChainHub.of(arena).add(self.set, self.bset)
 
     @staticmethod

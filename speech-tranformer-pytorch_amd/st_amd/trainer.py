@@ -149,11 +149,53 @@ class TrainStep:
         self._cut = (enc, enc_leaf.grad)
         return loss.detach()
 
-    def _encoder_backward(self):
+    def _encoder_backward(self, fire_layers: bool = False):
+        """fire_layers (the collectives are being captured with the step): every time the backward has left an encoder layer,
+        the weight gradients deferred so far are flushed and the buckets that lie wholly in the finished layers start their
+        all-reduce - the exchange of the upper encoder layers runs under the backward of the lower ones instead of behind the
+        whole backward (the deferred weight gradients otherwise become final in ONE launch at its end)."""
         enc, d_enc = self._cut
         self._cut = None
-        with deferred_wgrads(True):
-            enc.backward(d_enc)
+        chains = self._encoder_chains() if fire_layers else None
+        if chains is not None:
+            chains.layer_hook = self._encoder_layer_done
+        try:
+            with deferred_wgrads(True):
+                enc.backward(d_enc)
+        finally:
+            if chains is not None:
+                chains.layer_hook = None
+
+    def _encoder_chains(self):
+        enc = getattr(self.model, "encoder", None)
+        if enc is None or not hasattr(enc, "row_chains") or self._encoder_layer_offsets() is None:
+            return None
+        return enc.row_chains(arena_of(self.model))
+
+    def _encoder_layer_offsets(self):
+        """First element of every encoder layer in the flat gradient buffer - None unless the layers lie in stack order with
+        everything that is not the encoder behind them (the layout ParamArena builds from module order)."""
+        hit = getattr(self, "_enc_layer_lo", False)
+        if hit is not False:
+            return hit
+        arena = arena_of(self.model)
+        los = [min(arena.offset[id(p)] for p in layer.parameters()) for layer in self.model.encoder.layer_stack]
+        his = [max(arena.offset[id(p)] + arena.size[id(p)] for p in layer.parameters()) for layer in self.model.encoder.layer_stack]
+        cut = self._decoder_grad_start()
+        ok = all(his[i] <= los[i + 1] for i in range(len(los) - 1)) and cut < arena.total and his[-1] <= cut
+        self._enc_layer_lo = los if ok else None
+        return self._enc_layer_lo
+
+    def _encoder_layer_done(self, first_finished: int) -> None:
+        los = self._encoder_layer_offsets()
+        if los is None or first_finished >= len(los):
+            return
+        lo = los[first_finished]
+        red = self.reducer
+        if any(blo >= lo and not red._fired[i] for i, (blo, _) in enumerate(red.buckets)):
+            from .functional import flush_deferred_wgrads
+            flush_deferred_wgrads()          # everything registered so far: the finished layers' weight (+ bias) gradients
+            red.fire_from(lo)
 
     def _decoder_grad_start(self) -> int:
         """First element of the flat gradient buffer that the encoder's backward no longer touches."""
@@ -340,7 +382,7 @@ class TrainStep:
                 with torch.cuda.graph(g_all, pool=pool, **mode):
                     cap.loss = self._forward_decoder_backward(*batch, layouts=layouts)
                     self.reducer.fire_from(self._decoder_grad_start())
-                    self._encoder_backward()
+                    self._encoder_backward(fire_layers=True)
                     self.reducer.synchronize()
                     cap.gnorm = self._clip_and_update()
             except Exception as e:  # noqa: BLE001 - a process group / RCCL build that cannot be captured: eager collectives

@@ -771,3 +771,84 @@ def test_packed_bucket_two_capacities_composition():
     """Two packed capacities: a batch takes the first it fits, the full-length batch the padded bucket."""
     with emulated_kernels():
         run_bucket_mode("cpu", use_graph=False, bucket_rows=[(250, 44), (340, 44)])
+
+
+def run_layerwise_bucket_firing(device):
+    """Data-parallel graph mode (trainer.TrainStep._capture, collectives in the step graph): while the encoder's backward
+    runs, the buckets that lie wholly in FINISHED encoder layers are handed to the all-reduce early
+    (``_encoder_backward(fire_layers=True)`` -> chains.EncoderBackward's layer hook -> flush of the deferred weight gradients
+    -> ``fire_from``).  The property that must hold: whatever a fired bucket holds at that moment is FINAL - nothing is
+    accumulated into it afterwards.  A recording stand-in for the reducer snapshots every bucket when it is fired; the
+    snapshots must equal the gradients after the whole backward, and buckets inside the upper encoder layers must in fact
+    fire before the backward ends."""
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd.arena import arena_of
+    from st_amd.trainer import TrainStep
+    from transformer.Optim import ScheduledOptim
+    torch.manual_seed(7)
+    cfg = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=20, num_enc_layer=4, num_dec_layer=1,
+                          n_heads=4, d_k=64, d_v=64, d_model=256, d_inner_hid=512, dropout=0.0, vocab_size=30))
+    m = M.Transformer(cfg)
+    U.init_parameters(m)
+    m = m.eval().to(device)
+    arena = arena_of(m)
+    batch = orc.synthetic_batch(4, 70, 9, 80, 30, seed=4, t_min=30, l_min=4)
+    x, tok, gt = batch["x"].to(device), batch["tokens"].to(device), batch["gt"].to(device)
+
+    class Recorder:          # the part of dp.GradReducer's interface the step uses in explicit mode
+        def __init__(self, total, per):
+            self.buckets, hi = [], total
+            while hi > 0:
+                lo = max(0, hi - per)
+                self.buckets.append((lo, hi))
+                hi = lo
+            self._fired = [False] * len(self.buckets)
+            self.active, self.world, self.group = True, 2, None
+            self.snap, self.order = {}, []
+
+        def fire_from(self, lo):
+            for i, (blo, bhi) in enumerate(self.buckets):
+                if blo >= lo and not self._fired[i]:
+                    self._fired[i] = True
+                    self.snap[i] = arena.grad[blo:bhi].detach().clone()
+                    self.order.append(i)
+
+        def synchronize(self):
+            self.fire_from(0)
+
+        def detach(self):
+            pass
+
+    red = Recorder(arena.total, 96 * 1024)           # 384 KB buckets: several per encoder layer
+    opt = ScheduledOptim(m, 256, U.AttrDict(n_warmup_steps=100))
+    step = TrainStep(m, opt, 30, max_grad_norm=1e9, reducer=red, use_graph=False)
+    in_len, tgt_len = batch["in_len"], batch["tgt_len"]
+    step._forward_decoder_backward(x[:, :int(in_len.max())], in_len, tok[:, :int(tgt_len.max())], tgt_len, gt[:, :int(tgt_len.max())])
+    lo_dec = step._decoder_grad_start()
+    red.fire_from(lo_dec)
+    n_dec = len(red.order)
+    assert step._encoder_layer_offsets() is not None and step._encoder_chains() is not None
+    step._encoder_backward(fire_layers=True)
+    early = len(red.order) - n_dec                 # fired from inside the encoder's backward
+    red.synchronize()
+    los = step._encoder_layer_offsets()
+    inside_upper = [i for i, (blo, bhi) in enumerate(red.buckets) if blo >= los[1] and bhi <= lo_dec]
+    assert inside_upper and early >= len(inside_upper) > 0, (early, inside_upper)
+    assert all(red.order.index(i) < len(red.order) - 1 for i in inside_upper)
+    for i, (blo, bhi) in enumerate(red.buckets):
+        assert torch.equal(red.snap[i], arena.grad[blo:bhi]), "bucket %d [%d, %d) changed after it was fired" % (i, blo, bhi)
+    # ... and the gradients are those of the plain single-graph step
+    m2 = M.Transformer(cfg)
+    m2.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    m2 = m2.eval().to(device)
+    opt2 = ScheduledOptim(m2, 256, U.AttrDict(n_warmup_steps=100))
+    step2 = TrainStep(m2, opt2, 30, max_grad_norm=1e9, use_graph=False)
+    step2._forward_backward(x[:, :int(in_len.max())], in_len, tok[:, :int(tgt_len.max())], tgt_len, gt[:, :int(tgt_len.max())])
+    a2 = arena_of(m2)
+    assert float((arena.grad - a2.grad).norm() / a2.grad.norm()) < 1e-5
+
+
+def test_layerwise_bucket_firing_composition():
+    with emulated_kernels():
+        run_layerwise_bucket_firing("cpu")

@@ -168,6 +168,13 @@ def test_row_chain_step_narrow_heads_gpu():
     comp.run_row_chain_step_narrow_heads("cuda")
 
 
+def test_layerwise_bucket_firing_gpu():
+    """tests/test_composition_cpu.py::run_layerwise_bucket_firing with the real kernels: a bucket handed to the all-reduce from
+    inside the encoder's backward never changes afterwards."""
+    from tests import test_composition_cpu as comp
+    comp.run_layerwise_bucket_firing("cuda")
+
+
 def test_row_chains_on_off_gpu():
     comp.run_row_chains_on_off("cuda", exact=False)
 
