@@ -744,8 +744,13 @@ def run_bucket_mode(device, use_graph, bucket_rows=None, T_cap=96, L_cap=12, t_m
         la, ga = sa(x, b["in_len"], tok, b["tgt_len"], gt)
         lb, gb = sb(x, b["in_len"], tok, b["tgt_len"], gt)
         la, ga, lb, gb = float(la), float(ga), float(lb), float(gb)
-        assert abs(la - lb) <= 2e-3 * abs(lb), (i, la, lb)
-        assert abs(ga - gb) <= 3e-2 * abs(gb), (i, ga, gb)
+        # The FIRST batch through a layout is the real check: same weights, same arithmetic, so the two steps agree to the order
+        # of the fp32 atomics (measured 2e-7 on the gradient, tools/dev/bucket_one_batch.py).  Later batches compare two
+        # TRAJECTORIES: the twins' weights differ by ~1e-9 after a step (atomics order), and a few steps on one bf16 rounding
+        # of a LayerNorm gain or a bias flips in one twin only - a 5e-5 jump of the loss that grows from there (2e-3 by the fifth
+        # batch with some kernel realisations, tools/dev/bucket_traj_probe.py; a defect in a layout shows up at O(1e-1))
+        assert abs(la - lb) <= (1e-5 if i == 0 else 5e-3) * abs(lb), (i, la, lb)
+        assert abs(ga - gb) <= (1e-4 if i == 0 else 3e-2) * abs(gb), (i, ga, gb)
         for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
             assert torch.isfinite(p).all(), (i, n)
         da = torch.cat([p.detach().reshape(-1) for p in ma.parameters()]).double()
