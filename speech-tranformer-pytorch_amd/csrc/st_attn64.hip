@@ -127,10 +127,25 @@ __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const 
 // VALU work hides under its own MFMAs - up to ~5 issues per 32-clock MFMA; VALU work of another wave of the SIMD does
 // not), every group fenced with sched_barrier(0) so the order below is the order in the binary.
 #define SB() __builtin_amdgcn_sched_barrier(0)
+// LAST: the utterance's last tile - `kleft` of its 64 keys exist.  The rows past them arrived as zeros (the descriptor's range
+// ends at the last key): such a key scores 0, weighs exp2(0) = 1 and multiplies a zero V row, so the context needs no mask; the
+// ROW SUM does, and gets it for free - the fragment of ones it is contracted with carries zeros at those keys.  (Subtracting
+// their count from an unmasked sum was tried first: with row sums below ~1 - config 3's heads - the cancellation sent two items
+// in three to the exact fall-back loop, attention forward 0.93 -> 1.54 ms.)
+template <bool LAST>
 __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], f32x16& lacc,
-                                               const bf16x8& ones, float c2) {
+                                               const bf16x8& ones, float c2, int kleft = 64) {
   constexpr int DK = 64;
   const int l = threadIdx.x & 63, hi = l >> 5;
+  auto ones_of = [&](int half_block) {      // keys half_block * 16 + 8 (j >> 2) + 4 hi + (j & 3): pack_acc8's contraction order
+    if constexpr (!LAST) return ones;
+    else {
+      bf16x8 f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (half_block * 16 + 8 * (j >> 2) + 4 * hi + (j & 3) < kleft) ? (bf16)1.f : (bf16)0.f;
+      return f;
+    }
+  };
   bf16x8 kf[4];
   f32x16 s0 = zero16(), s1 = zero16();
 #pragma unroll
@@ -163,7 +178,7 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
 #pragma unroll
   for (int r = 3; r < 6; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
-  lacc = mfma32(ones, pa, lacc);
+  lacc = mfma32(ones_of(0), pa, lacc);
   va0 = rd_tr<DK>(vs, 0, 32 + 4 * hi);
   va1 = rd_tr<DK>(vs, 32, 32 + 4 * hi);
 #pragma unroll
@@ -177,7 +192,7 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
 #pragma unroll
   for (int r = 11; r < 14; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
   SB();
-  lacc = mfma32(ones, pb, lacc);
+  lacc = mfma32(ones_of(1), pb, lacc);
   vb0 = rd_tr<DK>(vs, 0, 48 + 4 * hi);
   vb1 = rd_tr<DK>(vs, 32, 48 + 4 * hi);
 #pragma unroll
@@ -188,10 +203,10 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
   SB();
   o[0] = mfma32(va0, pa, o[0]);
   o[1] = mfma32(va1, pa, o[1]);
-  lacc = mfma32(ones, pa, lacc);
+  lacc = mfma32(ones_of(2), pa, lacc);
   o[0] = mfma32(vb0, pb, o[0]);
   o[1] = mfma32(vb1, pb, o[1]);
-  lacc = mfma32(ones, pb, lacc);
+  lacc = mfma32(ones_of(3), pb, lacc);
   SB();
 }
 
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
       store(ks);
       load(it + 1);
       __syncthreads();
-      if constexpr (!DROP && !EXACT) lean_tile_pipe(ks, ks + G::E, qf, o, lacc, ones, c2);
+      if constexpr (!DROP && !EXACT) lean_tile_pipe<false>(ks, ks + G::E, qf, o, lacc, ones, c2);
       else lean_tile<DROP, false, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
     }
     {
@@ -277,24 +292,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
       bf16* ks = smem + (it & 1) * 2 * G::E;
       store(ks);
       __syncthreads();
-      // The last tile WITHOUT a mask (plain-exponential attempt): its rows past the utterance's last key arrived as zeros, so
-      // such a key scores exactly 0, weighs exp2(0) = 1 - exactly, also as bf16 - and multiplies a zero V row: the context is
-      // untouched and the row sum is too large by the NUMBER of such keys, which is subtracted below.  The masked tile is a
-      // compiler-scheduled body with a compare + select per score: 3 us per item against 1.1 for the hot tile.
-      if constexpr (EXACT) lean_tile<DROP, true, true>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
-      else if constexpr (!DROP) lean_tile_pipe(ks, ks + G::E, qf, o, lacc, ones, c2);
-      else lean_tile<DROP, false, false>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
+      // the last tile: the hot tile again, its row-sum fragments masked (see lean_tile_pipe); the other paths mask per score
+      if constexpr (!DROP && !EXACT) lean_tile_pipe<true>(ks, ks + G::E, qf, o, lacc, ones, c2, lk - it * TILE);
+      else lean_tile<DROP, true, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
     }
     __syncthreads();           // the tile buffers are free (epilogue patches, or the second attempt)
     // matrix-pipe sums: every accumulator row of lane q holds the whole row sum (both key halves: the contraction spans them)
     ltot = (!DROP && !EXACT) ? lacc[0] : lsum + wave_xor32(lsum);
-    if constexpr (!EXACT) ltot -= (float)(ntiles * TILE - lk);
   };
   run(std::false_type{});
-  // (the count subtracted from the row sum is exact, the sum it is subtracted from is fp32: the difference is trusted while it
-  // is not small against the count - relative error ~1e-6 (count + l) / l - else the exact loop, which masks, repeats the item)
-  const float l_lo = fmaxf(F64_SMALL, 0.02f * (float)(ntiles * TILE - lk));
-  if (__syncthreads_or(q < lq && !(ltot > l_lo && ltot < F64_BIG))) {      // left the plain-exponential range
+  if (__syncthreads_or(q < lq && !(ltot > F64_SMALL && ltot < F64_BIG))) {      // left the plain-exponential range
     m = -INFINITY;
     run(std::true_type{});
   }
