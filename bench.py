@@ -359,6 +359,9 @@ def main():
                         "note": "one-rank RCCL group: the bucketed all-reduces run (captured in the step graph) but exchange nothing"}
             red1.detach()
             del step1
+            if os.environ.get("ST_BENCH_KEEP_PG") != "1":      # (development: keep the group alive for the passes that follow)
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
         except Exception as e:  # noqa: BLE001 - the headline must still be printed
             dp_probe = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -153,7 +153,10 @@ class GradReducer:
         self._fired = [False] * len(self.buckets)
         self._work = []
         backend = dist.get_backend(group) if self.active else "none"
-        self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
+        # SUM + one division, never ReduceOp.AVG: RCCL implements AVG as a pre-multiplied sum whose scalar lives in a small
+        # recycled pool - captured into a HIP graph with more than ~8 collectives per step, the replays read a stale scalar
+        # (round 4: config 3 with 16 MiB buckets, gradient norm 1.8 -> 3e7 from the first replay on; tools/dev/dp_vs_plain_traj.py)
+        self._avg_op = None
         self.exposed_wait_s = 0.0
         if self.active:
             arena.set_grad_ready_callback(self._on_ready)
@@ -212,13 +215,14 @@ class GradReducer:
         for i in range(len(self.buckets)):
             if not self._fired[i]:
                 self._fire(i)
+        summed = False
         for w, g, wire in self._work:
             w.wait()
             if wire is not None:
                 g.copy_(wire)
-                g.div_(self.world)
-            elif g is not None:
-                g.div_(self.world)
+            summed = summed or g is not None
+        if summed and self.world > 1:
+            self.arena.grad.div_(self.world)      # every bucket was summed: one pass over the flat buffer
         self._work = []
         self._filled = [0] * len(self.buckets)
         self._fired = [False] * len(self.buckets)

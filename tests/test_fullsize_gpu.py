@@ -591,3 +591,47 @@ def test_decode_scoring_at_the_benchmarked_shape_vs_fp64_oracle():
         f.write("\n".join(report) + "\n")
     assert float(err.abs().max()) < 0.1, report
     assert rms(err) <= max(0.08, 2.0 * rms(ferr)), report
+
+
+def test_config3_dp_step_with_captured_collectives_matches_the_plain_step():
+    """BASELINE config 3 (train_multi.py's model: 12+6 layers, d_model 512 - 152 MB of fp32 gradients) through the data-parallel
+    graph step on a one-rank RCCL group with 12 MiB buckets (13 collectives captured in the step graph) against the plain
+    single-graph step, same weights and batch, six steps: loss and clip norm must follow each other.  Round 4 found the replays
+    of this configuration returning a gradient norm of 3e7 instead of 1.8 with ``ReduceOp.AVG`` (RCCL's pre-multiplied sum keeps
+    its scalar in a recycled pool; more than ~8 captured collectives per step and a replay reads a stale one) - the reducer sums
+    and divides once instead (st_amd/dp.py)."""
+    import copy
+    import socket
+    import torch.distributed as dist
+    import transformer.Models as M
+    import transformer.Utils as U
+    from st_amd import dp, synthetic
+    from st_amd.arena import arena_of
+    from st_amd.trainer import TrainStep
+    from transformer.Optim import ScheduledOptim
+
+    x, tokens, in_len, tgt_len, gt = synthetic.make_batch(32, 1000, 50, 80, 4337, seed=0, t_min=500, l_min=25)
+    n = 8
+    xg, tg, gg, in_len, tgt_len = x[:n].cuda(), tokens[:n].cuda(), gt[:n].cuda(), in_len[:n], tgt_len[:n]
+    torch.manual_seed(0)
+    m0 = M.Transformer(U.AttrDict(C3))
+    U.init_parameters(m0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        out = {}
+        for mode in ("plain", "dp"):
+            m = copy.deepcopy(m0).eval().cuda()
+            opt = ScheduledOptim(m, C3["d_model"], U.AttrDict(n_warmup_steps=12000))
+            red = dp.GradReducer(arena_of(m), bucket_bytes=12 << 20, force=True) if mode == "dp" else None
+            step = TrainStep(m, opt, C3["vocab_size"], max_grad_norm=5.0, reducer=red, use_graph=True)
+            out[mode] = [tuple(float(v) for v in step(xg, in_len, tg, tgt_len, gg)) for _ in range(6)]
+            if red is not None:
+                assert step.dp_mode == "in-graph" and len(red.buckets) >= 12, (step.dp_mode, len(red.buckets))
+        for (la, ga), (lb, gb) in zip(out["plain"], out["dp"]):
+            assert abs(la - lb) <= 1e-3 * abs(la) and abs(ga - gb) <= 3e-2 * abs(ga), (out["plain"], out["dp"])
+    finally:
+        dist.destroy_process_group()
