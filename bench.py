@@ -359,9 +359,8 @@ def main():
                         "note": "one-rank RCCL group: the bucketed all-reduces run (captured in the step graph) but exchange nothing"}
             red1.detach()
             del step1
-            if os.environ.get("ST_BENCH_KEEP_PG") != "1":      # (development: keep the group alive for the passes that follow)
-                torch.cuda.synchronize()
-                dist.destroy_process_group()
+            # (the process group stays alive: with one in existence TrainStep captures in "thread_local" mode - destroying it
+            # here let a later "global"-mode capture collide with the dying watchdog thread's event queries)
         except Exception as e:  # noqa: BLE001 - the headline must still be printed
             dp_probe = {"error": "%s: %s" % (type(e).__name__, e)}
 
