@@ -33,6 +33,11 @@ typedef void* st_stream_t; /* hipStream_t */
 /* Library ABI version (bumped on any signature change). */
 int st_version(void);
 
+/* Re-read the development switches that choose between a specialised attention kernel and the general one
+ * (ST_ATTN_FWD64=0, ST_ATTN_XS=0, ST_ATTN_BWD64=0|e).  They are read from the environment once, at the first
+ * attention call; a host that changes one afterwards (same-process A/B runs in tests/ and tools/dev/) calls this. */
+int st_env_refresh(void);
+
 /* Epilogue selector of st_gemm. */
 enum {
   ST_EPI_BF16 = 0,       /* D(bf16) = acc (+ bias)                                   */
@@ -361,9 +366,13 @@ int st_cast_bf16(st_stream_t stream, const float* src, void* dst, long long n);
 /* clip_grad_norm_ + Adam over the flat fp32 parameter buffer in one pass (train.py:45-46, transformer/Optim.py:
  * Adam(betas = (beta1, beta2), eps)): g *= min(1, max_norm / (*gnorm + 1e-6)) (gnorm NULL: no clipping), then the
  * update of torch.optim.Adam at step count *step (already incremented) and learning rate *lr - all three device
- * scalars.  n: elements, a multiple of 4; p, g, m (exp_avg), v (exp_avg_sq): fp32 [n]. */
+ * scalars.  n: elements, a multiple of 4; p, g, m (exp_avg), v (exp_avg_sq): fp32 [n].
+ * grad_scale: the buffer holds gradient / grad_scale - 1 / world behind a SUMMING all-reduce (train_multi.py:161-163:
+ * Horovod averages), 1 otherwise; the factor is applied together with the clip coefficient (g is left holding the
+ * clipped, averaged gradient), *gnorm must be the norm of the scaled gradient (st_grad_norm with the same grad_scale). */
 int st_adam_clip(st_stream_t stream, long long n, float* p, float* g, float* m, float* v, const float* lr,
-                 const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps);
+                 const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps,
+                 float grad_scale);
 
 /* Zero the unassigned tail rows of a list of row matrices in one launch (packed bucket layouts: the rows behind the
  * batch's last utterance belong to nobody; the kernels never write them, so they must read as zeros).  table (device,
@@ -372,11 +381,12 @@ int st_adam_clip(st_stream_t stream, long long n, float* p, float* g, float* m, 
 int st_zero_tails(st_stream_t stream, const long long* table, int n_max);
 
 /* total_norm of clip_grad_norm_ (train.py:45) over the flat fp32 gradient buffer g [n] (n % 4 == 0) as one launch:
- * *gnorm = ||g||_2 (partials added in a fixed order, fp64), and - when step is not NULL - *step += 1, the optimiser's
+ * *gnorm = grad_scale * ||g||_2 (partials added in a fixed order, fp64), and - when step is not NULL - *step += 1, the optimiser's
  * step count st_adam_clip then reads.  scratch: st_grad_norm_blocks() + 1 floats owned by the caller, the last one
  * zero before the first call (the kernel leaves it zero). */
 int st_grad_norm_blocks(void);
-int st_grad_norm(st_stream_t stream, const float* g, long long n, float* scratch, float* gnorm, float* step);
+int st_grad_norm(st_stream_t stream, const float* g, long long n, float* scratch, float* gnorm, float* step,
+                 float grad_scale);
 
 /* Cross-entropy over ragged logits rows (train.py:40,120: nn.CrossEntropyLoss(ignore_index = 0), mean over the
  * non-ignored tokens).  logits f32 [R, ldl] (V valid columns; padding columns holding -1e30 may be counted as valid),

@@ -546,30 +546,48 @@ int attn_impl() {
   return v;
 }
 
-// long non-causal problems with 64-wide heads take the plain-exponential forward of st_attn64.hip
-bool env_off(const char* name) {      // development switches read at every call (same-process A/B runs): NAME=0 turns a path off
-  const char* e = getenv(name);
-  return e && e[0] == '0';
+// development switches (same-process A/B runs of the specialised kernels against the general ones): read from the
+// environment ONCE, and again only when a host asks (st_env_refresh: tests and tools/dev call it after changing a variable) -
+// the production dispatch never calls getenv
+struct AttnEnv {
+  bool fwd64_off, xs_off;      // ST_ATTN_FWD64=0, ST_ATTN_XS=0
+  int bwd64;                   // ST_ATTN_BWD64: 0 = default (streams), 1 = "0" (general kernels), 2 = "e" (streams in eval mode only)
+};
+AttnEnv read_attn_env() {
+  auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+  const char* b = getenv("ST_ATTN_BWD64");
+  return {off("ST_ATTN_FWD64"), off("ST_ATTN_XS"), (b && b[0] == '0') ? 1 : (b && b[0] == 'e') ? 2 : 0};
 }
-bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
-  return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1 && !env_off("ST_ATTN_FWD64");
+AttnEnv& attn_env() {
+  static AttnEnv e = read_attn_env();
+  return e;
 }
 
-// ... and the hand-scheduled backward of st_attn_bwd64.hip (no dropout, delta supplied by the producer of dO).  ST_ATTN_BWD64=0
-// (read at every call: a development switch for same-process A/B runs) keeps the general kernels
+// long non-causal problems with 64-wide heads take the plain-exponential forward of st_attn64.hip
+bool fwd_long64(int d_k, int max_q, int max_k, int causal) {
+  return d_k == 64 && !causal && max_q > 128 && attn_impl() != 1 && !attn_env().fwd64_off;
+}
+
+// ... and the hand-scheduled backward of st_attn_bwd64.hip (delta supplied by the producer of dO).  ST_ATTN_BWD64=0 keeps the
+// general kernels, =e the streams in eval mode only (no dropout variant)
 bool bwd_long64(int d_k, int max_q, int max_k, int causal, bool drop) {
   if (!(d_k == 64 && !causal && max_q > 128 && max_k > 128 && attn_impl() != 1)) return false;
-  const char* e = getenv("ST_ATTN_BWD64");      // "0": the general kernels; "e": the streams in eval mode only (no dropout variant)
-  if (e && e[0] == '0') return false;
-  return !(drop && e && e[0] == 'e');
+  const int mode = attn_env().bwd64;
+  return mode == 0 || (mode == 2 && !drop);
 }
 
 // few queries against many keys with 64-wide heads (the decoder-encoder attention) take the forward of st_attn_xs.hip
 bool fwd_xs(int d_k, int max_q, int max_k, int causal) {
-  return d_k == 64 && key_split(max_q, max_k, causal) && attn_impl() != 1 && !env_off("ST_ATTN_XS");
+  return d_k == 64 && key_split(max_q, max_k, causal) && attn_impl() != 1 && !attn_env().xs_off;
 }
 
 }  // namespace
+
+extern "C" int st_env_refresh(void) {
+  // re-read the development switches ST_ATTN_FWD64 / ST_ATTN_XS / ST_ATTN_BWD64 (cached at first use otherwise)
+  attn_env() = read_attn_env();
+  return 0;
+}
 
 extern "C" int st_attn_tile_rows(int which, int d_k, int max_q, int max_k, int causal) {
   // rows per work-list tile of the kernel that will serve this problem: which = 0 forward (query tiles),
@@ -709,7 +727,9 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   if (O == nullptr && (run_q || run_k) && !ks2 && bwd_long64(d_k, max_q, max_k, causal, drop) && lddq % 8 == 0) {
     AttnArgs ak = a;
     const int nq = run_q ? plan(a, work_q, n_work_q, B, H, max_q) : 0, nk = run_k ? plan(ak, work_k, n_work_k, B, H, max_k) : 0;
-    if (const char* tp = getenv("ST_ATTN_TRACE_PTR")) a.Ores = (bf16*)strtoull(tp, nullptr, 0);      // development: per-workgroup clock stamps
+#ifdef ST_DEV_TRACE      // development builds only (ST_DEV_TRACE=1 python -m st_amd.build): per-workgroup clock stamps, tools/dev/attn_bwd64_trace.py
+    if (const char* tp = getenv("ST_ATTN_TRACE_PTR")) a.Ores = (bf16*)strtoull(tp, nullptr, 0);
+#endif
     return st_attn_bwd64_launch(stream, &a, &ak, nq, nk, drop ? 1 : 0);
   }
   if (run_q && run_k && O == nullptr) {

@@ -250,9 +250,11 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, size_t n4, const float* lr_p,
                                                         const float* step_p, const float* gnorm_p, float max_norm,
-                                                        float beta1, float beta2, float eps) {
+                                                        float beta1, float beta2, float eps, float grad_scale) {
   const float lr = *lr_p, step = *step_p;
-  const float coef = gnorm_p ? fminf(max_norm / (*gnorm_p + 1e-6f), 1.0f) : 1.0f;
+  // grad_scale: what the buffer still has to be multiplied by to be THE gradient (1 / world behind a summing all-reduce:
+  // the rank average costs no pass of its own); *gnorm_p is the norm of the scaled gradient (st_grad_norm's grad_scale)
+  const float coef = (gnorm_p ? fminf(max_norm / (*gnorm_p + 1e-6f), 1.0f) : 1.0f) * grad_scale;
   const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
   const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, f
 // (*step += 1, optional) and resets the ticket for the next launch.  Replaces torch.linalg.vector_norm (52 MB at 2.6 TB/s
 // plus a memset) and the separate step increment: three graph nodes -> one.
 __global__ __launch_bounds__(1024) void grad_norm_kernel(const float* __restrict__ g, size_t n4, float* partial, unsigned* ticket,
-                                                        float* __restrict__ gnorm, float* step) {
+                                                        float* __restrict__ gnorm, float* step, float grad_scale) {
   __shared__ float red[16];      // 1024 threads x four 16-byte loads in flight = 64 KB per workgroup, 16 MB over the chip
                                  // (256 threads: 4 MB in flight = ~2 TB/s at ~2 us memory latency: 18 us for 52 MB)
   __shared__ bool last;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(1024) void grad_norm_kernel(const float* __restrict
     __syncthreads();
   }
   if (tid == 0) {
-    *gnorm = (float)sqrt(redd[0]);
+    *gnorm = (float)sqrt(redd[0]) * grad_scale;      // ||grad_scale * g||
     if (step) *step += 1.0f;
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1265,7 +1267,8 @@ extern "C" int st_zero_tails(hipStream_t stream, const long long* table, int n_m
 
 extern "C" int st_grad_norm_blocks(void) { return 1024; }
 
-extern "C" int st_grad_norm(hipStream_t stream, const float* g, long long n, float* scratch, float* gnorm, float* step) {
+extern "C" int st_grad_norm(hipStream_t stream, const float* g, long long n, float* scratch, float* gnorm, float* step,
+                            float grad_scale) {
   // scratch: st_grad_norm_blocks() + 1 floats, the last one (the ticket) zero before the first call
   if (n <= 0 || (n & 3) || !g || !scratch || !gnorm) return -1;
   const size_t n4 = (size_t)n / 4;
@@ -1274,20 +1277,21 @@ extern "C" int st_grad_norm(hipStream_t stream, const float* g, long long n, flo
   int blocks = (int)((n4 + 1023) / 1024);
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(grad_norm_kernel, dim3(blocks), dim3(1024), 0, stream, g, n4, scratch, reinterpret_cast<unsigned*>(scratch + 1024),
-                     gnorm, step);
+                     gnorm, step, grad_scale);
   ST_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int st_adam_clip(hipStream_t stream, long long n, float* p, float* g, float* m, float* v, const float* lr,
-                            const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps) {
+                            const float* step, const float* gnorm, float max_norm, float beta1, float beta2, float eps,
+                            float grad_scale) {
   if (n <= 0) return 0;
   if ((n & 3) || !p || !g || !m || !v || !lr || !step) return -1;
   const size_t n4 = (size_t)n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, n4, lr, step, gnorm, max_norm, beta1,
-                     beta2, eps);
+                     beta2, eps, grad_scale);
   ST_CHECK_LAUNCH();
   return 0;
 }

@@ -152,11 +152,10 @@ class GradReducer:
         self._filled = [0] * len(self.buckets)
         self._fired = [False] * len(self.buckets)
         self._work = []
-        backend = dist.get_backend(group) if self.active else "none"
-        # SUM + one division, never ReduceOp.AVG: RCCL implements AVG as a pre-multiplied sum whose scalar lives in a small
+        # SUM + one scale, never ReduceOp.AVG: RCCL implements AVG as a pre-multiplied sum whose scalar lives in a small
         # recycled pool - captured into a HIP graph with more than ~8 collectives per step, the replays read a stale scalar
-        # (round 4: config 3 with 16 MiB buckets, gradient norm 1.8 -> 3e7 from the first replay on; tools/dev/dp_vs_plain_traj.py)
-        self._avg_op = None
+        # (round 4: config 3 with 16 MiB buckets, gradient norm 1.8 -> 3e7 from the first replay on; tools/dev/dp_vs_plain_traj.py).
+        # The 1 / world itself costs no pass when the caller folds it into the clip + Adam kernel: synchronize(divide=False)
         self.exposed_wait_s = 0.0
         if self.active:
             arena.set_grad_ready_callback(self._on_ready)
@@ -178,9 +177,6 @@ class GradReducer:
             wire = g.to(self.wire_dtype)
             w = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((w, g, wire))
-        elif self._avg_op is not None:
-            w = dist.all_reduce(g, op=self._avg_op, group=self.group, async_op=True)
-            self._work.append((w, None, None))
         else:
             w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._work.append((w, g, None))
@@ -190,12 +186,12 @@ class GradReducer:
         all-reduces are issued explicitly with :meth:`reduce_all`)."""
         self.arena.set_grad_ready_callback(None)
 
-    def reduce_all(self) -> None:
-        """All-reduce every bucket now (in production order) and finish the average."""
+    def reduce_all(self, divide: bool = True) -> float:
+        """All-reduce every bucket now (in production order) and finish the average (see :meth:`synchronize`)."""
         if not self.active:
-            return
+            return 1.0
         self._fired = [False] * len(self.buckets)
-        self.synchronize()
+        return self.synchronize(divide)
 
     def fire_from(self, lo: int) -> None:
         """Explicit mode (after :meth:`detach`): start the all-reduce of every bucket that lies wholly at or above
@@ -207,11 +203,15 @@ class GradReducer:
             if blo >= lo and not self._fired[i]:
                 self._fire(i)
 
-    def synchronize(self) -> None:
+    def synchronize(self, divide: bool = True) -> float:
         """Flush buckets that never filled, wait for every all-reduce and finish the
-        average; afterwards ``arena.grad`` holds the rank-mean gradient."""
+        average; afterwards ``arena.grad`` holds the rank-mean gradient.
+        divide=False: leave the rank SUM in ``arena.grad`` and return the factor that still has to be applied (1 / world) -
+        for callers that fold it into their next pass over the buffer (trainer.TrainStep: st_grad_norm / st_adam_clip take it
+        as ``grad_scale``; saves a read-modify-write of the whole flat buffer per step: 53 MB at config 2, 195 MB at config 3).
+        -> the factor left to apply (1.0 when nothing is)."""
         if not self.active:
-            return
+            return 1.0
         for i in range(len(self.buckets)):
             if not self._fired[i]:
                 self._fire(i)
@@ -221,8 +221,13 @@ class GradReducer:
             if wire is not None:
                 g.copy_(wire)
             summed = summed or g is not None
+        left = 1.0
         if summed and self.world > 1:
-            self.arena.grad.div_(self.world)      # every bucket was summed: one pass over the flat buffer
+            if divide:
+                self.arena.grad.div_(self.world)      # every bucket was summed: one pass over the flat buffer
+            else:
+                left = 1.0 / self.world
         self._work = []
         self._filled = [0] * len(self.buckets)
         self._fired = [False] * len(self.buckets)
+        return left

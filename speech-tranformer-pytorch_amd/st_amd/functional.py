@@ -601,32 +601,47 @@ class CtcPlan:
         dev = targets.device
         B, L = targets.shape
         self.B, self.L, self.C, self.T = B, L, L + 1, in_rows.max_len
-        tl = target_lengths.to(device=dev, dtype=torch.int64)
-        il = input_lengths.to(device=dev, dtype=torch.int64)
-        pos = torch.arange(L, device=dev)
-        valid = pos.view(1, -1) < tl.view(-1, 1)
-        # ext = [blank, label 0, label 1, ...]: the class of an entry is the index of the FIRST entry with the same vocabulary
-        # id (a label equal to the blank id - this repository's synthetic ground truth ends every utterance with id 0 - is the
-        # blank's class 0, exactly as ctc_loss treats it on the dense alphabet)
-        ext = torch.cat([torch.full((B, 1), int(blank), dtype=torch.int64, device=dev), targets.to(torch.int64)], 1)      # [B, L + 1]
-        first = (ext.unsqueeze(2) == ext.unsqueeze(1)).to(torch.int8).argmax(dim=2)                                      # [B, L + 1]
-        self.classes = first[:, 1:].contiguous()                                      # the targets ctc_loss is given
-        self.cols = ext.to(I32).contiguous()                                          # class -> vocabulary column
-        idx = torch.arange(L + 1, device=dev).view(1, -1)
-        keep = (first == idx) & torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), valid], 1)
-        self.scat = torch.where(keep, ext, torch.full_like(ext, -1)).to(I32).contiguous()   # gradients return through first occurrences only
-        # an utterance whose frames cannot spell its labels has an infinite loss: zero_infinity drops it from the objective
-        rep = ((targets[:, 1:] == targets[:, :-1]) & valid[:, 1:]).sum(1) if L > 1 else torch.zeros(B, dtype=torch.int64, device=dev)
-        self.finite = (il >= tl + rep)
-        self.tl = tl.clamp_min(1)
+        self.blank = int(blank)
+        self._tl = target_lengths.to(device=dev, dtype=torch.int64)
+        self._il = input_lengths.to(device=dev, dtype=torch.int64)
+        # the label-derived tensors (filled by refresh_labels; a captured step reads them by address)
+        self.classes = torch.zeros(B, L, dtype=torch.int64, device=dev)               # the targets ctc_loss is given
+        self.cols = torch.zeros(B, L + 1, dtype=I32, device=dev)                      # class -> vocabulary column
+        self.scat = torch.zeros(B, L + 1, dtype=I32, device=dev)                      # gradients return through first occurrences only
+        self.finite = torch.zeros(B, dtype=torch.bool, device=dev)
+        self.tl = self._tl.clamp_min(1)
         self.in_len_host = [int(v) for v in input_lengths.tolist()]
         self.tgt_len_host = [int(v) for v in target_lengths.tolist()]
+        self.refresh_labels(targets)
         self.rowmap = in_rows.scatter_index(self.T)
         self.lp = torch.zeros(B, self.T, self.C, dtype=F32, device=dev)              # frames past a length stay 0 (never read)
         self.g_lp = torch.zeros(B, self.T, self.C, dtype=F32, device=dev)            # ctc_loss's gradient, staged for the backward graph
         self.roww = torch.zeros(B, dtype=F32, device=dev)                            # weight of utterance b's softmax term
         self.one = torch.ones(1, dtype=F32, device=dev)
         self.v_pad = v_pad
+
+
+    def refresh_labels(self, targets) -> None:
+        """(Re)derive everything that depends on the label VALUES, written in place: a loader that refills the same static
+        target buffer with new labels of the same lengths keeps its batch signature (addresses, shapes, lengths), so
+        JointTrainStep calls this on every step - a handful of tiny device ops - instead of trusting a plan built from the
+        first batch's contents."""
+        dev, B, L = targets.device, self.B, self.L
+        tl = self._tl
+        valid = torch.arange(L, device=dev).view(1, -1) < tl.view(-1, 1)
+        # ext = [blank, label 0, label 1, ...]: the class of an entry is the index of the FIRST entry with the same vocabulary
+        # id (a label equal to the blank id - this repository's synthetic ground truth ends every utterance with id 0 - is the
+        # blank's class 0, exactly as ctc_loss treats it on the dense alphabet)
+        ext = torch.cat([torch.full((B, 1), self.blank, dtype=torch.int64, device=dev), targets.to(torch.int64)], 1)     # [B, L + 1]
+        first = (ext.unsqueeze(2) == ext.unsqueeze(1)).to(torch.int8).argmax(dim=2)                                      # [B, L + 1]
+        self.classes.copy_(first[:, 1:])
+        self.cols.copy_(ext)
+        idx = torch.arange(L + 1, device=dev).view(1, -1)
+        keep = (first == idx) & torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), valid], 1)
+        self.scat.copy_(torch.where(keep, ext, torch.full_like(ext, -1)))
+        # an utterance whose frames cannot spell its labels has an infinite loss: zero_infinity drops it from the objective
+        rep = ((targets[:, 1:] == targets[:, :-1]) & valid[:, 1:]).sum(1) if L > 1 else torch.zeros(B, dtype=torch.int64, device=dev)
+        self.finite.copy_(self._il >= tl + rep)
 
 
 class CtcProjFn(torch.autograd.Function):
@@ -678,6 +693,29 @@ class AttnTap:
         AttnTap.active = self._prev
         return False
 
+    @staticmethod
+    def record(mod, Q, K, q_rows, k_rows, causal):
+        """append `mod`'s probability map for projected queries Q / keys K (row matrices, head h at columns h * d_k)"""
+        s = mod._st
+        scale = 1.0 / math.sqrt(s.d_model // s.n_head)
+        AttnTap.active.maps.append((mod, nv.attn_probs(Q, K, q_rows.off, q_rows.len, k_rows.off, k_rows.len, s.n_head, q_rows.max_len,
+                                                       k_rows.max_len, causal, scale)))
+
+    @staticmethod
+    def record_chain(layers, pres, q_rows, kv_rows):
+        """The maps of a layer stack whose forward ran as row chains WITHOUT the autograd replay (no gradient wanted: the
+        sublayer Functions, which feed the tap otherwise, are never called).  pres: chains.SubPre tuples per layer -
+        (self-attention, feed-forward) for an encoder, (self-attention, encoder-decoder attention, feed-forward) for a decoder."""
+        if AttnTap.active is None or pres is None:
+            return
+        for layer, pre in zip(layers, pres):
+            a = pre[0]
+            d = layer.slf_attn._st.d_model
+            AttnTap.record(layer.slf_attn, a.qkv[:, :d], a.qkv[:, d:2 * d], q_rows, q_rows, len(pre) == 3)
+            if len(pre) == 3:
+                b = pre[1]
+                AttnTap.record(layer.enc_attn, b.qkv, b.kvbuf[:, :d], q_rows, kv_rows, False)
+
     def of(self, module, Lq, Lk):
         """the maps of `module`'s calls, zero-padded to [B, h, Lq, Lk] (the padded batch layout of the reference)"""
         out = []
@@ -707,8 +745,7 @@ class MhaFn(torch.autograd.Function):
                 x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, any(ctx.needs_input_grad), scale)
         if AttnTap.active is not None:
             Qm, Km = (qkv[:, :d], qkv[:, d:2 * d]) if x_kv is None else (qkv, kvbuf[:, :d])
-            AttnTap.active.maps.append((mod, nv.attn_probs(Qm, Km, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len,
-                                                           k_rows.max_len, causal, scale)))
+            AttnTap.record(mod, Qm, Km, q_rows, k_rows, causal)
         ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask

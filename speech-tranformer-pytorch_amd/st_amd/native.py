@@ -28,6 +28,7 @@ _c_long = ctypes.c_long
 # name -> argtypes (restype is int everywhere); must mirror include/st_hip.h exactly.
 SIGNATURES = {
     "st_version": [],
+    "st_env_refresh": [],
     "st_gemm": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                 _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p],
     "st_gemm_stacked": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
@@ -105,10 +106,10 @@ SIGNATURES = {
                   _c_void_p, _c_int],
     "st_zero_tails": [_c_void_p, _c_void_p, _c_int],
     "st_grad_norm_blocks": [],
-    "st_grad_norm": [_c_void_p, _c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p],
+    "st_grad_norm": [_c_void_p, _c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_float],
     "st_cache_reorder": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int],
     "st_adam_clip": [_c_void_p, _c_ll, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                     _c_float, _c_float, _c_float, _c_float],
+                     _c_float, _c_float, _c_float, _c_float, _c_float],
     "st_probe_tr16": [_c_void_p, _c_void_p, _c_void_p],
     "st_probe_mfma": [_c_void_p, _c_void_p, _c_void_p, _c_void_p],
 }
@@ -216,6 +217,12 @@ def _stream() -> int:
     """Raw handle of torch's current stream on the current device (torch.cuda.current_stream() builds a Stream object
     per call: ~8 us of host time, measurable in the eager decode loop's ~100 launches per step)."""
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def env_refresh() -> None:
+    """After changing ST_ATTN_FWD64 / ST_ATTN_XS / ST_ATTN_BWD64 in os.environ: make the library re-read them (it caches the
+    switches at its first attention call; the production dispatch never calls getenv)."""
+    load().st_env_refresh()
 
 
 def _check(rc: int, what: str) -> None:
@@ -1124,9 +1131,9 @@ def grad_norm_scratch(device):
     return torch.zeros(_norm_blocks() + 1, dtype=F32, device=device)
 
 
-def grad_norm(g, scratch, out, step=None):
-    """out (fp32 scalar tensor) = ||g||_2 over the flat fp32 buffer g; step (fp32 scalar tensor, optional) += 1 - see
-    st_grad_norm."""
+def grad_norm(g, scratch, out, step=None, grad_scale=1.0):
+    """out (fp32 scalar tensor) = grad_scale * ||g||_2 over the flat fp32 buffer g; step (fp32 scalar tensor, optional) += 1 -
+    see st_grad_norm."""
     if not (g.is_cuda and g.dtype == F32 and g.is_contiguous() and g.numel() % 4 == 0):
         raise ValueError("grad_norm: g must be a contiguous fp32 GPU buffer of a multiple of 4 elements")
     _vec(scratch, F32, _norm_blocks() + 1, "scratch")
@@ -1134,7 +1141,8 @@ def grad_norm(g, scratch, out, step=None):
         if t is not None and not (t.is_cuda and t.dtype == F32 and t.numel() == 1):
             raise ValueError("grad_norm: %s must be an fp32 scalar on the GPU" % nm)
     _tag("grad_norm", g.numel(), io=(4.0 * g.numel(),))
-    _check(load().st_grad_norm(_stream(), g.data_ptr(), g.numel(), scratch.data_ptr(), out.data_ptr(), _p(step)), "st_grad_norm")
+    _check(load().st_grad_norm(_stream(), g.data_ptr(), g.numel(), scratch.data_ptr(), out.data_ptr(), _p(step), float(grad_scale)),
+           "st_grad_norm")
     return out
 
 
@@ -1146,17 +1154,18 @@ def cast_bf16(src, dst):
     return dst
 
 
-def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps):
-    """In place: g *= min(1, max_norm / (gnorm + 1e-6)); (p, m, v) <- Adam(p, g, m, v; lr, step).  lr / step / gnorm are
-    0-dim fp32 device tensors (gnorm None: no clipping)."""
+def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps, grad_scale=1.0):
+    """In place: g *= grad_scale * min(1, max_norm / (gnorm + 1e-6)); (p, m, v) <- Adam(p, g, m, v; lr, step).  lr / step /
+    gnorm are 0-dim fp32 device tensors (gnorm None: no clipping); grad_scale: see st_adam_clip (1 / world behind a summing
+    all-reduce)."""
     for t in (p, g, m, v):
         assert t.is_cuda and t.dtype == F32 and t.is_contiguous() and t.numel() == p.numel()
     for t in (lr, step) + ((gnorm,) if gnorm is not None else ()):
         assert t.is_cuda and t.dtype == F32 and t.numel() == 1
     _tag("adam_clip", p.numel(), io=(32.0 * p.numel(),))      # p, g, m, v read; p, m, v written; g zeroed (fp32)
     _check(load().st_adam_clip(_stream(), p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr.data_ptr(),
-                               step.data_ptr(), _p(gnorm), float(max_norm), float(beta1), float(beta2), float(eps)),
-           "st_adam_clip")
+                               step.data_ptr(), _p(gnorm), float(max_norm), float(beta1), float(beta2), float(eps),
+                               float(grad_scale)), "st_adam_clip")
 
 
 def probe_tr16(inp, out):

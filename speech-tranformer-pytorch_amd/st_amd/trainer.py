@@ -205,21 +205,26 @@ class TrainStep:
         others = [arena.offset[id(p)] for p in arena.params if id(p) not in enc]
         return cut if not others or min(others) >= cut else arena.total      # interleaved layout: nothing fires early
 
-    def _clip_and_update(self):
+    def _fold_scale(self) -> bool:
+        """The rank average's 1 / world is folded into the norm + clip + Adam kernels (no pass of its own over the flat buffer)."""
+        return getattr(self.optimizer, "arena", None) is not None
+
+    def _clip_and_update(self, grad_scale: float = 1.0):
         if getattr(self.optimizer, "arena", None) is not None:
             # global norm (one launch over the flat buffer: st_grad_norm, which also advances the step count), then clip +
-            # Adam as one pass (st_adam_clip)
-            return self.optimizer.step_captured(grad_norm=True, max_norm=self.max_grad_norm)
+            # Adam as one pass (st_adam_clip); grad_scale: the reducer left the rank sum (GradReducer.synchronize(divide=False))
+            return self.optimizer.step_captured(grad_norm=True, max_norm=self.max_grad_norm, grad_scale=grad_scale)
+        if grad_scale != 1.0:
+            arena_of(self.model).grad.mul_(grad_scale)
         grad_norm = clip_grad_norm_flat(arena_of(self.model), self.max_grad_norm)
         self.optimizer.step_captured()
         return grad_norm
 
     def _eager(self, batch, layouts=None):
         loss = self._forward_backward(*batch, layouts=layouts)
-        if self.reducer is not None:
-            self.reducer.synchronize()
+        scale = self.reducer.synchronize(divide=not self._fold_scale()) if self.reducer is not None else 1.0
         self.optimizer.update_learning_rate(self.global_step)
-        return loss, self._clip_and_update()
+        return loss, self._clip_and_update(scale)
 
     def __call__(self, inputs, input_lengths, targets, target_lengths, ground_truth):
         """inputs [B, T, F] / targets, ground_truth [B, L] on the GPU; lengths on host or GPU."""
@@ -330,9 +335,9 @@ class TrainStep:
         if cap.g_enc is not None:
             self.reducer.fire_from(cap.dec_lo)           # decoder-side buckets: exchanged while the encoder's backward runs
             cap.g_enc.replay()
-            self.reducer.synchronize()
+            self.reducer.synchronize(divide=not self._fold_scale())      # (the captured update applies 1 / world: _capture)
         elif self.reducer is not None and cap.g_opt is not None:
-            self.reducer.reduce_all()
+            self.reducer.reduce_all(divide=not self._fold_scale())
         # (cap.g_opt None with a reducer: the collectives were captured inside g_fb - nothing happens on the host)
         if cap.g_opt is not None:
             cap.g_opt.replay()
@@ -383,8 +388,7 @@ class TrainStep:
                     cap.loss = self._forward_decoder_backward(*batch, layouts=layouts)
                     self.reducer.fire_from(self._decoder_grad_start())
                     self._encoder_backward(fire_layers=True)
-                    self.reducer.synchronize()
-                    cap.gnorm = self._clip_and_update()
+                    cap.gnorm = self._clip_and_update(self.reducer.synchronize(divide=not self._fold_scale()))
             except Exception as e:  # noqa: BLE001 - a process group / RCCL build that cannot be captured: eager collectives
                 failure = e
             # every rank must take the same mode (a rank replaying captured collectives beside one that issues them from the
@@ -431,8 +435,11 @@ class TrainStep:
                 cap.loss = self._forward_backward(*batch, captured=True, layouts=layouts)
                 cap.gnorm = self._clip_and_update()
             return cap
+        # (the collectives run eagerly between the graphs and leave the rank SUM: the captured update carries the 1 / world)
+        left = 1.0 / self.reducer.world if (self.reducer is not None and self.reducer.active and self.reducer.world > 1
+                                            and self._fold_scale()) else 1.0
         with torch.cuda.graph(cap.g_opt, pool=pool, **mode):
-            cap.gnorm = self._clip_and_update()
+            cap.gnorm = self._clip_and_update(left)
         # capture only records; the step that triggered it is executed by the replay that follows
         return cap
 
@@ -530,10 +537,24 @@ class JointTrainStep:
     def _part_b(self, enc, enc_in, lp, plan):
         with deferred_wgrads(True):
             torch.autograd.backward([enc, lp], [enc_in.grad, plan.g_lp])
-        gnorm = self.optimizer.step_captured(grad_norm=True, max_norm=self.max_grad_norm) \
-            if getattr(self.optimizer, "arena", None) is not None else None
-        if self.head_optimizer is not None:
-            self.head_optimizer.step()
+        if getattr(self.optimizer, "arena", None) is None:
+            if self.head_optimizer is not None:
+                self.head_optimizer.step()
+            return None
+        if self.head_optimizer is None:
+            return self.optimizer.step_captured(grad_norm=True, max_norm=self.max_grad_norm)
+        # train.py:45 clips everything that is being optimised: the global norm runs over the model's flat gradient AND the
+        # CTC head's (its buffers live outside the arena), and both are scaled by the same coefficient
+        arena = arena_of(self.model)
+        self.optimizer.norm_scratch(arena.grad.device)
+        g_model = nv.grad_norm(arena.grad, self.optimizer._norm_scratch, torch.empty((), dtype=torch.float32, device=arena.grad.device))
+        gw, gb = self.head._st_gw, self.head._st_gb
+        gnorm = torch.sqrt(g_model * g_model + (gw * gw).sum() + (gb * gb).sum())
+        coef = torch.clamp(self.max_grad_norm / (gnorm + 1e-6), max=1.0)
+        gw.mul_(coef)
+        gb.mul_(coef)
+        self.optimizer.step_captured(grad_norm=gnorm, max_norm=self.max_grad_norm)       # (advances the step count itself)
+        self.head_optimizer.step()
         return gnorm
 
     def _joint(self, att, ctc):
@@ -567,6 +588,10 @@ class JointTrainStep:
             # the CTC labels are the ground truth of train.py:40 (label ids, PAD = blank = 0 past each length)
             self._plan = self.head.plan(batch[4], batch[3], batch[1], self._layouts[0])
             self._keep = batch
+        else:
+            # same addresses, shapes and lengths - but the CONTENTS of the label buffer may be a new batch's (a loader that
+            # refills static buffers): the plan's label-derived tensors are a derived copy, re-made in place every step
+            self._plan.refresh_labels(batch[4])
         plan, layouts = self._plan, self._layouts
         self.optimizer.update_learning_rate(self.global_step)
         main = torch.cuda.current_stream()
@@ -579,8 +604,25 @@ class JointTrainStep:
             gnorm = self._part_b(enc, enc_in, lp, plan)
             return self._joint(att, ctc), att, ctc, gnorm
         if self._cap is None:
+            # as TrainStep._capture: everything lazily created must exist BEFORE the capture - Adam's flat state (a captured
+            # zero-fill would reset it on every replay), the process-wide scratch the step's kernels share (split-K partials and
+            # tickets, the norm's block partials: inside a capture they would land in this graph's private pool), the seed
             if hasattr(self.optimizer, "_flat_state") and getattr(self.optimizer, "arena", None) is not None:
                 self.optimizer._flat_state()
+            nv.splitk_scratch(inputs.device)
+            if hasattr(self.optimizer, "norm_scratch"):
+                self.optimizer.norm_scratch(inputs.device)
+            if self._seed is None or self._seed.device != inputs.device:
+                self._seed = torch.empty((), dtype=torch.float32, device=inputs.device)
+            if self.head_optimizer is not None:
+                groups = self.head_optimizer.param_groups
+                if not all(g.get("capturable", False) for g in groups):
+                    raise ValueError("JointTrainStep(use_graph=True): head_optimizer must be built with capturable=True "
+                                     "(its step is captured in graph B)")
+                if any(len(self.head_optimizer.state.get(q, {})) == 0 for g in groups for q in g["params"]):
+                    raise ValueError("JointTrainStep(use_graph=True): head_optimizer has no state yet - run at least one eager "
+                                     "step first (graph_warmup >= 1): state created inside the capture would be reset by "
+                                     "every replay")
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
             ga1, ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -83,6 +83,9 @@ class Encoder(nn.Module):
                 with torch.no_grad():
                     e_out, pres = ec.forward(self.layer_stack, e, rows, need_bwd)
                 if not need_bwd:
+                    # (no autograd replay below, so the sublayer Functions - whose forward feeds an active AttnTap - never
+                    # run: return_attns under torch.no_grad() takes its maps from the chains' own q | k | v buffers)
+                    F_.AttnTap.record_chain(self.layer_stack, pres, rows, rows)
                     return e_out, rows
             for l, layer in enumerate(self.layer_stack):
                 e, link = layer.forward_rows(e, rows, link, pre=pres[l] if pres is not None else None)
@@ -162,6 +165,7 @@ class Decoder(nn.Module):
                     with torch.no_grad():
                         y_out, pres = dc.forward(self.layer_stack, y, kv, t_rows, in_rows, need_bwd)
                     if not need_bwd:
+                        F_.AttnTap.record_chain(self.layer_stack, pres, t_rows, in_rows)      # (see Encoder.forward_rows)
                         return y_out, t_rows
                 for l, layer in enumerate(self.layer_stack):
                     y, link = layer.forward_rows(y, kv, t_rows, in_rows, F_.CrossKvSlot(ckv, l), link,

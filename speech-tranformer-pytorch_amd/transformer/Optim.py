@@ -62,21 +62,29 @@ class ScheduledOptim(object):
             self._norm_scratch = nv.grad_norm_scratch(device)
         return self._norm_scratch
 
-    def step_captured(self, grad_norm=None, max_norm=None):
+    def step_captured(self, grad_norm=None, max_norm=None, grad_scale=1.0):
         """The update alone (rate already set with update_learning_rate) - what a HIP graph captures.
         With ``grad_norm`` and ``max_norm`` on the flat-arena path, gradient clipping (train.py:45) and the Adam update are
         two launches over the buffers: ``st_grad_norm`` (the global norm; also advances the step count) and
         ``st_adam_clip`` (clip + the arithmetic of torch's fused Adam, on this optimizer's own state tensors).
-        grad_norm: True = compute it here (returned as a device scalar), or a device scalar already computed."""
+        grad_norm: True = compute it here (returned as a device scalar), or a device scalar already computed.
+        grad_scale: the gradient buffer still has to be multiplied by this (st_amd.dp.GradReducer.synchronize(divide=False)
+        leaves the rank SUM and returns 1 / world): folded into the norm and the clip coefficient - no pass of its own."""
         group = self.optimizer.param_groups[0]
         plain = not (group["weight_decay"] or group["amsgrad"] or group["maximize"])
         if self.arena is None or grad_norm is None:
+            if grad_scale != 1.0:
+                for q in self.optimizer.param_groups[0]["params"]:
+                    if q.grad is not None:
+                        q.grad.mul_(grad_scale)
             self.optimizer.step()
             return None
         if not plain:
             # weight decay / amsgrad / maximize: torch's own Adam does the update, the clipping still happens here (train.py:45
             # clips whatever optimizer follows) - the norm over the flat gradient, the gradient scaled in place, no host sync
             g = self._flat_state()[0].grad
+            if grad_scale != 1.0:
+                g.mul_(grad_scale)
             if grad_norm is True:
                 grad_norm = torch.linalg.vector_norm(g.float())
             if max_norm is not None:
@@ -87,12 +95,13 @@ class ScheduledOptim(object):
         p, st = self._flat_state()
         if grad_norm is True:
             self.norm_scratch(p.device)
-            grad_norm = nv.grad_norm(p.grad, self._norm_scratch, torch.empty((), dtype=torch.float32, device=p.device), step=st["step"])
+            grad_norm = nv.grad_norm(p.grad, self._norm_scratch, torch.empty((), dtype=torch.float32, device=p.device), step=st["step"],
+                                     grad_scale=grad_scale)
         else:
             st["step"].add_(1)
         beta1, beta2 = group["betas"]
         nv.adam_clip(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], self.lr_tensor, st["step"], grad_norm, max_norm,
-                     beta1, beta2, group["eps"])
+                     beta1, beta2, group["eps"], grad_scale=grad_scale)
         return grad_norm
 
     def zero_grad(self):

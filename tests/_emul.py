@@ -116,8 +116,8 @@ def gemm_ws(X, W, out, bias=None, relu=False, drop=None, stack=None):
     return gemm(X, W, out, bias=bias, epi=nv.EPI_BF16_RELU if relu else nv.EPI_BF16, drop=drop, stack=stack)
 
 
-def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps):
-    coef = 1.0 if gnorm is None else min(float(max_norm) / (float(gnorm) + 1e-6), 1.0)
+def adam_clip(p, g, m, v, lr, step, gnorm, max_norm, beta1, beta2, eps, grad_scale=1.0):
+    coef = (1.0 if gnorm is None else min(float(max_norm) / (float(gnorm) + 1e-6), 1.0)) * float(grad_scale)
     g.mul_(coef)
     m.lerp_(g, 1.0 - beta1)
     v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
@@ -577,8 +577,8 @@ def grad_norm_scratch(device):
     return torch.zeros(1025, dtype=torch.float32, device=device)
 
 
-def grad_norm(g, scratch, out, step=None):
-    out.copy_(torch.linalg.vector_norm(g.double()).float())
+def grad_norm(g, scratch, out, step=None, grad_scale=1.0):
+    out.copy_((torch.linalg.vector_norm(g.double()) * float(grad_scale)).float())
     if step is not None:
         step.add_(1)
     return out

@@ -42,3 +42,19 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         native.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16),
                     torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+def test_generated_instruction_streams_are_the_generators_output(tmp_path):
+    """csrc/st_attn_bwd64_*.inc are GENERATED (tools/gen_attn_bwd64.py): the committed files must be what the committed
+    generator writes, byte for byte (no hand edit of either side goes unnoticed)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if not k.startswith("BWD64_")}      # the development knobs change the output
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_bwd64.py"), str(tmp_path)], check=True, env=env,
+                   stdout=subprocess.DEVNULL)
+    csrc = os.path.join(ROOT, "speech-tranformer-pytorch_amd", "csrc")
+    made = sorted(os.listdir(tmp_path))
+    assert made == sorted(n for n in os.listdir(csrc) if n.startswith("st_attn_bwd64_") and n.endswith(".inc")), made
+    for name in made:
+        with open(os.path.join(tmp_path, name), "rb") as a, open(os.path.join(csrc, name), "rb") as b:
+            assert a.read() == b.read(), name

@@ -350,6 +350,28 @@ def run_return_attns(golden_dir, device):
                 assert a[b, :, :, nk:].abs().max().item() == 0 if nk < a.shape[3] else True
     for a in sa:          # feature_info_mask: no probability above the diagonal
         assert torch.triu(a.double().cpu(), 1).abs().max().item() == 0
+    # the production width (d_model 256: the layer stacks run as row chains, and under no_grad the sublayer Functions
+    # that feed the tap are never replayed - ADVICE r4): the maps must come out, and equal the grad-enabled call's
+    import oracle as orc
+    cfg2 = U.AttrDict(dict(feature_dim=80, max_inputs_length=100, max_target_length=20, num_enc_layer=2, num_dec_layer=2, n_heads=4,
+                           d_k=64, d_v=64, d_model=256, d_inner_hid=512, dropout=0.0, vocab_size=30, return_attns=True))
+    m2 = M.Transformer(cfg2).eval().to(device)
+    b2 = orc.synthetic_batch(3, 70, 9, 80, 30, seed=4, t_min=30, l_min=4)
+    args = (b2["x"].to(device), b2["in_len"], b2["tokens"].to(device), b2["tgt_len"])
+    with torch.no_grad():
+        lg_n, maps_n = m2(*args)
+    lg_g, maps_g = m2(*args)
+    assert m2.encoder._st_chains[1] is not None and m2.decoder._st_chains[1] is not None, "row chains were not taken"
+    # (not bit-equal: when a backward will follow, the decoder's attentions multiply P in as hi + lo bf16 parts - DESIGN section 3)
+    assert rel(lg_n, lg_g.detach()) < 1e-2
+    for fam_n, fam_g in zip(maps_n, maps_g):
+        assert len(fam_n) == len(fam_g) == 2
+        for a, g in zip(fam_n, fam_g):
+            assert a.shape == g.shape and (a - g).abs().max().item() < 5e-3 and abs(a.sum().item() - g.sum().item()) < 1e-2
+    with torch.no_grad():      # ... and through the stand-alone Encoder / Decoder entry points
+        y, ea2 = m2.encoder(args[0], args[1], return_attns=True)
+        _, sa2, ca2 = m2.decoder(args[2], args[3], args[1], y, return_attns=True)
+    assert len(ea2) == len(sa2) == len(ca2) == 2 and all((a - g).abs().max().item() < 5e-3 for a, g in zip(ea2, maps_g[0]))
 
 
 def test_return_attns_composition(golden_dir):

@@ -657,6 +657,7 @@ def test_attention_backward_streams_with_dropout(lens, p, monkeypatch):
     outs = {}
     for mode in ("e", "1"):
         monkeypatch.setenv("ST_ATTN_BWD64", mode)
+        nv.env_refresh()          # (the library caches its development switches)
         got = [torch.full((M, d), float("nan"), dtype=BF16, device="cuda") for _ in range(3)]
         nv.attn_bwd(Q, K, V, None, dO, lse, delta, *got, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False, scale,
                     work_q=wq, work_k=wk, drop=drop)
@@ -666,7 +667,8 @@ def test_attention_backward_streams_with_dropout(lens, p, monkeypatch):
         assert torch.isfinite(b.float()).all(), nm
         check(b, a, 6e-3, "backward streams with dropout p = %s: %s" % (p, nm))
     # and the masks matter: without them the result is far away (guards against a variant that silently ignores the Drop)
-    monkeypatch.setenv("ST_ATTN_BWD64", "1")
+    monkeypatch.delenv("ST_ATTN_BWD64")
+    nv.env_refresh()
     plain = [torch.zeros(M, d, dtype=BF16, device="cuda") for _ in range(3)]
     nv.attn_bwd(Q, K, V, None, dO, lse, delta, *plain, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False, scale, work_q=wq, work_k=wk)
     assert float((plain[2].float() - outs["1"][2].float()).norm() / outs["1"][2].float().norm()) > 0.1
@@ -756,6 +758,27 @@ def test_adam_clip_matches_torch_clip_and_fused_adam():
     check(m, st["exp_avg"], 1e-6, "adam_clip exp_avg")
     check(v, st["exp_avg_sq"], 1e-6, "adam_clip exp_avg_sq")
     assert float(step) == float(st["step"])
+
+
+def test_grad_scale_folds_the_rank_average_into_norm_clip_and_adam():
+    """grad_scale (st_grad_norm, st_adam_clip): a buffer that holds world x the gradient (what a SUMMING all-reduce leaves,
+    st_amd.dp.GradReducer.synchronize(divide=False)) updated with grad_scale = 1 / world == the divided buffer updated with
+    grad_scale 1: the norm, the clipped gradient left in the buffer, the parameters and both moments."""
+    n, max_norm, world = 40000, 5.0, 8
+    torch.manual_seed(5)
+    p0 = torch.randn(n, device="cuda")
+    lr_t = torch.full((), 2e-3, device="cuda")
+    for gs in (0.2, 0.002):            # clipped / not clipped
+        g = torch.randn(n, device="cuda") * gs
+        res = []
+        for buf, scale in ((g * world, 1.0 / world), (g.clone(), 1.0)):
+            p, m, v, step = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros((), device="cuda")
+            gn = nv.grad_norm(buf, nv.grad_norm_scratch("cuda"), torch.empty((), device="cuda"), step=step, grad_scale=scale)
+            nv.adam_clip(p, buf, m, v, lr_t, step, gn, max_norm, 0.9, 0.98, 1e-9, grad_scale=scale)
+            res.append((gn.clone(), buf, p, m, v))
+        assert abs(float(res[0][0]) - float(torch.linalg.vector_norm(g.double()))) < 1e-5 * float(res[0][0])
+        for a, b, what in zip(res[0], res[1], ("norm", "gradient left in the buffer", "parameters", "exp_avg", "exp_avg_sq")):
+            check(a, b, 1e-6, "grad_scale: " + what)
 
 
 def test_zero_tails_zeroes_exactly_the_unassigned_rows():

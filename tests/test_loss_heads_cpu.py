@@ -126,3 +126,28 @@ def test_ctc_head_over_ragged_rows_small_alphabet_vs_dense_reference():
         if ilen is in_len2:                         # the infeasible utterance contributes nothing, to the value or to any gradient
             o, n = segs[1][1], segs[1][2]
             assert float(got[1][o:o + n].abs().max()) == 0.0
+
+
+def test_ctc_plan_refresh_labels_equals_a_fresh_plan():
+    """functional.CtcPlan.refresh_labels (called by JointTrainStep on every step: a loader may refill the label buffer in
+    place) must leave exactly what a plan built from the new labels holds - in the SAME tensors (a captured step reads them by
+    address)."""
+    import torch
+    from st_amd import functional as F_
+    torch.manual_seed(1)
+    B, L, V = 5, 9, 12
+    tgt_len = torch.tensor([9, 4, 7, 1, 6])
+    in_len = torch.tensor([30, 12, 20, 7, 11])
+    rows = F_.Rows.packed(in_len, "cpu")
+    valid = torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)
+    lab_a = torch.where(valid, torch.randint(1, V, (B, L)), torch.zeros(B, L, dtype=torch.int64))
+    lab_b = torch.where(valid, torch.randint(1, V, (B, L)), torch.zeros(B, L, dtype=torch.int64))
+    lab_b[0, :5] = 3                                     # repeated labels: the feasibility flag depends on the VALUES
+    plan = F_.CtcPlan(lab_a, tgt_len, in_len, rows, 0, 16)
+    ptrs = [t.data_ptr() for t in (plan.classes, plan.cols, plan.scat, plan.finite)]
+    plan.refresh_labels(lab_b)
+    fresh = F_.CtcPlan(lab_b, tgt_len, in_len, rows, 0, 16)
+    assert ptrs == [t.data_ptr() for t in (plan.classes, plan.cols, plan.scat, plan.finite)]
+    for name in ("classes", "cols", "scat", "finite"):
+        assert torch.equal(getattr(plan, name), getattr(fresh, name)), name
+    assert not torch.equal(plan.classes, F_.CtcPlan(lab_a, tgt_len, in_len, rows, 0, 16).classes)

@@ -516,3 +516,73 @@ def test_graph_cache_serves_a_cycle_of_batches():
     for (l0, g0), (l1, g1) in zip(o0, o1):
         assert abs(l0 - l1) <= 1e-3 * abs(l0) and abs(g0 - g1) <= 1e-2 * abs(g0), (o0, o1)
     assert float((p0 - p1).norm() / p0.norm()) < 5e-3
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_joint_trainstep_follows_refilled_labels_and_clips_the_head(use_graph):
+    """JointTrainStep (BASELINE config 4), two properties ADVICE r4 asked for:
+    (1) a loader that refills the SAME static label buffer with new labels of the same lengths (the batch signature - addresses,
+        shapes, lengths - does not change) must train CTC against the new labels: the step on refilled buffers reports the CTC
+        loss a fresh JointTrainStep reports for those labels;
+    (2) the clip norm runs over the model's gradient AND the CTC head's (train.py:45 clips everything that is optimised), and
+        the head's gradient is scaled by the same coefficient."""
+    import torch
+    from st_amd import synthetic
+    from st_amd.trainer import JointTrainStep
+    from transformer.Loss import CTCAttentionLoss
+    from transformer.Models import Transformer
+    from transformer.Optim import ScheduledOptim
+    from transformer.Utils import AttrDict, init_parameters
+
+    cfg = AttrDict(dict(feature_dim=80, max_inputs_length=200, max_target_length=32, num_enc_layer=2, num_dec_layer=2, n_heads=4,
+                        d_k=64, d_v=64, d_model=256, d_inner_hid=512, dropout=0.0, vocab_size=30))
+    inputs, targets, in_len, tgt_len, truth = synthetic.make_batch(4, 160, 20, 80, 30, seed=1, t_min=100, l_min=6)
+    _, _, _, _, truth2 = synthetic.make_batch(4, 160, 20, 80, 30, seed=7, t_min=100, l_min=6)
+    L = truth.shape[1]
+    valid = torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)
+    labels2 = torch.where(valid, truth2[:, :L].clamp_min(1), torch.zeros_like(truth))       # other labels, the same lengths
+
+    def build(max_norm):
+        torch.manual_seed(0)
+        model = Transformer(cfg).cuda()
+        init_parameters(model)
+        model.eval()
+        head = CTCAttentionLoss(256, 30, ctc_weight=0.3).cuda()
+        head._st_prepare("cuda")
+        opt = ScheduledOptim(model, 256, AttrDict(n_warmup_steps=1e9))       # ~zero learning rate: the weights stay put
+        hopt = torch.optim.Adam(head.parameters(), lr=1e-12, betas=(0.9, 0.98), eps=1e-9, capturable=True)
+        return model, head, JointTrainStep(model, opt, head, max_grad_norm=max_norm, head_optimizer=hopt, use_graph=use_graph,
+                                           graph_warmup=1)
+
+    x, t, gt = inputs.cuda(), targets.cuda(), truth.cuda()
+    _, _, step = build(1e9)
+    for _ in range(3):
+        first = step(x, in_len, t, tgt_len, gt)
+    gt.copy_(labels2)                                   # the loader refills the buffer in place
+    for _ in range(2):
+        refilled = step(x, in_len, t, tgt_len, gt)
+    torch.cuda.synchronize()
+    _, _, fresh_step = build(1e9)
+    for _ in range(3):
+        fresh = fresh_step(x, in_len, t, tgt_len, gt)
+    torch.cuda.synchronize()
+    assert abs(float(first[2]) - float(fresh[2])) > 1e-2 * abs(float(fresh[2])), "the two label sets must differ in their CTC loss"
+    assert abs(float(refilled[2]) - float(fresh[2])) < 2e-3 * abs(float(fresh[2])), (float(refilled[2]), float(fresh[2]))
+    assert abs(float(refilled[1]) - float(fresh[1])) < 2e-3 * abs(float(fresh[1]))
+
+    # (2) unclipped run: the norms of the two gradient buffers; clipped run: the reported norm and both buffers scaled
+    from st_amd.arena import arena_of
+    m0, h0, s0 = build(1e9)
+    m1, h1, s1 = build(0.05)
+    for _ in range(3):
+        r0 = s0(x, in_len, t, tgt_len, gt)
+        r1 = s1(x, in_len, t, tgt_len, gt)
+    torch.cuda.synchronize()
+    g_model, g_head = arena_of(m0).grad.double(), torch.cat([h0._st_gw.reshape(-1), h0._st_gb]).double()
+    want = float(torch.sqrt((g_model * g_model).sum() + (g_head * g_head).sum()))
+    assert abs(float(r0[3]) - want) < 1e-3 * want and abs(float(r1[3]) - want) < 1e-2 * want, (float(r0[3]), float(r1[3]), want)
+    coef = 0.05 / (want + 1e-6)
+    assert coef < 0.5
+    c_head = torch.cat([h1._st_gw.reshape(-1), h1._st_gb]).double()
+    assert float((c_head - coef * g_head).norm() / (coef * g_head).norm()) < 2e-2
+    assert float((arena_of(m1).grad.double() - coef * g_model).norm() / (coef * g_model).norm()) < 2e-2

@@ -72,6 +72,7 @@ def run_case(lens, seed, check_ref=True, time_it=False, label=""):
     outs = {}
     for mode in ("0", "1"):
         os.environ["ST_ATTN_BWD64"] = mode
+        nv.env_refresh()
         dQ = torch.full((M, d), float("nan"), dtype=BF16, device=dev)
         dK, dV = torch.full_like(dQ, float("nan")), torch.full_like(dQ, float("nan"))
         nv.attn_bwd(Q, K, V, None, dOg, lse, delta, dQ, dK, dV, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False, scale,
@@ -99,6 +100,7 @@ def run_case(lens, seed, check_ref=True, time_it=False, label=""):
     if time_it:
         for mode in ("0", "1"):
             os.environ["ST_ATTN_BWD64"] = mode
+            nv.env_refresh()
             dQ, dK, dV = (torch.empty(M, d, dtype=BF16, device=dev) for _ in range(3))
             f = lambda: nv.attn_bwd(Q, K, V, None, dOg, lse, delta, dQ, dK, dV, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False,
                                     scale, work_q=wq, work_k=wk)

@@ -42,6 +42,7 @@ def run_case(lens, seed, p=0.1, time_it=False, label=""):
     outs = {}
     for mode in ("e", "1"):
         os.environ["ST_ATTN_BWD64"] = mode
+        nv.env_refresh()
         dQ, dK, dV = (torch.full((M, d), float("nan"), dtype=BF16, device=dev) for _ in range(3))
         nv.attn_bwd(Q, K, V, None, dO, lse, delta, dQ, dK, dV, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False, scale,
                     work_q=wq, work_k=wk, drop=drop)
@@ -61,6 +62,7 @@ def run_case(lens, seed, p=0.1, time_it=False, label=""):
     if time_it:
         for mode in ("e", "1"):
             os.environ["ST_ATTN_BWD64"] = mode
+            nv.env_refresh()
             dQ, dK, dV = (torch.empty(M, d, dtype=BF16, device=dev) for _ in range(3))
             for parts, nm in ((3, "all"), (1, "dq"), (2, "dkv")):
                 f = lambda: nv.attn_bwd(Q, K, V, None, dO, lse, delta, dQ, dK, dV, q_off, q_len, q_off, q_len, H, max(lens), max(lens),

@@ -44,6 +44,7 @@ def bench(lens, label, modes=("1",)):
     out = []
     for mode in modes:
         os.environ["ST_ATTN_BWD64"] = mode
+        nv.env_refresh()
         for parts, nm, mf in ((3, "all", 28), (1, "dq", 12), (2, "dkv", 16)):
             f = lambda: nv.attn_bwd(Q, K, V, None, dO, lse, delta, dQ, dK, dV, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False,
                                     scale, parts=parts, work_q=wq, work_k=wk)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Dev: per-workgroup clock stamps of the hand-scheduled attention backward (merged launch, config-2 encoder batch):
-effective shader clock, item durations by body, slot occupancy over time, the drain."""
+effective shader clock, item durations by body, slot occupancy over time, the drain.
+Needs a DEVELOPMENT build of the library (the shipped one has no trace hook):
+    ST_DEV_TRACE=1 python -m st_amd.build   (or `ST_DEV_TRACE=1 python __graft_entry__.py`) before running this script."""
 import math
 import os
 import sys

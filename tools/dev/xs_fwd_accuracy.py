@@ -42,6 +42,7 @@ for qs, label in ((0.7, "random q, k (|s| ~ 3)"), (0.15, "near-uniform attention
     print(label)
     for mode in ("1", "0"):
         os.environ["ST_ATTN_XS"] = mode
+        nv.env_refresh()
         O = torch.empty(Mq, d, dtype=BF16, device=dev)
         Ores = torch.empty(Mq, d, dtype=BF16, device=dev)
         lse = torch.empty(H * Mq, dtype=F32, device=dev)

@@ -26,7 +26,7 @@ The emitter tracks outstanding LDS / VMEM operations and inserts the counted s_w
 software hazards a hand-written stream must respect (hipcc's recogniser does not see inline asm; rules read off hipcc's
 own output: MFMA result -> VALU / memory read 12 wait states, VALU write -> MFMA source 2, transcendental -> VALU 1).
 
-usage: python tools/gen_attn_bwd64.py     (rewrites the two .inc files; the output is deterministic)
+usage: python tools/gen_attn_bwd64.py [out_dir]     (rewrites the .inc files, by default in csrc/; the output is deterministic)
 """
 import os
 import sys
@@ -961,9 +961,11 @@ def generate(cls):
     raise RuntimeError("the join states did not converge")
 
 
-def main():
+def main(out_dir=None):
+    """out_dir: where the .inc files go (default: the product's csrc/; tests/test_abi_cpu.py generates into a scratch
+    directory and compares with the committed files)"""
     here = os.path.dirname(os.path.abspath(__file__))
-    csrc = os.path.join(os.path.dirname(here), "speech-tranformer-pytorch_amd", "csrc")
+    csrc = out_dir or os.path.join(os.path.dirname(here), "speech-tranformer-pytorch_amd", "csrc")
     for name, cls in (("dkv", DKV), ("dq", DQ), ("dkv_drop", DKVDrop), ("dq_drop", DQDrop)):
         e = generate(cls)
         head = ("// GENERATED by tools/gen_attn_bwd64.py - do not edit.  Instruction stream of the %s body of csrc/st_attn_bwd64.hip\n"
@@ -986,4 +988,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
