@@ -37,6 +37,7 @@ C3 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_
           d_k=64, d_v=64, d_model=512, d_inner_hid=1024, dropout=0.1, vocab_size=4337)
 
 LOGIT_TOL, GRAD_TOL_TENSOR, GRAD_TOL_MEDIAN, GRAD_TOL_GLOBAL = 2e-2, 8e-2, 4e-2, 3e-2
+TRAIN_FLOOR_X = 1.25     # training mode: global / median gradient error within this factor of the bf16 reference's (same masks)
 
 
 def rel(a, b):
@@ -278,7 +279,28 @@ def _gpu_masks(sites, in_len, tgt_len, H):
 
 def test_config2_training_mode_full_size_vs_fp64_oracle():
     """BASELINE config 2 at the benchmarked size under model.train() (how train.py:21 runs the reference): loss, logits and
-    every gradient against the fp64 oracle with the kernels' own masks."""
+    every gradient against the fp64 oracle with the kernels' own masks.
+
+    Three mask draws, because ONE draw says little: over eleven mask seeds (profiles/r05_train_parity_seeds.txt) the ratio of the
+    HIP path's global gradient error to that of the reference arithmetic under bf16 autocast WITH THE SAME MASKS ranges from
+    0.86 to 1.12 (mean 0.94; round 4's "regression" 4.02e-2 -> 4.37e-2 was the draw of seed 20260928, the high end, and is
+    the same to four digits with the general attention-backward kernels: ST_ATTN_BWD64=e).  Bounds: every draw within
+    TRAIN_FLOOR_X of its floor (and the per-tensor bounds of run_train_mode_parity), the MEAN ratio over the draws <= 1.05
+    global and <= 1.08 in the per-tensor median."""
+    res = [run_train_mode_parity(seed, out_name="parity_c2_b32_train%s.txt" % ("" if i == 0 else "_seed%d" % seed))
+           for i, seed in enumerate((20260928, 1, 2))]
+    rg = [r["glob"] / r["floor_glob"] for r in res]
+    rm = [r["med"] / r["floor_med"] for r in res]
+    note = "ratios to the bf16 reference over three mask draws: global %s, median %s" % (
+        " ".join("%.3f" % v for v in rg), " ".join("%.3f" % v for v in rm))
+    with open(os.path.join(ROOT, "gpurun_out", "parity_c2_b32_train.txt"), "a") as f:
+        f.write("# " + note + "\n")
+    assert sum(rg) / len(rg) <= 1.05 and sum(rm) / len(rm) <= 1.08, note
+
+
+def run_train_mode_parity(mask_seed, out_name="parity_c2_b32_train.txt", check=True):
+    """-> dict(glob, med, worst, floor_glob, floor_med, floor_worst, logits); tools/dev/train_parity_sweep.py runs it over
+    several mask seeds and attention-kernel variants (the spread of the figures = their realisation noise)."""
     import transformer.Models as M
     import transformer.Utils as U
     from st_amd import functional as F_, rng, synthetic
@@ -296,7 +318,7 @@ def test_config2_training_mode_full_size_vs_fp64_oracle():
     L = int(tgt_len.max())
     valid = (torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)).cuda()
     rng.seed_tensor("cuda")
-    rng.manual_seed(20260928)
+    rng.manual_seed(mask_seed)
     sites, orig_site = [], rng.site
 
     def recording_site(dev, p):
@@ -358,16 +380,22 @@ def test_config2_training_mode_full_size_vs_fp64_oracle():
              "per-tensor rel-L2 (worst first):   HIP path | reference-in-bf16 | tensor"]
     lines += ["  %.3e  %.3e  %-58s |g| = %.3e" % r for r in rows]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "parity_c2_b32_train.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", out_name), "w") as f:
         f.write("\n".join(lines) + "\n")
     head = "\n".join(lines[:12])
-    # training-mode tolerances: logits / global / median twice the eval-mode ones (dropout thins every reduction) or 1.5x the
-    # bf16 reference's own error; per tensor 1e-1 or 1.5x the bf16 reference's
+    out = dict(glob=glob, med=med, worst=rows[0][0], floor_glob=floor_glob, floor_med=fl[len(fl) // 2], floor_worst=fl[-1],
+               logits=logit_rel, loss=loss.item(), loss_oracle=truth["loss"].item())
+    if not check:
+        return out
+    # training-mode tolerances: as eval mode, measured against the reference's own arithmetic under bf16 autocast WITH THE SAME
+    # MASKS (the noise floor of this configuration): global / median within TRAIN_FLOOR_X x the floor (the absolute bounds only
+    # matter where the floor is tiny); per tensor 1e-1 or 1.5x the bf16 reference's
     assert logit_rel < 2 * LOGIT_TOL, head
     assert abs(loss.item() - truth["loss"].item()) < 2e-2 * truth["loss"].item(), head
-    assert glob < max(2 * GRAD_TOL_GLOBAL, 1.5 * floor_glob) and med < max(2 * GRAD_TOL_MEDIAN, 1.5 * fl[len(fl) // 2]), head
+    assert glob < max(GRAD_TOL_GLOBAL, TRAIN_FLOOR_X * floor_glob) and med < max(GRAD_TOL_MEDIAN, TRAIN_FLOOR_X * fl[len(fl) // 2]), head
     bad = [r for r in rows if r[0] > max(1.25 * GRAD_TOL_TENSOR, 1.5 * r[1])]      # (measured worst: 7.6e-2 vs 9.5e-2 for the bf16 reference)
     assert not bad, "\n".join([head, "outside max(1e-1, 1.5 x bf16 reference):"] + ["  %.3e  %.3e  %s" % r[:3] for r in bad])
+    return out
 
 
 def test_config4_joint_ctc_attention_at_stated_shape_vs_fp64_oracle():
