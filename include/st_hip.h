@@ -186,7 +186,11 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
                  unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed,
                  unsigned drop1_salt,
                  int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
-                 int post_blocks, const float* bp, void* P, int ldp, void* split_work, long long split_bytes);
+                 int post_blocks, const float* bp, void* P, int ldp, void* split_work, long long split_bytes,
+                 float post_kscale);
+/* post_kscale (post_blocks == 3: a q | k | v projection; 0 or 1 = plain): the KEY block leaves as (acc + bias) * post_kscale,
+ * scaled in fp32 before its one rounding to bf16 - pass scale * log2(e) and hand the result to st_attn_fwd / st_attn_bwd /
+ * st_attn_probs with k_prescaled = 1 (below). */
 
 /* relu_bits (st_row_chain: optional output, st_row_chain_bwd: input): which hidden values of the feed-forward sublayer are
  * > 0 after ReLU and dropout (the mask of SubLayers.py:25's backward), one bit per value in a layout private to the two
@@ -240,11 +244,15 @@ int st_attn_tile_rows(int which, int d_k, int max_q, int max_k, int causal);
  * ragged batch is list-scheduled longest-first; a tile is
  * st_attn_tile_rows(0, ...) query rows; NULL = enumerate every tile of every
  * utterance up to max_q.  drop_*: dropout on the attention
- * probabilities (Attention.py:89); pass the same values to st_attn_bwd. */
+ * probabilities (Attention.py:89); pass the same values to st_attn_bwd.
+ * k_prescaled: K holds scale * log2(e) * (key projection) - scaled once, in the fp32 epilogue of the GEMM that produced it
+ * (st_row_chain's post_kscale) - so q . K is the score in the log2 domain and no kernel multiplies per score; forward,
+ * backward and st_attn_probs of one sublayer must agree on it.  Results are those of k_prescaled = 0 on the unscaled keys
+ * up to the one rounding of K; dK (st_attn_bwd) is the gradient of the UNSCALED key projection either way. */
 int st_attn_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
                 int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off, const int* k_len, int B,
                 int H, int d_k, int max_q, int max_k, int q_rows_total, int causal, float scale, const int* work,
-                int n_work, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+                int n_work, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int k_prescaled);
 
 /* The decoder-encoder attention of Layers.py:41 TOGETHER with what stands between it and the self-attention in front of it:
  * cur = LN(ctxA Wo^T + bo + R) (the self-attention's output_linear + residual + layernorm, Attention.py:92-94; out0 / xhat0 /
@@ -287,7 +295,7 @@ int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
                 void* dK, int lddk, void* dV, int lddv, const int* q_off, const int* q_len, const int* k_off,
                 const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
                 float scale, int parts, const int* work_q, int n_work_q, const int* work_k, int n_work_k,
-                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int k_prescaled);
 
 /* row_pos[off[b]+t] = t (and row_seq[...] = b if non-null), t < len[b]:
  * the per-row position the PE add needs (Embedding.py:21-29). */
@@ -426,7 +434,7 @@ int st_ctc_dlogits(st_stream_t stream, const float* logits, int ldl, int R, int 
  * never write these maps. */
 int st_attn_probs(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, float* P, const int* q_off,
                   const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int Lq, int Lk, int causal,
-                  float scale);
+                  float scale, int k_prescaled);
 
 /* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
 int st_probe_tr16(st_stream_t stream, const void* in, void* out);

@@ -31,7 +31,7 @@
 #include "st_attn_common.cuh"
 
 // st_attn64.hip (AttnArgs passed by address: the type is local to each translation unit, the layout is shared)
-extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop);
+extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop, int kpre);
 // st_attn_xs.hip: few queries against many keys (the decoder-encoder attention), 64-wide heads
 extern "C" int st_attn_xs_fwd_launch(hipStream_t stream, const void* args, int grid_x, int drop, const void* f1, const void* self);
 extern "C" void st_attn_xs_self_args(void* out, const void* Q, const void* K, const void* V, int ld, void* O, void* Ores, int ldo,
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, (KS > 1 || DK > 64) ? 1 : 2) void attn_fwd_ker
   const int q = q0 + qw * 32 + (l & 31);
   const bool q_ok = q < lq;
   const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
-  const float c2 = a.scale * 1.4426950408889634f;  // scores -> log2 domain
+  const float c2 = a.c2;  // scores -> log2 domain (scale * log2 e; 1 when K arrives pre-scaled)
   const Drop dr = make_drop(a.drop);
   const int bh = b * a.H + h;
 
@@ -243,7 +243,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
   const int q = q0 + qw * 32 + (l & 31);
   const bool q_ok = q < lq;
   const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
-  const float c2 = a.scale * 1.4426950408889634f;
+  const float c2 = a.c2;
   const Drop dr = make_drop(a.drop);
   const int bh = b * a.H + h;
 
@@ -346,7 +346,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[d][r] += xch[(d * 16 + r) * 64];
   }
-  store_rows<DK>(smem + qw * 32 * DK, dq, a.scale, a.dQ + (size_t)a.q_off[b] * a.lddq + h * DK, a.lddq,
+  store_rows<DK>(smem + qw * 32 * DK, dq, a.dq_scale, a.dQ + (size_t)a.q_off[b] * a.lddq + h * DK, a.lddq,
                  q0 + qw * 32, min(32, lq - (q0 + qw * 32)));
 }
 
@@ -376,7 +376,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int bid, bf
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
   const int key = k0 + wave * 32 + (l & 31);
   const size_t krow = (size_t)a.k_off[b] + min(key, lk - 1);
-  const float c2 = a.scale * 1.4426950408889634f;
+  const float c2 = a.c2;
   const Drop dr = make_drop(a.drop);
   const int bh = b * a.H + h;
 
@@ -601,7 +601,7 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
                            void* O, int ldo, void* Ores, float* lse, const int* q_off, const int* q_len, const int* k_off,
                            const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
                            float scale, const int* work, int n_work, const unsigned* drop_seed, unsigned drop_salt,
-                           int drop_thresh, float drop_scale) {
+                           int drop_thresh, float drop_scale, int k_prescaled) {
   if (B <= 0 || H <= 0 || max_q <= 0 || (work && n_work <= 0)) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
@@ -610,12 +610,12 @@ extern "C" int st_attn_fwd(hipStream_t stream, const void* Q, int ldq, const voi
   AttnArgs a = {};
   a.Q = (const bf16*)Q; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
   a.O = (bf16*)O; a.ldo = ldo; a.Ores = (bf16*)Ores; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
-  a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
+  a.q_rows_total = q_rows_total; a.causal = causal; set_score_scales(a, scale, k_prescaled);
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   a.psplit = (Ores != nullptr && max_q <= 64) ? 1 : 0;     // the decoder's attentions, when a backward will follow
   if (fwd_long64(d_k, max_q, max_k, causal)) {
     dim3 grid(plan(a, work, n_work, B, H, max_q));
-    return st_attn64_fwd_launch(stream, &a, (int)grid.x, drop ? 1 : 0);
+    return st_attn64_fwd_launch(stream, &a, (int)grid.x, drop ? 1 : 0, k_prescaled ? 1 : 0);
   }
   const bool ks2 = key_split(max_q, max_k, causal);   // one 64-row query tile per utterance == the 128-row tile 0
   if (fwd_xs(d_k, max_q, max_k, causal))
@@ -657,7 +657,7 @@ int attn_f1_impl(hipStream_t stream, const void* ctxA, int lda, const void* R, i
   AttnArgs a = {};
   a.Q = (const bf16*)Qout; a.ldq = ldq; a.K = (const bf16*)K; a.ldk = ldk; a.V = (const bf16*)V; a.ldv = ldv;
   a.O = (bf16*)O; a.ldo = ldo; a.Ores = (bf16*)Ores; a.lse = lse; a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
-  a.q_rows_total = q_rows_total; a.causal = 0; a.scale = scale;
+  a.q_rows_total = q_rows_total; a.causal = 0; set_score_scales(a, scale, 0);
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   a.psplit = (Ores != nullptr && max_q <= 64) ? 1 : 0;
   alignas(16) char f1[256];
@@ -708,7 +708,7 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
                            const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q,
                            int max_k, int q_rows_total, int causal, float scale, int parts, const int* work_q,
                            int n_work_q, const int* work_k, int n_work_k, const unsigned* drop_seed,
-                           unsigned drop_salt, int drop_thresh, float drop_scale) {
+                           unsigned drop_salt, int drop_thresh, float drop_scale, int k_prescaled) {
   if (B <= 0 || H <= 0 || max_q <= 0 || max_k <= 0) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
@@ -719,7 +719,7 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   a.O = (bf16*)O; a.ldo = ldo; a.dO = (const bf16*)dO; a.lddo = lddo; a.lse = (float*)lse; a.delta = delta;
   a.dQ = (bf16*)dQ; a.lddq = lddq; a.dK = (bf16*)dK; a.lddk = lddk; a.dV = (bf16*)dV; a.lddv = lddv;
   a.q_off = q_off; a.q_len = q_len; a.k_off = k_off; a.k_len = k_len;
-  a.q_rows_total = q_rows_total; a.causal = causal; a.scale = scale;
+  a.q_rows_total = q_rows_total; a.causal = causal; set_score_scales(a, scale, k_prescaled);
   const bool drop = set_drop(a, drop_seed, drop_salt, drop_thresh, drop_scale);
   dim3 block(256);
   const bool ks2 = key_split(max_q, max_k, causal);

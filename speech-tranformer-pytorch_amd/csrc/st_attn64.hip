@@ -132,10 +132,13 @@ __device__ __forceinline__ void lean_tile(const bf16* ks, const bf16* vs, const 
 // ROW SUM does, and gets it for free - the fragment of ones it is contracted with carries zeros at those keys.  (Subtracting
 // their count from an unmasked sum was tried first: with row sums below ~1 - config 3's heads - the cancellation sent two items
 // in three to the exact fall-back loop, attention forward 0.93 -> 1.54 ms.)
-template <bool LAST>
+// KPRE: the keys arrive pre-scaled (AttnArgs::c2 == 1: K~ = scale log2e K from the projection's fp32 epilogue) - the scores
+// leave the matrix pipe in the log2 domain and are exponentiated as they are (no multiply per score: -1.5 us per launch)
+template <bool LAST, bool KPRE>
 __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, const bf16x8 (&qf)[4], f32x16 (&o)[2], f32x16& lacc,
                                                const bf16x8& ones, float c2, int kleft = 64) {
   constexpr int DK = 64;
+  auto ex = [&](float s) { return __builtin_amdgcn_exp2f(KPRE ? s : s * c2); };
   const int l = threadIdx.x & 63, hi = l >> 5;
   auto ones_of = [&](int half_block) {      // keys half_block * 16 + 8 (j >> 2) + 4 hi + (j & 3): pack_acc8's contraction order
     if constexpr (!LAST) return ones;
@@ -164,7 +167,7 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
   for (int t = 0; t < 4; ++t) {      // S1 = Q K1^T under exp(S0)
     s1 = mfma32(kf[t], qf[t], s1);
 #pragma unroll
-    for (int r = 4 * t; r < 4 * t + 4; ++r) s0[r] = __builtin_amdgcn_exp2f(s0[r] * c2);
+    for (int r = 4 * t; r < 4 * t + 4; ++r) s0[r] = ex(s0[r]);
     SB();
   }
   bf16x8 pa = pack_acc8(s0, 0), pb = pack_acc8(s0, 8);
@@ -172,31 +175,31 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
   // P0 V0 (+ row sums) under exp(S1)
   o[0] = mfma32(va0, pa, o[0]);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+  for (int r = 0; r < 3; ++r) s1[r] = ex(s1[r]);
   SB();
   o[1] = mfma32(va1, pa, o[1]);
 #pragma unroll
-  for (int r = 3; r < 6; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+  for (int r = 3; r < 6; ++r) s1[r] = ex(s1[r]);
   SB();
   lacc = mfma32(ones_of(0), pa, lacc);
   va0 = rd_tr<DK>(vs, 0, 32 + 4 * hi);
   va1 = rd_tr<DK>(vs, 32, 32 + 4 * hi);
 #pragma unroll
-  for (int r = 6; r < 8; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+  for (int r = 6; r < 8; ++r) s1[r] = ex(s1[r]);
   SB();
   o[0] = mfma32(vb0, pb, o[0]);
 #pragma unroll
-  for (int r = 8; r < 11; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+  for (int r = 8; r < 11; ++r) s1[r] = ex(s1[r]);
   SB();
   o[1] = mfma32(vb1, pb, o[1]);
 #pragma unroll
-  for (int r = 11; r < 14; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+  for (int r = 11; r < 14; ++r) s1[r] = ex(s1[r]);
   SB();
   lacc = mfma32(ones_of(1), pb, lacc);
   vb0 = rd_tr<DK>(vs, 0, 48 + 4 * hi);
   vb1 = rd_tr<DK>(vs, 32, 48 + 4 * hi);
 #pragma unroll
-  for (int r = 14; r < 16; ++r) s1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+  for (int r = 14; r < 16; ++r) s1[r] = ex(s1[r]);
   SB();
   pa = pack_acc8(s1, 0);
   pb = pack_acc8(s1, 8);
@@ -210,7 +213,7 @@ __device__ __forceinline__ void lean_tile_pipe(const bf16* ks, const bf16* vs, c
   SB();
 }
 
-template <bool DROP>
+template <bool DROP, bool KPRE>
 __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
   constexpr int DK = 64, NT = 4, ND = 2;
   using G = TileGeo<DK>;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5;
   const int q = q0 + wave * 32 + (l & 31);
   const size_t qrow = (size_t)a.q_off[b] + min(q, lq - 1);
-  const float c2 = a.scale * 1.4426950408889634f;
+  const float c2 = a.c2;      // scale * log2 e, or 1 when the keys arrive pre-scaled (KPRE)
   const Drop dr = make_drop(a.drop);
   const int bh = b * a.H + h;
   const int ntiles = (lk + TILE - 1) / TILE;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
       store(ks);
       load(it + 1);
       __syncthreads();
-      if constexpr (!DROP && !EXACT) lean_tile_pipe<false>(ks, ks + G::E, qf, o, lacc, ones, c2);
+      if constexpr (!DROP && !EXACT) lean_tile_pipe<false, KPRE>(ks, ks + G::E, qf, o, lacc, ones, c2);
       else lean_tile<DROP, false, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
     }
     {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
       store(ks);
       __syncthreads();
       // the last tile: the hot tile again, its row-sum fragments masked (see lean_tile_pipe); the other paths mask per score
-      if constexpr (!DROP && !EXACT) lean_tile_pipe<true>(ks, ks + G::E, qf, o, lacc, ones, c2, lk - it * TILE);
+      if constexpr (!DROP && !EXACT) lean_tile_pipe<true, KPRE>(ks, ks + G::E, qf, o, lacc, ones, c2, lk - it * TILE);
       else lean_tile<DROP, true, EXACT>(ks, ks + G::E, qf, o, m, lsum, lacc, ones, it * TILE, lk, q, dr, bh, c2);
     }
     __syncthreads();           // the tile buffers are free (epilogue patches, or the second attempt)
@@ -317,10 +320,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd64_kernel(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args_, int grid_x, int drop) {
+extern "C" int st_attn64_fwd_launch(hipStream_t stream, const void* args_, int grid_x, int drop, int kpre) {
   const AttnArgs& a = *static_cast<const AttnArgs*>(args_);
   dim3 grid(grid_x), block(256);
-  if (drop) hipLaunchKernelGGL((attn_fwd64_kernel<true>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((attn_fwd64_kernel<false>), grid, block, 0, stream, a);
+  // (the dropout variant and the exact fall-back loop multiply by a.c2 = 1 when the keys are pre-scaled: one instantiation)
+  if (drop) hipLaunchKernelGGL((attn_fwd64_kernel<true, false>), grid, block, 0, stream, a);
+  else if (kpre) hipLaunchKernelGGL((attn_fwd64_kernel<false, true>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_fwd64_kernel<false, false>), grid, block, 0, stream, a);
   return (int)hipGetLastError();
 }

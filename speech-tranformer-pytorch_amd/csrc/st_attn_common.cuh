@@ -34,8 +34,23 @@ struct AttnArgs {
                                   // recomputes - sum_k dS(q, k) = 0 to ~2^-16 instead of ~2^-9 (matters where the keys
                                   // are nearly identical and dQ / dK are differences of almost equal terms); small-Lq only
   float scale;                    // 1/sqrt(d_k)
+  // K as the kernels read it is either the key projection itself (k_prescaled = 0) or K~ = scale * log2(e) * K, scaled ONCE in
+  // the fp32 epilogue of the GEMM that produced it (k_prescaled = 1: st_row_chain's post_kscale): q . k~ is then the score in
+  // the log2 domain as it leaves the matrix pipe - no multiply per score in any kernel, and forward and both backward bodies
+  // exponentiate bit-identical scores.  (Pre-multiplying a register-resident operand and rounding it to bf16 a second time -
+  // rounds 3 / 4 - perturbs every score by ~2^-9 |q||k|, differently in each kernel: profiles/r05_bwd64_accuracy_before.txt.)
+  // c2: what a raw score q . k is multiplied by on its way into exp2 (scale * log2 e, or 1); dq_scale: what the dQ body's
+  // sum dS K is multiplied by (scale, or ln 2 when the K it multiplied was K~).  dK = scale * dS^T Q is the gradient of the
+  // UNSCALED key projection either way (d/dk = scale log2e * d/dk~, and dS_log2 = ln2 dS).
+  float c2, dq_scale;
   DropArgs drop;                  // attention-probability dropout (Attention.py:89), training mode only
 };
+
+inline void set_score_scales(AttnArgs& a, float scale, int k_prescaled) {
+  a.scale = scale;
+  a.c2 = k_prescaled ? 1.f : scale * 1.4426950408889634f;
+  a.dq_scale = k_prescaled ? 0.6931471805599453f : scale;
+}
 
 // blockIdx.x -> (utterance, head, tile)
 __device__ __forceinline__ void decode_item(const AttnArgs& a, int bid, int& b, int& h, int& tile) {

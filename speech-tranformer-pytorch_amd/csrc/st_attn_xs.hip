@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
   const int q0 = tile * XQ;
   if (q0 >= lq) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hi = l >> 5, r32 = l & 31;
-  const float c2 = a.scale * 1.4426950408889634f;
+  const float c2 = a.c2;
   const Drop dr = make_drop(a.drop);
   const int bh = b * a.H + h;
   const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;

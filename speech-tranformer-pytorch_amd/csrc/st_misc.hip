@@ -1460,9 +1460,10 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict_
 
 extern "C" int st_attn_probs(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, float* P, const int* q_off,
                              const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int Lq, int Lk,
-                             int causal, float scale) {
+                             int causal, float scale, int k_prescaled) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
   if (!Q || !K || !P || !q_off || !q_len || !k_off || !k_len) return -1;
+  if (k_prescaled) scale = 0.6931471805599453f;      // K holds scale * log2(e) * k: q . K is the score in the log2 domain
   if (d_k <= 0 || (d_k & 7) || (ldq & 7) || (ldk & 7)) return -2;
   const size_t smem = (size_t)(Lk + d_k + 8) * sizeof(float);
   if (smem > 64 * 1024 || (long long)B * H * Lq > 0x7fffffffLL) return -3;

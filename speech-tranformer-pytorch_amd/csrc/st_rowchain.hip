@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
       f32x16 acc[MT];
       zero_acc(acc);
       block_mma(c, cur, acc);
-      epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0);
+      epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0, nullptr, u == 1 ? a.post_kscale : 1.f);
       __syncthreads();
       tile_out(c, st, a.P + u * 256, a.ldp);
     }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
         f32x16 acc[MT];
         zero_acc(acc);
         block_mma(c, cur, acc);
-        epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0);
+        epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0, nullptr, u == 1 ? a.post_kscale : 1.f);
         __syncthreads();
         tile_out(c, st, a.P + u * 256, a.ldp);
       }
@@ -835,7 +835,8 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
                             float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
                             unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed, unsigned drop1_salt,
                             int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh, float drop2_scale,
-                            int post_blocks, const float* bp, void* P, int ldp, void* split_work, long long split_bytes) {
+                            int post_blocks, const float* bp, void* P, int ldp, void* split_work, long long split_bytes,
+                            float post_kscale) {
   if (M <= 0) return 0;
   const bool pre = R != nullptr, ffn = d_ff > 0, post = post_blocks > 0;
   if (!A || !wfrag || (lda & 7) || (!pre && !ffn && !post)) return -1;
@@ -856,6 +857,7 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   a.drop2.seed = on2 ? drop_seed : nullptr; a.drop2.salt = drop2_salt; a.drop2.thresh = on2 ? drop2_thresh : 0;
   a.drop2.scale = on2 ? drop2_scale : 1.f;
   a.nb = post_blocks; a.bp = bp; a.P = (bf16*)P; a.ldp = ldp;
+  a.post_kscale = (post_blocks == 3 && post_kscale > 0.f) ? post_kscale : 1.f;      // (0 = not given)
   const int mt = row_tiles(M);
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
   const bool drop = on1 || on2;

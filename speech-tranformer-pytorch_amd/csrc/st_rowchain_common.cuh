@@ -35,6 +35,8 @@ struct ChainArgs {
   DropArgs drop1, drop2;
   // POST
   int nb; const float* bp; bf16* P; int ldp;
+  float post_kscale;                 // projection block 1 (the keys of a q | k | v projection) leaves as (acc + bias) * post_kscale:
+                                     // the attention kernels' k_prescaled operand (st_attn_common.cuh); 1 = plain
   // split feed-forward (row_chain_split_kernel): nc partial-sum slots of 32 x 256 fp32 per row block, then one ticket per block
   float* split_ws; unsigned* split_tickets;
 };
@@ -121,7 +123,7 @@ __device__ __forceinline__ void tile_out(const Ctx<MT>& c, const bf16* t, bf16* 
 // bits (optional): this wave's 64 words of ChainArgs::relu_bits for the block
 template <bool RELU, bool DROP, int MT>
 __device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[MT], const float* bias, bf16* t, const Drop& d,
-                                          int gcol0, int ncols, unsigned long long* bits = nullptr) {
+                                          int gcol0, int ncols, unsigned long long* bits = nullptr, float oscale = 1.f) {
   uint32_t pos_lo = 0, pos_hi = 0;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -135,7 +137,7 @@ __device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = acc[mt][4 * g + e] + bb[e];
+        float v = (acc[mt][4 * g + e] + bb[e]) * oscale;
         if (RELU) v = fmaxf(v, 0.f);
         if (DROP && d.on()) v = d.keep(db, e) ? v * d.scale : 0.f;
         o[e] = (bf16)v;

@@ -157,7 +157,8 @@ class ChainHub:
 class SubPre:
     """What a sublayer's autograd Function (functional.MhaFn / FfnFn) takes INSTEAD of launching its forward kernels:
     the tensors those kernels would have produced, and the dropout sites that were used."""
-    __slots__ = ("qkv", "kvbuf", "ctx", "ores", "lse", "h", "bits", "out", "xhat", "rstd", "drop", "drop1", "drop2", "bwd", "key")
+    __slots__ = ("qkv", "kvbuf", "ctx", "ores", "lse", "h", "bits", "out", "xhat", "rstd", "drop", "drop1", "drop2", "bwd", "key",
+                 "kpre")      # kpre: the key columns of qkv hold scale * log2(e) * k (native.attn_fwd's k_prescaled)
 
     def __init__(self):
         for k in self.__slots__:
@@ -276,16 +277,23 @@ class EncoderChains:
     projection - so an encoder layer is two launches (attention, chain) instead of five.  At encoder-sized row counts the
     kernel gives a workgroup 96 rows (24,060 rows = 251 workgroups = one round of the CUs)."""
 
+    PRESCALE_KEYS = True      # (tests switch it off to compare the chain path bit for bit with the per-GEMM path)
+
     def __init__(self, layers, arena):
         self.arena = arena
         self.set = ChainSet(arena.device)
         ids = []
         n = len(layers)
+        # layer 0's q | k | v projection: a chain of its own (three blocks, no PRE / FFN) - every encoder layer's keys leave
+        # their projection PRE-SCALED by scale * log2(e) in the chain's fp32 epilogue (st_row_chain's post_kscale), so that no
+        # attention kernel multiplies per score and forward and backward exponentiate identical scores (st_attn_common.cuh)
+        q0 = self.set.add(blocks_of(layers[0].slf_attn._st.w_qkv))
         for l, layer in enumerate(layers):
             sa, ff = layer.slf_attn._st, layer.pos_ffn._st
             nxt = blocks_of(layers[l + 1].slf_attn._st.w_qkv) if l + 1 < n else []
             ids.append(self.set.add(blocks_of(sa.w_o) + ffn_blocks(ff.w1, ff.w2) + nxt))
         self.set.finalize()
+        self.q0 = self.set.chain(q0, False)
         self.e = [self.set.chain(c, True) for c in ids]
         # backward chains, stored in running order (last layer first): [next layer's q|k|v projection] + feed-forward +
         # output_linear, all read transposed
@@ -316,7 +324,7 @@ class EncoderChains:
     def forward(self, layers, x, rows, need_bwd: bool):
         """The encoder's layer stack on frame rows x [M, 256] (front-end output): per layer self-attention, then the chain.
         -> (output rows, [(self-attention, feed-forward) SubPre per layer]); nothing here is recorded by autograd."""
-        from .functional import attn_work, linear_fwd, rows_buffer
+        from .functional import attn_work, rows_buffer
         M, d = x.shape
         dev = x.device
 
@@ -329,18 +337,20 @@ class EncoderChains:
         s0 = layers[0].slf_attn._st
         H = s0.n_head
         scale = 1.0 / math.sqrt(d // H)
+        kpre = bool(self.PRESCALE_KEYS)
+        kscale = scale * nv.K_LOG2_SCALE if kpre else 0.0
         work = attn_work(rows, rows, False, d // H, H)[0]
         qkv = E(M, 3 * d)
-        linear_fwd(x, s0.w_qkv, qkv, s0.b_qkv)
+        nv.row_chain(x, self.q0, post=(3, s0.b_qkv, qkv), post_kscale=kscale)
         pres = []
         n = len(layers)
         for l, layer in enumerate(layers):
             sa, ff = layer.slf_attn, layer.pos_ffn
             a, f = SubPre(), SubPre()
-            a.qkv, a.drop = qkv, sa._drop(dev)
+            a.qkv, a.drop, a.kpre = qkv, sa._drop(dev), kpre
             a.ctx, a.lse, a.ores = EZ(M, d, rows), E(H * M, dt=F32), (EZ(M, d, rows) if need_bwd else None)
             nv.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a.ctx, a.lse, rows.off, rows.len, rows.off, rows.len,
-                        H, rows.max_len, False, scale, work=work, drop=a.drop, max_k=rows.max_len, ores=a.ores)
+                        H, rows.max_len, False, scale, work=work, drop=a.drop, max_k=rows.max_len, ores=a.ores, k_prescaled=kpre)
             a.out, f.out, f.h = E(M, d), E(M, d), E(M, ff._st.d_ff)
             if need_bwd:
                 a.xhat, a.rstd, f.xhat, f.rstd = E(M, d), E(M, dt=F32), E(M, d), E(M, dt=F32)
@@ -352,7 +362,7 @@ class EncoderChains:
             nv.row_chain(a.ctx, self.e[l], pre=(x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
                          ffn=(ff._st.d_ff, ff._st.b1, ff._st.b2, ff._st.gamma, ff._st.beta, f.h, f.out, f.xhat, f.rstd, f.drop1,
                               f.drop2, f.bits),
-                         post=(3, nxt.b_qkv, qkv) if nxt is not None else None)
+                         post=(3, nxt.b_qkv, qkv) if nxt is not None else None, post_kscale=kscale)
             x = f.out
             pres.append((a, f))
         if need_bwd and self.use_bwd:

@@ -694,12 +694,13 @@ class AttnTap:
         return False
 
     @staticmethod
-    def record(mod, Q, K, q_rows, k_rows, causal):
-        """append `mod`'s probability map for projected queries Q / keys K (row matrices, head h at columns h * d_k)"""
+    def record(mod, Q, K, q_rows, k_rows, causal, kpre=False):
+        """append `mod`'s probability map for projected queries Q / keys K (row matrices, head h at columns h * d_k; kpre: the
+        keys are pre-scaled - native.attn_fwd's k_prescaled)"""
         s = mod._st
         scale = 1.0 / math.sqrt(s.d_model // s.n_head)
         AttnTap.active.maps.append((mod, nv.attn_probs(Q, K, q_rows.off, q_rows.len, k_rows.off, k_rows.len, s.n_head, q_rows.max_len,
-                                                       k_rows.max_len, causal, scale)))
+                                                       k_rows.max_len, causal, scale, k_prescaled=kpre)))
 
     @staticmethod
     def record_chain(layers, pres, q_rows, kv_rows):
@@ -711,7 +712,7 @@ class AttnTap:
         for layer, pre in zip(layers, pres):
             a = pre[0]
             d = layer.slf_attn._st.d_model
-            AttnTap.record(layer.slf_attn, a.qkv[:, :d], a.qkv[:, d:2 * d], q_rows, q_rows, len(pre) == 3)
+            AttnTap.record(layer.slf_attn, a.qkv[:, :d], a.qkv[:, d:2 * d], q_rows, q_rows, len(pre) == 3, bool(a.kpre))
             if len(pre) == 3:
                 b = pre[1]
                 AttnTap.record(layer.enc_attn, b.qkv, b.kvbuf[:, :d], q_rows, kv_rows, False)
@@ -745,11 +746,12 @@ class MhaFn(torch.autograd.Function):
                 x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, any(ctx.needs_input_grad), scale)
         if AttnTap.active is not None:
             Qm, Km = (qkv[:, :d], qkv[:, d:2 * d]) if x_kv is None else (qkv, kvbuf[:, :d])
-            AttnTap.record(mod, Qm, Km, q_rows, k_rows, causal)
+            AttnTap.record(mod, Qm, Km, q_rows, k_rows, causal, bool(pre is not None and pre.kpre))
         ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
         ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers share one encoder-gradient buffer (or CrossKv's)
+        ctx.kpre = bool(pre is not None and pre.kpre)     # the saved keys are pre-scaled (chains.EncoderChains): tell the backward
         ctx.up, ctx.down = up, down
         ctx.chain = (pre.bwd, pre.key) if pre is not None and pre.bwd is not None else None   # chains.ChainBackward
         if down is not None:
@@ -848,7 +850,8 @@ class MhaFn(torch.autograd.Function):
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
         _, work_q, work_k = attn_work(q_rows, k_rows, ctx.causal, d // H, H)
         nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
-                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop)
+                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop,
+                    k_prescaled=ctx.kpre)
         dx_kv = None
         # row-chain stacks: everything down to the previous attention's backward kernel is one launch
         dx_q = ctx.chain[0].input_grad(ctx.chain[1], dqkv, ds) if ctx.chain is not None and ctx.needs_input_grad[0] else None

@@ -48,7 +48,7 @@ SIGNATURES = {
     "st_row_chain": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
-                     _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_ll],
+                     _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_ll, _c_float],
     "st_row_chain_mask_words": [_c_int, _c_int],
     "st_gemm_splitk": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                        _c_void_p, _c_ll],
@@ -64,7 +64,7 @@ SIGNATURES = {
     "st_attn_tile_rows": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "st_attn_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
+                    _c_float, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
     "st_attn_f1_applicable": [_c_int, _c_int, _c_int, _c_int],
     "st_attn_f1_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p,
                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int,
@@ -78,14 +78,14 @@ SIGNATURES = {
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float],
+                    _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_ctc_gather": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p],
     "st_ctc_dlogits": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
                        _c_void_p, _c_void_p, _c_void_p, _c_int],
     "st_attn_probs": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                      _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float],
+                      _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int],
     "st_feat_stack": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                       _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int],
     "st_unpack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
@@ -445,7 +445,10 @@ def wfrag_build(table):
     _check(load().st_wfrag_build(_stream(), table.data_ptr(), table.shape[0]), "st_wfrag_build")
 
 
-def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
+K_LOG2_SCALE = 1.4426950408889634      # log2(e): a pre-scaled key projection holds scale * K_LOG2_SCALE * k (attn_fwd's k_prescaled)
+
+
+def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0):
     """One launch for a chain of row-wise layers over decoder-sized row counts (csrc/st_rowchain.hip).
     ``chain``: st_amd.chains.Chain (the fragment streams of this chain's weight blocks); A [M, 256] bf16.
     pre  = (R, bo, gamma, beta, out, xhat, rstd):                 cur = LN(A Wo^T + bo + R)
@@ -453,6 +456,8 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
            H (the hidden activation, the weight gradient's operand) may be None when no backward follows
            relu_bits (int64 [chain_mask_words(M, d_ff)]) receives the H > 0 mask row_chain_bwd reads
     post = (n_blocks_out, bias, P):                               P = cur Wp^T + bias, Wp [256 n_blocks_out, 256]
+    post_kscale (n_blocks_out == 3 only; 0 = plain): the KEY block of a q | k | v projection leaves multiplied by it (in fp32,
+    before its one rounding) - scale * K_LOG2_SCALE for attention kernels called with k_prescaled=True.
     xhat / rstd may be None when no backward follows."""
     _mat(A, BF16, "A")
     M, d = A.shape
@@ -504,7 +509,7 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
                              0 if R is None else R.stride(0), _p(bo), _p(g0), _p(be0), _p(out0), _p(xhat0), _p(rstd0),
                              int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(relu_bits), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
                              s1[1], s1[2], s1[3], s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0),
-                             _p(work), 0 if work is None else work.numel() * work.element_size())
+                             _p(work), 0 if work is None else work.numel() * work.element_size(), float(post_kscale))
     _check(rc, "st_row_chain")
 
 
@@ -681,11 +686,13 @@ def attn_tile_rows(which: int, d_k: int, max_q: int, max_k: int, causal: bool) -
 
 
 def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None,
-             max_k=0, ores=None):
+             max_k=0, ores=None, k_prescaled=False):
     """max_k (longest key sequence) only selects the kernel variant: <= 64 queries against >= 256 keys take
     the key-split path."""
     """work: optional int32 device list of (b << 16) | q_tile, heaviest first (functional.attn_work).
-    ores (optional, bf16, O's shape and stride): receives bf16(O_fp32 - bf16(O_fp32))."""
+    ores (optional, bf16, O's shape and stride): receives bf16(O_fp32 - bf16(O_fp32)).
+    k_prescaled: K holds scale * log2(e) * (key projection) (st_attn_fwd; row_chain's post_kscale) - the backward and
+    attn_probs of the same sublayer must be told the same."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
         _mat(t, BF16, nm)
     if ores is not None:
@@ -702,7 +709,7 @@ def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal,
     rc = load().st_attn_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             O.data_ptr(), O.stride(0), _p(ores), lse.data_ptr(), q_off.data_ptr(), q_len.data_ptr(),
                             k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(max_q), int(max_k), rows, int(causal),
-                            float(scale), *_work(work), *_drop(drop))
+                            float(scale), *_work(work), *_drop(drop), int(bool(k_prescaled)))
     _check(rc, "st_attn_fwd")
     return O
 
@@ -812,8 +819,9 @@ def attn_sf1_fwd(qkv, Os, lses, pre, post, chain, K, V, O, lse, q_off, q_len, k_
 
 
 def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
-             parts=3, work_q=None, work_k=None, drop=None):
-    """parts: 1 = dQ (+delta) kernel, 2 = dK/dV kernel (needs delta from part 1), 3 = both."""
+             parts=3, work_q=None, work_k=None, drop=None, k_prescaled=False):
+    """parts: 1 = dQ (+delta) kernel, 2 = dK/dV kernel (needs delta from part 1), 3 = both.
+    k_prescaled: as attn_fwd; dK is the gradient of the UNSCALED key projection either way."""
     for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
         _mat(t, BF16, nm)
     if O is not None:      # O = None: delta is an INPUT (produced with dO by gemm(..., epi=EPI_BF16_DELTA)); one launch
@@ -825,7 +833,7 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
     if _TIMING is not None and parts == 3 and O is not None:   # profile the two kernels of the call separately
         for part in (1, 2):
             attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal,
-                     scale, parts=part, work_q=work_q, work_k=work_k, drop=drop)
+                     scale, parts=part, work_q=work_q, work_k=work_k, drop=drop, k_prescaled=k_prescaled)
         return
     _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts, io=(Q, K, V, O, dO, dQ, dK, dV, lse, delta))
     rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
@@ -834,7 +842,7 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
                             dQ.data_ptr(), dQ.stride(0), dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0),
                             q_off.data_ptr(), q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k,
                             int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),
-                            *_work(work_k), *_drop(drop))
+                            *_work(work_k), *_drop(drop), int(bool(k_prescaled)))
     _check(rc, "st_attn_bwd")
 
 
@@ -872,7 +880,7 @@ def ctc_dlogits(logits, lse, rowmap, T, roww, scat, gsmall, grad_out, dlogits, V
                                  dlogits.stride(0)), "st_ctc_dlogits")
 
 
-def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):
+def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale, k_prescaled=False):
     """The attention probabilities of one sublayer, materialised: f32 [B, n_head, Lq, Lk] (zeros at masked keys and in the
     rows of padding positions).  Q, K: bf16 row matrices (column slices of the q | k | v projection are fine)."""
     for t, nm in ((Q, "Q"), (K, "K")):
@@ -883,7 +891,7 @@ def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):
     _tag("attn_probs", B, n_head, d_k, int(Lq), int(Lk))
     rc = load().st_attn_probs(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), P.data_ptr(), q_off.data_ptr(),
                               q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k, int(Lq), int(Lk), int(causal),
-                              float(scale))
+                              float(scale), int(bool(k_prescaled)))
     _check(rc, "st_attn_probs")
     return P
 

@@ -194,7 +194,7 @@ def relu_bits_from(H):
     return out
 
 
-def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
+def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0):
     """csrc/st_rowchain.hip as a composition of the emulated kernels it replaces (same roundings: every intermediate the
     separate kernels round to bf16 is rounded here too)."""
     blocks = list(chain.blocks)
@@ -227,7 +227,13 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6):
         cur = out1
     if post:
         nb, bp, P = post
-        gemm(cur, torch.cat(take(nb), 0), P, bias=bp)
+        if nb == 3 and post_kscale not in (0.0, 1.0):       # the key block leaves scaled, in fp32, before its one rounding
+            wp = torch.cat(take(nb), 0)
+            acc = cur[:A.shape[0]].float() @ wp.float().t() + bp.float()
+            acc[:, 256:512] *= float(post_kscale)
+            P[:A.shape[0]] = acc.to(BF16)
+        else:
+            gemm(cur, torch.cat(take(nb), 0), P, bias=bp)
     assert not blocks
 
 
@@ -295,12 +301,14 @@ def ln_bwd(dy, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, mask=
     return dx
 
 
-def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h):
+def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h, k_prescaled=False):
     dk = Q.shape[1] // H
     qo, ql, ko, kl = int(q_off[b]), int(q_len[b]), int(k_off[b]), int(k_len[b])
     cs = slice(h * dk, (h + 1) * dk)
     q = Q[qo:qo + ql, cs].float()
     k = K[ko:ko + kl, cs].float()
+    if k_prescaled:       # K holds scale * log2(e) * k: the emulation works on k (the kernels never undo the scale - they skip theirs)
+        k = k / (scale * nv.K_LOG2_SCALE)
     v = V[ko:ko + kl, cs].float()
     s = q @ k.t() * scale
     if causal:
@@ -309,11 +317,11 @@ def _attn_core(Q, K, V, q_off, q_len, k_off, k_len, H, causal, scale, b, h):
 
 
 def attn_fwd(Q, K, V, O, lse, q_off, q_len, k_off, k_len, n_head, max_q, causal, scale, work=None, drop=None,
-             max_k=0, ores=None):
+             max_k=0, ores=None, k_prescaled=False):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):
-            q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h)
+            q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h, k_prescaled)
             p = torch.softmax(s, -1)
             if _on(drop):   # the kernel drops un-normalised weights and folds 1/(1-p) into the final 1/l
                 p = p * keep_qk(drop, b * n_head + h, *s.shape)
@@ -354,11 +362,11 @@ def attn_sf1_fwd(qkv, Os, lses, pre, post, chain, K, V, O, lse, q_off, q_len, k_
 
 
 def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal, scale,
-             parts=3, work_q=None, work_k=None, drop=None):
+             parts=3, work_q=None, work_k=None, drop=None, k_prescaled=False):
     rows = Q.shape[0]
     for b in range(q_off.numel()):
         for h in range(n_head):
-            q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h)
+            q, k, v, s, qs, ks, cs = _attn_core(Q, K, V, q_off, q_len, k_off, k_len, n_head, causal, scale, b, h, k_prescaled)
             p = torch.exp2(s / math.log(2.0) - lse.view(n_head, rows)[h, qs].unsqueeze(-1))
             do = dO[qs, cs].float()
             if O is not None:
@@ -402,7 +410,7 @@ def ctc_dlogits(logits, lse, rowmap, T, roww, scat, gsmall, grad_out, dlogits, V
         dlogits[r, sc[keep].long()] = (g[int(rowmap[r])][keep] * grad_out.reshape(())).to(BF16)
 
 
-def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):
+def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale, k_prescaled=False):
     B = q_off.numel()
     d_k = Q.shape[1] // n_head
     P = torch.zeros(B, n_head, int(Lq), int(Lk))
@@ -411,7 +419,7 @@ def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale):
         for h in range(n_head):
             q = Q[qo:qo + lq, h * d_k:(h + 1) * d_k].float()
             k = K[ko:ko + lk, h * d_k:(h + 1) * d_k].float()
-            s = q @ k.t() * scale
+            s = q @ k.t() * (math.log(2.0) if k_prescaled else scale)
             if causal:
                 s = s.masked_fill(torch.ones(lq, lk, dtype=torch.bool).triu(1), float("-inf"))
             P[b, h, :lq, :lk] = torch.softmax(s, -1)

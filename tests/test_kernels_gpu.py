@@ -295,6 +295,116 @@ def test_attention_bwd_delta_supplied(case, use_work):
         check(g_.cpu()[rows], r_[rows], tol, "attention (delta supplied) %s %s" % (case, nm))
 
 
+# Pre-scaled keys (round 5): K~ = bf16(scale * log2(e) * k), scaled in the fp32 epilogue of the projection that produced the keys
+# (st_row_chain's post_kscale), handed over with k_prescaled = True - no kernel multiplies per score, forward and both backward
+# bodies exponentiate bit-identical scores.  Against the emulation on the SAME K~ (it divides the scale out in fp32): every kernel
+# family - the long-sequence forward and the backward streams, the general kernels (short, causal, 32- and 128-wide heads), the
+# padded layout - forward, backward with delta supplied (one launch) and st_attn_probs.
+PRESCALED_CASES = [
+    (3, 4, 64, None, [200, 131, 64], False, True),
+    (2, 4, 64, None, [1000, 640], False, True),
+    (4, 4, 64, None, [417, 96, 33, 160], False, False),
+    (2, 4, 64, None, [300, 257], True, True),
+    (2, 4, 32, None, [300, 131], False, True),
+    (3, 2, 128, None, [200, 131, 64], False, True),
+]
+
+
+@pytest.mark.parametrize("case", PRESCALED_CASES)
+def test_attention_prescaled_keys(case):
+    c = _attn_case(*case, seed=31)
+    H, Mq, Mk, d = c["H"], c["Mq"], c["Mk"], c["d"]
+    dk = d // H
+    kt = (c["K"].float() * (c["scale"] * nv.K_LOG2_SCALE)).to(BF16)      # what the projection's epilogue hands over
+    meta_c = [c[k] for k in ("q_off", "q_len", "k_off", "k_len")]
+    O, lse = torch.zeros(Mq, d, dtype=BF16), torch.zeros(H * Mq, dtype=F32)
+    em.attn_fwd(c["Q"], kt, c["V"], O, lse, *meta_c, H, c["max_q"], c["causal"], c["scale"], max_k=c["max_k"], k_prescaled=True)
+    delta = (c["dO"].float() * O.float()).view(Mq, H, dk).sum(-1).t().contiguous().view(-1)
+    ref = [torch.zeros(Mq, d, dtype=BF16), torch.zeros(Mk, d, dtype=BF16), torch.zeros(Mk, d, dtype=BF16)]
+    em.attn_bwd(c["Q"], kt, c["V"], None, c["dO"], lse, delta, *ref, *meta_c, H, c["max_q"], c["max_k"], c["causal"], c["scale"],
+                k_prescaled=True)
+    meta = [cu(m) for m in meta_c]
+    Og, lseg = torch.zeros(Mq, d, dtype=BF16, device="cuda"), torch.zeros(H * Mq, dtype=F32, device="cuda")
+    nv.attn_fwd(cu(c["Q"]), cu(kt), cu(c["V"]), Og, lseg, *meta, H, c["max_q"], c["causal"], c["scale"], max_k=c["max_k"], k_prescaled=True)
+    check(Og, O, 1.5e-2, "prescaled keys %s O" % (case,))
+    check(lseg, lse, 2e-3, "prescaled keys %s lse" % (case,))
+    got = [torch.full((Mq, d), float("nan"), dtype=BF16, device="cuda")] + \
+          [torch.full((Mk, d), float("nan"), dtype=BF16, device="cuda") for _ in range(2)]
+    nv.attn_bwd(cu(c["Q"]), cu(kt), cu(c["V"]), None, cu(c["dO"]), cu(lse), cu(delta), *got, *meta, H, c["max_q"], c["max_k"], c["causal"],
+                c["scale"], k_prescaled=True)
+    for g_, r_, nm, tol, off, ln in zip(got, ref, ("dQ", "dK", "dV"), (2.5e-2, 2.5e-2, 2e-2), ("q_off", "k_off", "k_off"),
+                                        ("q_len", "k_len", "k_len")):
+        rows = torch.cat([torch.arange(int(o), int(o) + int(n)) for o, n in zip(c[off], c[ln])])
+        assert torch.isfinite(g_.float().cpu()[rows]).all(), "non-finite %s %s" % (nm, case)
+        check(g_.cpu()[rows], r_[rows], tol, "prescaled keys %s %s" % (case, nm))
+    # ... and the result is that of the plain call on the unscaled keys, up to the keys' one extra rounding realisation
+    plain = [torch.zeros(Mq, d, dtype=BF16, device="cuda")] + [torch.zeros(Mk, d, dtype=BF16, device="cuda") for _ in range(2)]
+    nv.attn_bwd(cu(c["Q"]), cu(c["K"]), cu(c["V"]), None, cu(c["dO"]), cu(lse), cu(delta), *plain, *meta, H, c["max_q"], c["max_k"],
+                c["causal"], c["scale"])
+    for g_, p_, nm, off, ln in zip(got, plain, ("dQ", "dK", "dV"), ("q_off", "k_off", "k_off"), ("q_len", "k_len", "k_len")):
+        rows = torch.cat([torch.arange(int(o), int(o) + int(n)) for o, n in zip(c[off], c[ln])])      # (padded layout: the rest is untouched)
+        check(g_.cpu()[rows], p_.cpu()[rows], 3e-2, "prescaled vs plain keys %s %s" % (case, nm))
+    Lq, Lk = c["max_q"], c["max_k"]
+    P = nv.attn_probs(cu(c["Q"]), cu(kt), *meta, H, Lq, Lk, c["causal"], c["scale"], k_prescaled=True)
+    check(P, em.attn_probs(c["Q"], kt, *meta_c, H, Lq, Lk, c["causal"], c["scale"], k_prescaled=True), 1e-4, "attn_probs, prescaled keys %s" % (case,))
+
+
+def test_attention_backward_streams_stay_accurate_when_attention_is_sharp():
+    """What the pre-scaled keys are for (profiles/r05_bwd64_accuracy_*.txt): with peaky attention (q, k three times larger: the
+    regime of a TRAINED model) the backward streams of round 4 - register-resident operand pre-multiplied by scale * log2 e and
+    re-rounded to bf16, a different perturbation of every score in each body - were 3.3x less accurate than the general kernels
+    (14x at six times larger q, k).  With K~ from the producer they must be as accurate: each of dQ / dK / dV within 1.25x of
+    the general kernels' error against an fp64 reference."""
+    torch.manual_seed(5)
+    H, dk, lens = 4, 64, [417, 300, 520, 191]
+    d, M, scale = H * dk, sum(lens), 1 / math.sqrt(dk)
+    qkv = torch.randn(M, 3 * d) * 0.7
+    qkv[:, :2 * d] *= 3.0
+    k32 = qkv[:, d:2 * d].clone()
+    qkv = qkv.to(BF16)
+    Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    kt = (k32 * (scale * nv.K_LOG2_SCALE)).to(BF16)          # one rounding, as the projection's epilogue does it
+    dO = (torch.randn(M, d) * 0.5).to(BF16)
+    off = [sum(lens[:i]) for i in range(len(lens))]
+    ti = lambda v: torch.tensor(v, dtype=I32, device="cuda")
+    meta = [ti(off), ti(lens), ti(off), ti(lens)]
+
+    def reference(Kx, prescaled):
+        out = [torch.zeros(M, d, dtype=torch.float64) for _ in range(3)]
+        for o, L in zip(off, lens):
+            for h in range(H):
+                sl = slice(h * dk, (h + 1) * dk)
+                q, k, v, do = (t[o:o + L, sl].double() for t in (Q, Kx, V, dO))
+                if prescaled:
+                    k = k / (scale * nv.K_LOG2_SCALE)
+                p = torch.softmax(q @ k.T * scale, -1)
+                dl = (do * (p @ v)).sum(-1, keepdim=True)
+                ds = p * (do @ v.T - dl)
+                out[0][o:o + L, sl], out[1][o:o + L, sl], out[2][o:o + L, sl] = ds @ k * scale, ds.T @ q * scale, p.T @ do
+        return out
+
+    def run(Kx, prescaled, streams):
+        os.environ["ST_ATTN_BWD64"] = "1" if streams else "0"
+        nv.env_refresh()
+        O, Ores = (torch.empty(M, d, dtype=BF16, device="cuda") for _ in range(2))
+        lse = torch.empty(H * M, dtype=F32, device="cuda")
+        nv.attn_fwd(cu(Q), cu(Kx), cu(V), O, lse, *meta, H, max(lens), False, scale, max_k=max(lens), ores=Ores, k_prescaled=prescaled)
+        delta = (cu(dO).float() * (O.float() + Ores.float())).view(M, H, dk).sum(-1).t().contiguous().view(-1)
+        got = [torch.full((M, d), float("nan"), dtype=BF16, device="cuda") for _ in range(3)]
+        nv.attn_bwd(cu(Q), cu(Kx), cu(V), None, cu(dO), lse, delta, *got, *meta, H, max(lens), max(lens), False, scale, k_prescaled=prescaled)
+        ref = reference(Kx, prescaled)
+        return [float((a.double().cpu() - r).norm() / r.norm()) for a, r in zip(got, ref)]
+
+    try:
+        general = run(K, False, False)
+        streams = run(kt, True, True)
+    finally:
+        os.environ.pop("ST_ATTN_BWD64", None)
+        nv.env_refresh()
+    for e_s, e_g, nm in zip(streams, general, ("dQ", "dK", "dV")):
+        assert e_s < 1.25 * e_g and e_s < 6e-3, "sharp attention, %s: streams %.3e vs general kernels %.3e" % (nm, e_s, e_g)
+
+
 @pytest.mark.parametrize("name", ["mha_self_small", "mha_self_small_causal", "mha_cross_small"])
 def test_attn_probs_kernel_vs_reference_maps(name, golden_dir):
     """st_attn_probs against the reference's own `attns` (Attention.py:89,96; fixtures generated by importing the reference:
@@ -937,7 +1047,10 @@ def test_gemm_splitk_matches_gemm(M, N, K, splits, ycm):
 # ---- row chains (csrc/st_rowchain.hip) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["pre+post1", "pre+ffn+post3", "pre+ffn", "ffn", "ffn+post1", "pre+ffn+post3+drop",
-                                     "pre+ffn+post3+split", "pre+ffn+split", "ffn+split", "ffn+post1+split", "pre+ffn+post3+drop+split"])
+                                     "pre+ffn+post3+split", "pre+ffn+split", "ffn+split", "ffn+post1+split", "pre+ffn+post3+drop+split",
+                                     # ks: the key block of the q | k | v projection leaves pre-scaled (post_kscale); post3 alone =
+                                     # the encoder's layer-0 projection as a chain of its own
+                                     "post3+ks", "pre+ffn+post3+ks", "pre+ffn+post3+ks+split"])
 def test_row_chain_matches_the_separate_kernels(M, variant):
     """One st_row_chain launch == output_linear + residual + LayerNorm, feed-forward sublayer and the next projection as
     separate kernels (the emulation composes their emulations): every tensor the backward reads, ragged last row block,
@@ -992,7 +1105,7 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
         rc(a_in, ch,
            pre=(r_in, f(bo), f(g0), f(be0), o["out0"], o["xhat0"], o["rstd0"]) if has_pre else None,
            ffn=(dff, f(b1), f(b2), f(g1), f(be1), o["H"], o["out1"], o["xhat1"], o["rstd1"], d1, d2, o.get("bits")) if has_ffn else None,
-           post=(nb, f(bp), o["P"]) if nb else None)
+           post=(nb, f(bp), o["P"]) if nb else None, **({"post_kscale": 0.125 * nv.K_LOG2_SCALE} if "ks" in parts else {}))
         return o
 
     split_work = torch.zeros(nv.split_work_words(), dtype=torch.int32, device="cuda") if "split" in parts else None

@@ -3,7 +3,9 @@
 frames, 4 heads of 64): dQ / dK / dV of the generated instruction streams (csrc/st_attn_bwd64.hip: the register-resident
 operand pre-multiplied by scale * log2 e and re-rounded to bf16) and of the general kernels (ST_ATTN_BWD64=0: scores scaled
 in fp32) against an fp64 reference on the same bf16 inputs - eval mode and with attention dropout (the forward's own masks,
-re-derived with the host implementation of the counter hash, tests/_emul.py).  `sharp` = the same with 3x larger q / k
+re-derived with the host implementation of the counter hash, tests/_emul.py).  Third column (round 5, what the product runs):
+the streams on PRE-SCALED keys K~ = bf16(scale log2e k) from an fp32 key projection (one rounding, as st_row_chain's epilogue
+does it; k_prescaled = 1) against the fp64 reference on those keys.  `sharp` = the same with 3x larger q / k
 (score spread 9x: peaky attention, where a perturbed score matters most).  VERDICT r4 "weak 1" asked for this table."""
 import math
 import os
@@ -45,7 +47,7 @@ def reference(Q, K, V, dO, lens, drop):
     for b, L in enumerate(lens):
         for h in range(H):
             sl = slice(h * dk, (h + 1) * dk)
-            q, k, v, do = (t[off:off + L, sl].double() for t in (Q, K, V, dO))
+            q, k, v, do = (t[off:off + L, sl].double() for t in (Q, K, V, dO))      # (K may be an fp32 matrix: the pre-scaled keys divided back)
             p = torch.softmax(q @ k.T * scale, -1)
             m = keep_mask(drop, b * H + h, L, L) if drop is not None else None
             pd = p * m if m is not None else p
@@ -72,6 +74,7 @@ def run(lens, gain, p, label):
     M = int(lens_t.sum())
     g = (torch.randn(M, 3 * d, device=dev) * 0.7)
     g[:, :2 * d] *= gain
+    k32 = g[:, d:2 * d].clone()
     g = g.to(BF16)
     dO = (torch.randn(M, d, device=dev) * 0.5).to(BF16)
     Q, K, V = g[:, :d], g[:, d:2 * d], g[:, 2 * d:]
@@ -95,8 +98,22 @@ def run(lens, gain, p, label):
                     work_q=wq, work_k=wk, drop=drop)
         torch.cuda.synchronize()
         out[name] = [rel(a, r) for a, r in zip(got, ref)]
-    print("%-34s streams dQ %.3e dK %.3e dV %.3e | general dQ %.3e dK %.3e dV %.3e | ratio %.3f %.3f %.3f"
-          % (label, *out["streams"], *out["general"], *(a / b for a, b in zip(out["streams"], out["general"]))), flush=True)
+    # the product's form: keys pre-scaled once from their fp32 values
+    c2 = scale * nv.K_LOG2_SCALE
+    Kt = (k32 * c2).to(BF16)
+    os.environ["ST_ATTN_BWD64"] = "1"
+    nv.env_refresh()
+    nv.attn_fwd(Q, Kt, V, O, lse, q_off, q_len, q_off, q_len, H, max(lens), False, scale, work=wf, max_k=max(lens), drop=drop, ores=Ores,
+                k_prescaled=True)
+    delta = (dO.float() * (O.float() + Ores.float())).view(M, H, dk).sum(-1).t().contiguous().view(-1)
+    ref_t = reference(Q, (Kt.float() / c2), V, dO, lens, drop)
+    got = [torch.full((M, d), float("nan"), dtype=BF16, device=dev) for _ in range(3)]
+    nv.attn_bwd(Q, Kt, V, None, dO, lse, delta, *got, q_off, q_len, q_off, q_len, H, max(lens), max(lens), False, scale,
+                work_q=wq, work_k=wk, drop=drop, k_prescaled=True)
+    torch.cuda.synchronize()
+    out["kpre"] = [rel(a, r) for a, r in zip(got, ref_t)]
+    print("%-34s streams, re-rounded operand dQ %.3e dK %.3e dV %.3e | general dQ %.3e dK %.3e dV %.3e | streams, pre-scaled keys dQ %.3e dK %.3e dV %.3e"
+          % (label, *out["streams"], *out["general"], *out["kpre"]), flush=True)
 
 
 if __name__ == "__main__":
