@@ -436,6 +436,21 @@ int st_attn_probs(st_stream_t stream, const void* Q, int ldq, const void* K, int
                   const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int Lq, int Lk, int causal,
                   float scale, int k_prescaled);
 
+/* Attention under an ARBITRARY dense mask / with keys and values from different tensors - the general form of
+ * Attention.py:82-90 that no reference call site uses (they all pass a key-padding or key-padding | causal mask and k == v,
+ * which st_attn_fwd serves through lengths): a slow path (one workgroup per (utterance, head, query) / key, fp32 FMAs) that
+ * closes the module boundary.  Padded layout: utterance b owns query rows b Lq .. of Q / O / dO / dQ and key rows b Lk .. of
+ * K / V / dK / dV; head h = columns h d_k ..; d_k % 8 == 0.  mask: uint8 [B, Lq, Lk], nonzero = masked (NULL: none); a row
+ * with every key masked yields a zero context and zero gradients (the reference: NaN).  lse / delta: f32 [H, B Lq] (natural
+ * log); P (nullable, f32 [B, H, Lq, Lk]): the probabilities before dropout (Attention.py:96).  drop_*: as everywhere. */
+int st_attn_dense_fwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                      const unsigned char* mask, void* O, int ldo, float* lse, float* P, int B, int H, int d_k, int Lq, int Lk,
+                      float scale, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+int st_attn_dense_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                      const unsigned char* mask, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
+                      void* dK, int lddk, void* dV, int lddv, int B, int H, int d_k, int Lq, int Lk, float scale,
+                      const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
+
 /* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
 int st_probe_tr16(st_stream_t stream, const void* in, void* out);
 int st_probe_mfma(st_stream_t stream, const void* A, const void* Bt, float* D);

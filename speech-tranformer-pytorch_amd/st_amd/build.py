@@ -20,7 +20,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libst_hip.so")
 STAMP = LIB + ".srchash"
 SOURCES = ["st_gemm_sym.hip", "st_wgrad.hip", "st_gemm_ws.hip", "st_gemm_ln.hip", "st_gemm_lnbwd.hip", "st_rowchain.hip", "st_attn.hip",
-           "st_attn64.hip", "st_attn_bwd64.hip", "st_attn_xs.hip", "st_misc.hip"]
+           "st_attn64.hip", "st_attn_bwd64.hip", "st_attn_xs.hip", "st_attn_dense.hip", "st_misc.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result"]
 # per-file additions (none today; a kernel that owns all 512 registers per lane would want "-mllvm -amdgpu-mfma-vgpr-form":
 # left to its heuristics the compiler then puts score accumulators into AGPRs and pays a v_accvgpr_read per score)

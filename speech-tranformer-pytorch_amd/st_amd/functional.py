@@ -889,6 +889,61 @@ class MhaFn(torch.autograd.Function):
         return dx_q, dx_kv, None, None, None, None, None, None, None, None, None, None, None
 
 
+class DenseMhaFn(torch.autograd.Function):
+    """MultiHeadAttention.forward in its GENERAL form (Attention.py:64-96): an arbitrary dense mask [B, Lq, Lk] and / or keys and
+    values projected from different tensors.  No reference call site needs it (they pass k == v and one of the two mask families
+    the fused kernels serve through lengths); it closes the module boundary with a slow path: three projection GEMMs,
+    st_attn_dense_fwd / _bwd (one workgroup per query / key, no MFMA), then the usual output_linear + residual (q, repair R2) +
+    LayerNorm.  Padded layouts only; rows are [B Lq] / [B Lk]."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, anchor, mod, mask, B, Lq, Lk, drop=None, want_attn=False):
+        s = mod._st
+        d, H = s.d_model, s.n_head
+        scale = 1.0 / math.sqrt(d // H)
+        Q, K, V = _empty(B * Lq, d, xq), _empty(B * Lk, d, xq), _empty(B * Lk, d, xq)
+        nv.gemm(xq, s.w_q, Q, bias=s.b_q)
+        nv.gemm(xk, s.w_kv[:d], K, bias=s.b_kv[:d])
+        nv.gemm(xv, s.w_kv[d:], V, bias=s.b_kv[d:])
+        attn_ctx = _empty(B * Lq, d, xq)
+        lse = torch.empty(H * B * Lq, dtype=F32, device=xq.device)
+        probs = nv.attn_dense_fwd(Q, K, V, mask, attn_ctx, lse, B, H, Lq, Lk, scale, drop=drop, want_probs=want_attn)
+        out, xhat = _empty(B * Lq, d, xq), _empty(B * Lq, d, xq)
+        rstd = torch.empty(B * Lq, dtype=F32, device=xq.device)
+        nv.gemm_ln(attn_ctx, s.w_o, s.b_o, xq, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)
+        ctx.save_for_backward(xq, xk, xv, Q, K, V, attn_ctx, lse, xhat, rstd, mask)
+        ctx.mod, ctx.dims, ctx.scale, ctx.drop = mod, (B, Lq, Lk), scale, drop
+        ctx.mark_non_differentiable(*([probs] if probs is not None else []))
+        return (out, probs) if want_attn else out
+
+    @staticmethod
+    def backward(ctx, dout, *_):
+        xq, xk, xv, Q, K, V, attn_ctx, lse, xhat, rstd, mask = ctx.saved_tensors
+        mod = ctx.mod
+        s, arena = mod._st, mod._st_arena
+        d, H = s.d_model, s.n_head
+        B, Lq, Lk = ctx.dims
+        arena.attach_grads(s.params, s.lo, s.hi)
+        ds = _empty(B * Lq, d, xq)
+        nv.ln_bwd(dout.contiguous(), xhat, rstd, s.gamma, ds, s.g_gamma, s.g_beta, s.g_b_o)
+        wgrad(ds, attn_ctx, s.g_w_o)
+        dctx = _empty(B * Lq, d, xq)
+        dgrad(ds, s.w_o, dctx)
+        dQ, dK, dV = _empty(B * Lq, d, xq), _empty(B * Lk, d, xq), _empty(B * Lk, d, xq)
+        delta = torch.empty(H * B * Lq, dtype=F32, device=xq.device)
+        nv.attn_dense_bwd(Q, K, V, mask, dctx, lse, delta, dQ, dK, dV, B, H, Lq, Lk, ctx.scale, drop=ctx.drop)
+        wgrad(dQ, xq, s.g_w_q, gB=s.g_b_q)
+        wgrad(dK, xk, s.g_w_kv[:d], gB=s.g_b_kv[:d])
+        wgrad(dV, xv, s.g_w_kv[d:], gB=s.g_b_kv[d:])
+        dxq = _empty(B * Lq, d, xq)
+        dgrad(dQ, s.w_q, dxq, epi=nv.EPI_BF16_ADD, aux=ds)              # + the residual's gradient
+        dxk, dxv = _empty(B * Lk, d, xq), _empty(B * Lk, d, xq)
+        dgrad(dK, s.w_kv[:d], dxk)
+        dgrad(dV, s.w_kv[d:], dxv)
+        arena.grads_ready(s.lo, s.hi)
+        return dxq, dxk, dxv, None, None, None, None, None, None, None, None
+
+
 class FfnFn(torch.autograd.Function):
     """out = LN(x + fc2(relu(fc1(x))))   (SubLayers.py:24-28)."""
 

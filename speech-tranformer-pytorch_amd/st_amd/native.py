@@ -86,6 +86,11 @@ SIGNATURES = {
                        _c_void_p, _c_void_p, _c_void_p, _c_int],
     "st_attn_probs": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                       _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int],
+    "st_attn_dense_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                          _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_uint, _c_int, _c_float],
+    "st_attn_dense_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                          _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                          _c_float, _c_void_p, _c_uint, _c_int, _c_float],
     "st_feat_stack": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                       _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int],
     "st_unpack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
@@ -894,6 +899,39 @@ def attn_probs(Q, K, q_off, q_len, k_off, k_len, n_head, Lq, Lk, causal, scale, 
                               float(scale), int(bool(k_prescaled)))
     _check(rc, "st_attn_probs")
     return P
+
+
+def attn_dense_fwd(Q, K, V, mask, O, lse, B, n_head, Lq, Lk, scale, drop=None, want_probs=False):
+    """Attention under an arbitrary dense mask (uint8 [B, Lq, Lk], nonzero = masked; None = no mask) over padded row matrices
+    Q [B Lq, H d_k], K / V [B Lk, H d_k] (see st_attn_dense_fwd: the slow general path).  -> P (f32 [B, H, Lq, Lk]) or None."""
+    for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
+        _mat(t, BF16, nm)
+    d_k = Q.shape[1] // n_head
+    if mask is not None and not (mask.is_cuda and mask.dtype == torch.uint8 and mask.is_contiguous() and tuple(mask.shape) == (B, Lq, Lk)):
+        raise ValueError("attn_dense_fwd: mask must be a contiguous uint8 [B, Lq, Lk] tensor on the GPU")
+    if Q.shape[0] != B * Lq or K.shape[0] != B * Lk or V.shape[0] != B * Lk:
+        raise ValueError("attn_dense_fwd: padded layouts expected (B Lq query rows, B Lk key rows)")
+    _vec(lse, F32, n_head * B * Lq, "lse")
+    P = torch.empty(B, n_head, Lq, Lk, dtype=F32, device=Q.device) if want_probs else None
+    _tag("attn_dense", B, n_head, d_k, Lq, Lk)
+    rc = load().st_attn_dense_fwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0), _p(mask),
+                                  O.data_ptr(), O.stride(0), lse.data_ptr(), _p(P), B, n_head, d_k, int(Lq), int(Lk), float(scale),
+                                  *_drop(drop))
+    _check(rc, "st_attn_dense_fwd")
+    return P
+
+
+def attn_dense_bwd(Q, K, V, mask, dO, lse, delta, dQ, dK, dV, B, n_head, Lq, Lk, scale, drop=None):
+    for t, nm in ((Q, "Q"), (K, "K"), (V, "V"), (dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
+        _mat(t, BF16, nm)
+    d_k = Q.shape[1] // n_head
+    _vec(lse, F32, n_head * B * Lq, "lse"), _vec(delta, F32, n_head * B * Lq, "delta")
+    _tag("attn_dense_bwd", B, n_head, d_k, Lq, Lk)
+    rc = load().st_attn_dense_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0), _p(mask),
+                                  dO.data_ptr(), dO.stride(0), lse.data_ptr(), delta.data_ptr(), dQ.data_ptr(), dQ.stride(0),
+                                  dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0), B, n_head, d_k, int(Lq), int(Lk),
+                                  float(scale), *_drop(drop))
+    _check(rc, "st_attn_dense_bwd")
 
 
 def feat_stack(x, in_len, stats, left, right, interval, out_off, out_len, max_out_len, out):

@@ -25,7 +25,9 @@ class MultiHeadAttention(nn.Module):
         kernel never materialises the [B, h, Lq, Lk] tensor; every caller in the
         reference discards it, train.py:39);
       * ``mask`` may be a :class:`LengthMask`; a dense mask is analysed back
-        into lengths (slow path);
+        into lengths (device sync), and a dense mask that is neither a key-padding nor a
+        key-padding | causal mask - or ``k is not v`` - takes the general slow path
+        (st_amd.functional.DenseMhaFn: no reference call site does);
       * training-mode dropout draws counter-based masks inside the kernels (st_amd/rng.py): same distribution as
         nn.Dropout with p quantised to 1/256, a different random stream.
     """
@@ -90,9 +92,29 @@ class MultiHeadAttention(nn.Module):
                                   drop, kv_acc, up, down, pre)
 
     # ---- reference API -------------------------------------------------------------------------
+    def _forward_dense(self, q, k, v, mask):
+        """The general form (any dense mask, k and v different tensors): st_amd.functional.DenseMhaFn."""
+        B, Lq, d = q.shape
+        Lk = k.shape[1]
+        if v.shape[1] != Lk or k.shape[0] != B or v.shape[0] != B:
+            raise ValueError("MultiHeadAttention: k and v must have the same batch size and length")
+        if isinstance(mask, LengthMask):       # (built from the longest utterance: pad to this call's [Lq, Lk], padded keys masked)
+            m = mask.dense(q.device)
+            mask = torch.ones(B, Lq, Lk, dtype=torch.bool, device=q.device)
+            mask[:, :m.shape[1], :m.shape[2]] = m[:, :Lq, :Lk]
+            if m.shape[1] < Lq:
+                mask[:, m.shape[1]:] = mask[:, m.shape[1] - 1:m.shape[1]]
+        m8 = None if mask is None else mask.to(device=q.device).reshape(B, Lq, Lk).ne(0).to(torch.uint8).contiguous()
+        arena = arena_of(self)
+        with arena.scope():
+            args = [t.reshape(-1, d).to(torch.bfloat16) for t in (q, k, v)]
+            res = F_.DenseMhaFn.apply(*args, self.linear_q.weight, self, m8, B, Lq, Lk, self._drop(q.device), bool(self.return_attn))
+        out, attns = res if self.return_attn else (res, None)
+        return out.to(q.dtype).view(B, Lq, d), attns
+
     def forward(self, q, k, v, mask=None):
         if k is not v:
-            raise NotImplementedError("HIP path: key and value must be the same tensor (as in every reference call site)")
+            return self._forward_dense(q, k, v, mask)
         B, Lq, d = q.shape
         Lk = k.shape[1]
         dev = q.device
@@ -101,7 +123,10 @@ class MultiHeadAttention(nn.Module):
         elif isinstance(mask, LengthMask):
             k_len, causal = mask.k_len, mask.causal
         else:
-            k_len, causal = lengths_from_mask(mask)
+            fam = lengths_from_mask(mask)
+            if fam is None:            # neither of the two mask families of Utils.py: the general slow path
+                return self._forward_dense(q, k, v, mask)
+            k_len, causal = fam
         q_rows = F_.Rows.padded(B, Lq, dev)
         k_rows = F_.Rows.padded(B, Lk, dev, k_len)
         xq = q.reshape(B * Lq, d).to(torch.bfloat16)

@@ -59,8 +59,9 @@ def feature_info_mask(seq_length):
 
 def lengths_from_mask(mask):
     """Recover (k_len[B], causal) from a dense [B, Lq, Lk] mask built by the two
-    functions above; raises if the mask is not of that family.  Slow generic path
-    (device sync) for callers that hand MultiHeadAttention a foreign dense mask."""
+    functions above; None if the mask is not of that family (MultiHeadAttention then
+    takes st_amd.functional.DenseMhaFn).  A device sync: for callers that hand
+    MultiHeadAttention a dense mask instead of a LengthMask."""
     mask = mask.bool()
     B, Lq, Lk = mask.shape
     k_len = (~mask[:, -1, :]).sum(-1)
@@ -71,7 +72,7 @@ def lengths_from_mask(mask):
         tri = torch.ones(Lq, Lk, dtype=torch.bool, device=mask.device).triu(1)
         if torch.equal(mask, pad | tri):
             return k_len, True
-    raise NotImplementedError("MultiHeadAttention(HIP): mask is neither a key-padding mask nor key-padding|causal")
+    return None          # a foreign mask: MultiHeadAttention takes its general (slow) path
 
 
 def learn_rate(d_model, n_warmup_steps, current_step):

@@ -385,6 +385,47 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
             dV[ks, cs] = (pv.to(BF16).float().t() @ do).to(BF16)
 
 
+def _dense_core(Q, K, V, mask, b, h, n_head, Lq, Lk, scale, drop):
+    dk = Q.shape[1] // n_head
+    cs = slice(h * dk, (h + 1) * dk)
+    qs, ks = slice(b * Lq, (b + 1) * Lq), slice(b * Lk, (b + 1) * Lk)
+    q, k, v = Q[qs, cs].float(), K[ks, cs].float(), V[ks, cs].float()
+    s = q @ k.t() * scale
+    if mask is not None:
+        s = s.masked_fill(mask[b].bool(), float("-inf"))
+    dead = torch.isinf(s).all(-1, keepdim=True)                 # every key masked: zero context, zero gradients
+    p = torch.where(dead, torch.zeros_like(s), torch.softmax(torch.where(dead, torch.zeros_like(s), s), -1))
+    keep = keep_qk(drop, b * n_head + h, Lq, Lk).float() * drop.scale if _on(drop) else torch.ones_like(p)
+    return q, k, v, s, p, keep, qs, ks, cs, dead
+
+
+def attn_dense_fwd(Q, K, V, mask, O, lse, B, n_head, Lq, Lk, scale, drop=None, want_probs=False):
+    P = torch.zeros(B, n_head, Lq, Lk) if want_probs else None
+    for b in range(B):
+        for h in range(n_head):
+            q, k, v, s, p, keep, qs, ks, cs, dead = _dense_core(Q, K, V, mask, b, h, n_head, Lq, Lk, scale, drop)
+            O[qs, cs] = ((p * keep) @ v).to(BF16)
+            l = torch.logsumexp(torch.where(dead, torch.zeros_like(s), s), -1)
+            lse.view(n_head, B * Lq)[h, qs] = torch.where(dead.squeeze(-1), torch.full_like(l, float("inf")), l)
+            if P is not None:
+                P[b, h] = p
+    return P
+
+
+def attn_dense_bwd(Q, K, V, mask, dO, lse, delta, dQ, dK, dV, B, n_head, Lq, Lk, scale, drop=None):
+    for b in range(B):
+        for h in range(n_head):
+            q, k, v, s, p, keep, qs, ks, cs, dead = _dense_core(Q, K, V, mask, b, h, n_head, Lq, Lk, scale, drop)
+            do = dO[qs, cs].float()
+            dp = (do @ v.t()) * keep
+            dl = (p * dp).sum(-1, keepdim=True)
+            delta.view(n_head, B * Lq)[h, qs] = dl.squeeze(-1)
+            ds = p * (dp - dl)
+            dQ[qs, cs] = (ds @ k * scale).to(BF16)
+            dK[ks, cs] = (ds.t() @ q * scale).to(BF16)
+            dV[ks, cs] = ((p * keep).t() @ do).to(BF16)
+
+
 def ctc_gather(logits, rowmap, T, cols, lse, lp, V=None):
     V = logits.shape[1] if V is None else V
     l = torch.logsumexp(logits[:, :V].float(), dim=1)
@@ -603,7 +644,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "ctc_gather", "ctc_dlogits", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "attn_dense_fwd", "attn_dense_bwd", "ctc_gather", "ctc_dlogits", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "beam_work_words", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 

@@ -247,6 +247,57 @@ def run_standalone_modules(golden_dir, device):
     check_param_grads(ff, fx, "pffn_medium")
 
 
+def run_general_attention(golden_dir, device):
+    """MultiHeadAttention.forward in its general form (Attention.py:64-96): an arbitrary dense mask, k is not v - the slow dense
+    path (st_attn_dense_fwd / _bwd behind functional.DenseMhaFn) against fixtures generated by importing the reference: output,
+    the returned probabilities, the input gradients of q / k / v and every parameter gradient."""
+    import transformer.Attention as A
+
+    def w_of(fx):
+        return {k[2:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("w/")}
+
+    def check_param_grads(mod, fx, name):
+        for n, p in mod.named_parameters():
+            g, t = p.grad.detach().cpu().double(), torch.from_numpy(fx["f64/g/" + n])
+            if "linear_k.bias" in n:          # analytically zero (softmax is shift-invariant): absolute bound
+                assert g.abs().max().item() < 0.25 * mod.linear_q.bias.grad.abs().max().item() + 1e-6, (name, n)
+                continue
+            assert rel(g, t) < GRAD_TOL_TENSOR, (name, n, rel(g, t))
+
+    for name in ("mha_dense_mask", "mha_dense_mask_kv"):
+        fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+        d, h = fx["q"].shape[-1], int(fx["n_head"])
+        mha = A.MultiHeadAttention(h, d, d // h, d // h).eval()
+        mha.load_state_dict(w_of(fx))
+        mha = mha.to(device)
+        mha.return_attn = True
+        q, k = (torch.from_numpy(fx[n]).to(device).requires_grad_(True) for n in ("q", "k"))
+        v = torch.from_numpy(fx["v"]).to(device).requires_grad_(True) if "v" in fx else k
+        out, attn = mha(q, k, v, torch.from_numpy(fx["mask"]).to(device))
+        (out * torch.from_numpy(fx["dy"]).to(device)).sum().backward()
+        assert rel(out.detach().cpu(), torch.from_numpy(fx["f64/out"])) < 2e-2, name
+        assert rel(attn.detach().cpu(), torch.from_numpy(fx["f64/attn"])) < 2e-2, name
+        assert rel(q.grad.cpu(), torch.from_numpy(fx["f64/dq"])) < 6e-2, (name, rel(q.grad.cpu(), torch.from_numpy(fx["f64/dq"])))
+        assert rel(k.grad.cpu(), torch.from_numpy(fx["f64/dk"])) < 6e-2, (name, rel(k.grad.cpu(), torch.from_numpy(fx["f64/dk"])))
+        if "v" in fx:
+            assert rel(v.grad.cpu(), torch.from_numpy(fx["f64/dv"])) < 6e-2, name
+        check_param_grads(mha, fx, name)
+    # a row whose keys are ALL masked: zero context (the reference: NaN), finite everywhere, no gradient through that row's scores
+    mha = A.MultiHeadAttention(4, 128, 32, 32).eval().to(device)
+    x = torch.randn(2, 5, 128, device=device, requires_grad=True)
+    mask = torch.zeros(2, 5, 5, dtype=torch.bool, device=device)
+    mask[1, 2] = True
+    mask[0, 0, 3] = True                      # (and a mask outside the two families, so that the dense path is taken)
+    y, _ = mha(x, x, x, mask)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+
+
+def test_general_attention_composition(golden_dir):
+    with emulated_kernels():
+        run_general_attention(golden_dir, "cpu")
+
+
 def test_standalone_modules_composition(golden_dir):
     with emulated_kernels():
         run_standalone_modules(golden_dir, "cpu")

@@ -26,6 +26,11 @@ def test_standalone_modules_gpu(golden_dir):
     comp.run_standalone_modules(golden_dir, "cuda")
 
 
+def test_general_attention_gpu(golden_dir):
+    """arbitrary dense masks / k is not v: the slow dense kernels against the reference-import fixtures"""
+    comp.run_general_attention(golden_dir, "cuda")
+
+
 def test_encoder_padded_api_gpu(golden_dir):
     comp.run_encoder_padded_api(golden_dir, "cuda")
 

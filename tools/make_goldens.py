@@ -217,6 +217,40 @@ def mha_case(name, b, lq, lk, d, h, q_len, k_len, causal, cross, seed, full=True
     save(name, **out)
 
 
+def mha_dense_case(name, b, lq, lk, d, h, seed, split_kv):
+    """The GENERAL form of MultiHeadAttention.forward (Attention.py:64-96): an arbitrary dense mask (random here, every query
+    keeps at least one key - the reference gives NaN otherwise; the mask of the module's own ``__main__`` demo,
+    Attention.py:100-102, is of this kind) and, with split_kv, keys and values projected from DIFFERENT tensors.  No call site
+    of the reference uses either; the product serves them through its slow dense path (st_attn_dense_fwd / _bwd).
+    Needs repair R2 when lq != lk or k is not v (residual q)."""
+    torch.manual_seed(seed)
+    mha = A.MultiHeadAttention(h, d, d // h, d // h).eval()
+    rand_weights(mha, seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    q0, k0, dy0 = torch.randn(b, lq, d, generator=g), torch.randn(b, lk, d, generator=g), torch.randn(b, lq, d, generator=g)
+    v0 = torch.randn(b, lk, d, generator=g) if split_kv else None
+    mask = torch.rand(b, lq, lk, generator=g) < 0.4
+    mask[:, :, 0] &= ~mask.all(-1)                      # a fully masked row keeps key 0
+    out = {"n_head": np.array(h), "repair": "R2", "mask": mask.numpy(), "q": np32(q0), "k": np32(k0), "dy": np32(dy0)}
+    if split_kv:
+        out["v"] = np32(v0)
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        m = A.MultiHeadAttention(h, d, d // h, d // h).eval()
+        m.load_state_dict(mha.state_dict())
+        m = m.to(dt)
+        q, k = (t.detach().clone().to(dt).requires_grad_(True) for t in (q0, k0))
+        v = v0.detach().clone().to(dt).requires_grad_(True) if split_kv else k
+        y, attn = m(q, k, v, mask)
+        (y * dy0.to(dt)).sum().backward()
+        conv = np32 if tag == "f32" else np64
+        out[tag + "/out"], out[tag + "/dq"], out[tag + "/dk"], out[tag + "/attn"] = conv(y), conv(q.grad), conv(k.grad), conv(attn)
+        if split_kv:
+            out[tag + "/dv"] = conv(v.grad)
+        out.update(grads_np(m, conv, tag + "/g/"))
+    out.update(state_np(mha, np32))
+    save(name, **out)
+
+
 def fx_pffn(name="pffn", d=16, dff=32, shape=(2, 7), seed=7):
     torch.manual_seed(seed)
     ff = S.PositionwiseFeedForward(d, dff).eval()
@@ -392,4 +426,7 @@ if __name__ == "__main__":
     mha_case("mha_cross_c2", 2, 50, 400, 128, 2, [50, 33], [400, 273], False, True, 170, repair="R2", slim=True)
     ref, cfg = fx_c1_step()
     fx_dp8(ref, cfg)
+    # the general form of MultiHeadAttention.forward (round 5): arbitrary dense masks, keys and values from different tensors
+    mha_dense_case("mha_dense_mask", 2, 9, 9, 128, 4, 180, split_kv=False)
+    mha_dense_case("mha_dense_mask_kv", 3, 11, 23, 128, 4, 190, split_kv=True)
     remove_repairs()
