@@ -39,8 +39,8 @@
 //     changes nothing (+-0.5 us): no single unit is the limiter - 30 % of the launch is fixed cost per item, and the loop is
 //     the sum of a matrix-pipe part at ~70 % efficiency, a staging part and an issue part of comparable size.
 // Work decomposition as in the general kernel: 4 waves x 32 query rows per (utterance, head, 128-row tile), 64-key
-// tiles through a padded LDS double buffer.  Tried on the same box and NOT kept (tools/dev/st_attn64_variants.hip,
-// DESIGN.md section 5): 64 query rows per wave with one workgroup per CU (44-46 us: nothing hides a single wave's
+// tiles through a padded LDS double buffer.  Tried on the same box and NOT kept (LABNOTES.md; the variant sources
+// are in the git history): 64 query rows per wave with one workgroup per CU (44-46 us: nothing hides a single wave's
 // s_waitcnt time), with two (spills at 256 registers: 59 us), a hand-staggered instruction stream pinned with
 // sched_group_barrier (44 us; the sched_barrier(0) fences above are what finally held an order), 128-key stages (54 us),
 // all fragment reads of a tile issued up front (39 us), packed adds
