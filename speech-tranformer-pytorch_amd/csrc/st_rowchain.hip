@@ -154,14 +154,15 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
   __shared__ bool last;
   Ctx<MT> c;
   c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
-  const int parts = a.nc, block = blockIdx.x / parts, part = blockIdx.x - block * parts;
+  const int parts = a.split_parts, cpp = a.nc / parts, block = blockIdx.x / parts, part = blockIdx.x - block * parts;
   c.row0 = block * RB; c.nvalid = min(RB, a.M - c.row0);
   const bf16x8* base = a.wfrag + (size_t)c.wave * a.wave_frags * 64;
-  // stream order: [PRE] [W1_0 W2_0] .. [W1_(nc-1) W2_(nc-1)] [POST blocks]; this workgroup multiplies PRE, its chunk's two
-  // blocks and - if it turns out to be the last - POST.  The ring always holds the block being multiplied and is refilled
-  // from c.ws, so c.ws is pointed at the block that comes NEXT for this workgroup before every block_mma.
+  // stream order: [PRE] [W1_0 W2_0] .. [W1_(nc-1) W2_(nc-1)] [POST blocks]; this workgroup multiplies PRE, the two blocks of
+  // each of its cpp chunks (consecutive in the stream) and - if it turns out to be the last - POST.  The ring always holds the
+  // block being multiplied and is refilled from c.ws, so c.ws is pointed at the block that comes NEXT for this workgroup
+  // before every block_mma that is not followed by its stream neighbour.
   auto at_block = [&](int b) { return base + (size_t)b * 16 * 64; };
-  const int b_chunk = (PRE ? 1 : 0) + 2 * part, b_post = (PRE ? 1 : 0) + 2 * parts;
+  const int b_chunk = (PRE ? 1 : 0) + 2 * part * cpp, b_post = (PRE ? 1 : 0) + 2 * a.nc;
   c.ws = at_block(PRE ? 0 : b_chunk);
 #pragma unroll
   for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
@@ -204,17 +205,22 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
   f32x16 acc2[MT];
   zero_acc(acc2);
   {
-    const int dff = parts * 256;
-    bf16* hc = f0;       // (free: the residual's last read precedes epi_ln's barriers; without PRE never written)
-    f32x16 acc1[MT];
-    zero_acc(acc1);
-    block_mma(c, cur, acc1);                  // W1 chunk; refills: the W2 chunk right behind it
-    epi_store<true, DROP>(c, acc1, a.b1 + part * 256, hc, d1, part * 256, dff,
-                          a.relu_bits ? a.relu_bits + ((size_t)(block * parts + part) * NW + c.wave) * 64 : nullptr);
-    __syncthreads();
-    c.ws = at_block(b_post);                  // (POST's first block, on the chance that this workgroup is the last)
-    block_mma(c, hc, acc2);
-    if (a.H) tile_out(c, hc, a.H + part * 256, dff);
+    const int dff = a.nc * 256;
+    for (int j = 0; j < cpp; ++j) {
+      // hidden tiles alternate f0, f1 as in row_chain_kernel: f0 is free (the residual's last read precedes epi_ln's barriers;
+      // without PRE never written), f1 (PRE's xhat staging, copied out by part 0) is first written behind chunk 0's barrier
+      const int ch = part * cpp + j;
+      bf16* hc = (j & 1) ? f1 : f0;
+      f32x16 acc1[MT];
+      zero_acc(acc1);
+      block_mma(c, cur, acc1);                  // W1 chunk; refills: the W2 chunk right behind it
+      epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff,
+                            a.relu_bits ? a.relu_bits + ((size_t)(block * a.nc + ch) * NW + c.wave) * 64 : nullptr);
+      __syncthreads();
+      if (j + 1 == cpp) c.ws = at_block(b_post);      // (POST's first block, on the chance that this workgroup is the last)
+      block_mma(c, hc, acc2);
+      if (a.H) tile_out(c, hc, a.H + ch * 256, dff);
+    }
   }
   // ---- the partial leaves through the L2 (write-through), the ticket says who merges
   float* slot = a.split_ws + (size_t)block * parts * (512 * 16);
@@ -298,7 +304,7 @@ struct ChainBwdArgs {
   // TAIL
   const bf16* O; const bf16* Ores; int ldo; bf16* dctx; int lddc; float* delta;
   // split feed-forward (row_chain_bwd_split_kernel): as ChainArgs
-  float* split_ws; unsigned* split_tickets;
+  float* split_ws; unsigned* split_tickets; int split_parts;
 };
 
 // LayerNorm backward over the 256 columns held by the 8 waves.  acc = the GEMM result; t_aux holds the addend and receives
@@ -629,11 +635,11 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArg
   __shared__ bool last;
   Ctx<MT> c;
   c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
-  const int parts = a.nc, block = blockIdx.x / parts, part = blockIdx.x - block * parts;
+  const int parts = a.split_parts, cpp = a.nc / parts, block = blockIdx.x / parts, part = blockIdx.x - block * parts;
   c.row0 = block * RB; c.nvalid = min(RB, a.M - c.row0);
   const bf16x8* base = a.wfrag + (size_t)c.wave * a.wave_frags * 64;
   auto at_block = [&](int b) { return base + (size_t)b * 16 * 64; };
-  const int nbh = HEAD ? a.nb : 0, b_chunk = nbh + 2 * part, b_tail = nbh + 2 * parts;
+  const int nbh = HEAD ? a.nb : 0, b_chunk = nbh + 2 * part * cpp, b_tail = nbh + 2 * a.nc;
   c.ws = at_block(nbh > 0 ? 0 : b_chunk);
 #pragma unroll
   for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
@@ -694,28 +700,33 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArg
   zero_acc(acc2);
   TileRegs<MT> xr;
   {
-    const int dff = parts * 256;
-    bf16* hc = fa;
-    const unsigned long long relu = a.relu_bits[((size_t)(block * parts + part) * NW + c.wave) * 64 + c.l];
-    f32x16 acc1[MT];
-    zero_acc(acc1);
-    block_mma(c, cur, acc1);                   // ds x W2[:, chunk]; refills: W1[chunk, :] right behind
+    const int dff = a.nc * 256;
+    for (int j = 0; j < cpp; ++j) {
+      const int ch = part * cpp + j;
+      bf16* hc = (j & 1) ? fb : fa;            // (as row_chain_bwd_kernel: rewritten two chunks later, the next chunk's barrier in between)
+      const unsigned long long relu = a.relu_bits[((size_t)(block * a.nc + ch) * NW + c.wave) * 64 + c.l];
+      f32x16 acc1[MT];
+      zero_acc(acc1);
+      block_mma(c, cur, acc1);                   // ds x W2[:, chunk]; refills: W1[chunk, :] right behind
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 o;
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bf16 v = (bf16)(acc1[0][4 * g + e] * a.mask_scale);
-        const int b = 4 * g + e;
-        o[e] = (((uint32_t)relu >> b) & 1u) ? v : (bf16)0.f;
+        for (int e = 0; e < 4; ++e) {
+          const bf16 v = (bf16)(acc1[0][4 * g + e] * a.mask_scale);
+          const int b = 4 * g + e;
+          o[e] = (((uint32_t)relu >> b) & 1u) ? v : (bf16)0.f;
+        }
+        *reinterpret_cast<bf16x4*>(hc + c.r * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
       }
-      *reinterpret_cast<bf16x4*>(hc + c.r * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
+      __syncthreads();
+      if (j + 1 == cpp) {
+        tile_load(c, a.xhat_b, DM, xr);          // (used by the last arriver only; asked for by all: nobody knows yet)
+        c.ws = at_block(b_tail);
+      }
+      block_mma(c, hc, acc2);                    // dH chunk x W1[chunk, :]
+      tile_out(c, hc, a.dH + ch * 256, dff);
     }
-    __syncthreads();
-    tile_load(c, a.xhat_b, DM, xr);            // (used by the last arriver only; asked for by all: nobody knows yet)
-    c.ws = at_block(b_tail);
-    block_mma(c, hc, acc2);                    // dH chunk x W1[chunk, :]
-    tile_out(c, hc, a.dH + part * 256, dff);
   }
   float* slot = a.split_ws + (size_t)block * parts * (512 * 16);
   {
@@ -748,9 +759,10 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_split_kernel(ChainBwdArg
         acc2[0][2 * i + 1] += __uint_as_float((unsigned)(v[i] >> 32));
       }
     }
-    // dy = acc2 + ds (in place over the ds tile), xhat_b into fb (free since HEAD's last barrier), ds_b into the chunk's tile
-    bf16* tx = fb;
-    bf16* td = fa;
+    // dy = acc2 + ds (in place over the ds tile), xhat_b into the tile the last chunk did not use, ds_b into the other (both
+    // behind the merge's barriers: every wave is past its MFMAs and copies on them)
+    bf16* tx = (cpp & 1) ? fb : fa;
+    bf16* td = (cpp & 1) ? fa : fb;
     tile_store(c, xr, tx);
     __syncthreads();
     epi_lnbwd<false>(c, acc2, cur, tx, td, a.rstd_b, a.gamma_b, off, red, a.ds_b, a.dgamma_b, a.dbeta_b, a.dbias_b);
@@ -823,6 +835,19 @@ int row_tiles(int M) {
 }
 }  // namespace
 
+namespace {
+// Workgroups per 32-row block that share the feed-forward's hidden dimension (row_chain_split_kernel / _bwd_split_kernel): the
+// largest divisor of nc (the 256-column chunks of d_ff, at most 8) that keeps blocks x parts within one round of the chip
+// (256 workgroups, and the ticket table's 256 entries); 0 = no split.  Decoder-sized M: parts = nc (1,206 rows: 38 x 4); a
+// 4-utterance shard's encoder (3,120 rows = 98 blocks): 2 - two chunks per part.
+int split_parts_for(int blocks, int nc) {
+  if (nc < 2 || nc > 8 || blocks > 128) return 0;
+  for (int p = nc; p >= 2; --p)
+    if (nc % p == 0 && blocks * p <= 256) return p;
+  return 0;
+}
+}  // namespace
+
 // 64-bit words of the relu_bits buffer st_row_chain writes and st_row_chain_bwd reads for M rows and this d_ff
 extern "C" int st_row_chain_mask_words(int M, int d_ff) {
   if (M <= 0 || d_ff <= 0) return 0;
@@ -862,15 +887,17 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
   const bool drop = on1 || on2;
   // the feed-forward's hidden dimension over nc workgroups per row block (row_chain_split_kernel): decoder-sized M only
-  a.split_ws = nullptr; a.split_tickets = nullptr;
-  if (split_work && ffn && mt == 1 && a.nc >= 2 && a.nc <= 8 && (int)grid.x * a.nc <= 256) {
+  a.split_ws = nullptr; a.split_tickets = nullptr; a.split_parts = 0;
+  const int sp = split_parts_for((int)grid.x, a.nc);
+  if (split_work && ffn && mt == 1 && sp >= 2) {
     // layout: 256 tickets (one per row block; at a FIXED place - launches of different M share the scratch, and a ticket
     // must never lie where another launch leaves partial sums), then the partials
-    const size_t words = (size_t)grid.x * a.nc * 512 * 16;
+    const size_t words = (size_t)grid.x * sp * 512 * 16;
     if (split_bytes < (long long)((256 + words) * 4)) return -6;
     a.split_tickets = (unsigned*)split_work;
     a.split_ws = (float*)split_work + 256;
-    const dim3 sgrid(grid.x * a.nc);
+    a.split_parts = sp;
+    const dim3 sgrid(grid.x * sp);
 #define ST_SPLIT(PRE_, POST_)                                                                                        \
   do {                                                                                                               \
     if (drop) hipLaunchKernelGGL((row_chain_split_kernel<PRE_, POST_, true>), sgrid, blk, 0, stream, a);             \
@@ -946,13 +973,15 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
   const int mt = row_tiles(M);
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
-  a.split_ws = nullptr; a.split_tickets = nullptr;
-  if (split_work && ffn && mt == 1 && a.nc >= 2 && a.nc <= 8 && (int)grid.x * a.nc <= 256) {      // see st_row_chain
-    const size_t words = (size_t)grid.x * a.nc * 512 * 16;
+  a.split_ws = nullptr; a.split_tickets = nullptr; a.split_parts = 0;
+  const int sp = split_parts_for((int)grid.x, a.nc);
+  if (split_work && ffn && mt == 1 && sp >= 2) {      // see st_row_chain
+    const size_t words = (size_t)grid.x * sp * 512 * 16;
     if (split_bytes < (long long)((256 + words) * 4)) return -6;
     a.split_tickets = (unsigned*)split_work;
     a.split_ws = (float*)split_work + 256;
-    const dim3 sgrid(grid.x * a.nc);
+    a.split_parts = sp;
+    const dim3 sgrid(grid.x * sp);
 #define ST_BSPLIT(HEAD_, TAIL_)                                                                                        \
   do {                                                                                                                 \
     if (drop) hipLaunchKernelGGL((row_chain_bwd_split_kernel<HEAD_, TAIL_, true>), sgrid, blk, 0, stream, a);          \

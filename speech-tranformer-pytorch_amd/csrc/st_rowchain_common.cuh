@@ -37,8 +37,10 @@ struct ChainArgs {
   int nb; const float* bp; bf16* P; int ldp;
   float post_kscale;                 // projection block 1 (the keys of a q | k | v projection) leaves as (acc + bias) * post_kscale:
                                      // the attention kernels' k_prescaled operand (st_attn_common.cuh); 1 = plain
-  // split feed-forward (row_chain_split_kernel): nc partial-sum slots of 32 x 256 fp32 per row block, then one ticket per block
-  float* split_ws; unsigned* split_tickets;
+  // split feed-forward (row_chain_split_kernel): `split_parts` partial-sum slots of 32 x 256 fp32 per row block, then one ticket
+  // per block; a part owns nc / split_parts consecutive hidden chunks (1 at decoder size; 2 when M / 32 x nc workgroups would
+  // not fit one round of the chip - a 4-utterance shard's encoder: 98 row blocks x 2)
+  float* split_ws; unsigned* split_tickets; int split_parts;
 };
 
 // fragments in flight per wave: with three row tiles a fragment feeds three MFMAs (it is consumed a third as often), and

@@ -305,6 +305,13 @@ class EncoderChains:
             ids[l] = self.bset.add(head + ffn_blocks_bwd(ff.w1, ff.w2) + t_blocks(blocks_of(sa.w_o)))
         self.bset.finalize()
         self.bwd = [self.bset.chain(ids[l], True) for l in range(n)]
+        # small batches (a strong-scaling shard: 4 utterances = 3,120 rows = 98 blocks of 32 rows on 256 CUs): the kernel cuts
+        # the feed-forward's hidden dimension over two workgroups per row block (st_row_chain's split_work; ignored at the sizes
+        # that take 64- / 96-row workgroups)
+        if os.environ.get("ST_CHAIN_SPLIT", "1") not in ("0", "d"):      # (development switch; "d": the decoder's chains only)
+            work = torch.zeros(nv.split_work_words(), dtype=torch.int32, device=arena.device)
+            for ch in self.e + self.bwd:
+                ch.split_work = work
         self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
         self.layer_hook = None      # optional callable(first_finished_layer): EncoderBackward.input_grad / trainer.TrainStep
         ChainHub.of(arena).add(self.set, self.bset)

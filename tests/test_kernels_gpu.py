@@ -1045,7 +1045,7 @@ def test_gemm_splitk_matches_gemm(M, N, K, splits, ycm):
 
 
 # ---- row chains (csrc/st_rowchain.hip) -----------------------------------------------------------------------------
-@pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
+@pytest.mark.parametrize("M", [5, 320, 1206, 3120, 9000, 17000, 24700])      # 3120: 98 row blocks - a split chain takes two chunks per part; 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["pre+post1", "pre+ffn+post3", "pre+ffn", "ffn", "ffn+post1", "pre+ffn+post3+drop",
                                      "pre+ffn+post3+split", "pre+ffn+split", "ffn+split", "ffn+post1+split", "pre+ffn+post3+drop+split",
                                      # ks: the key block of the q | k | v projection leaves pre-scaled (post_kscale); post3 alone =
@@ -1263,7 +1263,7 @@ def test_attn_sf1_fwd_equals_the_three_launches(case):
     assert float(b["O"].float().abs().sum()) > 0 and float(b["ctx"].float().abs().sum()) > 0
 
 
-@pytest.mark.parametrize("M", [5, 320, 1206, 9000, 17000, 24700])      # 24700: past one round of 96-row tiles -> two rounds of 64-row ones
+@pytest.mark.parametrize("M", [5, 320, 1206, 3120, 9000, 17000, 24700])      # 3120: 98 row blocks - a split chain takes two chunks per part; 24700: past one round of 96-row tiles -> two rounds of 64-row ones
 @pytest.mark.parametrize("variant", ["head1+tail", "head3+ffn+tail", "ffn+tail", "head3+ffn+tail+drop", "head3+ffn", "tail",
                                      "head0+ffn+tail+drop", "head3+ffn+tail+split", "ffn+tail+split", "head3+ffn+tail+drop+split",
                                      "head3+ffn+split", "head0+ffn+tail+drop+split", "ffn+split"])
