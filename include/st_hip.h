@@ -81,6 +81,13 @@ int st_gemm(st_stream_t stream, int x_cmajor, int y_cmajor, const void* X, int l
             int ldd, int M, int N, int Kc, float* bias, const void* aux, int ldaux, int epi, int splits,
             const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, const void* aux2);
 
+/* D (bf16 [M, N]) = X Y^T + bias (operands row-major as st_gemm's plain forward form) with the output columns
+ * [col_lo, col_hi) - multiples of 32 - multiplied by `scale` in fp32 BEFORE their one rounding to bf16: the q | k | v
+ * projection of Attention.py:74-76 with its key block pre-scaled by scale * log2(e) for st_attn_fwd / st_attn_bwd's
+ * k_prescaled mode (the row chains do the same through st_row_chain's post_kscale). */
+int st_gemm_kscale(st_stream_t stream, const void* X, int ldx, const void* Y, int ldy, void* D, int ldd, int M, int N, int Kc,
+                   float* bias, int col_lo, int col_hi, float scale);
+
 /* D (bf16 [M, N]) = X Y^T (y_cmajor as st_gemm) for FEW output tiles and a LONG contraction (the vocabulary projection's input
  * gradient, Models.py:151 backward: 1,206 x 256 over 4,344): the contraction is cut `splits` ways over workgroups, every
  * split leaves its fp32 partial tile in `work` (write-through) and the last one to finish a tile adds them in split order

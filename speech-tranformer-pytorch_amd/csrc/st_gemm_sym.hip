@@ -57,6 +57,9 @@ struct GemmArgs {
   DropArgs drop;   // EPI_BF16_RELU: dropout after the ReLU (SubLayers.py:25); EPI_BF16_MASK: .scale on the survivors
   // EPI_BF16 with splits > 1 (st_gemm_splitk): fp32 partial tiles of the contraction splits and one ticket per output tile
   float* split_ws; unsigned* split_tickets;
+  // EPI_BF16 (st_gemm_kscale): output columns [cs_lo, cs_hi) - multiples of 32 - leave as (acc + bias) * cs, scaled in fp32 before
+  // their one rounding: the pre-scaled KEYS of a q | k | v projection (st_attn_common.cuh: k_prescaled)
+  int cs_lo, cs_hi; float cs;
 };
 
 // Column of a contraction-major tile element after the swizzle: bits 5-6 of the column are XORed with (c-row & 3).
@@ -430,9 +433,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int ts, int ti, int
         bf16x4 o;
         uint32_t bits = 0;
         if (EPI == EPI_BF16_RELU && DROP) bits = dr.bits(drop_counter_rc(i0 + il, j0 + jl, a.N));   // training only
+        const float cs = (EPI == EPI_BF16 && j0 + jl >= a.cs_lo && j0 + jl < a.cs_hi) ? a.cs : 1.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[x][y][4 * g + e] + bv[y][g][e];
+          if (EPI == EPI_BF16) v *= cs;
           if (EPI == EPI_BF16_RELU) {
             v = fmaxf(v, 0.f);
             if (DROP) v = dr.keep(bits, e) ? v * dr.scale : 0.f;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_group_kernel(GroupArgs g) {
   a.X = p.X; a.ldx = p.ldx; a.Y = p.Y; a.ldy = p.ldy; a.D = p.D; a.ldd = p.ldd;
   a.M = p.M; a.N = p.N; a.Kc = p.Kc; a.bias = p.bias; a.aux = nullptr; a.ldaux = 0; a.aux2 = nullptr;
   a.c_per_split = p.c_per_split; a.tiles_i = p.tiles_i; a.tiles_j = p.tiles_j; a.splits = p.splits;
-  a.head_dim = 0; a.yseg_shift = 31; a.yseg_extra = 0; a.bias_extra = 0;
+  a.head_dim = 0; a.yseg_shift = 31; a.yseg_extra = 0; a.bias_extra = 0; a.cs_lo = a.cs_hi = 0; a.cs = 1.f;
   a.drop.seed = nullptr; a.drop.salt = 0; a.drop.thresh = 0; a.drop.scale = 1.f;
   // compact walk (no XCD padding): these are decoder-sized problems of 4 .. 70 tiles whose operands fit every L2 - the
   // XCD-local walk of the single-problem launch would put a problem with two row tiles and one split on XCDs 0 and 1 only
@@ -596,7 +601,8 @@ int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int
               int ldy, void* D, int ldd, int M, int N, int Kc, float* bias, const void* aux,
               int ldaux, int epi, int splits, const unsigned* drop_seed, unsigned drop_salt,
               int drop_thresh, float drop_scale, int y_block_rows, long y_block_stride,
-              long bias_block_stride, const void* aux2, void* split_work = nullptr, long long split_bytes = 0) {
+              long bias_block_stride, const void* aux2, void* split_work = nullptr, long long split_bytes = 0, int cs_lo = 0,
+              int cs_hi = 0, float cs = 1.f) {
   if (M <= 0 || N <= 0 || Kc <= 0) return 0;
   int yseg_shift = 31;
   if (y_block_rows > 0) {   // power-of-two multiple of 128 rows per block; forward and dgrad operands only
@@ -618,6 +624,7 @@ int gemm_impl(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int
   if (splits < 1) splits = 1;
   if (epi != EPI_F32_ATOMIC && epi != EPI_F32_ATOMIC_T && !(epi == EPI_BF16 && split_work)) splits = 1;
   a.split_ws = nullptr; a.split_tickets = nullptr;
+  a.cs_lo = cs_lo; a.cs_hi = cs_hi; a.cs = cs;
   a.X = (const bf16*)X; a.ldx = ldx; a.Y = (const bf16*)Y; a.ldy = ldy; a.D = D; a.ldd = ldd;
   a.M = M; a.N = N; a.Kc = Kc; a.bias = bias; a.aux = (const bf16*)aux; a.ldaux = ldaux;
   a.aux2 = epi == EPI_BF16_DELTA ? (const bf16*)aux2 : nullptr;
@@ -652,6 +659,15 @@ extern "C" int st_gemm_splitk(hipStream_t stream, int y_cmajor, const void* X, i
   if (!work || splits < 1) return -1;
   return gemm_impl(stream, 0, y_cmajor, X, ldx, Y, ldy, D, ldd, M, N, Kc, nullptr, nullptr, 0, EPI_BF16, splits, nullptr, 0u, 0, 1.f,
                    0, 0, 0, nullptr, work, work_bytes);
+}
+
+// D (bf16 [M, N]) = (X Y^T + bias), columns [col_lo, col_hi) multiplied by `scale` in fp32 before the rounding: the q | k | v
+// projection (Attention.py:74-76) with its KEY block pre-scaled for the attention kernels' k_prescaled mode
+extern "C" int st_gemm_kscale(hipStream_t stream, const void* X, int ldx, const void* Y, int ldy, void* D, int ldd, int M, int N,
+                              int Kc, float* bias, int col_lo, int col_hi, float scale) {
+  if ((col_lo & 31) || (col_hi & 31) || col_lo < 0 || col_hi < col_lo || col_hi > N) return -9;
+  return gemm_impl(stream, 0, 0, X, ldx, Y, ldy, D, ldd, M, N, Kc, bias, nullptr, 0, EPI_BF16, 1, nullptr, 0u, 0, 1.f, 0, 0, 0, nullptr,
+                   nullptr, 0, col_lo, col_hi, scale);
 }
 
 extern "C" int st_gemm_stacked(hipStream_t stream, int x_cmajor, int y_cmajor, const void* X, int ldx, const void* Y,

@@ -305,10 +305,11 @@ class EncoderChains:
             ids[l] = self.bset.add(head + ffn_blocks_bwd(ff.w1, ff.w2) + t_blocks(blocks_of(sa.w_o)))
         self.bset.finalize()
         self.bwd = [self.bset.chain(ids[l], True) for l in range(n)]
-        # small batches (a strong-scaling shard: 4 utterances = 3,120 rows = 98 blocks of 32 rows on 256 CUs): the kernel cuts
-        # the feed-forward's hidden dimension over two workgroups per row block (st_row_chain's split_work; ignored at the sizes
-        # that take 64- / 96-row workgroups)
-        if os.environ.get("ST_CHAIN_SPLIT", "1") not in ("0", "d"):      # (development switch; "d": the decoder's chains only)
+        # (no split_work for the encoder's chains: cutting the hidden dimension over workgroups changes the fp32 summation order
+        # per row, and WHICH split a launch takes depends on its row count - an utterance's activations would then depend on what
+        # else is in the batch / on the data-parallel shard size.  Measured: a 4-utterance shard 1.667 -> 1.650 ms with a two-way
+        # split, tests/test_modules_gpu.py::test_full_size_batch_split_invariance 5e-3 -> 1.6e-2.  Not worth it.  LABNOTES round 5.)
+        if os.environ.get("ST_CHAIN_SPLIT", "1") == "e":      # (development switch: the measurement above)
             work = torch.zeros(nv.split_work_words(), dtype=torch.int32, device=arena.device)
             for ch in self.e + self.bwd:
                 ch.split_work = work

@@ -741,17 +741,21 @@ class MhaFn(torch.autograd.Function):
         if pre is not None:
             qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd = (pre.qkv, pre.kvbuf, pre.ctx, pre.ores, pre.lse, pre.out,
                                                                 pre.xhat, pre.rstd)
+            kpre = bool(pre.kpre)
         else:
+            # non-causal self-attention (an encoder layer on the per-GEMM path: config 3's width, the stand-alone module): the
+            # projection hands the attention kernels PRE-SCALED keys, as the encoder's row chains do (chains.EncoderChains)
+            kpre = x_kv is None and not causal and MhaFn.PRESCALE_KEYS
             qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd = MhaFn.compute(
-                x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, any(ctx.needs_input_grad), scale)
+                x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, any(ctx.needs_input_grad), scale, kpre)
         if AttnTap.active is not None:
             Qm, Km = (qkv[:, :d], qkv[:, d:2 * d]) if x_kv is None else (qkv, kvbuf[:, :d])
-            AttnTap.record(mod, Qm, Km, q_rows, k_rows, causal, bool(pre is not None and pre.kpre))
+            AttnTap.record(mod, Qm, Km, q_rows, k_rows, causal, kpre)
         ctx.save_for_backward(x_q, x_kv, qkv, kvbuf, attn_ctx, lse, xhat, rstd, ores)
         ctx.mod, ctx.q_rows, ctx.k_rows, ctx.causal, ctx.scale = mod, q_rows, k_rows, causal, scale
         ctx.drop = drop          # attention-probability dropout (Attention.py:89): the backward regenerates the mask
         ctx.kv_acc = kv_acc      # decoder-encoder attention: the layers share one encoder-gradient buffer (or CrossKv's)
-        ctx.kpre = bool(pre is not None and pre.kpre)     # the saved keys are pre-scaled (chains.EncoderChains): tell the backward
+        ctx.kpre = kpre          # the saved keys are pre-scaled: the backward must be told
         ctx.up, ctx.down = up, down
         ctx.chain = (pre.bwd, pre.key) if pre is not None and pre.bwd is not None else None   # chains.ChainBackward
         if down is not None:
@@ -765,15 +769,21 @@ class MhaFn(torch.autograd.Function):
             return out.view_as(out)
         return out
 
+    PRESCALE_KEYS = True      # (tests switch it off together with chains.EncoderChains.PRESCALE_KEYS)
+
     @staticmethod
-    def compute(x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, need_bwd, scale):
-        """The forward launches of one attention sublayer -> (qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd)."""
+    def compute(x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, need_bwd, scale, kpre=False):
+        """The forward launches of one attention sublayer -> (qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd).
+        kpre: the key block of the q | k | v projection leaves pre-scaled by scale * log2(e) (native.attn_fwd's k_prescaled)."""
         d, H = s.d_model, s.n_head
         Mq = x_q.shape[0]
         self_attn = x_kv is None
         if self_attn:
             qkv = _empty(Mq, 3 * d, x_q)
-            linear_fwd(x_q, s.w_qkv, qkv, s.b_qkv)
+            if kpre:
+                nv.gemm_kscale(x_q, s.w_qkv, qkv, s.b_qkv, d, 2 * d, scale * nv.K_LOG2_SCALE)
+            else:
+                linear_fwd(x_q, s.w_qkv, qkv, s.b_qkv)
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             kvbuf = None
         else:
@@ -795,7 +805,8 @@ class MhaFn(torch.autograd.Function):
         ores = rows_buffer(Mq, d, q_rows, x_q.device) if need_bwd else None
         lse = torch.empty(H * Mq, dtype=F32, device=x_q.device)
         nv.attn_fwd(Q, K, V, attn_ctx, lse, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H, q_rows.max_len, causal,
-                    scale, work=attn_work(q_rows, k_rows, causal, d // H, H)[0], drop=drop, max_k=k_rows.max_len, ores=ores)
+                    scale, work=attn_work(q_rows, k_rows, causal, d // H, H)[0], drop=drop, max_k=k_rows.max_len, ores=ores,
+                    k_prescaled=kpre)
         out, xhat = _empty(Mq, d, x_q), _empty(Mq, d, x_q)
         rstd = torch.empty(Mq, dtype=F32, device=x_q.device)
         nv.gemm_ln(attn_ctx, s.w_o, s.b_o, x_q, s.gamma, s.beta, out, xhat, rstd, eps=LN_EPS)

@@ -50,6 +50,8 @@ SIGNATURES = {
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
                      _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_ll, _c_float],
     "st_row_chain_mask_words": [_c_int, _c_int],
+    "st_gemm_kscale": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
+                       _c_float],
     "st_gemm_splitk": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                        _c_void_p, _c_ll],
     "st_row_chain_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -362,6 +364,19 @@ def gemm_ws(X, W, out, bias=None, relu=False, drop=None, stack=None):
     rc = load().st_gemm_ws(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
                            M, N, K, _p(bias), int(relu), *(_drop(drop) if relu else _drop(None)), block_rows, w_stride, b_stride)
     _check(rc, "st_gemm_ws")
+    return out
+
+
+def gemm_kscale(X, W, out, bias, col_lo, col_hi, scale):
+    """out = X W^T + bias with columns [col_lo, col_hi) scaled by `scale` in fp32 before the rounding (st_gemm_kscale): a
+    q | k | v projection whose key block leaves pre-scaled (attn_fwd's k_prescaled)."""
+    _mat(X, BF16, "X"), _mat(W, BF16, "W"), _mat(out, BF16, "out")
+    M, K = X.shape
+    N = W.shape[0]
+    _vec(bias, F32, N, "bias")
+    _tag("gemm", 0, 0, M, N, K, EPI_BF16, io=(2.0 * M * K, 2.0 * N * K, 2.0 * M * N, 0, 0))
+    _check(load().st_gemm_kscale(_stream(), X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0),
+                                 M, N, K, _p(bias), int(col_lo), int(col_hi), float(scale)), "st_gemm_kscale")
     return out
 
 

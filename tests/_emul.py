@@ -112,6 +112,13 @@ def gemm_splitk(X, Y, out, splits, y_cmajor=False):
     return gemm(X, Y, out, y_cmajor=y_cmajor)
 
 
+def gemm_kscale(X, W, out, bias, col_lo, col_hi, scale):
+    acc = X.float() @ W.float().t() + (bias.float() if bias is not None else 0.0)
+    acc[:, col_lo:col_hi] *= float(scale)
+    out[:X.shape[0], :W.shape[0]] = acc.to(BF16)
+    return out
+
+
 def gemm_ws(X, W, out, bias=None, relu=False, drop=None, stack=None):
     return gemm(X, W, out, bias=bias, epi=nv.EPI_BF16_RELU if relu else nv.EPI_BF16, drop=drop, stack=stack)
 
@@ -644,7 +651,7 @@ def cast_bf16(src, dst):
     return dst
 
 
-_NAMES = ["gemm", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "attn_dense_fwd", "attn_dense_bwd", "ctc_gather", "ctc_dlogits", "row_index", "pack_rows", "unpack_rows",
+_NAMES = ["gemm", "gemm_kscale", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "attn_dense_fwd", "attn_dense_bwd", "ctc_gather", "ctc_dlogits", "row_index", "pack_rows", "unpack_rows",
           "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "beam_work_words", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 

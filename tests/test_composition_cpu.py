@@ -709,11 +709,11 @@ def run_row_chains_on_off(device, exact):
                 # one rounding: another rounding realisation than the per-GEMM path) - switched off, the two paths must agree
                 # bit for bit; switched on (the product), to rounding
                 assert abs(l1 - l0) <= 2e-3 * abs(l0) and rel(lg1, lg0) < 2e-2 and rel(g1, g0) < GRAD_TOL_TENSOR, (training, l1, l0)
-                EncoderChains.PRESCALE_KEYS = False
+                EncoderChains.PRESCALE_KEYS = F_.MhaFn.PRESCALE_KEYS = False
                 try:
-                    l1, lg1, g1 = run(True)
+                    (l1, lg1, g1), (l0, lg0, g0) = run(True), run(False)
                 finally:
-                    EncoderChains.PRESCALE_KEYS = True
+                    EncoderChains.PRESCALE_KEYS = F_.MhaFn.PRESCALE_KEYS = True
                 assert l1 == l0 and torch.equal(lg1, lg0) and torch.equal(g1, g0), (training, l1, l0)
             else:
                 # two bf16 pipelines with different accumulation orders: rounding flips are amplified layer by layer on

@@ -45,7 +45,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
 
 
-def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_norm=5.0):
+def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_norm=5.0, seed=0):
     import transformer.Models as M
     import transformer.Utils as U
     from st_amd import synthetic
@@ -53,7 +53,7 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
     from st_amd.trainer import TrainStep
     from transformer.Optim import ScheduledOptim
 
-    torch.manual_seed(0)
+    torch.manual_seed(seed)                        # (the weights' seed: tools/dev/c3_kpre_ab.py varies it)
     model = M.Transformer(U.AttrDict(cfg))
     U.init_parameters(model)                       # train.py:116
     w = {k: v.detach().clone() for k, v in model.state_dict().items()}

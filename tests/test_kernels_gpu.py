@@ -841,6 +841,23 @@ def test_gemm_stacked_weights(M, blocks, rows, K):
         assert torch.equal(dx, dref), "stacked dgrad differs from the gathered GEMM"
 
 
+@pytest.mark.parametrize("M,d,K", [(300, 128, 128), (24060, 512, 512), (777, 256, 256)])
+def test_gemm_kscale_scales_the_key_block_before_its_rounding(M, d, K):
+    """st_gemm_kscale: a q | k | v projection whose KEY block leaves multiplied by scale * log2(e) in fp32, rounded once (the
+    per-GEMM path's form of st_row_chain's post_kscale); the other two blocks are st_gemm's, bit for bit."""
+    x, W, b = g(M, K, seed=1), g(3 * d, K, seed=2, scale=K ** -0.5), g(3 * d, seed=3, dtype=F32)
+    ks = 0.125 * nv.K_LOG2_SCALE
+    got = nv.gemm_kscale(cu(x), cu(W), torch.full((M, 3 * d), float("nan"), dtype=BF16, device="cuda"), cu(b), d, 2 * d, ks)
+    plain = nv.gemm(cu(x), cu(W), torch.zeros(M, 3 * d, dtype=BF16, device="cuda"), bias=cu(b))
+    assert torch.equal(got[:, :d], plain[:, :d]) and torch.equal(got[:, 2 * d:], plain[:, 2 * d:])
+    ref = em.gemm_kscale(x, W, torch.zeros(M, 3 * d, dtype=BF16), b, d, 2 * d, ks)
+    check(got, ref, 1e-2, "gemm_kscale")
+    acc = (x.float() @ W.float().t() + b)[:, d:2 * d] * ks
+    err_once = (got[:, d:2 * d].float().cpu() - acc).norm() / acc.norm()
+    err_twice = ((plain[:, d:2 * d].float().cpu() * ks).to(BF16).float() - acc).norm() / acc.norm()
+    assert err_once < 0.8 * err_twice, (float(err_once), float(err_twice))      # one rounding, not two
+
+
 def test_adam_clip_matches_torch_clip_and_fused_adam():
     """st_adam_clip == clip_grad_norm_ (global norm over the flat buffer) followed by torch.optim.Adam(fused, capturable)
     with a device learning-rate tensor, over several steps with a changing rate (the Noam schedule) and gradients both
