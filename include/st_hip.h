@@ -199,21 +199,6 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
  * scaled in fp32 before its one rounding to bf16 - pass scale * log2(e) and hand the result to st_attn_fwd / st_attn_bwd /
  * st_attn_probs with k_prescaled = 1 (below). */
 
-/* The decoder's backward between the encoder-decoder attention's backward kernel and the next backward chain as ONE launch per
- * layer (Layers.py:39-41 under autograd): st_row_chain_bwd's HEAD (one block: dP = d(q) of the encoder-decoder attention, G =
- * the residual's gradient, the LayerNorm backward of the self-attention sublayer -> ds_a + column sums) and TAIL (ds_a Wo =
- * d(context), delta) - wfrag = that two-block chain's stream -, then, in the same workgroup, st_attn_bwd of the utterance's causal
- * SELF-attention on the layer's q | k | v projection (qkv_q / _k / _v, leading dimension ld_qkv, head h at columns h * 64; lse
- * from its forward) into dq / dk / dv (leading dimension ld_dqkv).  One workgroup per utterance: rows utt_off[b] .. +
- * utt_len[b] of every row matrix, utt_len <= max_len <= 64, 4 heads of 64 (d_model 256); -10 otherwise (callers then issue
- * st_row_chain_bwd + st_attn_bwd).  dctx / delta may be NULL.  Results are those of the two launches up to summation order. */
-int st_dec_b1s_bwd(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, const void* dP, int ldp,
-                   const void* G, int ldg, const void* xhat_a, const float* rstd_a, const float* gamma_a, void* ds_a,
-                   float* dgamma_a, float* dbeta_a, float* dbias_a, const void* O, const void* Ores, int ldo, void* dctx, int lddc,
-                   float* delta, const int* utt_off, const int* utt_len, int B, int max_len, const void* qkv_q, const void* qkv_k,
-                   const void* qkv_v, int ld_qkv, const float* lse, void* dq, void* dk, void* dv, int ld_dqkv, float scale,
-                   const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale);
-
 /* relu_bits (st_row_chain: optional output, st_row_chain_bwd: input): which hidden values of the feed-forward sublayer are
  * > 0 after ReLU and dropout (the mask of SubLayers.py:25's backward), one bit per value in a layout private to the two
  * kernels; st_row_chain_mask_words(M, d_ff) 64-bit words.  The backward chain reads these instead of H. */

@@ -22,7 +22,6 @@
 // accumulates), so the hidden tile never exceeds 16 KB of LDS.  Measured (M = 1206, d_ff 1024): the feed-forward
 // sublayer alone 25.5 us as two launches -> 15.9 us, bound by one CU's 64 B/clk vector-memory path (1 MB of weights
 // per workgroup).
-#include "st_attn_common.cuh"
 #include "st_rowchain_common.cuh"
 #include <cstdlib>
 #include <type_traits>
@@ -306,140 +305,7 @@ struct ChainBwdArgs {
   const bf16* O; const bf16* Ores; int ldo; bf16* dctx; int lddc; float* delta;
   // split feed-forward (row_chain_bwd_split_kernel): as ChainArgs
   float* split_ws; unsigned* split_tickets; int split_parts;
-  // SELF (st_dec_b1s_bwd): one workgroup per UTTERANCE (rows utt_off[b] .. + utt_len[b], <= 64) instead of per 32 MT-row block,
-  // and behind TAIL the backward of the utterance's causal self-attention (Attention.py:82-90 under autograd, Layers.py:39):
-  // dctx and delta never leave the chip on their way there.  s_q / s_k / s_v: the layer's q | k | v projection (head h at columns
-  // h * 64), s_lse its forward's log-sum-exp [H, M] (log2 domain); s_dq / s_dk / s_dv receive the gradients.
-  const int* utt_off; const int* utt_len;
-  const bf16* s_q; const bf16* s_k; const bf16* s_v; int s_ld; const float* s_lse;
-  bf16* s_dq; bf16* s_dk; bf16* s_dv; int s_ldd; float s_scale; DropArgs s_drop;
 };
-
-// The backward of ONE utterance's causal self-attention with <= 64 positions and 64-wide heads, inside the workgroup that just
-// produced its d(context) (st_dec_b1s_bwd): wave w serves head w >> 1, first as the owner of the 32 QUERIES half = w & 1 (dQ:
-// lane = query, registers = keys - attn_bwd_dq_body's arithmetic), then as the owner of the 32 KEYS `half` (dK, dV: lane =
-// key, registers = queries - attn_bwd_dkv_body's).  All four operand tiles are resident in LDS ([64][256] at the chains' row
-// stride): tq / tk / tv = the q | k | v projection, tdo = d(context); stat = [4][64] delta then [4][64] lse.  No streaming, no
-// barrier: every wave reads finished tiles and writes its own rows of dq | dk | dv.
-template <bool DROP>
-__device__ __forceinline__ void self_attn_bwd64(const ChainBwdArgs& a, int b, int row0, int len, const bf16* tq, const bf16* tk,
-                                                const bf16* tv, const bf16* tdo, const float* stat, int wave, int l) {
-  const int h = wave >> 1, half = wave & 1, hi = l >> 5, r = l & 31;
-  if (half * 32 >= len) return;                         // (wave-uniform) this wave's 32 positions lie past the utterance
-  const float c2 = a.s_scale * 1.4426950408889634f;
-  const Drop dr = make_drop(a.s_drop);
-  const int bh = b * 4 + h, col0 = h * 64;
-  const float* s_dl = stat + h * 64;
-  const float* s_ls = stat + 256 + h * 64;
-  const int me = half * 32 + r;                         // this lane's position (query in part 1, key in part 2)
-  {   // ---- part 1: dQ of query `me`
-    bf16x8 qf[4], dof[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      qf[t] = frag_nat(tq, AS, me, col0 + t * 16 + hi * 8);
-      dof[t] = frag_nat(tdo, AS, me, col0 + t * 16 + hi * 8);
-    }
-    const float lse = s_ls[me], dl = s_dl[me];
-    f32x16 dq[2] = {zero16(), zero16()};
-    for (int kb = 0; kb <= half; ++kb) {                // causal: key blocks up to the query's own
-      f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s = mfma32(frag_nat(tk, AS, kb * 32 + r, col0 + t * 16 + hi * 8), qf[t], s);
-        dp = mfma32(frag_nat(tv, AS, kb * 32 + r, col0 + t * 16 + hi * 8), dof[t], dp);
-      }
-      if (DROP) {
-        bool keep[16];
-        keep16<true>(dr, bh, me, kb * 32, hi, keep);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dp[i] = keep[i] ? dp[i] * dr.scale : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kb * 32 + acc_row(i, hi);
-        const float p = (key > me || key >= len) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[i], c2, -lse));
-        s[i] = p * (dp[i] - dl);
-      }
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 dsf = pack_acc8(s, 8 * hf);
-        const int base = kb * 32 + 16 * hf + 4 * hi;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) dq[d] = mfma32(frag_tr(tk, AS, col0 + d * 32, base, base + 8), dsf, dq[d]);
-      }
-    }
-    if (me < len) {
-      bf16* g = a.s_dq + (size_t)(row0 + me) * a.s_ldd + col0;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)(dq[d][4 * gq + e] * a.s_scale);
-          *reinterpret_cast<bf16x4*>(g + d * 32 + 8 * gq + 4 * hi) = o;
-        }
-    }
-  }
-  {   // ---- part 2: dK, dV of key `me`
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      kf[t] = frag_nat(tk, AS, me, col0 + t * 16 + hi * 8);
-      vf[t] = frag_nat(tv, AS, me, col0 + t * 16 + hi * 8);
-    }
-    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-    for (int qb = half; qb < 2 && qb * 32 < len; ++qb) {     // causal: query blocks from the key's own on
-      f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s = mfma32(frag_nat(tq, AS, qb * 32 + r, col0 + t * 16 + hi * 8), kf[t], s);
-        dp = mfma32(frag_nat(tdo, AS, qb * 32 + r, col0 + t * 16 + hi * 8), vf[t], dp);
-      }
-      bool keep[16];
-      if (DROP) {
-        keep16<false>(dr, bh, me, qb * 32, hi, keep);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dp[i] = keep[i] ? dp[i] * dr.scale : 0.f;
-      }
-      f32x16 p;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int q = qb * 32 + acc_row(i, hi);
-        const float pv = (me > q || q >= len) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[i], c2, -s_ls[q]));
-        s[i] = pv * (dp[i] - s_dl[q]);
-        p[i] = DROP ? (keep[i] ? pv * dr.scale : 0.f) : pv;
-      }
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack_acc8(p, 8 * hf), dsf = pack_acc8(s, 8 * hf);
-        const int base = qb * 32 + 16 * hf + 4 * hi;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          dv[d] = mfma32(frag_tr(tdo, AS, col0 + d * 32, base, base + 8), pf, dv[d]);
-          dk[d] = mfma32(frag_tr(tq, AS, col0 + d * 32, base, base + 8), dsf, dk[d]);
-        }
-      }
-    }
-    if (me < len) {
-      bf16* gk = a.s_dk + (size_t)(row0 + me) * a.s_ldd + col0;
-      bf16* gv = a.s_dv + (size_t)(row0 + me) * a.s_ldd + col0;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          bf16x4 ok, ov;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            ok[e] = (bf16)(dk[d][4 * gq + e] * a.s_scale);
-            ov[e] = (bf16)dv[d][4 * gq + e];
-          }
-          *reinterpret_cast<bf16x4*>(gk + d * 32 + 8 * gq + 4 * hi) = ok;
-          *reinterpret_cast<bf16x4*>(gv + d * 32 + 8 * gq + 4 * hi) = ov;
-        }
-    }
-  }
-}
 
 // LayerNorm backward over the 256 columns held by the 8 waves.  acc = the GEMM result; t_aux holds the addend and receives
 // dy (bf16, rounded once as acc + addend, before the dropout mask) in place; t_xhat the saved normalised values; dx goes
@@ -552,20 +418,14 @@ __device__ __forceinline__ void epi_lnbwd(const Ctx<MT>& c, f32x16 (&acc)[MT], b
   }
 }
 
-// SELF (0 / 1 / 2 = with attention dropout): one workgroup per utterance + the causal self-attention backward behind TAIL
-// (ChainBwdArgs: utt_off ...; MT = 2, HEAD and TAIL, no FFN: st_dec_b1s_bwd)
-template <bool HEAD, bool FFN, bool TAIL, bool DROP, int MT, int SELF = 0>
+template <bool HEAD, bool FFN, bool TAIL, bool DROP, int MT>
 __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
   constexpr int RB = 32 * MT, TE = RB * AS;
-  __shared__ __attribute__((aligned(16))) bf16 tiles[(SELF ? 4 : 3) * TE];
+  __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
   __shared__ float red[2][NW * 32 * MT];
   Ctx<MT> c;
   c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
-  if constexpr (SELF != 0) {
-    c.row0 = a.utt_off[blockIdx.x]; c.nvalid = min(RB, a.utt_len[blockIdx.x]);
-  } else {
-    c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
-  }
+  c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
   c.ws = a.wfrag + (size_t)c.wave * a.wave_frags * 64;
 #pragma unroll
   for (int i = 0; i < Ring<MT>::D; ++i) c.ring[i] = c.ws[i * 64 + c.l];
@@ -588,16 +448,6 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
   const Drop da = make_drop(a.drop_a), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
   bf16* cur;          // the running gradient ds
   bf16 *fa, *fb;      // the two other tiles
-  // SELF: the utterance's q | k | v are asked for NOW (48 registers through the chain): the self-attention phase at the end of the
-  // launch then starts from tiles that arrived long ago; q goes to the fourth tile at once (nobody else uses it)
-  TileRegs<MT> s_rk, s_rv;
-  if constexpr (SELF != 0) {
-    TileRegs<MT> s_rq;
-    tile_load(c, a.s_q, a.s_ld, s_rq);
-    tile_load(c, a.s_k, a.s_ld, s_rk);
-    tile_load(c, a.s_v, a.s_ld, s_rv);
-    tile_store(c, s_rq, tiles + 3 * TE);
-  }
 
   if (HEAD) {
     // t0: the dP blocks one after the other, then ds_a; t1: G -> dy; t2: xhat_a
@@ -714,36 +564,12 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
       if (c.hi == 0) red[0][(c.wave * MT + mt) * 32 + c.r] = part;     // this wave's 32 columns of the row: half a head
     }
     __syncthreads();
-    if constexpr (SELF != 0) {
-      // the utterance's q | k | v -> the fourth tile, fa, fb (O / Ores were last read before the barrier above); delta and the
-      // forward's log-sum-exp -> red[1] as [4][64] + [4][64]; d(context) stays where it is (cur).  dctx / delta still go to
-      // HBM when the caller wants them (tests); the self-attention reads neither from there.
-      bf16* t3 = tiles + 3 * TE;
-      float* stat = &red[1][0];
-      {
-        const int h = c.tid >> 6, row = c.tid & 63, mt = row >> 5, r = row & 31;      // threads 0..255: delta, 256..511: lse
-        if (c.tid < 256) {
-          const float dl = red[0][((2 * h) * MT + mt) * 32 + r] + red[0][((2 * h + 1) * MT + mt) * 32 + r];
-          stat[c.tid] = dl;
-          if (a.delta && row < c.nvalid) a.delta[(size_t)h * a.M + c.row0 + row] = dl;
-        } else {
-          const int hh = h - 4;
-          stat[c.tid] = row < c.nvalid ? a.s_lse[(size_t)hh * a.M + c.row0 + row] : 0.f;
-        }
-      }
-      if (a.dctx) tile_out(c, cur, a.dctx, a.lddc);
-      tile_store(c, s_rk, fa);
-      tile_store(c, s_rv, fb);
-      __syncthreads();
-      self_attn_bwd64<SELF == 2>(a, blockIdx.x, c.row0, c.nvalid, t3, fa, fb, cur, stat, c.wave, c.l);
-    } else {
-      tile_out(c, cur, a.dctx, a.lddc);
-      // delta[h][row]: heads are 64 columns = two waves
-      for (int i = c.tid; i < 4 * RB; i += 512) {
-        const int h = i / RB, row = i % RB, mt = row >> 5, r = row & 31;
-        if (row < c.nvalid)
-          a.delta[(size_t)h * a.M + c.row0 + row] = red[0][((2 * h) * MT + mt) * 32 + r] + red[0][((2 * h + 1) * MT + mt) * 32 + r];
-      }
+    tile_out(c, cur, a.dctx, a.lddc);
+    // delta[h][row]: heads are 64 columns = two waves
+    for (int i = c.tid; i < 4 * RB; i += 512) {
+      const int h = i / RB, row = i % RB, mt = row >> 5, r = row & 31;
+      if (row < c.nvalid)
+        a.delta[(size_t)h * a.M + c.row0 + row] = red[0][((2 * h) * MT + mt) * 32 + r] + red[0][((2 * h + 1) * MT + mt) * 32 + r];
     }
   }
   {
@@ -1190,45 +1016,6 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   else if (head) ST_BWD(true, false, false);
   else ST_BWD(false, false, true);
 #undef ST_BWD
-  ST_CHECK_LAUNCH();
-  return 0;
-}
-
-// The decoder's backward between the encoder-decoder attention's backward kernel and the next chain, as ONE launch per layer
-// (Layers.py:39-41 under autograd): chain B1 - HEAD: d(q) Wq + G through the LayerNorm backward of the self-attention sublayer
-// (ds_a and its three column sums), TAIL: ds_a Wo = d(context), delta - and, behind it in the same workgroup, the backward of the
-// utterance's causal SELF-attention (st_attn_bwd's arithmetic: dq | dk | dv).  One workgroup per utterance (<= 64 target
-// positions, 64-row tiles; 4 heads of 64): d(context) and delta stay on the chip, and the 8 us launch of the few-rows attention
-// backward leaves the decoder's dependent chain.  dctx / delta may be NULL (nobody else reads them).
-extern "C" int st_dec_b1s_bwd(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, const void* dP, int ldp,
-                              const void* G, int ldg, const void* xhat_a, const float* rstd_a, const float* gamma_a, void* ds_a,
-                              float* dgamma_a, float* dbeta_a, float* dbias_a, const void* O, const void* Ores, int ldo, void* dctx,
-                              int lddc, float* delta, const int* utt_off, const int* utt_len, int B, int max_len, const void* qkv_q,
-                              const void* qkv_k, const void* qkv_v, int ld_qkv, const float* lse, void* dq, void* dk, void* dv,
-                              int ld_dqkv, float scale, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh,
-                              float drop_scale) {
-  if (B <= 0 || M <= 0) return 0;
-  if (max_len > 64 || n_blocks != 2) return -10;      // callers then issue st_row_chain_bwd + st_attn_bwd
-  if (!wfrag || !dP || !G || !xhat_a || !rstd_a || !gamma_a || !ds_a || !O || !utt_off || !utt_len || !qkv_q || !qkv_k || !qkv_v ||
-      !lse || !dq || !dk || !dv)
-    return -1;
-  if ((ldp & 7) || ldp < 256 || (ldg & 7) || (ldo & 7) || (dctx && (lddc & 7)) || (ld_qkv & 7) || (ld_dqkv & 3)) return -2;
-  ChainBwdArgs a = {};
-  a.M = M; a.wfrag = (const bf16x8*)wfrag; a.wave_frags = n_blocks * 16 + DEPTH;
-  a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
-  a.nb = 1; a.dP = (const bf16*)dP; a.ldp = ldp; a.G = (const bf16*)G; a.ldg = ldg; a.xhat_a = (const bf16*)xhat_a;
-  a.rstd_a = rstd_a; a.gamma_a = gamma_a; a.drop_a.seed = nullptr; a.drop_a.salt = 0; a.drop_a.thresh = 0; a.drop_a.scale = 1.f;
-  a.ds_a = (bf16*)ds_a; a.dgamma_a = dgamma_a; a.dbeta_a = dbeta_a; a.dbias_a = dbias_a;
-  a.nc = 0; a.mask_scale = 1.f;
-  a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
-  a.utt_off = utt_off; a.utt_len = utt_len;
-  a.s_q = (const bf16*)qkv_q; a.s_k = (const bf16*)qkv_k; a.s_v = (const bf16*)qkv_v; a.s_ld = ld_qkv; a.s_lse = lse;
-  a.s_dq = (bf16*)dq; a.s_dk = (bf16*)dk; a.s_dv = (bf16*)dv; a.s_ldd = ld_dqkv; a.s_scale = scale;
-  const bool drop = drop_seed != nullptr && drop_thresh > 0;
-  a.s_drop.seed = drop ? drop_seed : nullptr; a.s_drop.salt = drop_salt; a.s_drop.thresh = drop ? drop_thresh : 0;
-  a.s_drop.scale = drop ? drop_scale : 1.f;
-  if (drop) hipLaunchKernelGGL((row_chain_bwd_kernel<true, false, true, false, 2, 2>), dim3(B), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((row_chain_bwd_kernel<true, false, true, false, 2, 1>), dim3(B), dim3(512), 0, stream, a);
   ST_CHECK_LAUNCH();
   return 0;
 }

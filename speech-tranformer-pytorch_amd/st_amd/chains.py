@@ -257,18 +257,6 @@ class DecoderBackward(ChainBackward):
         arena = self.layers[l].slf_attn._st_arena
         arena.attach_grads(sa.params, sa.lo, sa.hi)
         M = a.out.shape[0]
-        rows = getattr(self, "t_rows", None)
-        if rows is not None and self.owner.fuse_b1s and nv.dec_b1s_ok(sa.d_model, sa.n_head, rows.max_len):
-            # chain B1 AND the causal self-attention's backward as ONE launch, one workgroup per utterance (st_dec_b1s_bwd):
-            # d(context) and delta stay on the chip; the self-attention's MhaFn.backward finds its dq | dk | dv ready
-            from .functional import rows_buffer
-            ds_s = rows_buffer(M, BLK, rows, a.out.device)      # (the launch writes utterance rows only: zeros elsewhere on padded layouts)
-            dqkv = rows_buffer(M, 3 * BLK, rows, a.out.device)
-            nv.dec_b1s_bwd(self.owner.bwd1[l], M, (dproj, ds, a.xhat, a.rstd, sa.gamma, ds_s, sa.g_gamma, sa.g_beta, sa.g_b_o),
-                           (a.ctx, a.ores, None, None), rows.off, rows.len, rows.max_len, a.qkv, a.lse, dqkv,
-                           1.0 / math.sqrt(BLK // sa.n_head), drop=a.drop)
-            self.done[("self", l)] = dict(ds=ds_s, dctx=None, delta=None, dqkv=dqkv)
-            return ds_s
         ds_s, dctx = self._empty(a.out, BLK), self._empty(a.out, BLK)
         delta = torch.empty(sa.n_head * M, dtype=F32, device=a.out.device)
         nv.row_chain_bwd(self.owner.bwd1[l], M,
@@ -429,7 +417,6 @@ class DecoderChains:
             for ch in self.bwd2:
                 ch.split_work = self.f2[0].split_work       # (forward and backward launches are ordered on one stream)
         self.bwd1 = [self.bset.chain(b1[l], True) for l in range(n)]
-        self.fuse_b1s = os.environ.get("ST_DEC_B1S", "1") != "0"      # (development switch: chain B1 + self-attention backward as one launch)
         self.use_bwd = sa.n_head * 64 == BLK        # the delta epilogue's heads are 64 columns
         self.layer_hook = None      # optional callable(first_finished_layer): EncoderBackward.input_grad / trainer.TrainStep
         ChainHub.of(arena).add(self.set, self.bset)
@@ -510,7 +497,6 @@ class DecoderChains:
             pres.append((a, b, f))
         if need_bwd and self.use_bwd:
             cb = DecoderBackward(self, list(layers), pres)
-            cb.t_rows = t_rows
             for l, (a, b, f) in enumerate(pres):
                 a.bwd = b.bwd = f.bwd = cb
                 a.key, b.key, f.key = ("self", l), ("cross", l), ("ffn", l)

@@ -841,10 +841,7 @@ class MhaFn(torch.autograd.Function):
             # d(context) and, in the same launch, delta = rowsum(d(context) * context) per head: the two attention
             # backward kernels then depend on nothing but finished buffers and run as ONE launch
             nv.gemm(ds, s.w_o, dctx, epi=nv.EPI_BF16_DELTA, aux=attn_ctx, y_cmajor=True, delta=delta, head_dim=d // H, aux2=ores)
-        fused = got is not None and got.get("dqkv") is not None      # (st_dec_b1s_bwd already ran this attention's backward)
-        if fused:
-            dqkv = got["dqkv"]
-        elif x_kv is None:
+        if x_kv is None:
             Q, K, V = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             # key rows past k_len (padded layout only) get no gradient: they must read as zeros
             dqkv = rows_buffer(Mq, 3 * d, k_rows, x_q.device)
@@ -862,11 +859,10 @@ class MhaFn(torch.autograd.Function):
             else:
                 dkv = rows_buffer(x_kv.shape[0], 2 * d, k_rows, x_q.device)
             dQ, dK, dV = dqkv, dkv[:, :d], dkv[:, d:]
-        if not fused:
-            _, work_q, work_k = attn_work(q_rows, k_rows, ctx.causal, d // H, H)
-            nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
-                        q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop,
-                        k_prescaled=ctx.kpre)
+        _, work_q, work_k = attn_work(q_rows, k_rows, ctx.causal, d // H, H)
+        nv.attn_bwd(Q, K, V, None, dctx, lse, delta, dQ, dK, dV, q_rows.off, q_rows.len, k_rows.off, k_rows.len, H,
+                    q_rows.max_len, k_rows.max_len, ctx.causal, ctx.scale, work_q=work_q, work_k=work_k, drop=ctx.drop,
+                    k_prescaled=ctx.kpre)
         dx_kv = None
         # row-chain stacks: everything down to the previous attention's backward kernel is one launch
         dx_q = ctx.chain[0].input_grad(ctx.chain[1], dqkv, ds) if ctx.chain is not None and ctx.needs_input_grad[0] else None

@@ -50,10 +50,6 @@ SIGNATURES = {
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
                      _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_ll, _c_float],
     "st_row_chain_mask_words": [_c_int, _c_int],
-    "st_dec_b1s_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
-                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
-                       _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                       _c_int, _c_float, _c_void_p, _c_uint, _c_int, _c_float],
     "st_gemm_kscale": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
                        _c_float],
     "st_gemm_splitk": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -535,36 +531,6 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0
                              s1[1], s1[2], s1[3], s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0),
                              _p(work), 0 if work is None else work.numel() * work.element_size(), float(post_kscale))
     _check(rc, "st_row_chain")
-
-
-def dec_b1s_ok(d_model, n_head, max_len) -> bool:
-    """Shapes st_dec_b1s_bwd serves: the row chains' width, 4 heads of 64, utterances of at most 64 target positions."""
-    return d_model == 256 and n_head == 4 and int(max_len) <= 64
-
-
-def dec_b1s_bwd(chain, M, head, tail, utt_off, utt_len, max_len, qkv, lse, dqkv, scale, drop=None):
-    """One launch for the decoder's backward chain B1 AND the causal self-attention's backward (st_dec_b1s_bwd), one workgroup per
-    utterance.  head = (dP, G, xhat, rstd, gamma, ds, g_gamma, g_beta, g_bias) as row_chain_bwd's with one block; tail = (O, Ores,
-    dctx or None, delta or None); qkv [M, 768] = the layer's q | k | v projection, lse its forward's [4 M]; dqkv [M, 768] receives
-    dq | dk | dv."""
-    dP, G, xhat, rstd, gamma, ds, dga, dbe, dbi = head
-    O, Ores, dctx, delta = tail
-    for t, nm in ((dP, "dP"), (G, "G"), (xhat, "xhat"), (ds, "ds"), (O, "O"), (qkv, "qkv"), (dqkv, "dqkv")):
-        _mat(t, BF16, nm)
-    if qkv.shape[1] != 768 or dqkv.shape[1] != 768 or chain.n_blocks != 2:
-        raise ValueError("dec_b1s_bwd: d_model 256 (q | k | v of 768 columns) and a two-block chain expected")
-    B = utt_off.numel()
-    _vec(utt_off, I32, B, "utt_off"), _vec(utt_len, I32, B, "utt_len"), _vec(lse, F32, 4 * M, "lse"), _vec(rstd, F32, M, "rstd")
-    d = 256
-    _tag("row_chain_bwd", M, 2, 0, io=((dP, M), (G, M), (xhat, M), (ds, M), (O, M), (Ores, M), (qkv, M), (dqkv, M), 2.0 * 256 * 256 * 2))
-    sd = _drop(drop)
-    rc = load().st_dec_b1s_bwd(_stream(), M, chain.stream.data_ptr(), 2, int(chain.next_blocks), dP.data_ptr(), dP.stride(0), G.data_ptr(),
-                               G.stride(0), xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), ds.data_ptr(), _p(dga), _p(dbe), _p(dbi),
-                               O.data_ptr(), _p(Ores), O.stride(0), _p(dctx), 0 if dctx is None else dctx.stride(0), _p(delta),
-                               utt_off.data_ptr(), utt_len.data_ptr(), B, int(max_len), qkv.data_ptr(), qkv[:, d:].data_ptr(),
-                               qkv[:, 2 * d:].data_ptr(), qkv.stride(0), lse.data_ptr(), dqkv.data_ptr(), dqkv[:, d:].data_ptr(),
-                               dqkv[:, 2 * d:].data_ptr(), dqkv.stride(0), float(scale), *sd)
-    _check(rc, "st_dec_b1s_bwd")
 
 
 def split_work_words() -> int:

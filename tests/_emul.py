@@ -244,22 +244,6 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0
     assert not blocks
 
 
-def dec_b1s_ok(d_model, n_head, max_len):
-    return d_model == 256 and n_head == 4 and int(max_len) <= 64
-
-
-def dec_b1s_bwd(chain, M, head, tail, utt_off, utt_len, max_len, qkv, lse, dqkv, scale, drop=None):
-    """st_dec_b1s_bwd as the two launches it replaces: the B1 chain, then the causal self-attention's backward."""
-    dP, G, xhat, rstd, gamma, ds, dga, dbe, dbi = head
-    O, Ores, dctx, delta = tail
-    dctx = dctx if dctx is not None else torch.zeros(M, 256, dtype=BF16, device=ds.device)
-    delta = delta if delta is not None else torch.zeros(4 * M, dtype=torch.float32, device=ds.device)
-    row_chain_bwd(chain, M, head=(1, dP, G, xhat, rstd, gamma, None, ds, dga, dbe, dbi), tail=(O, Ores, dctx, delta))
-    d = 256
-    attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], None, dctx, lse, delta, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-             utt_off, utt_len, utt_off, utt_len, 4, max_len, max_len, True, scale, drop=drop)
-
-
 def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     """csrc/st_rowchain.hip's backward chain as a composition of the emulated kernels it replaces."""
     blocks = list(chain.blocks)
@@ -668,7 +652,7 @@ def cast_bf16(src, dst):
 
 
 _NAMES = ["gemm", "gemm_kscale", "gemm_splitk", "gemm_ws", "adam_clip", "wgrad_group", "feat_stack", "gemm_lnbwd", "gemm_ln", "ln_bwd", "attn_fwd", "attn_f1_fwd", "attn_sf1_fwd", "attn_bwd", "attn_probs", "attn_dense_fwd", "attn_dense_bwd", "ctc_gather", "ctc_dlogits", "row_index", "pack_rows", "unpack_rows",
-          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "dec_b1s_bwd", "dec_b1s_ok", "chain_mask_words", "relu_bits_from", "beam_advance", "beam_work_words", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
+          "pack_grad", "embed_pe_fwd", "embed_bwd", "cast_bf16", "cache_reorder", "wfrag_depth", "wfrag_build", "row_chain", "row_chain_bwd", "chain_mask_words", "relu_bits_from", "beam_advance", "beam_work_words", "ce_fwd", "ce_bwd", "grad_norm", "grad_norm_scratch", "zero_tails", "decode_self_attn", "embed_step"]
 
 
 @contextlib.contextmanager

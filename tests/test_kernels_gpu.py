@@ -858,58 +858,6 @@ def test_gemm_kscale_scales_the_key_block_before_its_rounding(M, d, K):
     assert err_once < 0.8 * err_twice, (float(err_once), float(err_twice))      # one rounding, not two
 
 
-@pytest.mark.parametrize("lens,p", [([37, 50, 1, 64, 25, 33], 0.0), ([37, 50, 1, 64, 25, 33], 0.1), ([5], 0.0), ([64] * 32, 0.0)])
-def test_dec_b1s_bwd_equals_chain_plus_self_attention_backward(lens, p):
-    """st_dec_b1s_bwd (one launch, one workgroup per utterance) == st_row_chain_bwd(HEAD + TAIL) followed by st_attn_bwd(causal):
-    ds, the three column sums of the LayerNorm backward, dq | dk | dv - against the separate launches on the GPU (to rounding:
-    another summation order in the LayerNorm's column sums and the attention's products) and against their emulation."""
-    from st_amd import chains
-    d, H = 256, 4
-    M, B = sum(lens), len(lens)
-    scale = 1 / math.sqrt(64)
-    off = torch.tensor([sum(lens[:i]) for i in range(B)], dtype=I32)
-    ln = torch.tensor(lens, dtype=I32)
-    wq, wo = g(d, d, seed=1, scale=d ** -0.5), g(d, d, seed=2, scale=d ** -0.5)
-    dP, G, xhat = g(M, d, seed=3), g(M, d, seed=4), g(M, d, seed=5)
-    rstd, gamma = g(M, seed=6, dtype=F32).abs() + 0.5, 1 + 0.2 * g(d, seed=7, dtype=F32)
-    qkv = g(M, 3 * d, seed=8)
-    dn, de = _drops(31, p) if p else (None, None)
-    # the forward's context / lse (the chain's TAIL forms delta from them)
-    O, lse = torch.zeros(M, d, dtype=BF16), torch.zeros(H * M, dtype=F32)
-    Ores = torch.zeros(M, d, dtype=BF16)
-    em.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], O, lse, off, ln, off, ln, H, max(lens), True, scale, drop=de, ores=Ores)
-    blocks = lambda f: chains.t_blocks(chains.blocks_of(f(wq))) + chains.t_blocks(chains.blocks_of(f(wo)))
-
-    def run(dev, fused):
-        f = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t)
-        Z = lambda *sh, dt=BF16: torch.zeros(*sh, dtype=dt, device=dev)
-        o = dict(ds=Z(M, d), dga=Z(d, dt=F32), dbe=Z(d, dt=F32), dbi=Z(d, dt=F32), dqkv=torch.full((M, 3 * d), float("nan"), dtype=BF16, device=dev))
-        if dev == "cuda":
-            cs = chains.ChainSet("cuda")
-            cid = cs.add(blocks(f))
-            cs.finalize().rebuild()
-            ch, mod, dr = cs.chain(cid), nv, dn
-        else:
-            ch, mod, dr = chains.Chain(None, 2, blocks(f)), em, de
-        head = (f(dP), f(G), f(xhat), f(rstd), f(gamma), o["ds"], o["dga"], o["dbe"], o["dbi"])
-        if fused:
-            mod.dec_b1s_bwd(ch, M, head, (f(O), f(Ores), None, None), f(off), f(ln), max(lens), f(qkv), f(lse), o["dqkv"], scale, drop=dr)
-        else:
-            dctx, delta = Z(M, d), Z(H * M, dt=F32)
-            mod.row_chain_bwd(ch, M, head=(1,) + head[:5] + (None,) + head[5:], tail=(f(O), f(Ores), dctx, delta))
-            q_ = f(qkv)
-            mod.attn_bwd(q_[:, :d], q_[:, d:2 * d], q_[:, 2 * d:], None, dctx, f(lse), delta, o["dqkv"][:, :d], o["dqkv"][:, d:2 * d],
-                         o["dqkv"][:, 2 * d:], f(off), f(ln), f(off), f(ln), H, max(lens), max(lens), True, scale, drop=dr)
-        return o
-
-    got, two, ref = run("cuda", True), run("cuda", False), run("cpu", True)
-    assert torch.isfinite(got["dqkv"].float()).all()
-    for k, tol in (("ds", 1e-2), ("dga", 3e-3), ("dbe", 3e-3), ("dbi", 5e-3), ("dqkv", 2.5e-2)):
-        check(got[k], ref[k], tol, "dec_b1s_bwd vs emulation: %s" % k)
-        check(got[k], two[k], 1.5e-2 if k == "dqkv" else 3e-3, "dec_b1s_bwd vs the two launches: %s" % k)
-    assert torch.equal(got["ds"], two["ds"]), "the chain part must not depend on the workgroup's row range"
-
-
 def test_adam_clip_matches_torch_clip_and_fused_adam():
     """st_adam_clip == clip_grad_norm_ (global norm over the flat buffer) followed by torch.optim.Adam(fused, capturable)
     with a device learning-rate tensor, over several steps with a changing rate (the Noam schedule) and gradients both
