@@ -388,7 +388,8 @@ def main():
     # --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950 read correction applied); the summary
     # travels with the repo under profiles/ because counters cannot be collected inside the timed run.
     traffic, traffic_src = None, None
-    pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
+    pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                        "*pmc_traffic_c3.json" if args.config == 3 else "*pmc_traffic.json")))
     if pmc:
         with open(pmc[-1]) as f:
             pj = json.load(f)
