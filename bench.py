@@ -556,7 +556,7 @@ def main():
             torch.manual_seed(0)
             head = CTCAttentionLoss(CFG["d_model"], CFG["vocab_size"], ctc_weight=0.3).cuda()
             head._st_prepare("cuda")
-            head_opt = torch.optim.Adam(head.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, capturable=True)
+            head_opt = torch.optim.Adam(head.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, capturable=True, fused=True)
             jstep = JointTrainStep(model, optim, head, max_grad_norm=5.0, head_optimizer=head_opt, use_graph=not args.no_graph)
             for _ in range(4):
                 lj = jstep(xg, in_len, tg, tgt_len, gg)

@@ -496,6 +496,10 @@ class JointTrainStep:
     def _part_a1(self, batch, plan, layouts):
         inputs, in_len, targets, tgt_len, gt = batch
         in_rows, t_rows = layouts
+        # the plan's label-derived tensors are a derived copy of the label buffer: re-made in place at the head of every step
+        # (a loader may refill the buffer with new labels of the same lengths) - inside graph A1 when the step is captured, so
+        # the dozen tiny launches cost no host time (eagerly they were 0.36 ms of launch gaps per step)
+        plan.refresh_labels(gt)
         self.optimizer.zero_grad()
         self.head.zero_grad_buffers()
         rng.advance()
@@ -588,10 +592,6 @@ class JointTrainStep:
             # the CTC labels are the ground truth of train.py:40 (label ids, PAD = blank = 0 past each length)
             self._plan = self.head.plan(batch[4], batch[3], batch[1], self._layouts[0])
             self._keep = batch
-        else:
-            # same addresses, shapes and lengths - but the CONTENTS of the label buffer may be a new batch's (a loader that
-            # refills static buffers): the plan's label-derived tensors are a derived copy, re-made in place every step
-            self._plan.refresh_labels(batch[4])
         plan, layouts = self._plan, self._layouts
         self.optimizer.update_learning_rate(self.global_step)
         main = torch.cuda.current_stream()

@@ -27,7 +27,7 @@ xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()
 head = CTCAttentionLoss(256, 4337, ctc_weight=0.3).cuda()
 head._st_prepare("cuda")
 opt = ScheduledOptim(model, 256, U.AttrDict(n_warmup_steps=12000))
-hopt = torch.optim.Adam(head.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, capturable=True)
+hopt = torch.optim.Adam(head.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, capturable=True, fused=True)
 step = JointTrainStep(model, opt, head, 5.0, head_optimizer=hopt, use_graph=True)
 for _ in range(4):
     step(xg, in_len, tg, tgt_len, gg)
