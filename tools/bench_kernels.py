@@ -124,8 +124,8 @@ if "gemm" in which:
     report("wgrad_group encoder (24 problems)", us, fl, 0.0)
     from st_amd.functional import _wide_plan
     wide = _wide_plan(probs)
-    us = timeit(lambda: nv.wgrad_group(wide, wide=True), n=5)
-    report("wgrad_wide  encoder (24 problems, %d token splits)" % wide[0][4], us, fl, 0.0)
+    us = timeit(lambda: [nv.wgrad_group(w, wide=True) for w in wide], n=5)
+    report("wgrad_wide  encoder (24 problems, %d token splits)" % wide[0][0][4], us, fl, 0.0)
 
 if "attn" in which:
     def offs(lens):
