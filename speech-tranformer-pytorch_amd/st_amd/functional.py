@@ -332,8 +332,8 @@ WIDE_CHUNK = 48    # problems per st_wgrad_wide launch (csrc/st_wgrad.hip WIDE_M
 def _wide_plan(problems, cus: int = 256):
     """Launches of the 256 x 256-tile kernel (st_wgrad_wide): the problems in chunks of WIDE_CHUNK, each chunk with the token-split
     count that finishes first.  Items of one launch are equally long (tokens / splits) and one workgroup owns a CU, so a launch takes
-    ceil(tiles x splits / CUs) rounds of tokens / splits each, plus one round of fp32 atomics (256 KB per item, ~20 us for a chip-wide
-    round) per round of items.  Config 2 (85 tiles): 3 splits = 255 items, one round.  Config 3 (12 + 6 layers of width 512: 384
+    ceil(tiles x splits / CUs) rounds of tokens / splits each, plus ~50 us per round (prologue, 256 KB of fp32 atomics per item, the
+    ragged end of a round).  Config 2 (85 tiles): 3 splits = 255 items, one round.  Config 3 (12 + 6 layers of width 512: 384
     tiles in the first launch, 52 in the second) ran unsplit - 2 + 1 rounds of full-length items, 2.1 ms; 2 splits and 4 splits make it
     3 half rounds + 1 quarter round.  At least 256 tokens per item.  Returns a list of argument lists for nv.wgrad_group(wide=True)."""
     launches = []
@@ -341,11 +341,11 @@ def _wide_plan(problems, cus: int = 256):
         chunk = problems[c0:c0 + WIDE_CHUNK]
         tiles = sum(-(-p[0].shape[1] // 256) * -(-p[5] // 256) for p in chunk)
         rows = min(p[0].shape[0] for p in chunk)
-        unit_us = 600.0 * rows / 24060          # one full-length item (measured: 0.5-0.7 ms at 24,060 tokens)
+        unit_us = 800.0 * rows / 24060          # one full-length item with every CU busy (measured: 0.7-0.95 ms at 24,060 tokens)
         best, best_cost = 1, None
         for sp in range(1, max(1, min(rows // 256, 4 * cus // max(tiles, 1) + 1)) + 1):
             rounds = -(-tiles * sp // cus)
-            cost = rounds * (unit_us / sp + 20.0)
+            cost = rounds * (unit_us / sp + 50.0)      # + prologue, the atomic epilogue, the ragged end of a round (72 tiles: 3 splits 307-334 us, 7 splits 350)
             if best_cost is None or cost < best_cost - 1e-9:
                 best, best_cost = sp, cost
         launches.append([p[:4] + (best, p[5]) for p in chunk])
