@@ -15,9 +15,13 @@
 //   * XCD-aware walk: workgroup b runs on XCD b % 8; consecutive items (the tiles of one problem and one split, which
 //     share an operand) go to the same XCD, so the shared operand crosses the fabric once (PMC: 1.22 GB fetched per
 //     launch for 1.18 GB of operands).
+//   * (round 5) the two waves of a SIMD run half a k-step apart - one set of four waves owns the LDS pipe while the other owns
+//     the matrix pipes (ST_KSTEP): config 3's launches 644 -> 569 us on average (its 768 + 208 items are not HBM-bound); config 2's
+//     one launch is (1.34 GB at 4.7 TB/s with all 255 workgroups streaming) and stays at 286 us.
 // Measured (MI355X, config 2, 24 encoder problems = 227 GFLOP): 413 us -> 284 us without bias gradients, 297 us with
 // them; the launch then reads HBM at ~4.9 TB/s - the bound.  One workgroup alone on a CU runs at 57 % of the MFMA peak.
 #include "st_common.cuh"
+#include <cstdlib>
 
 namespace {
 
@@ -108,7 +112,7 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* p, int buf, int kk) {
 }
 
 // One work item: output tile (ti, tj) of problem `a` over token split ts.  CS: also the bias gradient.
-template <bool CS>
+template <bool CS, bool STAG>
 __device__ __forceinline__ void wide_body(const WideProblem& a, int local, bf16* smem) {
   const int tiles = a.tiles_i * a.tiles_j;
   const int ts = local / tiles, ti = (local % tiles) % a.tiles_i, tj = (local % tiles) / a.tiles_i;
@@ -180,21 +184,41 @@ __device__ __forceinline__ void wide_body(const WideProblem& a, int local, bf16*
       if (do_cs) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.y[0], pat, cs, 0, 0, 0);
     }
   };
-  // k-step kt (tile kt in buffer `cur`, its first half already in f0): tile kt+2 leaves its register stage for buffer
-  // (kt+2) & 3, tile kt+4 is requested into the stage; second half -> f1 | MFMAs f0 | first half of tile kt+1 -> f0 (its
-  // buffer was stored one step ago and the last barrier made it visible) | MFMAs f1 | barrier.
+  // STAG: the two waves of a SIMD (wave w and w + 4) run HALF A K-STEP APART.  The LDS pipe (96 KB of transposing fragment reads at
+  // ~120 B/clk + 32 KB of 16-byte writes at ~70 B/clk per k-step) is busy about as long as the matrix pipe (16 MFMAs per wave), and
+  // with one barrier per k-step all eight waves read together and multiply together.  Here a k-step is two barrier intervals: in
+  // one a wave stores / requests / reads ALL fragments of its tile (48 registers, as f0 + f1 held before), in the other it only
+  // multiplies; waves 4-7 enter one interval late (an extra barrier in front, waves 0-3 take theirs behind), so in every interval
+  // four waves own the LDS pipe and the other four the matrix pipes.  Tile k is read in intervals 2k (waves 0-3) and 2k + 1 (4-7);
+  // its buffer is rewritten with tile k + 4's predecessor k + 2 ... by stores in intervals 2k + 4 and 2k + 5: no new hazard.
 #define ST_KSTEP(SX, SY, CUR, LOAD, KT)                                  \
-  store(SX, SY, ((CUR) + 2) & 3);                                        \
-  LOAD(SX, SY, (KT) + 4);                                                \
-  read(f1, CUR, 1);                                                      \
-  __builtin_amdgcn_sched_barrier(0);                                     \
-  mma(f0);                                                               \
-  __builtin_amdgcn_sched_barrier(0);                                     \
-  read(f0, ((CUR) + 1) & 3, 0);                                          \
-  __builtin_amdgcn_sched_barrier(0);                                     \
-  mma(f1);                                                               \
-  __builtin_amdgcn_sched_barrier(0);   /* the MFMAs stay in front of the barrier: they cover the reads of f0 */ \
-  __syncthreads();
+  if (STAG) {                                                            \
+    store(SX, SY, ((CUR) + 2) & 3);                                      \
+    LOAD(SX, SY, (KT) + 4);                                              \
+    read(f0, CUR, 0);                                                    \
+    read(f1, CUR, 1);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    __syncthreads();                                                     \
+    mma(f0);                                                             \
+    mma(f1);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    __syncthreads();                                                     \
+  } else {                                                               \
+    /* tile kt in buffer `cur`, its first half already in f0: tile kt+2 leaves its register stage for buffer (kt+2) & 3, */ \
+    /* tile kt+4 is requested into the stage; second half -> f1 | MFMAs f0 | first half of tile kt+1 -> f0 (its buffer   */ \
+    /* was stored one step ago and the last barrier made it visible) | MFMAs f1 | barrier                                */ \
+    store(SX, SY, ((CUR) + 2) & 3);                                      \
+    LOAD(SX, SY, (KT) + 4);                                              \
+    read(f1, CUR, 1);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    mma(f0);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    read(f0, ((CUR) + 1) & 3, 0);                                        \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    mma(f1);                                                             \
+    __builtin_amdgcn_sched_barrier(0);   /* the MFMAs stay in front of the barrier: they cover the reads of f0 */ \
+    __syncthreads();                                                     \
+  }
 
   // buffers 0, 1 <- tiles 0, 1; register stages 0, 1 <- tiles 2, 3 (tiles past nk read zeros)
   load(sx0, sy0, 0);
@@ -204,7 +228,9 @@ __device__ __forceinline__ void wide_body(const WideProblem& a, int local, bf16*
   load(sx0, sy0, 2);
   load(sx1, sy1, 3);
   __syncthreads();
-  read(f0, 0, 0);
+  const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= 4;
+  if (STAG) { if (late) __syncthreads(); }
+  else read(f0, 0, 0);
   int kt = 0;
   // steady state without conditionals, so the compiler's s_waitcnt vmcnt() stays counted
   for (; kt + 8 <= nk_full; kt += 4) {
@@ -222,6 +248,7 @@ __device__ __forceinline__ void wide_body(const WideProblem& a, int local, bf16*
     if (kt + 3 >= nk) break;
     ST_KSTEP(sx1, sy1, 3, load, kt + 3)
   }
+  if (STAG && !late) __syncthreads();      // the early waves' share of the late waves' last interval
 #undef ST_KSTEP
 
   // D^T[j][i] += acc: the lane index i is the contiguous axis of dW -> coalesced fp32 atomics
@@ -247,6 +274,7 @@ __device__ __forceinline__ void wide_body(const WideProblem& a, int local, bf16*
   }
 }
 
+template <bool STAG>
 __global__ __launch_bounds__(512, 1) void wgrad_wide_kernel(WideArgs g) {
   __shared__ __attribute__((aligned(16))) bf16 smem[4 * NBUF * HALF_E];
   const int item = (int)(blockIdx.x & 7) * g.per_xcd + (int)(blockIdx.x >> 3);
@@ -254,8 +282,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_wide_kernel(WideArgs g) {
   int pi = 0;
   while (pi + 1 < g.n && item >= g.first[pi + 1]) ++pi;   // workgroup-uniform
   const WideProblem& a = g.p[pi];
-  if (a.bias != nullptr) wide_body<true>(a, item - g.first[pi], smem);
-  else wide_body<false>(a, item - g.first[pi], smem);
+  if (a.bias != nullptr) wide_body<true, STAG>(a, item - g.first[pi], smem);
+  else wide_body<false, STAG>(a, item - g.first[pi], smem);
 }
 
 }  // namespace
@@ -287,7 +315,9 @@ extern "C" int st_wgrad_wide(hipStream_t stream, int n, const void* const* X, co
     }
     if (g.n == 0) continue;
     g.per_xcd = (g.first[g.n] + 7) / 8;
-    hipLaunchKernelGGL(wgrad_wide_kernel, dim3(8 * g.per_xcd), dim3(512), 0, stream, g);
+    static const bool lockstep = [] { const char* e = getenv("ST_WGRAD_STAG"); return e != nullptr && e[0] == '0'; }();      // development: all waves in step
+    if (lockstep) hipLaunchKernelGGL(wgrad_wide_kernel<false>, dim3(8 * g.per_xcd), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL(wgrad_wide_kernel<true>, dim3(8 * g.per_xcd), dim3(512), 0, stream, g);
     ST_CHECK_LAUNCH();
   }
   return 0;
