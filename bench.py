@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--nccl-proto", type=str, default=None, help="sets NCCL_PROTO for RCCL (Simple / LL / LL128); recorded in config")
     ap.add_argument("--no-dp-probe", action="store_true", help="N = 1: skip the extra pass that runs the data-parallel code path "
                     "on a one-rank RCCL group to report what the exchange machinery itself costs (allreduce_exposed_ms)")
+    ap.add_argument("--probe-only", action="store_true", help="internal (the dp_probe child): print the timed region's ms/step and exit")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying "
                                                             "the captured HIP graph of the step")
     args = ap.parse_args()
@@ -294,6 +295,13 @@ def main():
         dist.all_reduce(frames, op=dist.ReduceOp.SUM)
     elapsed, frames = el.item(), frames.item()
     ms_step = elapsed / args.steps * 1e3
+    if args.probe_only:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(ms_step, 4), "dp_mode": getattr(step, "dp_mode", None),
+                              "dp_buckets": len(reducer.buckets) if reducer is not None else 0, "loss": round(float(loss), 4)}), flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     # ---- SURVEY 8d's protocol next to the contract's back-to-back mean: a device sync at both edges of EVERY step,
     # median of the per-step wall times; then the same with use_graph off (every kernel launched from Python: what a
@@ -340,27 +348,25 @@ def main():
         # N = 1: what the data-parallel machinery itself costs - the same step with a GradReducer on a ONE-rank RCCL group
         # (bucketed all-reduces captured inside the step graph); with no second GPU nothing is exchanged, so this is the
         # floor of `allreduce_exposed_ms` that the driver's N > 1 runs add their wire time to
+        # ... in a CHILD process (`--force-dp`: the main path of this file with the reducer on): ProcessGroupNCCL's watchdog
+        # thread can terminate a process around a capture (trainer.TrainStep._capture waits it out; round 5 saw it once in ~15
+        # runs before that) and no try / except catches std::terminate - the headline must not depend on it
+        import subprocess
         try:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1)
-            red1 = dp.GradReducer(arena, bucket_bytes=args.bucket_mb << 20, wire_dtype=torch.bfloat16 if args.wire_bf16 else None, force=True)
-            step1 = TrainStep(model, optim, CFG["vocab_size"], max_grad_norm=5.0, reducer=red1, use_graph=True)
-            for _ in range(4):
-                step1(xg, in_len, tg, tgt_len, gg)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step1(xg, in_len, tg, tgt_len, gg)
-            torch.cuda.synchronize()
-            ms1 = (time.perf_counter() - t1) / args.steps * 1e3
+            cmd = [sys.executable, os.path.abspath(__file__), "--force-dp", "--config", str(args.config), "--steps", str(args.steps),
+                   "--warmup", str(args.warmup), "--bucket-mb", str(args.bucket_mb), "--no-cpu-baseline", "--no-train-mode", "--no-decode",
+                   "--no-dp-probe", "--probe-only"] + (["--wire-bf16"] if args.wire_bf16 else [])
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if not line:
+                raise RuntimeError("child exited %d: %s" % (r.returncode, (r.stderr or "")[-300:].replace("\n", " | ")))
+            c = json.loads(line[-1])
+            ms1 = float(c["ms_per_step"])
             exposed_ms = round(ms1 - ms_step, 3)
-            dp_probe = {"ms_per_step": round(ms1, 3), "dp_mode": getattr(step1, "dp_mode", None), "buckets": len(red1.buckets),
-                        "note": "one-rank RCCL group: the bucketed all-reduces run (captured in the step graph) but exchange nothing"}
-            red1.detach()
-            del step1
-            # (the process group stays alive: with one in existence TrainStep captures in "thread_local" mode - destroying it
-            # here let a later "global"-mode capture collide with the dying watchdog thread's event queries)
+            dp_probe = {"ms_per_step": round(ms1, 3), "dp_mode": c.get("dp_mode"), "buckets": c.get("dp_buckets"),
+                        "note": "one-rank RCCL group in a child process (bench.py --force-dp): the bucketed all-reduces run (captured in "
+                                "the step graph) but exchange nothing"}
         except Exception as e:  # noqa: BLE001 - the headline must still be printed
             dp_probe = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -28,6 +28,8 @@ collectives between them.
 from __future__ import annotations
 
 import collections
+import os
+import time
 from typing import Optional
 
 import torch
@@ -357,6 +359,13 @@ class TrainStep:
         if self._seed is None or self._seed.device != dev:
             self._seed = torch.ones((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
+        if self.reducer is not None and self.reducer.active:
+            # The eager steps' all-reduces are finished on the GPU, but ProcessGroupNCCL's watchdog thread retires them on its own
+            # clock (a poll every 100 ms) - and a hipEventQuery of an EAGER collective's end event fails with "operation not permitted
+            # on an event last recorded in a capturing stream" once RCCL's stream has joined a capture, which terminates the process
+            # from the watchdog thread (round 5: tools/dev/dp_capture_stress.py - 6 of 16 processes of 12 captures each died; none of 16
+            # with this wait; the event cache off: 2 of 16).  Captures are rare (one per length signature): wait the watchdog out.
+            time.sleep(float(os.environ.get("ST_DP_DRAIN_MS", "300")) / 1e3)
         cap = _Captured()
         # the captured kernels read the ragged layouts (offsets, lengths, positions, attention work lists, scatter
         # index) by ADDRESS: pin the layout objects of this batch for as long as its graphs live (the layout cache may
@@ -417,6 +426,7 @@ class TrainStep:
                 TailBuffers.active.i = 0
             del g_all
             torch.cuda.synchronize()
+            time.sleep(float(os.environ.get("ST_DP_DRAIN_MS", "300")) / 1e3)      # (the agreement all-reduce above: see the wait before the capture)
             pool = torch.cuda.graph_pool_handle()
             cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if split:
