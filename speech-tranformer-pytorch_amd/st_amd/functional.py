@@ -314,7 +314,8 @@ class _Deferred:
     HIP graph.  The operand tensors stay referenced by the list until the launch is enqueued."""
     active = False
     pending = []
-    WIDE_ROWS = int(os.environ.get("ST_WIDE_ROWS", "8192"))          # token counts from here up take st_wgrad_wide (the variable: development)
+    WIDE_ROWS = int(os.environ.get("ST_WIDE_ROWS", "2048"))   # token counts from here up take st_wgrad_wide (8192 until round 5; a 4-utterance shard's
+                                                              # 3,120 rows: step 1.675 -> 1.639 ms with the wide kernel; the variable: development)
     ROWS_PER_SPLIT = 3072     # ~48 k-steps per workgroup; measured on config 2 (24060 rows): 8 splits beat 4, 12 and 16
 
     @staticmethod
