@@ -198,6 +198,10 @@ if "chain" in which:
         ra, rb = torch.rand(rows, device=dev) + 0.5, torch.rand(rows, device=dev) + 0.5
         dsa, dH, dsb, dctx, delta = E(rows, d_), E(rows, dff), E(rows, d_), E(rows, d_), E(4 * rows, dtype=F32)
         acc = [torch.zeros(d_, device=dev) for _ in range(6)]
+        if os.environ.get("ST_NO_DBIAS"):      # (development: what the chains' bias-gradient atomics cost)
+            acc[2] = acc[5] = None
+        if os.environ.get("ST_NO_COLSUMS"):
+            acc = [None] * 6
         bits = nv.relu_bits_from(Hm)
         us = timeit(lambda: nv.row_chain_bwd(chb, rows, head=(3, dqkv, dss, xc, ra, g0, None, dsa, acc[0], acc[1], acc[2]),
                                              ffn=(dff, bits, 1.0, dH, xy, rb, g1, dsb, acc[3], acc[4], acc[5]), tail=(O_, Or, dctx, delta)))
