@@ -356,7 +356,11 @@ def main():
             cmd = [sys.executable, os.path.abspath(__file__), "--force-dp", "--config", str(args.config), "--steps", str(args.steps),
                    "--warmup", str(args.warmup), "--bucket-mb", str(args.bucket_mb), "--no-cpu-baseline", "--no-train-mode", "--no-decode",
                    "--no-dp-probe", "--probe-only"] + (["--wire-bf16"] if args.wire_bf16 else [])
-            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+            # a clean stand-alone child: nothing of a torchrun agent's rendezvous (its store would be looked for at our port)
+            env = {k: v for k, v in os.environ.items()
+                   if not (k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                   "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME"))}
+            env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if not line:
