@@ -81,6 +81,7 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
   constexpr int DK = 64;
   __shared__ __attribute__((aligned(16))) float xch[XW * XSLOTS * 64 + 1024];   // 73,728 B (the V patches alias its head; SELF: 4 x 64-key V patches behind two tiles)
   __shared__ __attribute__((aligned(16))) bf16 patch[2 * 32 * DK];              // O rows (hi), Ores rows (lo)
+  __shared__ __attribute__((aligned(16))) float f1vec[F1 ? 4 * 256 : 4];         // the chain stage's bo | g0 | be0 | bq: epilogues read them from LDS (LVec)
 
   int b, h, tile;
   decode_item(a, blockIdx.x, b, h, tile);
@@ -153,6 +154,14 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
     };
     if (!SELF) touch_all();
     const bool writer = h == 0;                     // one of the four heads' workgroups stores the stage's outputs
+    // the stage's four epilogue vectors -> LDS (wave w < 4: vector w), requested with the residual tile: a vector load inside an
+    // epilogue would wait behind every K / V piece and weight fragment on request (vmcnt is in-order)
+    const float* vsrc = wave == 0 ? f.bo : wave == 1 ? f.g0 : wave == 2 ? f.be0 : f.bp;
+    f32x4 vreg = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 4) vreg = *reinterpret_cast<const f32x4*>(vsrc + 4 * l);
+    auto vec_store = [&]() { if (wave < 4) *reinterpret_cast<f32x4*>(f1vec + wave * 256 + 4 * l) = vreg; };
+    const LVec lbo{(const ST_LDS float*)f1vec}, lg0{(const ST_LDS float*)f1vec + 256}, lbe0{(const ST_LDS float*)f1vec + 512},
+        lbp{(const ST_LDS float*)f1vec + 768};
     if (SELF) {
       TileRegs<1> rr;
       tile_load(c, f.R, f.ldr, rr);
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
           }
       }
       tile_store(c, rr, f0);
+      vec_store();
       fetch_all();
       ring_start();
       touch_all();
@@ -264,17 +274,18 @@ __global__ __launch_bounds__(512, 1) void attn_xs_fwd_kernel(AttnArgs a, XF1Args
       tile_load(c, f.R, f.ldr, rr);
       tile_store(c, ra, cur);
       tile_store(c, rr, f0);
+      vec_store();
     }
     const Drop off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
     block_mma(c, cur, acc);
-    epi_ln<false>(c, acc, f.bo, f0, f.g0, f.be0, f.eps, off, cur, f1, red, writer ? f.out0 : nullptr, writer ? f.xhat0 : nullptr,
+    epi_ln<false>(c, acc, lbo, f0, lg0, lbe0, f.eps, off, cur, f1, red, writer ? f.out0 : nullptr, writer ? f.xhat0 : nullptr,
                   writer ? f.rstd0 : nullptr);
     zero_acc(acc);
     block_mma(c, f1, acc);                          // q = cur Wq^T (+ bq): staged in f0 (the residual: last read before epi_ln's barriers)
-    epi_store<false, false>(c, acc, f.bp, f0, off, 0, 0);
+    epi_store<false, false>(c, acc, lbp, f0, off, 0, 0);
     __syncthreads();
     if (writer) tile_out(c, f0, f.P, f.ldp);
 #pragma unroll

@@ -28,6 +28,63 @@
 
 namespace {
 
+// The forward chains' epilogue vectors as an LDS copy (32- and 64-row workgroups; LVec in st_rowchain_common.cuh): units of 256 floats -
+// 0 bo, 1 g0, 2 be0, 3 b2, 4 g1, 5 be1, 6 .. 6 + nc - 1 the chunks of b1, then the nb blocks of bp.  The launch passes
+// (6 + nc + nb) KB of dynamic LDS.  Wave w fetches units w, w + 8, w + 16, w + 24 (one 16-byte piece per lane) together with the
+// activation tiles and stores them behind the tiles' stores; chains with more than 32 units take further rounds.
+extern __shared__ __attribute__((aligned(16))) float chain_vecs[];
+__device__ __forceinline__ const float* chain_vec_src(const ChainArgs& a, int u) {
+  if (u < 6) return u == 0 ? a.bo : u == 1 ? a.g0 : u == 2 ? a.be0 : u == 3 ? a.b2 : u == 4 ? a.g1 : a.be1;
+  if (u < 6 + a.nc) return a.b1 ? a.b1 + (u - 6) * 256 : nullptr;
+  return a.bp ? a.bp + (u - 6 - a.nc) * 256 : nullptr;
+}
+struct VecStage {
+  f32x4 v[4];
+  __device__ __forceinline__ void load(const ChainArgs& a, int wave, int l, int u0) {
+    const int n = 6 + a.nc + a.nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = u0 + wave + 8 * i;
+      const float* src = u < n ? chain_vec_src(a, u) : nullptr;
+      v[i] = src ? *reinterpret_cast<const f32x4*>(src + 4 * l) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __device__ __forceinline__ void store(const ChainArgs& a, int wave, int l, int u0) const {
+    const int n = 6 + a.nc + a.nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = u0 + wave + 8 * i;
+      if (u < n) *reinterpret_cast<f32x4*>(chain_vecs + u * 256 + 4 * l) = v[i];
+    }
+  }
+};
+template <bool LDSV> struct ChainVecs;
+template <> struct ChainVecs<true> {
+  using V = LVec;
+  const ChainArgs& a;
+  __device__ __forceinline__ LVec at(int u) const { return LVec{(const ST_LDS float*)chain_vecs + u * 256}; }
+  __device__ __forceinline__ V bo() const { return at(0); }
+  __device__ __forceinline__ V g0() const { return at(1); }
+  __device__ __forceinline__ V be0() const { return at(2); }
+  __device__ __forceinline__ V b2() const { return at(3); }
+  __device__ __forceinline__ V g1() const { return at(4); }
+  __device__ __forceinline__ V be1() const { return at(5); }
+  __device__ __forceinline__ V b1(int ch) const { return at(6 + ch); }
+  __device__ __forceinline__ V bp(int u) const { return at(6 + a.nc + u); }
+};
+template <> struct ChainVecs<false> {
+  using V = const float*;
+  const ChainArgs& a;
+  __device__ __forceinline__ V bo() const { return a.bo; }
+  __device__ __forceinline__ V g0() const { return a.g0; }
+  __device__ __forceinline__ V be0() const { return a.be0; }
+  __device__ __forceinline__ V b2() const { return a.b2; }
+  __device__ __forceinline__ V g1() const { return a.g1; }
+  __device__ __forceinline__ V be1() const { return a.be1; }
+  __device__ __forceinline__ V b1(int ch) const { return a.b1 + ch * 256; }
+  __device__ __forceinline__ V bp(int u) const { return a.bp + u * 256; }
+};
+
 // MT = row tiles of 32 per workgroup.  1: decoder-sized row counts (as many workgroups as possible).  2: in between (a
 // strong-scaling shard of the batch).  3: encoder-sized
 // ones (24,060 rows = 251 workgroups = one round of the 256 CUs; every weight fragment feeds three MFMAs, so a
@@ -72,12 +129,20 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
   bf16* cur = tiles;             // A
   bf16* f0 = tiles + TE;         // residual, then the first free tile
   bf16* f1 = tiles + 2 * TE;
+  constexpr bool LV = MT <= 2;      // 32- and 64-row workgroups: the epilogue vectors from LDS (96-row ones have none to spare)
+  const ChainVecs<LV> vec{a};
   {   // A and the residual are requested together (one global round trip), then stored
     TileRegs<MT> ra, rr;
+    VecStage vs;
     tile_load(c, a.A, a.lda, ra);
     if (PRE) tile_load(c, a.R, a.ldr, rr);
+    if (LV) vs.load(a, c.wave, c.l, 0);
     tile_store(c, ra, cur);
     if (PRE) tile_store(c, rr, f0);
+    if (LV) {
+      vs.store(a, c.wave, c.l, 0);
+      for (int u0 = 32; u0 < 6 + a.nc + a.nb; u0 += 32) { vs.load(a, c.wave, c.l, u0); vs.store(a, c.wave, c.l, u0); }
+    }
   }
   const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
   __syncthreads();
@@ -87,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
     zero_acc(acc);
     block_mma(c, cur, acc);
     // xhat is staged in the A tile (every wave is past its MFMAs on it at epi_ln's first barrier), the output in f1
-    epi_ln<false>(c, acc, a.bo, f0, a.g0, a.be0, a.eps, off, cur, f1, red, a.out0, a.xhat0, a.rstd0);
+    epi_ln<false>(c, acc, vec.bo(), f0, vec.g0(), vec.be0(), a.eps, off, cur, f1, red, a.out0, a.xhat0, a.rstd0);
     // now: cur = f1; free: f0 (the residual: last read before epi_ln's barriers) and, one barrier later, the A tile (xhat0 is
     // still being copied out of it)
     bf16* t = cur; cur = f1; f1 = t;
@@ -103,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
       f32x16 acc1[MT];
       zero_acc(acc1);
       block_mma(c, cur, acc1);
-      epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff,
+      epi_store<true, DROP>(c, acc1, vec.b1(ch), hc, d1, ch * 256, dff,
                             a.relu_bits ? a.relu_bits + ((size_t)(blockIdx.x * a.nc + ch) * NW + c.wave) * 64 : nullptr);
       __syncthreads();
       block_mma(c, hc, acc2);
@@ -112,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
     // xhat goes to the tile the LAST chunk did not use (last read one chunk earlier), the output replaces cur in place
     // (its residual reads precede epi_ln's barriers, its MFMA reads too)
     bf16* tx = (a.nc & 1) ? f1 : f0;
-    epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, tx, cur, red, a.out1, a.xhat1, a.rstd1);
+    epi_ln<DROP>(c, acc2, vec.b2(), cur, vec.g1(), vec.be1(), a.eps, d2, tx, cur, red, a.out1, a.xhat1, a.rstd1);
     if (tx == f0) { f0 = f1; f1 = tx; }      // f0 = the tile free right now, f1 = xhat (still being copied out)
   }
   if (POST) {
@@ -122,7 +187,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(ChainArgs a) {
       f32x16 acc[MT];
       zero_acc(acc);
       block_mma(c, cur, acc);
-      epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0, nullptr, u == 1 ? a.post_kscale : 1.f);
+      epi_store<false, false>(c, acc, vec.bp(u), st, off, 0, 0, nullptr, u == 1 ? a.post_kscale : 1.f);
       __syncthreads();
       tile_out(c, st, a.P + u * 256, a.ldp);
     }
@@ -183,12 +248,17 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
   bf16* cur = tiles;
   bf16* f0 = tiles + TE;
   bf16* f1 = tiles + 2 * TE;
+  const ChainVecs<true> vec{a};
   {
     TileRegs<MT> ra, rr;
+    VecStage vs;
     tile_load(c, a.A, a.lda, ra);
     if (PRE) tile_load(c, a.R, a.ldr, rr);
+    vs.load(a, c.wave, c.l, 0);
     tile_store(c, ra, cur);
     if (PRE) tile_store(c, rr, f0);
+    vs.store(a, c.wave, c.l, 0);
+    for (int u0 = 32; u0 < 6 + a.nc + a.nb; u0 += 32) { vs.load(a, c.wave, c.l, u0); vs.store(a, c.wave, c.l, u0); }
   }
   const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
   __syncthreads();
@@ -198,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
     c.ws = at_block(b_chunk);
     block_mma(c, cur, acc);
     const bool w = part == 0;
-    epi_ln<false>(c, acc, a.bo, f0, a.g0, a.be0, a.eps, off, cur, f1, red, w ? a.out0 : nullptr, w ? a.xhat0 : nullptr,
+    epi_ln<false>(c, acc, vec.bo(), f0, vec.g0(), vec.be0(), a.eps, off, cur, f1, red, w ? a.out0 : nullptr, w ? a.xhat0 : nullptr,
                   w ? a.rstd0 : nullptr);
     bf16* t = cur; cur = f1; f1 = t;
   }
@@ -214,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
       f32x16 acc1[MT];
       zero_acc(acc1);
       block_mma(c, cur, acc1);                  // W1 chunk; refills: the W2 chunk right behind it
-      epi_store<true, DROP>(c, acc1, a.b1 + ch * 256, hc, d1, ch * 256, dff,
+      epi_store<true, DROP>(c, acc1, vec.b1(ch), hc, d1, ch * 256, dff,
                             a.relu_bits ? a.relu_bits + ((size_t)(block * a.nc + ch) * NW + c.wave) * 64 : nullptr);
       __syncthreads();
       if (j + 1 == cpp) c.ws = at_block(b_post);      // (POST's first block, on the chance that this workgroup is the last)
@@ -255,14 +325,14 @@ __global__ __launch_bounds__(512, 1) void row_chain_split_kernel(ChainArgs a) {
       }
     }
     // xhat goes to f1 (the A tile / PRE's xhat staging: last read two barriers ago), the output replaces cur in place
-    epi_ln<DROP>(c, acc2, a.b2, cur, a.g1, a.be1, a.eps, d2, f1, cur, red, a.out1, a.xhat1, a.rstd1);
+    epi_ln<DROP>(c, acc2, vec.b2(), cur, vec.g1(), vec.be1(), a.eps, d2, f1, cur, red, a.out1, a.xhat1, a.rstd1);
     if (POST) {
       for (int u = 0; u < a.nb; ++u) {
         bf16* st = (u & 1) ? f1 : f0;
         f32x16 acc[MT];
         zero_acc(acc);
         block_mma(c, cur, acc);
-        epi_store<false, false>(c, acc, a.bp + u * 256, st, off, 0, 0, nullptr, u == 1 ? a.post_kscale : 1.f);
+        epi_store<false, false>(c, acc, vec.bp(u), st, off, 0, 0, nullptr, u == 1 ? a.post_kscale : 1.f);
         __syncthreads();
         tile_out(c, st, a.P + u * 256, a.ldp);
       }
@@ -898,10 +968,12 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
     a.split_ws = (float*)split_work + 256;
     a.split_parts = sp;
     const dim3 sgrid(grid.x * sp);
+    const size_t vec_bytes = (size_t)(6 + a.nc + a.nb) * 1024;      // the epilogue vectors' LDS copy (ChainVecs)
+    if (vec_bytes > 48 * 1024) return -7;
 #define ST_SPLIT(PRE_, POST_)                                                                                        \
   do {                                                                                                               \
-    if (drop) hipLaunchKernelGGL((row_chain_split_kernel<PRE_, POST_, true>), sgrid, blk, 0, stream, a);             \
-    else hipLaunchKernelGGL((row_chain_split_kernel<PRE_, POST_, false>), sgrid, blk, 0, stream, a);                 \
+    if (drop) hipLaunchKernelGGL((row_chain_split_kernel<PRE_, POST_, true>), sgrid, blk, vec_bytes, stream, a);     \
+    else hipLaunchKernelGGL((row_chain_split_kernel<PRE_, POST_, false>), sgrid, blk, vec_bytes, stream, a);         \
   } while (0)
     if (pre && post) ST_SPLIT(true, true);
     else if (pre) ST_SPLIT(true, false);
@@ -911,17 +983,19 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
     ST_CHECK_LAUNCH();
     return 0;
   }
+  const size_t vec1 = (size_t)(6 + a.nc + a.nb) * 1024;      // 32- / 64-row workgroups: the epilogue vectors' LDS copy (ChainVecs)
+  if (mt <= 2 && vec1 > 48 * 1024) return -7;      // (d_ff up to 9,984)
 #define ST_CHAIN(PRE_, FFN_, POST_)                                                                               \
   do {                                                                                                            \
     if (mt == 3) {                                                                                                \
       if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 3>), grid, blk, 0, stream, a);      \
       else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 3>), grid, blk, 0, stream, a);          \
     } else if (mt == 2) {                                                                                         \
-      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 2>), grid, blk, 0, stream, a);      \
-      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 2>), grid, blk, 0, stream, a);          \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 2>), grid, blk, vec1, stream, a);   \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 2>), grid, blk, vec1, stream, a);       \
     } else {                                                                                                      \
-      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 1>), grid, blk, 0, stream, a);      \
-      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 1>), grid, blk, 0, stream, a);          \
+      if (drop) hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, true, 1>), grid, blk, vec1, stream, a);   \
+      else hipLaunchKernelGGL((row_chain_kernel<PRE_, FFN_, POST_, false, 1>), grid, blk, vec1, stream, a);       \
     }                                                                                                             \
   } while (0)
   if (pre && ffn && post) ST_CHAIN(true, true, true);

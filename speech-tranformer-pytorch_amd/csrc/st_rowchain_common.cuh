@@ -121,16 +121,28 @@ __device__ __forceinline__ void tile_out(const Ctx<MT>& c, const bf16* t, bf16* 
   }
 }
 
+// The epilogues' per-column vectors (bias / gamma / beta), from global memory or from a copy in LDS.  vmcnt is in-order: a vector load
+// issued in an epilogue waits behind every weight fragment the ring has on request - at 32 rows per workgroup (ring = one block ahead)
+// that is a full drain of the stream in front of EVERY epilogue (round 5: the 12-block chain at 1,206 rows 29.1 -> 25.6 us with the
+// loads replaced by constants).  32-row workgroups therefore copy the vectors into LDS once, in the prologue; 96-row workgroups have no
+// LDS to spare and lose 1.5 % to it.
+struct LVec {
+  const ST_LDS float* p;
+  __device__ __forceinline__ LVec operator+(int o) const { return LVec{p + o}; }
+};
+__device__ __forceinline__ f32x4 ld4(const float* p, int j) { return *reinterpret_cast<const f32x4*>(p + j); }
+__device__ __forceinline__ f32x4 ld4(LVec v, int j) { return *reinterpret_cast<const ST_LDS f32x4*>(v.p + j); }
+
 // acc + bias (+ReLU, dropout) -> bf16 into this wave's 32 columns of an LDS tile
 // bits (optional): this wave's 64 words of ChainArgs::relu_bits for the block
-template <bool RELU, bool DROP, int MT>
-__device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[MT], const float* bias, bf16* t, const Drop& d,
+template <bool RELU, bool DROP, int MT, class V>
+__device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[MT], V bias, bf16* t, const Drop& d,
                                           int gcol0, int ncols, unsigned long long* bits = nullptr, float oscale = 1.f) {
   uint32_t pos_lo = 0, pos_hi = 0;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl = c.wave * 32 + 8 * g + 4 * c.hi;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
+    const f32x4 bb = ld4(bias, jl);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 32 + c.r;
@@ -157,9 +169,9 @@ __device__ __forceinline__ void epi_store(const Ctx<MT>& c, const f32x16 (&acc)[
 
 // v = acc + bias + res; LayerNorm over the 256 columns held by the 8 waves; xhat -> t_xhat, (dropped) output -> t_out,
 // both then leave for HBM.  Two workgroup barriers inside, one before the copies out: on return t_out is complete.
-template <bool DROP, int MT>
-__device__ __forceinline__ void epi_ln(const Ctx<MT>& c, f32x16 (&acc)[MT], const float* bias, const bf16* res, const float* gamma,
-                                       const float* beta, float eps, const Drop& d, bf16* t_xhat, bf16* t_out,
+template <bool DROP, int MT, class V>
+__device__ __forceinline__ void epi_ln(const Ctx<MT>& c, f32x16 (&acc)[MT], V bias, const bf16* res, V gamma,
+                                       V beta, float eps, const Drop& d, bf16* t_xhat, bf16* t_out,
                                        float (*red)[NW * 32 * MT], bf16* g_out, bf16* g_xhat, float* g_rstd) {
   const int j0 = c.wave * 32;
   float sum[MT], sq[MT], mean[MT], rstd[MT];
@@ -168,7 +180,7 @@ __device__ __forceinline__ void epi_ln(const Ctx<MT>& c, f32x16 (&acc)[MT], cons
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl = j0 + 8 * g + 4 * c.hi;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + jl);
+    const f32x4 bb = ld4(bias, jl);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + (mt * 32 + c.r) * AS + jl);
@@ -213,8 +225,8 @@ __device__ __forceinline__ void epi_ln(const Ctx<MT>& c, f32x16 (&acc)[MT], cons
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int jl = j0 + 8 * g + 4 * c.hi;
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + jl);
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + jl);
+    const f32x4 g4 = ld4(gamma, jl);
+    const f32x4 b4 = ld4(beta, jl);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = mt * 32 + c.r;
