@@ -1,6 +1,6 @@
 # Dev: the round's committed artefacts in one GPU call (profiles/r05_*): PMC traffic first (bench.py credits the committed summary,
 # stamped with the SHA below), then the bench lines, the kernel trace, the step sequence, the issue mix; config 3 likewise.
-export TMPDIR=/tmp GIT_SHA=e882cb5
+export TMPDIR=/tmp GIT_SHA=7081455
 cd /root/repo
 bash tools/pmc_traffic.sh r05 > gpurun_out/pmc_r05.log 2>&1
 cp gpurun_out/pmc_r05_traffic.json profiles/r05_pmc_traffic.json; cp gpurun_out/pmc_r05_traffic.txt profiles/r05_pmc_traffic.txt
