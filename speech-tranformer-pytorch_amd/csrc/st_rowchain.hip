@@ -23,6 +23,7 @@
 // sublayer alone 25.5 us as two launches -> 15.9 us, bound by one CU's 64 B/clk vector-memory path (1 MB of weights
 // per workgroup).
 #include "st_rowchain_common.cuh"
+#include "st_rowchain_pipe.cuh"
 #include <cstdlib>
 #include <type_traits>
 
@@ -682,6 +683,9 @@ __global__ __launch_bounds__(256) void wfrag_build_kernel(const long long* __res
 }  // namespace
 
 extern "C" int st_wfrag_depth(void) { return DEPTH; }
+#ifdef ST_DEV_TRACE
+extern "C" int st_dev_chain_trace(long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &p, sizeof(p)); }
+#endif
 
 extern "C" int st_wfrag_build(hipStream_t stream, const long long* table, int n_blocks) {
   if (n_blocks <= 0) return 0;
@@ -980,6 +984,38 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
     else if (post) ST_SPLIT(false, true);
     else ST_SPLIT(false, false);
 #undef ST_SPLIT
+    ST_CHECK_LAUNCH();
+    return 0;
+  }
+  // 64- / 96-row workgroups, the encoder's shapes (PRE + FFN [+ POST], POST alone): the pipelined kernel (st_rowchain_pipe.cuh)
+  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();      // development switch
+  if (pipe_on && mt >= 2 && ((pre && ffn) || (!pre && !ffn && post))) {
+#ifdef ST_DEV_CHAIN_NULL
+  {       // development: which saved tensors does the launch's time hang on? (bit 0 H, 1 xhat, 2 out0, 3 P, 4 out1, 5 mask bits)
+    static const int nul = [] { const char* e = getenv("ST_CHAIN_NULL"); return e ? atoi(e) : 0; }();
+    if (nul & 1) a.H = nullptr;
+    if (nul & 2) a.xhat0 = a.xhat1 = nullptr;
+    if (nul & 4) a.out0 = nullptr;
+    if (nul & 8) a.P = nullptr;
+    if (nul & 16) a.out1 = nullptr;
+    if (nul & 32) a.relu_bits = nullptr;
+  }
+#endif
+#define ST_PIPE(PRE_, FFN_, POST_)                                                                                    \
+  do {                                                                                                                \
+    if (mt == 3) {                                                                                                    \
+      if (drop) hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, true, 3>), grid, blk, 0, stream, a);     \
+      else hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, false, 3>), grid, blk, 0, stream, a);         \
+    } else {                                                                                                          \
+      if (drop) hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, true, 2>), grid, blk, 0, stream, a);     \
+      else hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, false, 2>), grid, blk, 0, stream, a);         \
+    }                                                                                                                 \
+  } while (0)
+    if (pre && post) ST_PIPE(true, true, true);
+    else if (pre) ST_PIPE(true, true, false);
+    else if (mt == 3) hipLaunchKernelGGL((row_chain_pipe_kernel<false, false, true, false, 3>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((row_chain_pipe_kernel<false, false, true, false, 2>), grid, blk, 0, stream, a);
+#undef ST_PIPE
     ST_CHECK_LAUNCH();
     return 0;
   }

@@ -110,14 +110,27 @@ __device__ __forceinline__ void tile_store(const Ctx<MT>& c, const TileRegs<MT>&
     *reinterpret_cast<bf16x8*>(lds + rr * AS + cc * 8) = t.v[p];
   }
 }
-// LDS -> global as 512-byte row segments
+// LDS -> global as 512-byte row segments.  64- and 96-row workgroups (encoder-sized launches: 135 MB of saved tensors per forward
+// chain, read again by LATER kernels only) store write-through (sc1: the line does not stay in the XCD's L2).  Round 6, same
+// box, 24,060 rows: forward chain 58.7 -> 51.9 us, backward 66.2 -> 64.0 - with plain stores the dirty lines of a launch
+// (17 MB per XCD through a 4 MB write-back L2) sit between the weight stream and its readers.  Decoder-sized launches
+// (32-row workgroups) keep plain stores: their few hundred KB ARE read back from the L2 by the next kernel.
+#ifndef ST_TILE_OUT_SC1
+#define ST_TILE_OUT_SC1 1
+#endif
 template <int MT>
 __device__ __forceinline__ void tile_out(const Ctx<MT>& c, const bf16* t, bf16* g, int ld) {
 #pragma unroll
   for (int p = 0; p < 2 * MT; ++p) {
     const int id = c.tid + p * 512, rr = id >> 5, cc = id & 31;
-    if (rr < c.nvalid)
-      *reinterpret_cast<bf16x8*>(g + (size_t)(c.row0 + rr) * ld + cc * 8) = *reinterpret_cast<const bf16x8*>(t + rr * AS + cc * 8);
+    if (rr < c.nvalid) {
+      if (MT >= 2 && ST_TILE_OUT_SC1) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(t + rr * AS + cc * 8);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(g + (size_t)(c.row0 + rr) * ld + cc * 8), "v"(v) : "memory");
+      } else {
+        *reinterpret_cast<bf16x8*>(g + (size_t)(c.row0 + rr) * ld + cc * 8) = *reinterpret_cast<const bf16x8*>(t + rr * AS + cc * 8);
+      }
+    }
   }
 }
 

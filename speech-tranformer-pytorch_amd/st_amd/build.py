@@ -29,6 +29,10 @@ if os.environ.get("ST_MERGE_FENCE") == "1":
     # the last-arriver merges with language-level agent-scope release / acquire fences (csrc/st_common.cuh): the documented
     # conservative build; the flag is part of the source hash, so the library is rebuilt when the switch changes
     FLAGS = FLAGS + ["-DST_MERGE_FENCE=1"]
+if os.environ.get("ST_DEV_DEFS"):
+    # development: extra -D switches for same-box A/Bs of kernel variants (tools/dev/ab_defs.sh); part of the source hash, so
+    # every setting is its own library build.  The shipped library is built without.
+    FLAGS = FLAGS + os.environ["ST_DEV_DEFS"].split()
 if os.environ.get("ST_DEV_TRACE") == "1":
     # development: the per-workgroup clock-stamp hook of the attention backward streams (tools/dev/attn_bwd64_trace.py); the
     # shipped library has no code that writes through an address taken from the environment
