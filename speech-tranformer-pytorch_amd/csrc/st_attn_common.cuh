@@ -167,6 +167,9 @@ __device__ __forceinline__ void stream_tiles(int ntiles, L load, S store, C comp
   __syncthreads();   // the epilogue reuses the tile buffers
 }
 
+#ifndef ST_ATTN_SC1
+#define ST_ATTN_SC1 1      // the attention kernels' row stores write-through (store16_wt): whole step 2.844 -> 2.826 ms, same box (round 6); 0 = plain
+#endif
 // Store a transposed accumulator tile (lane = row, registers = DK columns) as coalesced rows:
 // through a wave-private [32][DK] LDS patch so HBM sees whole DK*2-byte row segments instead of
 // 64 scattered 8-byte writes per instruction.  `patch` is this wave's private 32*DK elements.
@@ -194,7 +197,7 @@ __device__ __forceinline__ void store_rows(bf16* patch, const f32x16* acc, float
   for (int p = 0; p < 32 * CPR / 64; ++p) {
     const int id = p * 64 + l, rr = id / CPR, c = id % CPR;
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rr * DK + ((c ^ (rr & (CPR - 1))) << 3));
-    if (rr < nvalid_rows) *reinterpret_cast<bf16x8*>(gbase + (size_t)(row0 + rr) * ld + c * 8) = v;
+    if (rr < nvalid_rows) store16<ST_ATTN_SC1>(gbase + (size_t)(row0 + rr) * ld + c * 8, v);
   }
 }
 
@@ -231,8 +234,8 @@ __device__ __forceinline__ void store_rows_pair(bf16* patch_hi, bf16* patch_lo, 
     const bf16x8 vh = *reinterpret_cast<const bf16x8*>(patch_hi + at);
     const bf16x8 vl = *reinterpret_cast<const bf16x8*>(patch_lo + at);
     if (rr < nvalid_rows) {
-      *reinterpret_cast<bf16x8*>(g_hi + (size_t)(row0 + rr) * ld + c * 8) = vh;
-      *reinterpret_cast<bf16x8*>(g_lo + (size_t)(row0 + rr) * ld + c * 8) = vl;
+      store16<ST_ATTN_SC1>(g_hi + (size_t)(row0 + rr) * ld + c * 8, vh);
+      store16<ST_ATTN_SC1>(g_lo + (size_t)(row0 + rr) * ld + c * 8, vl);
     }
   }
 }
@@ -353,8 +356,8 @@ __device__ __forceinline__ void store_rows_2(bf16* pa, bf16* pb, const f32x16* a
     const bf16x8 va = *reinterpret_cast<const bf16x8*>(pa + at);
     const bf16x8 vb = *reinterpret_cast<const bf16x8*>(pb + at);
     if (rr < nvalid_rows) {
-      *reinterpret_cast<bf16x8*>(ga + (size_t)(row0 + rr) * lda + c * 8) = va;
-      *reinterpret_cast<bf16x8*>(gb + (size_t)(row0 + rr) * ldb + c * 8) = vb;
+      store16<ST_ATTN_SC1>(ga + (size_t)(row0 + rr) * lda + c * 8, va);
+      store16<ST_ATTN_SC1>(gb + (size_t)(row0 + rr) * ldb + c * 8, vb);
     }
   }
 }

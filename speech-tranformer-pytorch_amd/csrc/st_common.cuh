@@ -144,6 +144,17 @@ template <typename T> __device__ __forceinline__ void touch(T& v) { asm volatile
 
 __device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+// 16-byte global store, write-through (sc1): the line does not stay in the XCD's L2.  For streams of output that only LATER
+// kernels read (round 6: with plain stores the dirty lines of an encoder-sized launch crowd the write-back L2 - st_rowchain_common.cuh).
+template <class V> __device__ __forceinline__ void store16_wt(void* p, V v) {
+  static_assert(sizeof(V) == 16, "store16_wt: 16 bytes");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+template <bool WT, class V> __device__ __forceinline__ void store16(void* p, V v) {
+  if (WT) store16_wt(p, v);
+  else *reinterpret_cast<V*>(p) = v;
+}
+
 // ---- dropout (training mode of nn.Dropout: Attention.py:89, SubLayers.py:25,27, Models.py:31) --------------
 // Counter-based: one 32-bit hash per counter yields FOUR 8-bit keep decisions, so a mask is a pure function of
 // (device seed, call-site salt, element index) - the backward kernels regenerate it instead of reading a saved

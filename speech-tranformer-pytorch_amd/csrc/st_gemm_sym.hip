@@ -20,6 +20,9 @@
 // the lane, Y rows over registers).  bf16 outputs leave through an LDS patch as 256-byte row segments.
 #include "st_common.cuh"
 
+#ifndef ST_GEMM_SC1
+#define ST_GEMM_SC1 0      // development: bf16 output rows write-through (store16_wt)
+#endif
 namespace {
 
 #ifndef ST_GEMM_BK
@@ -484,7 +487,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int ts, int ti, int
       if (i < a.M && j < a.N && ((id & 15) % cph) == 0)
         const_cast<float*>(a.bias)[(size_t)(j / a.head_dim) * a.M + i] = part;
     }
-    if (i < a.M && j < a.N) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j) = v;
+    if (i < a.M && j < a.N) store16<ST_GEMM_SC1>(reinterpret_cast<bf16*>(a.D) + (size_t)i * a.ldd + j, v);
   }
 }
 

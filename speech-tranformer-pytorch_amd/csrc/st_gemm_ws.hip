@@ -34,6 +34,9 @@
 // Epilogue: wave-private [32][64] patch (16-byte slots XOR-swizzled by row / 2) -> 128-byte row segments to HBM.
 #include "st_common.cuh"
 
+#ifndef ST_GEMM_SC1
+#define ST_GEMM_SC1 0
+#endif
 namespace {
 
 constexpr int WS_K = 256;                    // contraction length (held in registers per wave)
@@ -215,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(WsArgs a) {
     bf16* drow = a.D + (size_t)(grow + srow0) * a.ldd + n0 + sc * 8;
     if (grow + WS_CH <= a.M) {         // (uniform) no per-row guards
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x8*>(drow + (size_t)(8 * j) * a.ldd) = ov[j];
+      for (int j = 0; j < 4; ++j) store16<ST_GEMM_SC1>(drow + (size_t)(8 * j) * a.ldd, ov[j]);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (grow + 8 * j + srow0 < a.M) *reinterpret_cast<bf16x8*>(drow + (size_t)(8 * j) * a.ldd) = ov[j];
+        if (grow + 8 * j + srow0 < a.M) store16<ST_GEMM_SC1>(drow + (size_t)(8 * j) * a.ldd, ov[j]);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) DMAs must not outlive the workgroup's LDS

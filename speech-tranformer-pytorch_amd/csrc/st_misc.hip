@@ -233,6 +233,9 @@ __global__ void embed_bwd_kernel(const long long* __restrict__ tok, int L, const
   for (int f = threadIdx.x; f < D; f += blockDim.x) atomicAdd(dst + f, (float)src[f]);
 }
 
+#ifndef ST_ADAM_SC1
+#define ST_ADAM_SC1 0
+#endif
 __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n8) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8);
@@ -271,10 +274,10 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, f
       const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
       pp[e] -= step_size * mm[e] / denom;
     }
-    *reinterpret_cast<f32x4*>(g + i * 4) = gg;
-    *reinterpret_cast<f32x4*>(m + i * 4) = mm;
-    *reinterpret_cast<f32x4*>(v + i * 4) = vv;
-    *reinterpret_cast<f32x4*>(p + i * 4) = pp;
+    store16<ST_ADAM_SC1>(g + i * 4, gg);
+    store16<ST_ADAM_SC1>(m + i * 4, mm);
+    store16<ST_ADAM_SC1>(v + i * 4, vv);
+    store16<ST_ADAM_SC1>(p + i * 4, pp);
   }
 }
 

@@ -651,6 +651,9 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
   }
 }
 
+}  // namespace
+#include "st_rowchain_pipe_bwd.cuh"
+namespace {
 // Block descriptor table of st_wfrag_build: 4 x int64 per 256 x 256 weight block
 //   [0] address of the block's first element (row n0, column k0 of a row-major bf16 matrix)
 //   [1] leading dimension of that matrix (elements) | transposed << 32: the block is read as its TRANSPOSE (the data
@@ -989,7 +992,7 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   }
   // 64- / 96-row workgroups, the encoder's shapes (PRE + FFN [+ POST], POST alone): the pipelined kernel (st_rowchain_pipe.cuh)
   static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();      // development switch
-  if (pipe_on && mt >= 2 && ((pre && ffn) || (!pre && !ffn && post))) {
+  if (pipe_on && mt >= 2 && ((pre && ffn && (post_blocks == 0 || post_blocks == 1 || post_blocks == 3)) || (!pre && !ffn && post_blocks == 3))) {
 #ifdef ST_DEV_CHAIN_NULL
   {       // development: which saved tensors does the launch's time hang on? (bit 0 H, 1 xhat, 2 out0, 3 P, 4 out1, 5 mask bits)
     static const int nul = [] { const char* e = getenv("ST_CHAIN_NULL"); return e ? atoi(e) : 0; }();
@@ -1001,20 +1004,21 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
     if (nul & 32) a.relu_bits = nullptr;
   }
 #endif
-#define ST_PIPE(PRE_, FFN_, POST_)                                                                                    \
+#define ST_PIPE(PRE_, FFN_, NB_)                                                                                      \
   do {                                                                                                                \
     if (mt == 3) {                                                                                                    \
-      if (drop) hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, true, 3>), grid, blk, 0, stream, a);     \
-      else hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, false, 3>), grid, blk, 0, stream, a);         \
+      if (drop) hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, NB_, true, 3>), grid, blk, 0, stream, a);       \
+      else hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, NB_, false, 3>), grid, blk, 0, stream, a);           \
     } else {                                                                                                          \
-      if (drop) hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, true, 2>), grid, blk, 0, stream, a);     \
-      else hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, POST_, false, 2>), grid, blk, 0, stream, a);         \
+      if (drop) hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, NB_, true, 2>), grid, blk, 0, stream, a);       \
+      else hipLaunchKernelGGL((row_chain_pipe_kernel<PRE_, FFN_, NB_, false, 2>), grid, blk, 0, stream, a);           \
     }                                                                                                                 \
   } while (0)
-    if (pre && post) ST_PIPE(true, true, true);
-    else if (pre) ST_PIPE(true, true, false);
-    else if (mt == 3) hipLaunchKernelGGL((row_chain_pipe_kernel<false, false, true, false, 3>), grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL((row_chain_pipe_kernel<false, false, true, false, 2>), grid, blk, 0, stream, a);
+    if (pre && post_blocks == 3) ST_PIPE(true, true, 3);
+    else if (pre && post_blocks == 1) ST_PIPE(true, true, 1);
+    else if (pre) ST_PIPE(true, true, 0);
+    else if (mt == 3) hipLaunchKernelGGL((row_chain_pipe_kernel<false, false, 3, false, 3>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((row_chain_pipe_kernel<false, false, 3, false, 2>), grid, blk, 0, stream, a);
 #undef ST_PIPE
     ST_CHECK_LAUNCH();
     return 0;
@@ -1102,6 +1106,18 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
     else if (tail) ST_BSPLIT(false, true);
     else ST_BSPLIT(false, false);
 #undef ST_BSPLIT
+    ST_CHECK_LAUNCH();
+    return 0;
+  }
+  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();      // development switch
+  if (pipe_on && mt >= 2 && head && ffn && tail) {      // the encoder's shape: st_rowchain_pipe_bwd.cuh
+    if (mt == 3) {
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_pipe_kernel<true, 3>), grid, blk, 0, stream, a);
+      else hipLaunchKernelGGL((row_chain_bwd_pipe_kernel<false, 3>), grid, blk, 0, stream, a);
+    } else {
+      if (drop) hipLaunchKernelGGL((row_chain_bwd_pipe_kernel<true, 2>), grid, blk, 0, stream, a);
+      else hipLaunchKernelGGL((row_chain_bwd_pipe_kernel<false, 2>), grid, blk, 0, stream, a);
+    }
     ST_CHECK_LAUNCH();
     return 0;
   }

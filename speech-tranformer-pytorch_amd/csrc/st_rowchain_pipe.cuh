@@ -276,44 +276,66 @@ __device__ __forceinline__ void block_mma_p(Ctx<MT>& c, const bf16x8* cur_blk, c
 // workgroup barrier inside; the caller places the one behind.  red2: [MT][32 rows][8 waves x (sum, sq) + pad] floats, row
 // pitch 80 bytes (conflict-free 16-byte reads).
 constexpr int RED2_PITCH = 20;
+// x + the value of the lane 32 away: one v_permlane32_swap (VALU) instead of the ds_bpermute __shfl_xor becomes (an LDS round trip)
+__device__ __forceinline__ float wave_sum32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));      // a = {lo, lo}, b = {hi, hi}
+  return a + b;
+}
 template <bool DROP, int MT>
 __device__ __forceinline__ void epi_ln_p(const Ctx<MT>& c, f32x16 (&acc)[MT], const bf16* res, const BiasRegs& gamma, const BiasRegs& beta,
                                          float eps, const Drop& d, bf16* t_xhat, bf16* t_out, float* red2, float* g_rstd) {
   const int j0 = c.wave * 32;
+  // (written without a branch and with every LDS read of a pass in front of its arithmetic: the phase is a chain of latencies -
+  // 500 instructions in 2.4 us when each row tile waited for its own reads)
+  bf16x4 rr[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rr[mt][g] = *reinterpret_cast<const bf16x4*>(res + (mt * 32 + c.r) * AS + j0 + 8 * g + 4 * c.hi);
+  float s[MT], q[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    float s = 0.f, q = 0.f;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res + (mt * 32 + c.r) * AS + j0 + 8 * g + 4 * c.hi);
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = acc[mt][4 * g + e] + (float)rr[e];
-        acc[mt][4 * g + e] = v;
-        s += v;
-        q = fmaf(v, v, q);
+      for (int e = 0; e < 4; e += 2) {
+        const float v0 = acc[mt][4 * g + e] + (float)rr[mt][g][e], v1 = acc[mt][4 * g + e + 1] + (float)rr[mt][g][e + 1];
+        acc[mt][4 * g + e] = v0;
+        acc[mt][4 * g + e + 1] = v1;
+        s0 += v0; s1 += v1;
+        q0 = fmaf(v0, v0, q0); q1 = fmaf(v1, v1, q1);
       }
-    }
-    s += wave_xor32(s);
-    q += wave_xor32(q);
-    if (c.hi == 0) *reinterpret_cast<f32x2*>(red2 + (mt * 32 + c.r) * RED2_PITCH + 2 * c.wave) = f32x2{s, q};
+    s[mt] = s0 + s1;
+    q[mt] = q0 + q1;
   }
-  __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const float* rp = red2 + (mt * 32 + c.r) * RED2_PITCH;
-    float s = 0.f, q = 0.f;
+    s[mt] = wave_sum32(s[mt]);
+    q[mt] = wave_sum32(q[mt]);
+  }
 #pragma unroll
-    for (int w4 = 0; w4 < 4; ++w4) {
-      const f32x4 p = *reinterpret_cast<const f32x4*>(rp + 4 * w4);
-      s += p[0] + p[2];
-      q += p[1] + p[3];
-    }
-    const float mean = s * (1.f / DM);
-    const float var = fmaxf(q * (1.f / DM) - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    if (g_rstd && c.wave == 0 && c.hi == 0 && mt * 32 + c.r < c.nvalid) g_rstd[c.row0 + mt * 32 + c.r] = rstd;
-    const float nm = -mean * rstd;
+  for (int mt = 0; mt < MT; ++mt)      // (both halves of the wave hold the same sums and write them to the same place)
+    *reinterpret_cast<f32x2*>(red2 + (mt * 32 + c.r) * RED2_PITCH + 2 * c.wave) = f32x2{s[mt], q[mt]};
+  __syncthreads();
+  f32x4 pp[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) pp[mt][w4] = *reinterpret_cast<const f32x4*>(red2 + (mt * 32 + c.r) * RED2_PITCH + 4 * w4);
+  float rstd[MT], nm[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const float ss = (pp[mt][0][0] + pp[mt][0][2]) + (pp[mt][1][0] + pp[mt][1][2]) + ((pp[mt][2][0] + pp[mt][2][2]) + (pp[mt][3][0] + pp[mt][3][2]));
+    const float qq = (pp[mt][0][1] + pp[mt][0][3]) + (pp[mt][1][1] + pp[mt][1][3]) + ((pp[mt][2][1] + pp[mt][2][3]) + (pp[mt][3][1] + pp[mt][3][3]));
+    const float mean = ss * (1.f / DM);
+    const float var = fmaxf(qq * (1.f / DM) - mean * mean, 0.f);
+    rstd[mt] = rsqrtf(var + eps);
+    nm[mt] = -mean * rstd[mt];
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int jl = j0 + 8 * g + 4 * c.hi, row = mt * 32 + c.r;
@@ -322,7 +344,7 @@ __device__ __forceinline__ void epi_ln_p(const Ctx<MT>& c, f32x16 (&acc)[MT], co
       bf16x4 xh, o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float n = fmaf(acc[mt][4 * g + e], rstd, nm);
+        const float n = fmaf(acc[mt][4 * g + e], rstd[mt], nm[mt]);
         float v = fmaf(n, gamma.v[g][e], beta.v[g][e]);
         if (DROP && d.on()) v = d.keep(bits, e) ? v * d.scale : 0.f;
         xh[e] = (bf16)n;
@@ -331,12 +353,18 @@ __device__ __forceinline__ void epi_ln_p(const Ctx<MT>& c, f32x16 (&acc)[MT], co
       *reinterpret_cast<bf16x4*>(t_xhat + row * AS + jl) = xh;
       *reinterpret_cast<bf16x4*>(t_out + row * AS + jl) = o;
     }
+  if (g_rstd && c.wave == 0 && c.hi == 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (mt * 32 + c.r < c.nvalid) g_rstd[c.row0 + mt * 32 + c.r] = rstd[mt];
   }
 }
 
 // PRE + FFN [+ POST]  or  POST alone (the encoder's layer-0 projection); MT = 2, 3
-template <bool PRE, bool FFN, bool POST, bool DROP, int MT>
+template <bool PRE, bool FFN, int NB, bool DROP, int MT>
 __global__ __launch_bounds__(512, 1) void row_chain_pipe_kernel(ChainArgs a) {
+  constexpr bool POST = NB > 0;
+  static_assert(NB == 0 || NB == 1 || NB == 3, "pipelined chains: no, one or three projection blocks");
   static_assert((PRE && FFN) || (!PRE && !FFN && POST), "pipelined chains: PRE + FFN [+ POST] or POST alone");
   constexpr int RB = 32 * MT, TE = RB * AS;
   __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
@@ -435,111 +463,97 @@ __global__ __launch_bounds__(512, 1) void row_chain_pipe_kernel(ChainArgs a) {
     }
     __syncthreads();      // hidden chunk 0 complete in X; every wave is past its copies of Y (xhat0)
     TRP(5);
-    // from here: hidden chunk c lives in (c even ? X : Y)
+    // from here: hidden chunk c lives in (c even ? X : Y); its copy to H rides under W1_(c+1), the block in front of the W2_c that
+    // multiplies it (both only read the tile)
     for (int ch = 0; ch + 1 < nc; ++ch) {
       bf16* hc = (ch & 1) ? Y : X;          // chunk ch
-      bf16* ho = (ch & 1) ? X : Y;          // chunk ch - 1 (waiting for its copy), then chunk ch + 1 (written beside W2_ch)
+      bf16* hn = (ch & 1) ? X : Y;          // chunk ch + 1, written beside W2_ch (chunk ch - 1 left it one barrier ago)
       acc_init(acc1, nb1);
       if (ch + 2 < nc) bias_load(c, a.b1 + (ch + 2) * 256, nb1);
-      {       // W1_(ch+1) with the copy of chunk ch - 1 beside it
-        CopySide<MT, 1> cs{c, {tile_out_desc(c, ho, (a.H && ch > 0) ? a.H + (ch - 1) * 256 : nullptr, dff)}};
+      {
+        CopySide<MT, 1> cs{c, {tile_out_desc(c, hc, a.H ? a.H + ch * 256 : nullptr, dff)}};
         block_mma_p(c, blk(p0 + 2 * (ch + 1)), blk(p0 + 2 * ch + 1), cur, acc1, cs);
       }
       if (ch < 3) TRP(6 + 2 * ch);
-      if (ch > 0) __syncthreads();          // every wave is past its copy of chunk ch - 1: its tile takes chunk ch + 1
       {       // W2_ch with the epilogue of W1_(ch+1) beside it
-        EpiSide<true, DROP, MT> es{c, acc1, ho, d1, (ch + 1) * 256, dff, 1.f, bits_at(ch + 1)};
+        EpiSide<true, DROP, MT> es{c, acc1, hn, d1, (ch + 1) * 256, dff, 1.f, bits_at(ch + 1)};
         block_mma_p(c, blk(p0 + 2 * ch + 1), ch + 2 < nc ? blk(p0 + 2 * (ch + 2)) : blk(p0 + 2 * (ch + 1) + 1), hc, acc2, es);
       }
       __syncthreads();
       if (ch < 3) TRP(7 + 2 * ch);
     }
     BiasRegs g1, be1;
-    {       // the last chunk's W2 with the copy of the chunk before beside it; the LayerNorm vectors are requested in front
-      const int ch = nc - 1;
-      bf16* hc = (ch & 1) ? Y : X;
-      bf16* ho = (ch & 1) ? X : Y;
+    bf16* hl = ((nc - 1) & 1) ? Y : X;      // the last chunk
+    bf16* tx = ((nc - 1) & 1) ? X : Y;      // free
+    {       // the last chunk's W2 with its own copy beside it; the LayerNorm vectors are requested in front
       bias_load(c, a.g1, g1);
       bias_load(c, a.be1, be1);
       if (POST) bias_load(c, a.bp, nb1);
-      CopySide<MT, 1> cs{c, {tile_out_desc(c, ho, (a.H && ch > 0) ? a.H + (ch - 1) * 256 : nullptr, dff)}};
-      block_mma_p(c, blk(p0 + 2 * ch + 1), blk(q0), hc, acc2, cs);
-      __syncthreads();
+      CopySide<MT, 1> cs{c, {tile_out_desc(c, hl, a.H ? a.H + (nc - 1) * 256 : nullptr, dff)}};
+      block_mma_p(c, blk(p0 + 2 * (nc - 1) + 1), blk(q0), hl, acc2, cs);
       TRP(12);
     }
-    // chunk nc - 1 waits for its copy in hl; the other tile is free
-    bf16* hl = ((nc - 1) & 1) ? Y : X;
-    bf16* tx = ((nc - 1) & 1) ? X : Y;
+    // (no barrier: the LayerNorm's first pass reads only cur; its own barrier lies in front of the writes to tx and cur)
     epi_ln_p<DROP>(c, acc2, cur, g1, be1, a.eps, d2, tx, cur, red2, a.rstd1);      // xhat1 -> tx, out1 replaces cur in place
     __syncthreads();
     TRP(13);
-    pend[0] = tile_out_desc(c, hl, a.H ? a.H + (nc - 1) * 256 : nullptr, dff);
-    pend[1] = tile_out_desc(c, tx, a.xhat1, DM);
-    pend[2] = tile_out_desc(c, cur, a.out1, DM);
-    npend = 3;
+    pend[0] = tile_out_desc(c, tx, a.xhat1, DM);
+    pend[1] = tile_out_desc(c, cur, a.out1, DM);
+    npend = 2;
     X = hl; Y = tx;
   }
 
   if (POST) {
-    // block u's accumulators are finished beside block u + 1 (two sets, alternating) into the staging tiles X, Y (alternating),
-    // a staged block leaves beside block u + 2; the pending copies of the sublayer in front go first
+    // NB = 1 or 3 projection blocks, straight-line: block u's accumulators are finished beside block u + 1 (two sets, alternating)
+    // into the staging tiles X, Y (alternating), a staged block leaves beside block u + 2; the copies of the sublayer in front
+    // ride under block 0.  X (the last hidden chunk) is free: its readers are behind the LayerNorm's barriers; Y (xhat1) is free
+    // one barrier after block 0.
     f32x16 accA[MT], accB[MT];
-    const int nb = a.nb;
-    auto stage = [&](int u) { return (u & 1) ? Y : X; };
-    auto pdesc = [&](int u) { return tile_out_desc(c, stage(u), a.P ? a.P + u * 256 : nullptr, a.ldp); };
-    auto oscale = [&](int u) { return u == 1 ? a.post_kscale : 1.f; };
+    auto pdesc = [&](int u, bf16* st) { return tile_out_desc(c, st, a.P ? a.P + u * 256 : nullptr, a.ldp); };
     if (!FFN) bias_load(c, a.bp, nb1);
     acc_init(accA, nb1);
-    if (nb > 1) bias_load(c, a.bp + 256, nb1);
-    if (npend == 3) {
+    if (NB > 1) bias_load(c, a.bp + 256, nb1);
+    if (npend == 2) {
       CopySide<MT, 2> cs{c, {pend[0], pend[1]}};
       block_mma_p(c, blk(q0), blk(q0 + 1), cur, accA, cs);
     } else {
       NoSide ns;
       block_mma_p(c, blk(q0), blk(q0 + 1), cur, accA, ns);
     }
-    __syncthreads();      // X, Y free
     TRP(14);
-    // u = 1, 2, ..: block u beside the epilogue of block u - 1 and one copy (out1 first, then the staged blocks)
-    TileOut cp = npend == 3 ? pend[2] : tile_out_desc(c, cur, nullptr, DM);
-    for (int u = 1; u < nb; u += 2) {
-      {       // odd u: multiply into B, finish A (block u - 1) into stage(u - 1)
+    if (NB == 3) {
+      {       // block 1 -> B beside the epilogue of block 0 (A -> X)
         acc_init(accB, nb1);
-        if (u + 1 < nb) bias_load(c, a.bp + (u + 1) * 256, nb1);
-        EpiSide<false, false, MT> es{c, accA, stage(u - 1), off, 0, 0, oscale(u - 1), nullptr};
-        CopySide<MT, 1> cs{c, {cp}};
-        Both<EpiSide<false, false, MT>, CopySide<MT, 1>> both{es, cs};
-        block_mma_p(c, blk(q0 + u), blk(q0 + u + 1), cur, accB, both);
+        bias_load(c, a.bp + 512, nb1);
+        EpiSide<false, false, MT> es{c, accA, X, off, 0, 0, 1.f, nullptr};
+        block_mma_p(c, blk(q0 + 1), blk(q0 + 2), cur, accB, es);
         __syncthreads();
-        if (u == 1) TRP(15);
-        cp = pdesc(u - 1);
+        TRP(15);
       }
-      if (u + 1 < nb) {       // even u + 1: multiply into A, finish B (block u) into stage(u)
+      {       // block 2 -> A beside the epilogue of block 1 (B -> Y, the key block: pre-scaled) and the copy of block 0 (X)
         acc_init(accA, nb1);
-        if (u + 2 < nb) bias_load(c, a.bp + (u + 2) * 256, nb1);
-        EpiSide<false, false, MT> es{c, accB, stage(u), off, 0, 0, oscale(u), nullptr};
-        CopySide<MT, 1> cs{c, {cp}};
+        EpiSide<false, false, MT> es{c, accB, Y, off, 0, 0, a.post_kscale, nullptr};
+        CopySide<MT, 1> cs{c, {pdesc(0, X)}};
         Both<EpiSide<false, false, MT>, CopySide<MT, 1>> both{es, cs};
-        block_mma_p(c, blk(q0 + u + 1), blk(q0 + u + 2), cur, accA, both);
+        block_mma_p(c, blk(q0 + 2), blk(q0 + 3), cur, accA, both);
         __syncthreads();
-        if (u == 1) TRP(16);
-        cp = pdesc(u);
+        TRP(16);
       }
-    }
-    // the last block's epilogue and the last two copies are exposed
-    if ((nb - 1) & 1) {
-      EpiSide<false, false, MT> es{c, accB, stage(nb - 1), off, 0, 0, oscale(nb - 1), nullptr};
+      // the last block's epilogue and the last two copies are exposed
+      EpiSide<false, false, MT> es{c, accA, X, off, 0, 0, 1.f, nullptr};
       es.all();
+      tile_out_now(c, pdesc(1, Y));
+      __syncthreads();
+      tile_out_now(c, pdesc(2, X));
     } else {
-      EpiSide<false, false, MT> es{c, accA, stage(nb - 1), off, 0, 0, oscale(nb - 1), nullptr};
+      EpiSide<false, false, MT> es{c, accA, X, off, 0, 0, 1.f, nullptr};
       es.all();
+      __syncthreads();
+      tile_out_now(c, pdesc(0, X));
     }
-    tile_out_now(c, cp);
-    __syncthreads();
-    tile_out_now(c, pdesc(nb - 1));
   } else {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 2; ++i)
       if (i < npend) tile_out_now(c, pend[i]);
   }
   TRP(17);
