@@ -30,7 +30,10 @@ extern "C" {
 
 typedef void* st_stream_t; /* hipStream_t */
 
-/* Library ABI version (bumped on any signature change). */
+/* Library ABI version, bumped on any signature change (2: round 5's k_prescaled / dense attention / grad_scale arguments;
+ * 3: round 6).  A host binding must refuse a library whose st_version() differs from the header it was written against:
+ * through ctypes / dlsym a stale libst_hip.so would be called with shifted arguments (st_amd/native.py: ABI_VERSION). */
+#define ST_ABI_VERSION 3
 int st_version(void);
 
 /* Re-read the development switches that choose between a specialised attention kernel and the general one
@@ -461,6 +464,12 @@ int st_attn_dense_bwd(st_stream_t stream, const void* Q, int ldq, const void* K,
 /* Hardware probes used by tests to pin the MFMA / transposing-LDS-read layouts. */
 int st_probe_tr16(st_stream_t stream, const void* in, void* out);
 int st_probe_mfma(st_stream_t stream, const void* A, const void* Bt, float* D);
+
+/* The shader clock this part sustains under dense matrix work (the normaliser of bench.py's MFMA roofline: the nominal 2.4 GHz is
+ * not what an MI355X holds under chip-wide MFMA load).  n_wg workgroups of 256 threads (give one per CU) each run `iters` rounds of
+ * four independent 32 x 32 x 16 bf16 MFMAs per wave on non-trivial operands and leave {shader-clock ticks (s_memtime), wall ticks
+ * (s_memrealtime, 100 MHz)} of wave 0 in out[2 wg], out[2 wg + 1]: MHz = 100 ticks / wall.  ~2 ms at iters = 30000. */
+int st_clock_probe(st_stream_t stream, long long* out, int n_wg, int iters);
 
 #ifdef __cplusplus
 }

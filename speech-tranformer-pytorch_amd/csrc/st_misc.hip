@@ -1488,4 +1488,42 @@ extern "C" int st_probe_mfma(hipStream_t stream, const void* A, const void* Bt, 
   return 0;
 }
 
-extern "C" int st_version(void) { return 1; }
+namespace {
+// st_clock_probe: dense MFMA work on every SIMD, the shader clock against the 100 MHz wall clock
+__global__ __launch_bounds__(256) void clock_probe_kernel(long long* out, int iters) {
+  const int l = threadIdx.x & 63;
+  bf16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {       // (pseudo-random operands: the clock the part holds depends on how many bits toggle)
+    a[e] = (bf16)(0.001f * (float)((st_hash32(l * 8 + e + 17u * blockIdx.x) & 1023u)) - 0.5f);
+    b[e] = (bf16)(0.001f * (float)((st_hash32(l * 8 + e + 977u) & 1023u)) - 0.5f);
+  }
+  f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+  __syncthreads();
+  const long long t0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = mfma32(a, b, acc[j]);
+  }
+  const long long t1 = clock64(), w1 = wall_clock64();
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[j][e];
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = t1 - t0;
+    out[2 * blockIdx.x + 1] = w1 - w0;
+  }
+  if (s == 123456.789f) out[0] = 0;      // (keeps the accumulators alive)
+}
+}  // namespace
+
+extern "C" int st_clock_probe(hipStream_t stream, long long* out, int n_wg, int iters) {
+  if (!out || n_wg <= 0 || iters <= 0) return -1;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(n_wg), dim3(256), 0, stream, out, iters);
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int st_version(void) { return 3; }      // == ST_ABI_VERSION (include/st_hip.h) == native.ABI_VERSION

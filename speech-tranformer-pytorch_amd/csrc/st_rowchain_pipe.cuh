@@ -27,6 +27,9 @@
 
 namespace {
 
+#ifndef ST_PIPE_PRIO
+#define ST_PIPE_PRIO 0
+#endif
 #ifndef ST_PIPE_R_LATE
 #define ST_PIPE_R_LATE 1
 #endif
@@ -388,6 +391,9 @@ __global__ __launch_bounds__(512, 1) void row_chain_pipe_kernel(ChainArgs a) {
   TRP(0);
 #ifdef ST_DEV_TRACE
   if (g_chain_trace && threadIdx.x == 0) g_chain_trace[blockIdx.x * 32 + 30] = clock64();
+#endif
+#if ST_PIPE_PRIO
+  if (c.wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses every arbitration against its SIMD partner otherwise
 #endif
   bf16* T0 = tiles; bf16* T1 = tiles + TE; bf16* T2 = tiles + 2 * TE;
   const Drop d1 = make_drop(a.drop1), d2 = make_drop(a.drop2), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});

@@ -167,6 +167,9 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs
     touched = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.wfrag) + (size_t)ln * 128);
     __builtin_amdgcn_sched_barrier(0);
   }
+#if ST_PIPE_PRIO
+  if (c.wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched half loses every arbitration against its SIMD partner otherwise
+#endif
   bf16* T0 = tiles; bf16* T1 = tiles + TE; bf16* T2 = tiles + 2 * TE;
   const Drop da = make_drop(a.drop_a), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
   const int nbh = a.nb, nc = a.nc, b_tail = nbh + 2 * nc;      // stream: HEAD 0 .. | B1_c nbh + 2c, B2_c nbh + 2c + 1 | TAIL

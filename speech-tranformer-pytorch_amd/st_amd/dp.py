@@ -17,8 +17,9 @@ Design (one process per GPU, backend "nccl" == RCCL on ROCm):
     of a bucket has been written - ProcessGroupNCCL runs it on its own stream, ordered
     after the producing kernels by an event, so it overlaps the rest of backward;
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by
-    ONE link, so buckets are large (default 32 MiB) to amortise latency, and the
-    optional bf16 wire format halves the bytes on that link;
+    ONE link, so buckets are large to amortise latency (the constructor's default is 32 MiB; bench.py passes
+    --bucket-mb 8: seven buckets of config 2's 53 MB, so that the first all-reduces start while most of the
+    backward is still ahead), and the optional bf16 wire format halves the bytes on that link;
   * the reference clips BEFORE Horovod's synchronize (train_multi.py:66-68, clipping
     un-reduced gradients); here :meth:`GradReducer.synchronize` is called before the
     clip - a deliberate, documented fix.
@@ -47,6 +48,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
+            # ProcessGroupNCCL's flight recorder on: trainer.drain_collective_watchdog() reads from it when the watchdog thread
+            # has retired the eager collectives (a capture that contains collectives must not start before)
+            os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "512")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     from . import rng
     rng.set_rank(rank)           # per-rank dropout streams

@@ -330,7 +330,20 @@ class _Deferred:
 WIDE_CHUNK = 48    # problems per st_wgrad_wide launch (csrc/st_wgrad.hip WIDE_MAX: the descriptors travel as kernel arguments)
 
 
-def _wide_plan(problems, cus: int = 256):
+_CUS = {}
+
+
+def _device_cus(device) -> int:
+    """Compute units of the device the problems live on (256 on an MI355X; cached)."""
+    idx = torch.device(device).index if torch.device(device).type == "cuda" else None
+    if idx is None:
+        return 256
+    if idx not in _CUS:
+        _CUS[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+    return _CUS[idx]
+
+
+def _wide_plan(problems, cus: int = 0):
     """Launches of the 256 x 256-tile kernel (st_wgrad_wide): the problems in chunks of WIDE_CHUNK, each chunk with the token-split
     count that finishes first.  Items of one launch are equally long (tokens / splits) and one workgroup owns a CU, so a launch takes
     ceil(tiles x splits / CUs) rounds of tokens / splits each, plus ~50 us per round (prologue, 256 KB of fp32 atomics per item, the
@@ -338,6 +351,8 @@ def _wide_plan(problems, cus: int = 256):
     tiles in the first launch, 52 in the second) ran unsplit - 2 + 1 rounds of full-length items, 2.1 ms; 2 splits and 4 splits make it
     3 half rounds + 1 quarter round.  At least 256 tokens per item.  Returns a list of argument lists for nv.wgrad_group(wide=True)."""
     launches = []
+    if cus <= 0:
+        cus = _device_cus(problems[0][0].device) if problems else 256
     for c0 in range(0, len(problems), WIDE_CHUNK):
         chunk = problems[c0:c0 + WIDE_CHUNK]
         tiles = sum(-(-p[0].shape[1] // 256) * -(-p[5] // 256) for p in chunk)
@@ -763,7 +778,11 @@ class MhaFn(torch.autograd.Function):
         else:
             # non-causal self-attention (an encoder layer on the per-GEMM path: config 3's width, the stand-alone module): the
             # projection hands the attention kernels PRE-SCALED keys, as the encoder's row chains do (chains.EncoderChains)
-            kpre = x_kv is None and not causal and MhaFn.PRESCALE_KEYS
+            # (pre-scaled keys on the per-GEMM path go through st_gemm's column-range epilogue; where the weight-stationary
+            # st_gemm_ws serves the projection - width 256, encoder-sized row counts, 1.2-1.4x the tiled kernel - it is kept and
+            # the keys stay plain: both forms are exact to their one rounding, the attention kernels take either.  ADVICE r5)
+            kpre = (x_kv is None and not causal and MhaFn.PRESCALE_KEYS
+                    and not nv.ws_ok(x_q.shape[0], 3 * s.d_model, x_q.shape[1]))
             qkv, kvbuf, attn_ctx, ores, lse, out, xhat, rstd = MhaFn.compute(
                 x_q, x_kv, s, q_rows, k_rows, causal, drop, kv_acc, any(ctx.needs_input_grad), scale, kpre)
         if AttnTap.active is not None:

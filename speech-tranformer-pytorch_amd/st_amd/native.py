@@ -29,6 +29,7 @@ _c_long = ctypes.c_long
 SIGNATURES = {
     "st_version": [],
     "st_env_refresh": [],
+    "st_clock_probe": [_c_void_p, _c_void_p, _c_int, _c_int],
     "st_gemm": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int,
                 _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p],
     "st_gemm_stacked": [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
@@ -198,6 +199,9 @@ def lib_path() -> str:
     return _build.LIB
 
 
+ABI_VERSION = 3      # == ST_ABI_VERSION in include/st_hip.h == st_version() of the library this binding was written against
+
+
 def load(build_if_missing: bool = True):
     """dlopen libst_hip.so (building it first if hipcc is available)."""
     global _LIB
@@ -209,9 +213,21 @@ def load(build_if_missing: bool = True):
             raise RuntimeError("libst_hip.so not built: run `python __graft_entry__.py` (build())")
         _build.build_lib()
     cdll = ctypes.CDLL(path)
+    # the ABI version first: a library built from other sources would be called with shifted arguments
+    try:
+        cdll.st_version.restype = _c_int
+        ver = int(cdll.st_version())
+    except AttributeError:
+        ver = -1
+    if ver != ABI_VERSION:
+        raise RuntimeError("libst_hip.so at %s has ABI version %d, this binding needs %d: rebuild it (python __graft_entry__.py)"
+                           % (path, ver, ABI_VERSION))
+    missing = [name for name in SIGNATURES if not hasattr(cdll, name)]
+    if missing:
+        raise RuntimeError("libst_hip.so at %s lacks %s: rebuild it (python __graft_entry__.py)" % (path, ", ".join(missing)))
     lib = _Lib()
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(cdll, name)  # AttributeError here = header / library mismatch
+        fn = getattr(cdll, name)
         fn.argtypes = argtypes
         fn.restype = _c_int
         setattr(lib, name, _Timed(name, fn))
@@ -224,6 +240,20 @@ def _stream() -> int:
     """Raw handle of torch's current stream on the current device (torch.cuda.current_stream() builds a Stream object
     per call: ~8 us of host time, measurable in the eager decode loop's ~100 launches per step)."""
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def sustained_clock_mhz(device=None, iters: int = 30000) -> float:
+    """The shader clock (MHz) the device holds under ~2 ms of chip-wide dense MFMA work (st_clock_probe): median over the
+    compute units' own s_memtime / s_memrealtime ratios.  bench.py records it next to its roofline - the same commit measures
+    4-8 % apart on different boxes, and most of that is this number."""
+    dev = torch.device("cuda" if device is None else device)
+    n_wg = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    out = torch.zeros(2 * n_wg, dtype=torch.int64, device=dev)
+    for _ in range(2):       # (the first launch also pays the clock's ramp)
+        _check(load().st_clock_probe(_stream(), out.data_ptr(), n_wg, int(iters)), "st_clock_probe")
+    torch.cuda.synchronize(dev)
+    t = out.view(n_wg, 2).double().cpu()
+    return float((100.0 * t[:, 0] / t[:, 1].clamp_min(1)).median())
 
 
 def env_refresh() -> None:

@@ -360,12 +360,7 @@ class TrainStep:
             self._seed = torch.ones((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         if self.reducer is not None and self.reducer.active:
-            # The eager steps' all-reduces are finished on the GPU, but ProcessGroupNCCL's watchdog thread retires them on its own
-            # clock (a poll every 100 ms) - and a hipEventQuery of an EAGER collective's end event fails with "operation not permitted
-            # on an event last recorded in a capturing stream" once RCCL's stream has joined a capture, which terminates the process
-            # from the watchdog thread (round 5: tools/dev/dp_capture_stress.py - 6 of 16 processes of 12 captures each died; none of 16
-            # with this wait; the event cache off: 2 of 16).  Captures are rare (one per length signature): wait the watchdog out.
-            time.sleep(float(os.environ.get("ST_DP_DRAIN_MS", "300")) / 1e3)
+            drain_collective_watchdog()
         cap = _Captured()
         # the captured kernels read the ragged layouts (offsets, lengths, positions, attention work lists, scatter
         # index) by ADDRESS: pin the layout objects of this batch for as long as its graphs live (the layout cache may
@@ -426,7 +421,7 @@ class TrainStep:
                 TailBuffers.active.i = 0
             del g_all
             torch.cuda.synchronize()
-            time.sleep(float(os.environ.get("ST_DP_DRAIN_MS", "300")) / 1e3)      # (the agreement all-reduce above: see the wait before the capture)
+            drain_collective_watchdog()      # (the agreement all-reduce above: see the wait before the capture)
             pool = torch.cuda.graph_pool_handle()
             cap.g_fb, cap.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if split:
@@ -461,6 +456,46 @@ class _Bucket:
     def __init__(self):
         self.x = self.tok = self.gt = self.gt_flat = self.layouts = self.cap = self.tails = None
         self.seen = 0
+
+
+def drain_collective_watchdog(limit_s: float = 5.0) -> str:
+    """Before a capture that contains collectives: wait until ProcessGroupNCCL's watchdog thread has RETIRED every eager collective.
+
+    The eager steps' all-reduces are finished on the GPU after torch.cuda.synchronize(), but the watchdog retires them on its own
+    clock - and its hipEventQuery of an eager collective's end event fails with "operation not permitted on an event last recorded
+    in a capturing stream" once RCCL's stream has joined a capture, which terminates the process from the watchdog thread (round
+    5: tools/dev/dp_capture_stress.py - 6 of 16 processes of 12 captures each died).  Round 5 waited a fixed 300 ms; that is not a
+    synchronisation.  Now: the process group's flight recorder says for every collective whether the watchdog thread
+    has RETIRED it (the ``retired`` flag of ``_dump_nccl_trace`` entries is set by that thread, when it drops the work from its
+    list - unlike ``onlyActive`` and the ``state`` strings, which the dump call fills in itself by querying the events) - poll until
+    every recorded collective is retired.  The recorder must be on (``TORCH_NCCL_TRACE_BUFFER_SIZE`` > 0 before the process group is
+    created: ``enable_collective_recorder()``, called by bench.py and dp.GradReducer's callers); where it is off or absent the fixed
+    wait remains as the fallback (``ST_DP_DRAIN_MS``, default 300).  -> which of the two happened ("recorder" / "sleep")."""
+    torch.cuda.synchronize()
+    fallback_s = float(os.environ.get("ST_DP_DRAIN_MS", "300")) / 1e3
+    dump = getattr(torch._C._distributed_c10d, "_dump_nccl_trace", None) if torch.distributed.is_available() else None
+    if dump is not None and os.environ.get("ST_DP_DRAIN", "recorder") == "recorder":
+        import pickle
+        try:
+            t0 = time.time()
+            while time.time() - t0 < limit_s:
+                entries = pickle.loads(dump(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries")
+                if not entries or "retired" not in entries[0]:
+                    break                      # the recorder is off (or speaks another format): the fixed wait below
+                if all(e["retired"] for e in entries):
+                    return "recorder"
+                time.sleep(0.005)
+        except Exception:      # (an unexpected dump format: fall through to the fixed wait)
+            pass
+    time.sleep(fallback_s)
+    return "sleep"
+
+
+def enable_collective_recorder(entries: int = 512) -> None:
+    """Call BEFORE torch.distributed.init_process_group: turns ProcessGroupNCCL's flight recorder on (a ring of the last `entries`
+    collectives; off by default in this build), which is what lets drain_collective_watchdog() wait for the watchdog instead of
+    sleeping."""
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", str(entries))
 
 
 class _Captured:

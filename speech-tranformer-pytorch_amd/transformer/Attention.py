@@ -14,6 +14,16 @@ from st_amd.arena import arena_of, bundle
 from transformer.Utils import LengthMask, lengths_from_mask
 
 
+def _expand_mask(mask, B, Lq, Lk):
+    """A dense mask as the reference's ``masked_fill_`` takes it: anything that broadcasts to [B, Lq, Lk] ([B, 1, Lk] key-padding
+    masks, [Lq, Lk] causal masks ...)."""
+    if mask.dim() == 2:
+        mask = mask.unsqueeze(0)
+    if mask.dim() != 3:
+        raise ValueError("MultiHeadAttention: mask must broadcast to [batch, len_q, len_k], got shape %s" % (tuple(mask.shape),))
+    return mask.expand(B, Lq, Lk)
+
+
 class MultiHeadAttention(nn.Module):
     """q/k/v projections, masked scaled-dot-product attention per head, output
     projection, residual add and LayerNorm(eps=1e-6).
@@ -93,7 +103,11 @@ class MultiHeadAttention(nn.Module):
 
     # ---- reference API -------------------------------------------------------------------------
     def _forward_dense(self, q, k, v, mask):
-        """The general form (any dense mask, k and v different tensors): st_amd.functional.DenseMhaFn."""
+        """The general form (any dense mask - anything that broadcasts to [B, Lq, Lk], as the reference's masked_fill_ takes it -, k and
+        v different tensors): st_amd.functional.DenseMhaFn.  Two documented deviations from Attention.py:64-96 on this path
+        (INTEGRATION.md section 1): the residual added in front of the LayerNorm is ``q`` (R2: the reference adds ``v``, a shape
+        error whenever Lq != Lk and the same tensor for self-attention), and the returned ``attns`` are the probabilities BEFORE
+        dropout (A1: the reference returns them after ``self.dropout`` in training mode)."""
         B, Lq, d = q.shape
         Lk = k.shape[1]
         if v.shape[1] != Lk or k.shape[0] != B or v.shape[0] != B:
@@ -104,7 +118,7 @@ class MultiHeadAttention(nn.Module):
             mask[:, :m.shape[1], :m.shape[2]] = m[:, :Lq, :Lk]
             if m.shape[1] < Lq:
                 mask[:, m.shape[1]:] = mask[:, m.shape[1] - 1:m.shape[1]]
-        m8 = None if mask is None else mask.to(device=q.device).reshape(B, Lq, Lk).ne(0).to(torch.uint8).contiguous()
+        m8 = None if mask is None else _expand_mask(mask.to(device=q.device), B, Lq, Lk).ne(0).to(torch.uint8).contiguous()
         arena = arena_of(self)
         with arena.scope():
             args = [t.reshape(-1, d).to(torch.bfloat16) for t in (q, k, v)]
@@ -123,6 +137,7 @@ class MultiHeadAttention(nn.Module):
         elif isinstance(mask, LengthMask):
             k_len, causal = mask.k_len, mask.causal
         else:
+            mask = _expand_mask(mask, B, Lq, Lk)
             fam = lengths_from_mask(mask)
             if fam is None:            # neither of the two mask families of Utils.py: the general slow path
                 return self._forward_dense(q, k, v, mask)

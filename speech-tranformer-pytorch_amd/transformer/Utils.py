@@ -63,7 +63,7 @@ def lengths_from_mask(mask):
     takes st_amd.functional.DenseMhaFn).  A device sync: for callers that hand
     MultiHeadAttention a dense mask instead of a LengthMask."""
     mask = mask.bool()
-    B, Lq, Lk = mask.shape
+    B, Lq, Lk = mask.shape      # (callers with a broadcastable mask - [B, 1, Lk] - expand it first: MultiHeadAttention.forward does)
     k_len = (~mask[:, -1, :]).sum(-1)
     pad = torch.arange(Lk, device=mask.device).view(1, 1, -1) >= k_len.view(-1, 1, 1)
     if torch.equal(mask, pad.expand(B, Lq, Lk)):

@@ -20,7 +20,7 @@ def test_library_exports_header_symbols():
     assert declared == set(native.SIGNATURES), (declared ^ set(native.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.st_version() >= 1
+    assert lib.st_version() == native.ABI_VERSION
 
 
 def test_header_argument_counts_match_binding():

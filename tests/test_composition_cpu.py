@@ -291,6 +291,19 @@ def run_general_attention(golden_dir, device):
     y, _ = mha(x, x, x, mask)
     y.sum().backward()
     assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    # masks that BROADCAST to [B, Lq, Lk], as the reference's masked_fill_ takes them: a [B, 1, Lk] key-padding mask
+    # (one of the two families -> the fast path) and a [Lq, Lk] foreign mask (-> the dense path) equal their expanded forms
+    with torch.no_grad():
+        kp = torch.zeros(2, 1, 5, dtype=torch.bool, device=device)
+        kp[1, 0, 3:] = True
+        ya, _ = mha(x, x, x, kp)
+        yb, _ = mha(x, x, x, kp.expand(2, 5, 5).contiguous())
+        assert torch.equal(ya, yb)
+        fm = torch.zeros(5, 5, dtype=torch.bool, device=device)
+        fm[0, 2] = fm[3, 1] = True
+        ya, _ = mha(x, x, x, fm)
+        yb, _ = mha(x, x, x, fm.unsqueeze(0).expand(2, 5, 5).contiguous())
+        assert torch.equal(ya, yb)
 
 
 def test_general_attention_composition(golden_dir):

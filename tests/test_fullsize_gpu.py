@@ -651,6 +651,7 @@ def test_config3_dp_step_with_captured_collectives_matches_the_plain_step():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "512")      # (the flight recorder: trainer.drain_collective_watchdog)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         out = {}

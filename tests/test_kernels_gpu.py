@@ -684,6 +684,28 @@ def test_wgrad_wide_matches_fp32():
             check(gb, rb, 2e-5, "wgrad_wide db problem %d" % q)
 
 
+def test_wgrad_wide_at_decoder_side_shapes_through_the_plan():
+    """Since round 5 problems from 2,048 token rows up take st_wgrad_wide (_Deferred.WIDE_ROWS): the decoder side's ragged vocabulary
+    projection (N = 4,344 rows of the weight: 16 full tiles + a 248-row one) and a wide contraction (K_in = 2,048) at 2-4 k token
+    rows, planned by functional._wide_plan as the step plans them (the wide kernel was only tested at encoder shapes)."""
+    from st_amd.functional import _wide_plan
+    shapes = [(2304, 4344, 256, True), (3100, 256, 2048, True), (4000, 4344, 256, False), (2048, 1032, 2048, True)]
+    probs, ref = [], []
+    for q, (m, n, k, with_b) in enumerate(shapes):
+        dy, x = g(m, n, seed=110 + q), g(m, k, seed=160 + q)
+        init, b0 = g(n, k, seed=7, dtype=F32), g(1, n, seed=8, dtype=F32).view(-1)
+        probs.append((cu(x), cu(dy), cu(init.clone()), cu(b0.clone()) if with_b else None, 1, n))
+        ref.append((init + dy.float().t() @ x.float(), b0 + dy.float().sum(0)))
+    launches = _wide_plan(probs)
+    assert sum(len(l) for l in launches) == len(probs) and all(p[4] >= 1 for l in launches for p in l)
+    for l in launches:
+        nv.wgrad_group(l, wide=True)
+    for q, ((_, _, gw, gb, _, _), (rw, rb)) in enumerate(zip(probs, ref)):
+        check(gw, rw, 2e-5, "wgrad_wide (planned) dW problem %d" % q)
+        if gb is not None:
+            check(gb, rb, 2e-5, "wgrad_wide (planned) db problem %d" % q)
+
+
 def test_feat_stack_kernel():
     """st_feat_stack (CMVN + frame stacking + subsampling + ragged pack) against the oracle restatement of Dataset.py."""
     from tests import test_features_cpu as tf

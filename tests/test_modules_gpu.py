@@ -81,7 +81,7 @@ def test_native_library_is_loaded():
     """The GPU tests must run the HIP library, not a fallback."""
     from st_amd import native
     lib = native.load(build_if_missing=False)
-    assert lib.st_version() >= 1
+    assert lib.st_version() == native.ABI_VERSION
     with open("/proc/self/maps") as f:
         assert "libst_hip.so" in f.read()
 
@@ -291,6 +291,7 @@ def test_split_backward_graphs_with_reducer_match_single_graph():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "512")      # (the flight recorder: trainer.drain_collective_watchdog)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         cfg = AttrDict(dict(feature_dim=80, max_inputs_length=200, max_target_length=32, num_enc_layer=2,

@@ -24,6 +24,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 CFG = bench.CFG
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29541")
+os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "512")      # (the flight recorder: trainer.drain_collective_watchdog)
 dist.init_process_group("nccl", rank=0, world_size=1)
 torch.cuda.set_device(0)
 torch.manual_seed(0)

@@ -12,7 +12,8 @@ import sqlite3
 import sys
 
 CLASSES = [("gemm_wgrad", ("gemm_sym_kernel<true, true", "gemm_wgrad_group_kernel", "wgrad_wide_kernel")), ("gemm_dgrad", "gemm_sym_kernel<false, true"),
-           ("gemm_fwd", ("gemm_sym_kernel<false, false", "gemm_ws_kernel")), ("gemm_ln", "gemm_ln_kernel"), ("row_chain_bwd", "row_chain_bwd_kernel"), ("row_chain", "row_chain_kernel"), ("wfrag_build", "wfrag_build_kernel"), ("gemm_lnbwd", "gemm_lnbwd_kernel"),
+           ("gemm_fwd", ("gemm_sym_kernel<false, false", "gemm_ws_kernel")), ("gemm_ln", "gemm_ln_kernel"), ("row_chain_bwd", ("row_chain_bwd_kernel", "row_chain_bwd_pipe_kernel", "row_chain_bwd_split_kernel")),
+           ("row_chain", ("row_chain_kernel", "row_chain_pipe_kernel", "row_chain_split_kernel")), ("wfrag_build", "wfrag_build_kernel"), ("gemm_lnbwd", "gemm_lnbwd_kernel"),
            ("attn_fwd", ("attn_fwd_kernel", "attn_fwd64_kernel", "attn_xs_fwd_kernel")), ("attn_bwd_dq", "attn_bwd_dq_kernel"),
            ("attn_bwd_dkv", "attn_bwd_dkv_kernel"), ("attn_bwd", ("attn_bwd_kernel", "attn_bwd64_kernel")), ("ln_bwd", "ln_bwd_kernel")]
 
