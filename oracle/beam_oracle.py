@@ -3,9 +3,12 @@
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Parity: ``Beam`` is **pinned** - tests/golden/beam_trellis.npz is the
 trellis the reference's own Beam class produces (tools/make_beam_goldens.py imports /root/reference/transformer/Beam.py and
 applies repair R5, the floor division of line 65) and tests/test_decode_cpu.py holds this class, the product's
-transformer/Beam.py and st_beam_advance to it (indices bit-exact, scores <= 1e-6).  ``beam_search`` stays **unpinned**:
-`Decode.__init__` calls an obsolete `Transformer(...)` signature and `prob_projection` is undefined, so the reference's
-search driver cannot run and this part restates the INTENDED semantics line by line:
+transformer/Beam.py and st_beam_advance to it (indices bit-exact, scores <= 1e-6).  ``beam_search`` is **pinned** since round 6:
+`Decode.__init__` calls an obsolete `Transformer(...)` signature and `prob_projection` is undefined, but `decode_batch` itself
+runs once it is handed the (repaired, imported) reference model behind an adapter - tools/make_search_goldens.py executes the
+reference's own method text and writes tests/golden/beam_search.npz (five utterances, beam 4, n_best 2: four finish after 6-7
+tokens and leave the batch one by one - the compaction of Decode.py:112-165 -, one runs all 100 steps); this function reproduces it
+exactly (identical hypotheses, scores to 1e-9: tests/test_decode_cpu.py::test_search_driver_golden_pins_the_oracle).  What it restates:
 
 * ``Beam`` (Beam.py:13-116): scores start at 0, ``next_ys[0] = [BOS]*size``; ``advance(word_lk)`` takes
   ``[beam, V]`` log-probabilities, first step uses row 0 only (:48-51), top-k over the flattened beam x V array

@@ -37,7 +37,8 @@ C3 = dict(feature_dim=80, max_inputs_length=1000, max_target_length=50, num_enc_
           d_k=64, d_v=64, d_model=512, d_inner_hid=1024, dropout=0.1, vocab_size=4337)
 
 LOGIT_TOL, GRAD_TOL_TENSOR, GRAD_TOL_MEDIAN, GRAD_TOL_GLOBAL = 2e-2, 8e-2, 4e-2, 3e-2
-TRAIN_FLOOR_X = 1.25     # training mode: global / median gradient error within this factor of the bf16 reference's (same masks)
+TRAIN_FLOOR_X = 1.15     # training mode: global / median gradient error within this factor of the bf16 reference's (same masks;
+                         # round 6: was 1.25 - eleven seeds range 0.86 .. 1.12, profiles/r05_train_parity_seeds.txt)
 
 
 def rel(a, b):
@@ -45,7 +46,28 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
 
 
-def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_norm=5.0, seed=0):
+def sharpen_attention(model, factor):
+    """Scale every attention's query and key projections (weights and biases) by `factor`: the scores grow by factor^2 and the
+    softmax turns peaky - the regime a trained model lives in, and the one in which a re-rounded score operand shows (round 5:
+    the backward streams were 3-14x less accurate than the general kernels there until the keys were pre-scaled)."""
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".linear_q." in n or ".linear_k." in n:
+                p.mul_(factor)
+
+
+def train_on_one_batch_fp64(w, cfg, batch, n_steps, warmup=60, max_grad_norm=5.0):
+    """The oracle's weights after `n_steps` fp64 Adam steps on ONE batch (a short warm-up so that the schedule moves them): the
+    model memorises the batch and its attention sharpens the way training sharpens it.  -> state_dict-like dict of fp32 tensors."""
+    p64 = {k: v.double().cuda() for k, v in w.items()}
+    adam = None
+    for k in range(1, n_steps + 1):
+        out = orc.train_step(p64, batch, cfg["n_heads"], cfg["d_model"], warmup, k, max_grad_norm, adam_state=adam)
+        adam, p64 = out["adam"], out["params"]
+    return {k: v.float().cpu() for k, v in p64.items()}, out["loss"].item()
+
+
+def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_norm=5.0, seed=0, sharp=None, pretrain=0):
     import transformer.Models as M
     import transformer.Utils as U
     from st_amd import synthetic
@@ -56,14 +78,21 @@ def run_step_parity(cfg, n_utts, tag, use_graph=False, warmup=12000, max_grad_no
     torch.manual_seed(seed)                        # (the weights' seed: tools/dev/c3_kpre_ab.py varies it)
     model = M.Transformer(U.AttrDict(cfg))
     U.init_parameters(model)                       # train.py:116
-    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model = model.eval().cuda()                    # eval(): every Dropout is the identity (the oracle's parity mode)
+    if sharp:
+        sharpen_attention(model, sharp)
     x, tokens, in_len, tgt_len, gt = synthetic.make_batch(32, 1000, 50, cfg["feature_dim"], cfg["vocab_size"], seed=0,
                                                           t_min=500, l_min=25)
     x, tokens, in_len, tgt_len, gt = x[:n_utts], tokens[:n_utts], in_len[:n_utts], tgt_len[:n_utts], gt[:n_utts]
     if n_utts == 32:
         assert int(in_len.sum()) == 24060 and int(tgt_len.sum()) == 1206
     xg, tg, gg = x.cuda(), tokens.cuda(), gt.cuda()
+    if pretrain:       # the weights after `pretrain` fp64 steps of the oracle on this very batch
+        w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        wt, l_end = train_on_one_batch_fp64(w0, cfg, {"x": xg.double(), "in_len": in_len, "tokens": tg, "tgt_len": tgt_len, "gt": gg}, pretrain)
+        model.load_state_dict(wt)
+        print("pretrained %d fp64 steps on the batch: loss %.4f" % (pretrain, l_end))
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.eval().cuda()                    # eval(): every Dropout is the identity (the oracle's parity mode)
     L = int(tgt_len.max())
     valid = (torch.arange(L).view(1, -1) < tgt_len.view(-1, 1)).cuda()
 
@@ -164,6 +193,20 @@ def test_config2_trainstep_full_size_vs_fp64_oracle():
 def test_config2_trainstep_graph_full_size_vs_fp64_oracle():
     """The same step replayed from the HIP graph bench.py times."""
     run_step_parity(C2, 32, "c2_b32_graph", use_graph=True)
+
+
+def test_config2_full_size_sharp_attention_vs_fp64_oracle():
+    """VERDICT r5 (next 6a): the step-level table in the regime the pre-scaled keys exist for.  Config 2 at the benchmarked size
+    with every attention's q / k projections x 3 (scores x 9: peaky softmax rows), replayed from the graph as bench.py times it -
+    same tolerances as at Xavier initialisation."""
+    run_step_parity(C2, 32, "c2_b32_sharp3", use_graph=True, sharp=3.0)
+
+
+def test_config2_after_fp64_pretraining_vs_fp64_oracle():
+    """... and with the weights a short run of TRAINING produces: the oracle's own weights after 120 fp64 Adam steps on the batch
+    (8 utterances; warm-up 60: the loss falls by more than a nat and the attention maps sharpen), then one step of the product
+    against one step of the oracle from those weights."""
+    run_step_parity(C2, 8, "c2_b8_pretrained", use_graph=True, pretrain=120)
 
 
 def test_config3_depth_trainstep_vs_fp64_oracle():
@@ -298,7 +341,12 @@ def test_config2_training_mode_full_size_vs_fp64_oracle():
     assert sum(rg) / len(rg) <= 1.05 and sum(rm) / len(rm) <= 1.08, note
 
 
-def run_train_mode_parity(mask_seed, out_name="parity_c2_b32_train.txt", check=True):
+def test_config2_training_mode_sharp_attention_vs_fp64_oracle():
+    """Training mode (in-stream dropout masks, the streams' dropout variants) with every attention's q / k projections x 3."""
+    run_train_mode_parity(1, out_name="parity_c2_b32_train_sharp3.txt", sharp=3.0)
+
+
+def run_train_mode_parity(mask_seed, out_name="parity_c2_b32_train.txt", check=True, sharp=None):
     """-> dict(glob, med, worst, floor_glob, floor_med, floor_worst, logits); tools/dev/train_parity_sweep.py runs it over
     several mask seeds and attention-kernel variants (the spread of the figures = their realisation noise)."""
     import transformer.Models as M
@@ -310,6 +358,8 @@ def run_train_mode_parity(mask_seed, out_name="parity_c2_b32_train.txt", check=T
     torch.manual_seed(0)
     model = M.Transformer(U.AttrDict(cfg))
     U.init_parameters(model)
+    if sharp:
+        sharpen_attention(model, sharp)
     w = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.cuda().train()
     x, tokens, in_len, tgt_len, gt = synthetic.make_batch(32, 1000, 50, cfg["feature_dim"], cfg["vocab_size"], seed=0,

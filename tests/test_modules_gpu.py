@@ -128,6 +128,13 @@ def test_beam_search_decode_config5_shape_gpu():
     assert max(lengths) <= 14
 
 
+def test_search_driver_golden_gpu(golden_dir):
+    """transformer/Decode.py on the GPU (graph-replayed steps, KV cache, device-side beams) against the output of the reference's own
+    decode_batch (tests/golden/beam_search.npz, tools/make_search_goldens.py)."""
+    from tests import test_decode_cpu as dc
+    dc.run_search_golden(golden_dir, "cuda")
+
+
 def test_row_chain_step_gpu():
     """Decoder as attention kernels + row chains (d_model 256) against the fp64 oracle."""
     comp.run_row_chain_step("cuda")
