@@ -56,9 +56,10 @@ def sharpen_attention(model, factor):
                 p.mul_(factor)
 
 
-def train_on_one_batch_fp64(w, cfg, batch, n_steps, warmup=60, max_grad_norm=5.0):
-    """The oracle's weights after `n_steps` fp64 Adam steps on ONE batch (a short warm-up so that the schedule moves them): the
-    model memorises the batch and its attention sharpens the way training sharpens it.  -> state_dict-like dict of fp32 tensors."""
+def train_on_one_batch_fp64(w, cfg, batch, n_steps, warmup=400, max_grad_norm=5.0):
+    """The oracle's weights after `n_steps` fp64 Adam steps on ONE batch (warm-up 400, the trajectory test's schedule: the loss
+    falls by about a nat in 30 steps and the gradients stay healthy; 120 steps at warm-up 60 collapse this model onto the unigram
+    distribution - gradient norm 1.6e-3, nothing left to measure).  -> state_dict-like dict of fp32 tensors."""
     p64 = {k: v.double().cuda() for k, v in w.items()}
     adam = None
     for k in range(1, n_steps + 1):
@@ -197,16 +198,19 @@ def test_config2_trainstep_graph_full_size_vs_fp64_oracle():
 
 def test_config2_full_size_sharp_attention_vs_fp64_oracle():
     """VERDICT r5 (next 6a): the step-level table in the regime the pre-scaled keys exist for.  Config 2 at the benchmarked size
-    with every attention's q / k projections x 3 (scores x 9: peaky softmax rows), replayed from the graph as bench.py times it -
-    same tolerances as at Xavier initialisation."""
-    run_step_parity(C2, 32, "c2_b32_sharp3", use_graph=True, sharp=3.0)
+    with every attention's q / k projections x 2 (scores x 4: peaky softmax rows), replayed from the graph as bench.py times it -
+    same tolerance rules as at Xavier initialisation.  Measured (tools/dev/sharp_parity_scan.py): x 1.25 / 1.5 / 1.75 / 2 give
+    global 3.5e-2 / 3.1e-2 / 3.9e-2 / 5.8e-2 against 3.6e-2 / 3.4e-2 / 3.8e-2 / 6.5e-2 for the reference arithmetic under bf16
+    autocast.  x 3 (the verdict's figure) is past what this 6+6-layer random-weight model can measure: the gradient norm goes from
+    0.8 to 70 and the bf16 REFERENCE is 1.4 (rel-L2) away from fp64 - a one-hot softmax over 1,000 random keys flips its argmax
+    under any rounding."""
+    run_step_parity(C2, 32, "c2_b32_sharp2", use_graph=True, sharp=2.0)
 
 
 def test_config2_after_fp64_pretraining_vs_fp64_oracle():
-    """... and with the weights a short run of TRAINING produces: the oracle's own weights after 120 fp64 Adam steps on the batch
-    (8 utterances; warm-up 60: the loss falls by more than a nat and the attention maps sharpen), then one step of the product
-    against one step of the oracle from those weights."""
-    run_step_parity(C2, 8, "c2_b8_pretrained", use_graph=True, pretrain=120)
+    """... and with weights that TRAINING produced: the oracle's own weights after 30 fp64 Adam steps on the batch (8 utterances,
+    warm-up 400), then one step of the product against one step of the oracle from those weights."""
+    run_step_parity(C2, 8, "c2_b8_pretrained", use_graph=True, pretrain=30)
 
 
 def test_config3_depth_trainstep_vs_fp64_oracle():
@@ -342,8 +346,10 @@ def test_config2_training_mode_full_size_vs_fp64_oracle():
 
 
 def test_config2_training_mode_sharp_attention_vs_fp64_oracle():
-    """Training mode (in-stream dropout masks, the streams' dropout variants) with every attention's q / k projections x 3."""
-    run_train_mode_parity(1, out_name="parity_c2_b32_train_sharp3.txt", sharp=3.0)
+    """Training mode (in-stream dropout masks, the streams' dropout variants) with every attention's q / k projections x 1.5
+    (x 2 under dropout is past the measurable: the reference arithmetic under bf16 autocast is 0.67 rel-L2 from fp64 there, the
+    HIP path 0.51)."""
+    run_train_mode_parity(1, out_name="parity_c2_b32_train_sharp.txt", sharp=1.5)
 
 
 def run_train_mode_parity(mask_seed, out_name="parity_c2_b32_train.txt", check=True, sharp=None):
