@@ -202,6 +202,21 @@ int st_row_chain(st_stream_t stream, int M, const void* wfrag, int n_blocks, int
  * scaled in fp32 before its one rounding to bf16 - pass scale * log2(e) and hand the result to st_attn_fwd / st_attn_bwd /
  * st_attn_probs with k_prescaled = 1 (below). */
 
+/* The same chain at d_model = 512 (BASELINE config 3's encoder; csrc/st_rowchain_pipe512.cuh): A, R, out0, xhat0, out1, xhat1 are
+ * [M, 512] (leading dimension 512 for the outputs), the weight stream holds 256 x 256 blocks in the order
+ *   Wo: (h, j) -> 2 h + j  |  per hidden chunk c of 256: W1 (c, j = 0, 1), W2 (h = 0, 1; c)  |  per 256-column block u of the
+ *   projection: (u, j = 0, 1)          (h: output-column half, j: input-column half of the 512-wide matrices)
+ * - st_amd.chains.encoder512_blocks spells it.  PRE and FFN are both required; post_blocks is 0 or 6 (a q | k | v projection
+ * to 1,536 columns, key columns 512 .. 1023 scaled by post_kscale as st_row_chain does).  64-row workgroups; relu_bits:
+ * st_row_chain512_mask_words(M, d_ff) words.  n_blocks = 4 + 4 d_ff / 256 + 2 post_blocks. */
+int st_row_chain512(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A, int lda,
+                    const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
+                    float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
+                    unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed,
+                    unsigned drop1_salt, int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh,
+                    float drop2_scale, int post_blocks, const float* bp, void* P, int ldp, float post_kscale);
+int st_row_chain512_mask_words(int M, int d_ff);
+
 /* relu_bits (st_row_chain: optional output, st_row_chain_bwd: input): which hidden values of the feed-forward sublayer are
  * > 0 after ReLU and dropout (the mask of SubLayers.py:25's backward), one bit per value in a layout private to the two
  * kernels; st_row_chain_mask_words(M, d_ff) 64-bit words.  The backward chain reads these instead of H. */

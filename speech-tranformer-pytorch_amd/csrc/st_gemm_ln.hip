@@ -15,6 +15,9 @@
 #include "st_common.cuh"
 #include <cstdlib>
 
+#ifndef ST_GEMM_SC1
+#define ST_GEMM_SC1 0      // development: bf16 output rows write-through (store16_wt)
+#endif
 namespace {
 
 constexpr int BK = 32;
@@ -114,7 +117,7 @@ __device__ __forceinline__ void ln_store_block(bf16* patch, bf16* gbase, int ld,
   for (int p = 0; p < 8; ++p) {
     const int id = p * 64 + l, rr = id >> 4, c = id & 15;
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + rr * 128 + ((c ^ (rr & 15)) << 3));
-    if (rr < nvalid_rows) *reinterpret_cast<bf16x8*>(gbase + (size_t)rr * ld + c * 8) = v;
+    if (rr < nvalid_rows) store16<ST_GEMM_SC1>(gbase + (size_t)rr * ld + c * 8, v);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }

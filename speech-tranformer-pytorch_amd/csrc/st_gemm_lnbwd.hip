@@ -21,6 +21,9 @@
 #include "st_common.cuh"
 #include <cstdlib>
 
+#ifndef ST_GEMM_SC1
+#define ST_GEMM_SC1 0      // development: bf16 output rows write-through (store16_wt)
+#endif
 namespace {
 
 constexpr int BK = 32;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__((TALL ? 512 : 256), (TALL ? 1 : 2)) void gemm_lnbwd
     const int rr = (p * 64 + l) >> 4;
     const bf16x8 dxv = *reinterpret_cast<const bf16x8*>(p2 + rr * 128 + ((cc ^ (rr & 15)) << 3));
     if (rr < nvalid) {
-      *reinterpret_cast<bf16x8*>(gout + (size_t)rr * a.ldo + cc * 8) = dxv;
+      store16<ST_GEMM_SC1>(gout + (size_t)rr * a.ldo + cc * 8, dxv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) axs[e] += (float)dxv[e];
     }

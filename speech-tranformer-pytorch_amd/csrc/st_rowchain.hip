@@ -24,6 +24,7 @@
 // per workgroup).
 #include "st_rowchain_common.cuh"
 #include "st_rowchain_pipe.cuh"
+#include "st_rowchain_pipe512.cuh"
 #include <cstdlib>
 #include <type_traits>
 
@@ -1046,6 +1047,52 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
   else if (pre) ST_CHAIN(true, false, false);
   else ST_CHAIN(false, false, true);
 #undef ST_CHAIN
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- d_model = 512 (st_rowchain_pipe512.cuh): PRE + FFN [+ the six 256-column blocks of a q | k | v projection], 64-row workgroups
+extern "C" int st_row_chain512_mask_words(int M, int d_ff) {
+  if (M <= 0 || d_ff <= 0) return 0;
+  return ((M + 63) / 64) * (d_ff / 256) * NW * 64;
+}
+
+extern "C" int st_row_chain512(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, float eps, const void* A, int lda,
+                               const void* R, int ldr, const float* bo, const float* g0, const float* be0, void* out0, void* xhat0,
+                               float* rstd0, int d_ff, const float* b1, const float* b2, const float* g1, const float* be1, void* H,
+                               unsigned long long* relu_bits, void* out1, void* xhat1, float* rstd1, const unsigned* drop_seed,
+                               unsigned drop1_salt, int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh,
+                               float drop2_scale, int post_blocks, const float* bp, void* P, int ldp, float post_kscale) {
+  if (M <= 0) return 0;
+  if (!A || !wfrag || (lda & 7) || !R || (ldr & 7) || !bo || !g0 || !be0) return -1;
+  if (d_ff <= 0 || (d_ff & 255) || !b1 || !b2 || !g1 || !be1 || !out1) return -3;
+  if (post_blocks != 0 && post_blocks != 6) return -4;
+  if (post_blocks && (!bp || !P || (ldp & 7) || ldp < 256 * post_blocks)) return -4;
+  if (n_blocks != 4 + 4 * (d_ff / 256) + 2 * post_blocks) return -5;
+  ChainArgs a;
+  a.M = M; a.wfrag = (const bf16x8*)wfrag; a.wave_frags = n_blocks * 16 + DEPTH; a.eps = eps;
+  a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
+  a.A = (const bf16*)A; a.lda = lda; a.R = (const bf16*)R; a.ldr = ldr; a.bo = bo; a.g0 = g0; a.be0 = be0;
+  a.out0 = (bf16*)out0; a.xhat0 = (bf16*)xhat0; a.rstd0 = rstd0;
+  a.nc = d_ff / 256; a.b1 = b1; a.b2 = b2; a.g1 = g1; a.be1 = be1; a.H = (bf16*)H; a.relu_bits = relu_bits; a.out1 = (bf16*)out1;
+  a.xhat1 = (bf16*)xhat1; a.rstd1 = rstd1;
+  const bool on1 = drop_seed && drop1_thresh > 0, on2 = drop_seed && drop2_thresh > 0;
+  a.drop1.seed = on1 ? drop_seed : nullptr; a.drop1.salt = drop1_salt; a.drop1.thresh = on1 ? drop1_thresh : 0;
+  a.drop1.scale = on1 ? drop1_scale : 1.f;
+  a.drop2.seed = on2 ? drop_seed : nullptr; a.drop2.salt = drop2_salt; a.drop2.thresh = on2 ? drop2_thresh : 0;
+  a.drop2.scale = on2 ? drop2_scale : 1.f;
+  a.nb = post_blocks; a.bp = bp; a.P = (bf16*)P; a.ldp = ldp;
+  a.post_kscale = (post_blocks == 6 && post_kscale > 0.f) ? post_kscale : 1.f;
+  a.split_ws = nullptr; a.split_tickets = nullptr; a.split_parts = 0;
+  const dim3 grid((M + 63) / 64), blk(512);
+  const bool drop = on1 || on2;
+  if (post_blocks) {
+    if (drop) hipLaunchKernelGGL((row_chain512_kernel<true, true>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((row_chain512_kernel<true, false>), grid, blk, 0, stream, a);
+  } else {
+    if (drop) hipLaunchKernelGGL((row_chain512_kernel<false, true>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((row_chain512_kernel<false, false>), grid, blk, 0, stream, a);
+  }
   ST_CHECK_LAUNCH();
   return 0;
 }

@@ -63,13 +63,15 @@ template <int MT> __device__ __forceinline__ void acc_init(f32x16 (&acc)[MT], co
 // ---- a finished LDS tile on its way to HBM: piece p = rows (tid >> 5) + 16 p, 16 bytes at column (tid & 31) * 8
 struct TileOut {
   __amdgpu_buffer_rsrc_t rs;
-  const bf16* t;      // LDS tile
+  const bf16* t;      // LDS tile (256 columns of it: a 512-wide tile leaves as two of these)
   unsigned ld2;       // row pitch of the destination in bytes
+  int pitch;          // row pitch of the LDS tile in elements
 };
 template <int MT>
-__device__ __forceinline__ TileOut tile_out_desc(const Ctx<MT>& c, const bf16* t, bf16* g, int ld) {
+__device__ __forceinline__ TileOut tile_out_desc(const Ctx<MT>& c, const bf16* t, bf16* g, int ld, int pitch = AS) {
   TileOut o;
   o.t = t;
+  o.pitch = pitch;
   o.ld2 = (unsigned)ld * 2u;
   // (null destination: an empty range - every store is dropped)
   const unsigned long long base = g ? (unsigned long long)(g + (size_t)c.row0 * ld) : 0ull;
@@ -80,12 +82,17 @@ __device__ __forceinline__ TileOut tile_out_desc(const Ctx<MT>& c, const bf16* t
 }
 template <int MT> struct Pieces { bf16x8 v[2]; };
 __device__ __forceinline__ bf16x8 piece_read(const TileOut& o, int tid, int p) {
-  return *reinterpret_cast<const bf16x8*>(o.t + ((tid >> 5) + 16 * p) * AS + (tid & 31) * 8);
+  return *reinterpret_cast<const bf16x8*>(o.t + ((tid >> 5) + 16 * p) * o.pitch + (tid & 31) * 8);
 }
 __device__ __forceinline__ void piece_write(const TileOut& o, int tid, int p, bf16x8 v) {
-  const unsigned voff = (unsigned)(tid >> 5) * o.ld2 + (unsigned)(tid & 31) * 16u;
+  // The piece's row offset goes into the VECTOR offset, the scalar offset stays 0.  With a register in the soffset field hipcc
+  // (ROCm 7.2) lets the next VALU instruction overwrite the store's data registers at once, and gfx950 does not interlock that for
+  // a 16-byte store: st_row_chain512's exposed tail copied LDS ADDRESSES into out1 (buffer_store_dwordx4 v[12:15], .., s10 offen
+  // directly followed by v_add_u32 v12, ..: round 6, found by the dropout variant of tests/test_kernels_gpu.py::test_row_chain512_*).
+  // With soffset = 0 the compiler's hazard recogniser knows the store-data hazard and pads it.
+  const unsigned voff = ((unsigned)(tid >> 5) + 16u * (unsigned)p) * o.ld2 + (unsigned)(tid & 31) * 16u;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o.rs, voff, (unsigned)(16 * p) * o.ld2, ST_PIPE_OUT_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o.rs, voff, 0, ST_PIPE_OUT_AUX);
 }
 // exposed copy of a whole tile
 template <int MT> __device__ __forceinline__ void tile_out_now(const Ctx<MT>& c, const TileOut& o) {
@@ -130,7 +137,7 @@ __device__ __forceinline__ uint32_t f2u(float v) { return __builtin_bit_cast(uin
 // RELU: max(v, 0) and the mask bits (sign of the fp32 value; units and elements are visited in DESCENDING bit order, every bit
 // enters at the bottom of its word through v_alignbit, so bit 16 mt + 4 g + e ends where relu_bits_from() expects it; the
 // words are complemented at the end: set = kept)
-template <bool RELU, bool DROP, int MT>
+template <bool RELU, bool DROP, int MT, int PT = AS>
 __device__ __forceinline__ void epi_unit(const Ctx<MT>& c, const f32x16 (&acc)[MT], int mt, int g, bf16* t, const Drop& d, int gcol0, int ncols,
                                          float oscale, uint32_t& w_lo, uint32_t& w_hi) {
   const int row = mt * 32 + c.r, jl = c.wave * 32 + 8 * g + 4 * c.hi;
@@ -161,11 +168,11 @@ __device__ __forceinline__ void epi_unit(const Ctx<MT>& c, const f32x16 (&acc)[M
     // (pins the mask words here: left alone the compiler sinks all 16 MT v_alignbit behind the block's last MFMA)
     asm volatile("" : "+v"(w_lo), "+v"(w_hi));
   }
-  *reinterpret_cast<bf16x4*>(t + row * AS + jl) = o;
+  *reinterpret_cast<bf16x4*>(t + row * PT + jl) = o;
 }
 
 // the epilogue of a finished accumulator set as side work: 4 MT units over the eight groups, the mask words stored behind the last
-template <bool RELU, bool DROP, int MT> struct EpiSide {
+template <bool RELU, bool DROP, int MT, int PT = AS> struct EpiSide {
   const Ctx<MT>& c;
   const f32x16 (&acc)[MT];
   bf16* t;
@@ -176,7 +183,7 @@ template <bool RELU, bool DROP, int MT> struct EpiSide {
   uint32_t w_lo = 0, w_hi = 0;
   static constexpr int NU = 4 * MT;
   __device__ __forceinline__ void unit(int j) {      // j ascending = bits descending
-    epi_unit<RELU, DROP, MT>(c, acc, MT - 1 - j / 4, 3 - j % 4, t, d, gcol0, ncols, oscale, w_lo, w_hi);
+    epi_unit<RELU, DROP, MT, PT>(c, acc, MT - 1 - j / 4, 3 - j % 4, t, d, gcol0, ncols, oscale, w_lo, w_hi);
   }
   __device__ __forceinline__ void a(int) {}
   __device__ __forceinline__ void b(int k2) {
@@ -203,9 +210,9 @@ template <class S0, class S1> struct Both {
 
 // One 256 x 256 weight block as block_mma, the ring refilled from two places: the second half of THIS block (cur_blk), then the
 // first half of the block that is multiplied NEXT (nxt_blk) - the blocks are not visited in stream order.  Ring<MT>::D == 8.
-template <int MT, class Side>
-__device__ __forceinline__ void block_mma_p(Ctx<MT>& c, const bf16x8* cur_blk, const bf16x8* nxt_blk, const bf16* act, f32x16 (&acc)[MT],
-                                            Side&& side) {
+template <int PT, int MT, class Side>      // PT: row pitch of the activation tile in elements
+__device__ __forceinline__ void block_mma_pt(Ctx<MT>& c, const bf16x8* cur_blk, const bf16x8* nxt_blk, const bf16* act, f32x16 (&acc)[MT],
+                                             Side&& side) {
   static_assert(Ring<MT>::D == 8, "block_mma_p: half a block on request");
 #ifndef ST_PIPE_LDS_AHEAD
 #define ST_PIPE_LDS_AHEAD 0      // (1: the activation fragments of group k2 + 1 read while group k2 multiplies - measured at nothing, 24 registers)
@@ -216,14 +223,14 @@ __device__ __forceinline__ void block_mma_p(Ctx<MT>& c, const bf16x8* cur_blk, c
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xf[0][u][mt] = frag_nat(act, AS, mt * 32 + c.r, u * 16 + c.hi * 8);
+    for (int mt = 0; mt < MT; ++mt) xf[0][u][mt] = frag_nat(act, PT, mt * 32 + c.r, u * 16 + c.hi * 8);
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) {
     if (k2 < 7) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xf[(k2 + 1) & 1][u][mt] = frag_nat(act, AS, mt * 32 + c.r, (2 * k2 + 2 + u) * 16 + c.hi * 8);
+        for (int mt = 0; mt < MT; ++mt) xf[(k2 + 1) & 1][u][mt] = frag_nat(act, PT, mt * 32 + c.r, (2 * k2 + 2 + u) * 16 + c.hi * 8);
     }
     side.a(k2);
 #pragma unroll
@@ -251,7 +258,7 @@ __device__ __forceinline__ void block_mma_p(Ctx<MT>& c, const bf16x8* cur_blk, c
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[u][mt] = frag_nat(act, AS, mt * 32 + c.r, (2 * k2 + u) * 16 + c.hi * 8);
+      for (int mt = 0; mt < MT; ++mt) xf[u][mt] = frag_nat(act, PT, mt * 32 + c.r, (2 * k2 + u) * 16 + c.hi * 8);
     side.a(k2);
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -272,6 +279,12 @@ __device__ __forceinline__ void block_mma_p(Ctx<MT>& c, const bf16x8* cur_blk, c
     __builtin_amdgcn_sched_barrier(0);
   }
 #endif
+}
+
+template <int MT, class Side>
+__device__ __forceinline__ void block_mma_p(Ctx<MT>& c, const bf16x8* cur_blk, const bf16x8* nxt_blk, const bf16* act, f32x16 (&acc)[MT],
+                                            Side&& side) {
+  block_mma_pt<AS>(c, cur_blk, nxt_blk, act, acc, side);
 }
 
 // v = acc (bias inside) + res; LayerNorm over the 256 columns held by the 8 waves from ONE pass (sum, sum of squares) and one

@@ -79,6 +79,23 @@ def ffn_blocks(w1: torch.Tensor, w2: torch.Tensor) -> List[Tuple[torch.Tensor, i
     return out
 
 
+def encoder512_blocks(wo: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, wp=None):
+    """The block order of st_row_chain512 (csrc/st_rowchain_pipe512.cuh) for one encoder layer at d_model 512: Wo [512, 512] as
+    (h, j) -> 2 h + j; per hidden chunk c of 256: W1 rows c (j = 0, 1), W2 columns c (h = 0, 1); then the next layer's q | k | v
+    projection Wp [1536, 512] as (u, j) (h / u: 256-row block of the weight = output columns, j: 256-column block = input half)."""
+    d_ff = w1.shape[0]
+    if tuple(wo.shape) != (512, 512) or w1.shape[1] != 512 or tuple(w2.shape) != (512, d_ff) or d_ff % BLK:
+        raise ValueError("chains: d_model-512 weights must be [512, 512], [d_ff, 512] and [512, d_ff], d_ff a multiple of 256")
+    out = [(wo, h * BLK, j * BLK) for h in range(2) for j in range(2)]
+    for c in range(0, d_ff, BLK):
+        out += [(w1, c, 0), (w1, c, BLK), (w2, 0, c), (w2, BLK, c)]
+    if wp is not None:
+        if tuple(wp.shape) != (1536, 512):
+            raise ValueError("chains: the d_model-512 projection must be [1536, 512]")
+        out += [(wp, u * BLK, j * BLK) for u in range(6) for j in range(2)]
+    return out
+
+
 class ChainSet:
     def __init__(self, device):
         self.device = torch.device(device)
@@ -284,6 +301,20 @@ class EncoderChains:
         self.set = ChainSet(arena.device)
         ids = []
         n = len(layers)
+        self.d = layers[0].slf_attn._st.d_model
+        if self.d == 512:
+            # BASELINE config 3's width (round 6): forward chains only (st_row_chain512: output_linear + LayerNorm, feed-forward,
+            # the next layer's q | k | v projection per launch, 64-row workgroups); layer 0's projection and the whole backward
+            # stay on the per-GEMM kernels, which read the tensors the chain saved
+            for l, layer in enumerate(layers):
+                sa, ff = layer.slf_attn._st, layer.pos_ffn._st
+                ids.append(self.set.add(encoder512_blocks(sa.w_o, ff.w1, ff.w2, layers[l + 1].slf_attn._st.w_qkv if l + 1 < n else None)))
+            self.set.finalize()
+            self.q0 = None
+            self.e = [self.set.chain(c, True) for c in ids]
+            self.bset, self.bwd, self.use_bwd, self.layer_hook = None, [], False, None
+            ChainHub.of(arena).add(self.set)
+            return
         # layer 0's q | k | v projection: a chain of its own (three blocks, no PRE / FFN) - every encoder layer's keys leave
         # their projection PRE-SCALED by scale * log2(e) in the chain's fp32 epilogue (st_row_chain's post_kscale), so that no
         # attention kernel multiplies per score and forward and backward exponentiate identical scores (st_attn_common.cuh)
@@ -325,7 +356,9 @@ class EncoderChains:
             sa, ff = layer.slf_attn, layer.pos_ffn
             if any(getattr(m, "_st_arena", None) is not arena for m in (sa, ff)):
                 return None
-            if sa._st.d_model != BLK or ff._st.d_ff % BLK:
+            if sa._st.d_model not in (BLK, 512) or ff._st.d_ff % BLK:
+                return None
+            if sa._st.d_model == 512 and os.environ.get("ST_CHAIN512", "1") == "0":      # (development switch: the per-GEMM path)
                 return None
         return EncoderChains(layers, arena)
 
@@ -349,7 +382,12 @@ class EncoderChains:
         kscale = scale * nv.K_LOG2_SCALE if kpre else 0.0
         work = attn_work(rows, rows, False, d // H, H)[0]
         qkv = E(M, 3 * d)
-        nv.row_chain(x, self.q0, post=(3, s0.b_qkv, qkv), post_kscale=kscale)
+        if self.q0 is not None:
+            nv.row_chain(x, self.q0, post=(3, s0.b_qkv, qkv), post_kscale=kscale)
+        elif kpre:
+            nv.gemm_kscale(x, s0.w_qkv, qkv, s0.b_qkv, d, 2 * d, kscale)
+        else:
+            nv.gemm(x, s0.w_qkv, qkv, bias=s0.b_qkv)
         pres = []
         n = len(layers)
         for l, layer in enumerate(layers):
@@ -364,13 +402,13 @@ class EncoderChains:
                 a.xhat, a.rstd, f.xhat, f.rstd = E(M, d), E(M, dt=F32), E(M, d), E(M, dt=F32)
             f.drop1, f.drop2 = ff._drops(dev)
             if need_bwd and self.use_bwd:       # the backward chain masks with these bits instead of reading f.h
-                f.bits = torch.empty(nv.chain_mask_words(M, ff._st.d_ff), dtype=torch.int64, device=dev)
+                f.bits = torch.empty(nv.chain_mask_words(M, ff._st.d_ff, d), dtype=torch.int64, device=dev)
             nxt = layers[l + 1].slf_attn._st if l + 1 < n else None
             qkv = E(M, 3 * d) if nxt is not None else None
             nv.row_chain(a.ctx, self.e[l], pre=(x, sa._st.b_o, sa._st.gamma, sa._st.beta, a.out, a.xhat, a.rstd),
                          ffn=(ff._st.d_ff, ff._st.b1, ff._st.b2, ff._st.gamma, ff._st.beta, f.h, f.out, f.xhat, f.rstd, f.drop1,
                               f.drop2, f.bits),
-                         post=(3, nxt.b_qkv, qkv) if nxt is not None else None, post_kscale=kscale)
+                         post=(3 * d // BLK, nxt.b_qkv, qkv) if nxt is not None else None, post_kscale=kscale)
             x = f.out
             pres.append((a, f))
         if need_bwd and self.use_bwd:

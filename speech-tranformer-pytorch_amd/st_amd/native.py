@@ -51,6 +51,11 @@ SIGNATURES = {
                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
                      _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_ll, _c_float],
     "st_row_chain_mask_words": [_c_int, _c_int],
+    "st_row_chain512": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_uint, _c_int, _c_float,
+                        _c_int, _c_void_p, _c_void_p, _c_int, _c_float],
+    "st_row_chain512_mask_words": [_c_int, _c_int],
     "st_gemm_kscale": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int,
                        _c_float],
     "st_gemm_splitk": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -511,10 +516,15 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0
     xhat / rstd may be None when no backward follows."""
     _mat(A, BF16, "A")
     M, d = A.shape
-    if d != 256:
-        raise ValueError("row_chain: d_model 256 only")
+    if d not in (256, 512):
+        raise ValueError("row_chain: d_model 256 or 512")
     wfrag, n_blocks = chain.stream, chain.n_blocks
-    nb = (1 if pre else 0) + (2 * (ffn[0] // 256) if ffn else 0) + (post[0] if post else 0)
+    if d == 512:      # csrc/st_rowchain_pipe512.cuh: PRE + FFN [+ a q | k | v projection], 256 x 256 blocks of 512-wide matrices
+        if not (pre and ffn) or (post and post[0] != 6):
+            raise ValueError("row_chain (d_model 512): PRE and FFN are required, POST is a 1,536-column projection (6 blocks)")
+        nb = 4 + 4 * (ffn[0] // 256) + (12 if post else 0)
+    else:
+        nb = (1 if pre else 0) + (2 * (ffn[0] // 256) if ffn else 0) + (post[0] if post else 0)
     if nb != n_blocks or wfrag.numel() != 8 * (n_blocks * 16 + wfrag_depth()) * 512 or wfrag.dtype != BF16:
         raise ValueError("row_chain: the fragment stream does not match the chain")
     z = (None,) * 11
@@ -539,7 +549,7 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0
             assert H.stride(0) == d_ff and H.shape == (M, d_ff)
         assert out1.stride(0) == d and (xhat1 is None or xhat1.stride(0) == d)
         assert rstd1 is None or (rstd1.dtype == F32 and rstd1.numel() >= M)
-        assert relu_bits is None or (relu_bits.dtype == torch.int64 and relu_bits.is_contiguous() and relu_bits.numel() >= chain_mask_words(M, d_ff))
+        assert relu_bits is None or (relu_bits.dtype == torch.int64 and relu_bits.is_contiguous() and relu_bits.numel() >= chain_mask_words(M, d_ff, d))
     if post:
         _mat(P, BF16, "P"), _vec(bp, F32, 256 * pb, "bp")
         assert P.shape == (M, 256 * pb)
@@ -555,6 +565,13 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0
         raise ValueError("row_chain: chain.split_work must be a contiguous int32 tensor on the GPU")
     _tag("row_chain", M, n_blocks, d_ff, io=((A, M), (R, M), (out0, M), (xhat0, M), (H, M), relu_bits, (out1, M), (xhat1, M), (P, M),
                                              (rstd0, M), (rstd1, M), 2.0 * 256 * 256 * n_blocks))
+    if d == 512:
+        rc = load().st_row_chain512(_stream(), M, wfrag.data_ptr(), n_blocks, int(chain.next_blocks), float(eps), A.data_ptr(), A.stride(0),
+                                    _p(R), R.stride(0), _p(bo), _p(g0), _p(be0), _p(out0), _p(xhat0), _p(rstd0), int(d_ff), _p(b1), _p(b2),
+                                    _p(g1), _p(be1), _p(H), _p(relu_bits), _p(out1), _p(xhat1), _p(rstd1), _p(seed), s1[1], s1[2], s1[3],
+                                    s2[1], s2[2], s2[3], int(pb), _p(bp), _p(P), 0 if P is None else P.stride(0), float(post_kscale))
+        _check(rc, "st_row_chain512")
+        return
     rc = load().st_row_chain(_stream(), M, wfrag.data_ptr(), n_blocks, int(chain.next_blocks), float(eps), A.data_ptr(), A.stride(0), _p(R),
                              0 if R is None else R.stride(0), _p(bo), _p(g0), _p(be0), _p(out0), _p(xhat0), _p(rstd0),
                              int(d_ff), _p(b1), _p(b2), _p(g1), _p(be1), _p(H), _p(relu_bits), _p(out1), _p(xhat1), _p(rstd1), _p(seed),
@@ -608,18 +625,20 @@ def gemm_splitk(X, Y, out, splits, y_cmajor=False):
     return out
 
 
-def chain_mask_words(M: int, d_ff: int) -> int:
+def chain_mask_words(M: int, d_ff: int, d_model: int = 256) -> int:
     """int64 words of the ReLU-mask buffer a feed-forward row chain over M rows writes (row_chain) and reads (row_chain_bwd)."""
+    if d_model == 512:
+        return int(load()._cdll.st_row_chain512_mask_words(int(M), int(d_ff)))
     return int(load()._cdll.st_row_chain_mask_words(int(M), int(d_ff)))     # host-only: not a launch (bypasses the per-launch timer)
 
 
-def relu_bits_from(H):
+def relu_bits_from(H, d_model: int = 256):
     """The relu_bits buffer of a hidden activation H [M, d_ff] that did NOT come out of row_chain (a separate forward, a
     test): word ((workgroup * d_ff/256 + chunk) * 8 + wave) * 64 + lane, bit 16 mt + 4 g + e  <->  row
     workgroup * 32 MT + 32 mt + (lane & 31), column 256 chunk + 32 wave + 8 g + 4 (lane >> 5) + e - the accumulator layout
     of csrc/st_rowchain.hip (MT row tiles per workgroup as st_row_chain picks them for M)."""
     M, d_ff = H.shape
-    words = chain_mask_words(M, d_ff)
+    words = chain_mask_words(M, d_ff, d_model)
     nc = d_ff // 256
     n_wg = words // (nc * 512)
     mt_n = -(-M // (32 * n_wg))                       # rows per workgroup / 32

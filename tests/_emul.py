@@ -175,9 +175,11 @@ def wfrag_build(table):
     return None       # the emulated chain reads the weight blocks themselves (chains.Chain.blocks)
 
 
-def chain_mask_words(M, d_ff):
+def chain_mask_words(M, d_ff, d_model=256):
     """The real kernels' buffer size (include/st_hip.h: st_row_chain_mask_words); the emulation packs one bit per hidden
     value row-major into its first M * d_ff / 64 words."""
+    if d_model == 512:
+        return ((M + 63) // 64) * (d_ff // 256) * 8 * 64
     mt = 1 if (M + 31) // 32 <= 256 else 2 if (M + 63) // 64 <= 256 else 3
     return ((M + 32 * mt - 1) // (32 * mt)) * (d_ff // 256) * 8 * 64
 
@@ -195,8 +197,8 @@ def _unpack_bits(words, M, d_ff):
     return torch.from_numpy(b.astype(np.bool_)).view(M, d_ff)
 
 
-def relu_bits_from(H):
-    out = torch.zeros(chain_mask_words(*H.shape), dtype=torch.int64)
+def relu_bits_from(H, d_model=256):
+    out = torch.zeros(chain_mask_words(H.shape[0], H.shape[1], d_model), dtype=torch.int64)
     _pack_bits(H.float() > 0, out)
     return out
 
@@ -205,6 +207,30 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0
     """csrc/st_rowchain.hip as a composition of the emulated kernels it replaces (same roundings: every intermediate the
     separate kernels round to bf16 is rounded here too)."""
     blocks = list(chain.blocks)
+    if A.shape[1] == 512:      # csrc/st_rowchain_pipe512.cuh: the blocks of one GEMM are pieces of ONE weight tensor (chains.encoder512_blocks)
+        R, bo, g0, be0, out0, xhat0, rstd0 = pre
+        relu_bits = ffn[11] if len(ffn) == 12 else None
+        d_ff, b1, b2, g1, be1, H, out1, xhat1, rstd1, drop1, drop2 = ffn[:11]
+        wo, w1, w2 = blocks[0][0], blocks[4][0], blocks[6][0]
+        assert len(blocks) == 4 + 4 * (d_ff // 256) + (12 if post else 0)
+        M = A.shape[0]
+        out0 = torch.empty(M, 512, dtype=BF16, device=A.device) if out0 is None else out0
+        gemm_ln(A, wo, bo, R[:M], g0, be0, out0, xhat0, rstd0, eps=eps)
+        H = torch.empty(M, d_ff, dtype=BF16, device=A.device) if H is None else H
+        gemm(out0, w1, H, bias=b1, epi=nv.EPI_BF16_RELU, drop=drop1)
+        if relu_bits is not None:
+            _pack_bits(H[:M].float() > 0, relu_bits)
+        gemm_ln(H, w2, b2, out0, g1, be1, out1, xhat1, rstd1, eps=eps, drop=drop2, drop_where=2 if _on(drop2) else 0)
+        if post:
+            nb, bp, P = post
+            wp = blocks[4 + 4 * (d_ff // 256)][0]
+            if post_kscale not in (0.0, 1.0):
+                acc = out1[:M].float() @ wp.float().t() + bp.float()
+                acc[:, 512:1024] *= float(post_kscale)
+                P[:M] = acc.to(BF16)
+            else:
+                gemm(out1, wp, P, bias=bp)
+        return
 
     def take(n):
         out = [w[n0:n0 + 256, k0:k0 + 256] for w, n0, k0 in blocks[:n]]

@@ -60,6 +60,10 @@ def test_plans_decline_what_the_kernels_do_not_serve():
         assert m.decoder.row_chains(a) is None
         m8 = model(256, 8, 512)                 # d_k 32: forward chains yes, backward chains no (the delta epilogue's heads are 64 wide)
         assert m8.encoder.row_chains(arena_of(m8)).use_bwd is False
-        for bad in (model(128, 4, 256), model(512, 8, 1024), model(256, 4, 384)):
+        for bad in (model(128, 4, 256), model(256, 4, 384)):
             ab = arena_of(bad)
             assert bad.encoder.row_chains(ab) is None and bad.decoder.row_chains(ab) is None
+        m5 = model(512, 8, 1024)                # config 3's width: forward chains for the encoder (st_row_chain512), nothing else
+        a5 = arena_of(m5)
+        e5 = m5.encoder.row_chains(a5)
+        assert e5 is not None and e5.use_bwd is False and [c.n_blocks for c in e5.e] == [4 + 16] and m5.decoder.row_chains(a5) is None

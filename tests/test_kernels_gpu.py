@@ -1192,6 +1192,62 @@ def test_row_chain_matches_the_separate_kernels(M, variant):
         _zero_pattern_equal(got["H"], h, "row_chain dropout1 vs st_gemm")
 
 
+@pytest.mark.parametrize("M", [5, 64, 1000, 9000, 24060])
+@pytest.mark.parametrize("variant", ["post6", "plain", "post6+ks", "post6+drop", "drop"])
+def test_row_chain512_matches_the_separate_kernels(M, variant):
+    """st_row_chain512 (d_model 512: BASELINE config 3's encoder layer between two attention kernels as ONE launch) == output_linear +
+    residual + LayerNorm, the feed-forward sublayer and the next q | k | v projection as separate kernels: every tensor the backward
+    reads, the ReLU bits, ragged last row block, strided operand views, the dropout masks of st_gemm / st_gemm_ln."""
+    from st_amd import chains
+    d, dff = 512, 1024
+    parts = variant.split("+")
+    post, drop = "post6" in parts, "drop" in parts
+    wo, w1, w2 = g(d, d, seed=1, scale=d ** -0.5), g(dff, d, seed=2, scale=d ** -0.5), g(d, dff, seed=3, scale=dff ** -0.5)
+    wp = g(3 * d, d, seed=4, scale=d ** -0.5)
+    bo, b1, b2, bp = g(d, seed=5, dtype=F32), g(dff, seed=6, dtype=F32), g(d, seed=7, dtype=F32), g(3 * d, seed=8, dtype=F32)
+    g0, be0, g1, be1 = g(d, seed=9, dtype=F32) * 0.2 + 1, g(d, seed=10, dtype=F32) * 0.1, g(d, seed=11, dtype=F32) * 0.2 + 1, g(d, seed=12, dtype=F32) * 0.1
+    A, R = g(M, d, seed=13), g(M, d, seed=14)
+    dn1, de1 = _drops(21, 0.1) if drop else (None, None)
+    dn2, de2 = (nv.Drop(dn1.seed, 22, 0.1), em.Drop(de1.seed, 22, 0.1)) if drop else (None, None)
+
+    def run(dev, rc, d1, d2):
+        f = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t)
+        E = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+        o = dict(out0=E(M, d), xhat0=E(M, d), rstd0=E(M, dt=F32), H=E(M, dff), out1=E(M, d), xhat1=E(M, d), rstd1=E(M, dt=F32), P=E(M, 3 * d))
+        blocks = chains.encoder512_blocks(f(wo), f(w1), f(w2), f(wp) if post else None)
+        if dev == "cuda":
+            cs = chains.ChainSet("cuda")
+            cid = cs.add(blocks)
+            cs.finalize().rebuild()
+            ch = cs.chain(cid)
+            Aw = torch.zeros(M, d + 64, dtype=BF16, device="cuda")      # strided operand views
+            Aw[:, 32:32 + d] = f(A)
+            Rw = torch.zeros(M + 2, d + 8, dtype=BF16, device="cuda")
+            Rw[:M, :d] = f(R)
+            a_in, r_in = Aw[:, 32:32 + d], Rw[:M, :d]
+            o["bits"] = torch.zeros(nv.chain_mask_words(M, dff, d), dtype=torch.int64, device=dev)
+        else:
+            ch = chains.Chain(None, len(blocks), blocks)
+            a_in, r_in = A, R
+        rc(a_in, ch, pre=(r_in, f(bo), f(g0), f(be0), o["out0"], o["xhat0"], o["rstd0"]),
+           ffn=(dff, f(b1), f(b2), f(g1), f(be1), o["H"], o["out1"], o["xhat1"], o["rstd1"], d1, d2, o.get("bits")),
+           post=(6, f(bp), o["P"]) if post else None, **({"post_kscale": 0.125 * nv.K_LOG2_SCALE} if "ks" in parts else {}))
+        return o
+
+    got, ref = run("cuda", nv.row_chain, dn1, dn2), run("cpu", em.row_chain, de1, de2)
+    for n in ["out0", "xhat0", "rstd0", "H", "out1", "xhat1", "rstd1"] + (["P"] if post else []):
+        check(got[n], ref[n], 2e-3 if n.startswith("rstd") else 1e-2, "row_chain512 %s M=%d: %s" % (variant, M, n))
+    want = nv.relu_bits_from(got["H"], d)
+    diff = got["bits"] ^ want
+    nc, n_wg = dff // 256, want.numel() // (dff // 256 * 512)
+    sh = torch.arange(32, device="cuda", dtype=torch.int64)
+    bad = ((diff.unsqueeze(1) >> sh) & 1).view(n_wg, nc, 8, 2, 32, 2, 4, 4).permute(0, 5, 4, 1, 2, 6, 3, 7).reshape(n_wg * 64, dff)
+    assert int(bad[:M].sum()) == 0, "row_chain512 %s M=%d: relu_bits differ from H > 0 inside the valid rows" % (variant, M)
+    if drop:
+        _zero_pattern_equal(got["H"], ref["H"], "row_chain512 dropout1")
+        _zero_pattern_equal(got["out1"], ref["out1"], "row_chain512 dropout2")
+
+
 @pytest.mark.parametrize("case", ["train", "train+drop", "decode", "short-keys"])
 def test_attn_f1_fwd_equals_row_chain_plus_attn_fwd(case):
     """st_attn_f1_fwd (the decoder-encoder attention with its chain stage - output_linear + LayerNorm + q projection - in the
