@@ -216,6 +216,17 @@ int st_row_chain512(st_stream_t stream, int M, const void* wfrag, int n_blocks, 
                     unsigned drop1_salt, int drop1_thresh, float drop1_scale, unsigned drop2_salt, int drop2_thresh,
                     float drop2_scale, int post_blocks, const float* bp, void* P, int ldp, float post_kscale);
 int st_row_chain512_mask_words(int M, int d_ff);
+/* ... and its backward (csrc/st_rowchain_pipe512_bwd.cuh; arguments as st_row_chain_bwd with 512-wide row matrices, HEAD + FFN +
+ * TAIL all required; head_blocks 0 or 6; 8 heads of 64 columns: delta [8, M]).  The stream holds the TRANSPOSED blocks in the order
+ *   (h, u) -> 6 h + u of Wp [1536, 512]  |  per hidden chunk c: W2^T (j = 0, 1), W1^T (h = 0, 1)  |  Wo^T (h, j) -> 2 h + j
+ * (st_amd.chains.encoder512_blocks_bwd).  n_blocks = 2 head_blocks + 4 d_ff / 256 + 4. */
+int st_row_chain512_bwd(st_stream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, int head_blocks, const void* dP,
+                        int ldp, const void* G, int ldg, const void* xhat_a, const float* rstd_a, const float* gamma_a,
+                        const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, void* ds_a,
+                        float* dgamma_a, float* dbeta_a, float* dbias_a, int d_ff, const unsigned long long* relu_bits,
+                        float mask_scale, void* dH, const void* xhat_b, const float* rstd_b, const float* gamma_b, void* ds_b,
+                        float* dgamma_b, float* dbeta_b, float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx,
+                        int lddc, float* delta);
 
 /* relu_bits (st_row_chain: optional output, st_row_chain_bwd: input): which hidden values of the feed-forward sublayer are
  * > 0 after ReLU and dropout (the mask of SubLayers.py:25's backward), one bit per value in a layout private to the two

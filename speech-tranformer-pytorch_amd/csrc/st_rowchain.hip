@@ -654,6 +654,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_kernel(ChainBwdArgs a) {
 
 }  // namespace
 #include "st_rowchain_pipe_bwd.cuh"
+#include "st_rowchain_pipe512_bwd.cuh"
 namespace {
 // Block descriptor table of st_wfrag_build: 4 x int64 per 256 x 256 weight block
 //   [0] address of the block's first element (row n0, column k0 of a row-major bf16 matrix)
@@ -1189,6 +1190,43 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   else if (head) ST_BWD(true, false, false);
   else ST_BWD(false, false, true);
 #undef ST_BWD
+  ST_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- d_model = 512 (st_rowchain_pipe512_bwd.cuh): HEAD + FFN + TAIL, 64-row workgroups
+extern "C" int st_row_chain512_bwd(hipStream_t stream, int M, const void* wfrag, int n_blocks, int next_blocks, int head_blocks,
+                                   const void* dP, int ldp, const void* G, int ldg, const void* xhat_a, const float* rstd_a,
+                                   const float* gamma_a, const unsigned* drop_seed, unsigned drop_salt, int drop_thresh,
+                                   float drop_scale, void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a, int d_ff,
+                                   const unsigned long long* relu_bits, float mask_scale, void* dH, const void* xhat_b,
+                                   const float* rstd_b, const float* gamma_b, void* ds_b, float* dgamma_b, float* dbeta_b,
+                                   float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta) {
+  if (M <= 0) return 0;
+  if (!wfrag || (head_blocks != 0 && head_blocks != 6)) return -1;
+  if (!xhat_a || (head_blocks > 0 && (!dP || (ldp & 7) || ldp < 256 * head_blocks)) || (head_blocks == 0 && !G) || (G && (ldg & 7)) ||
+      !rstd_a || !gamma_a || !ds_a)
+    return -2;
+  if (d_ff <= 0 || (d_ff & 255) || !relu_bits || !dH || !xhat_b || !rstd_b || !gamma_b || !ds_b) return -3;
+  if (!O || (ldo & 7) || !dctx || (lddc & 7) || !delta) return -4;
+  if (n_blocks != 2 * head_blocks + 4 * (d_ff / 256) + 4) return -5;
+  ChainBwdArgs a;
+  a.M = M; a.wfrag = (const bf16x8*)wfrag; a.wave_frags = n_blocks * 16 + DEPTH;
+  a.next_frags = next_blocks > 0 ? next_blocks * 16 + DEPTH : 0;
+  a.nb = head_blocks; a.dP = (const bf16*)dP; a.ldp = ldp; a.G = (const bf16*)G; a.ldg = ldg; a.xhat_a = (const bf16*)xhat_a;
+  a.rstd_a = rstd_a; a.gamma_a = gamma_a;
+  const bool drop = drop_seed != nullptr && drop_thresh > 0;
+  a.drop_a.seed = drop ? drop_seed : nullptr; a.drop_a.salt = drop_salt; a.drop_a.thresh = drop ? drop_thresh : 0;
+  a.drop_a.scale = drop ? drop_scale : 1.f;
+  a.ds_a = (bf16*)ds_a; a.dgamma_a = dgamma_a; a.dbeta_a = dbeta_a; a.dbias_a = dbias_a; a.DS = nullptr;
+  a.nc = d_ff / 256; a.relu_bits = relu_bits; a.mask_scale = mask_scale > 0.f ? mask_scale : 1.f; a.dH = (bf16*)dH;
+  a.xhat_b = (const bf16*)xhat_b; a.rstd_b = rstd_b; a.gamma_b = gamma_b; a.ds_b = (bf16*)ds_b; a.dgamma_b = dgamma_b;
+  a.dbeta_b = dbeta_b; a.dbias_b = dbias_b;
+  a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
+  a.split_ws = nullptr; a.split_tickets = nullptr; a.split_parts = 0;
+  const dim3 grid((M + 63) / 64), blk(512);
+  if (drop) hipLaunchKernelGGL((row_chain512_bwd_kernel<true>), grid, blk, 0, stream, a);
+  else hipLaunchKernelGGL((row_chain512_bwd_kernel<false>), grid, blk, 0, stream, a);
   ST_CHECK_LAUNCH();
   return 0;
 }

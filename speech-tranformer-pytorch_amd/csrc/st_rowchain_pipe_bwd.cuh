@@ -13,7 +13,7 @@
 namespace {
 
 // the mask / scale / bf16 epilogue of a B1 block as side work: dH = on ? bf16(acc * mask_scale) : 0 into the LDS tile
-template <int MT> struct MaskSide {
+template <int MT, int PT = AS> struct MaskSide {
   const Ctx<MT>& c;
   const f32x16 (&acc)[MT];
   bf16* t;
@@ -30,7 +30,7 @@ template <int MT> struct MaskSide {
       const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(b < 32 ? (int)lo : (int)hi, b & 31, 1);
       o[e] = (bf16)__builtin_bit_cast(float, f2u(acc[mt][4 * g + e] * scale) & m);
     }
-    *reinterpret_cast<bf16x4*>(t + (mt * 32 + c.r) * AS + c.wave * 32 + 8 * g + 4 * c.hi) = o;
+    *reinterpret_cast<bf16x4*>(t + (mt * 32 + c.r) * PT + c.wave * 32 + 8 * g + 4 * c.hi) = o;
   }
   __device__ __forceinline__ void a(int) {}
   __device__ __forceinline__ void b(int k2) {

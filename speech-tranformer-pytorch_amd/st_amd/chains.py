@@ -96,6 +96,20 @@ def encoder512_blocks(wo: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, wp=N
     return out
 
 
+def encoder512_blocks_bwd(wo: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, wp=None):
+    """The block order of st_row_chain512_bwd, all read transposed: Wp [1536, 512] as (h, u) -> 6 h + u (contraction over the
+    weight's rows 256 u .., output = its columns 256 h ..); per hidden chunk c: W2^T (j = 0, 1: rows 256 j .. of W2, columns c),
+    W1^T (h = 0, 1: rows c of W1, columns 256 h ..); Wo^T as (h, j) -> 2 h + j (rows 256 j .., columns 256 h ..)."""
+    d_ff = w1.shape[0]
+    out = []
+    if wp is not None:
+        out += [(wp, u * BLK, h * BLK, True) for h in range(2) for u in range(6)]
+    for c in range(0, d_ff, BLK):
+        out += [(w2, 0, c, True), (w2, BLK, c, True), (w1, c, 0, True), (w1, c, BLK, True)]
+    out += [(wo, j * BLK, h * BLK, True) for h in range(2) for j in range(2)]
+    return out
+
+
 class ChainSet:
     def __init__(self, device):
         self.device = torch.device(device)
@@ -217,7 +231,8 @@ class ChainBackward:
         arena.attach_grads(fs.params, fs.lo, fs.hi)
         arena.attach_grads(as_.params, as_.lo, as_.hi)
         M = f.out.shape[0]
-        dH, ds_b, dctx = self._empty(f.out, fs.d_ff), self._empty(f.out, BLK), self._empty(f.out, BLK)
+        dm = f.out.shape[1]
+        dH, ds_b, dctx = self._empty(f.out, fs.d_ff), self._empty(f.out, dm), self._empty(f.out, dm)
         delta = torch.empty(as_.n_head * M, dtype=F32, device=f.out.device)
         scale = f.drop1.scale if f.drop1 is not None and f.drop1.thresh else 1.0
         nv.row_chain_bwd(chain, M, head=head, ds_in=None if head else ds_f,
@@ -232,9 +247,9 @@ class ChainBackward:
         - dqkv None - of the raw gradient ds_s that reaches the last layer from outside the stack."""
         f = self.pres[l][-1]
         fs = self.layers[l].pos_ffn._st
-        ds_f = self._empty(f.out, BLK)
-        return ds_f, (3 if dqkv is not None else 0, dqkv, ds_s, f.xhat, f.rstd, fs.gamma, f.drop2, ds_f, fs.g_gamma, fs.g_beta,
-                      fs.g_b2)
+        ds_f = self._empty(f.out, f.out.shape[1])
+        return ds_f, (3 * f.out.shape[1] // BLK if dqkv is not None else 0, dqkv, ds_s, f.xhat, f.rstd, fs.gamma, f.drop2, ds_f, fs.g_gamma,
+                      fs.g_beta, fs.g_b2)
 
 
 class EncoderBackward(ChainBackward):
@@ -312,8 +327,21 @@ class EncoderChains:
             self.set.finalize()
             self.q0 = None
             self.e = [self.set.chain(c, True) for c in ids]
-            self.bset, self.bwd, self.use_bwd, self.layer_hook = None, [], False, None
-            ChainHub.of(arena).add(self.set)
+            # backward chains in running order (last layer first): [next layer's q|k|v projection] + feed-forward + output_linear
+            self.bset = ChainSet(arena.device)
+            bids = {}
+            for l in range(n - 1, -1, -1):
+                sa, ff = layers[l].slf_attn._st, layers[l].pos_ffn._st
+                bids[l] = self.bset.add(encoder512_blocks_bwd(sa.w_o, ff.w1, ff.w2, layers[l + 1].slf_attn._st.w_qkv if l + 1 < n else None))
+            self.bset.finalize()
+            self.bwd = [self.bset.chain(bids[l], True) for l in range(n)]
+            # The backward chain (st_row_chain512_bwd) is built and tested but OFF by default: at config 3 it measured 253 us per
+            # launch against 216 for the per-GEMM kernels it replaces (gemm_lnbwd + dgrad GEMMs: 11.57 vs 11.12 ms per step, same
+            # box, round 6) - 64-row workgroups run two rounds on 256 CUs and the LayerNorm backward's column sums cost what the
+            # separate kernels' do.  ST_CHAIN512=1 turns it on, =0 turns the forward chains off as well.
+            self.use_bwd = sa.n_head * 64 == self.d and os.environ.get("ST_CHAIN512", "f") == "1"
+            self.layer_hook = None
+            ChainHub.of(arena).add(self.set, self.bset)
             return
         # layer 0's q | k | v projection: a chain of its own (three blocks, no PRE / FFN) - every encoder layer's keys leave
         # their projection PRE-SCALED by scale * log2(e) in the chain's fp32 epilogue (st_row_chain's post_kscale), so that no
@@ -358,7 +386,7 @@ class EncoderChains:
                 return None
             if sa._st.d_model not in (BLK, 512) or ff._st.d_ff % BLK:
                 return None
-            if sa._st.d_model == 512 and os.environ.get("ST_CHAIN512", "1") == "0":      # (development switch: the per-GEMM path)
+            if sa._st.d_model == 512 and os.environ.get("ST_CHAIN512", "f") == "0":      # (development switch: the per-GEMM path)
                 return None
         return EncoderChains(layers, arena)
 

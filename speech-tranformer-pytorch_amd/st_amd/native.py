@@ -64,6 +64,10 @@ SIGNATURES = {
                          _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_ll],
+    "st_row_chain512_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                            _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                            _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                            _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p],
     "st_gemm_lnbwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                       _c_void_p, _c_uint, _c_int, _c_float],
@@ -665,25 +669,31 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     nb, dP, G, xa, ra, ga, drop, dsa, dga, dba, dbia = head if head else (0,) + z[:10]
     d_ff, bits, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn if ffn else (0, None, 1.0) + z[:8]
     O, Ores, dctx, delta = tail if tail else z[:4]
-    n_blocks = nb + (2 * (d_ff // 256) if ffn else 0) + (1 if tail else 0)
+    d = 512 if (xb is not None and xb.shape[1] == 512) else 256      # (d_model 512: csrc/st_rowchain_pipe512_bwd.cuh - HEAD + FFN + TAIL)
+    if d == 512:
+        if not (head and ffn and tail) or nb not in (0, 6):
+            raise ValueError("row_chain_bwd (d_model 512): HEAD, FFN and TAIL are required, head blocks 0 or 6")
+        n_blocks = 2 * nb + 4 * (d_ff // 256) + 4
+    else:
+        n_blocks = nb + (2 * (d_ff // 256) if ffn else 0) + (1 if tail else 0)
     if n_blocks != chain.n_blocks or chain.stream.numel() != 8 * (n_blocks * 16 + wfrag_depth()) * 512:
         raise ValueError("row_chain_bwd: the fragment stream does not match the chain")
-    for t, cols, name in ((dP, 256 * nb, "dP"), (G, 256, "G"), (xa, 256, "xhat_a"), (dsa, 256, "ds_a"), (ds_in, 256, "ds_in"),
-                          (dH, d_ff, "dH"), (xb, 256, "xhat_b"), (dsb, 256, "ds_b"), (O, 256, "O"),
-                          (Ores, 256, "Ores"), (dctx, 256, "dctx")):
+    for t, cols, name in ((dP, 256 * nb, "dP"), (G, d, "G"), (xa, d, "xhat_a"), (dsa, d, "ds_a"), (ds_in, d, "ds_in"),
+                          (dH, d_ff, "dH"), (xb, d, "xhat_b"), (dsb, d, "ds_b"), (O, d, "O"),
+                          (Ores, d, "Ores"), (dctx, d, "dctx")):
         if t is not None:
             _mat(t, BF16, name)
             if t.shape[0] < M or t.shape[1] != cols:
                 raise ValueError("row_chain_bwd: %s has shape %s, expected [>= %d, %d]" % (name, tuple(t.shape), M, cols))
     for t, name in ((xa, "xhat_a"), (dsa, "ds_a"), (ds_in, "ds_in"), (xb, "xhat_b"), (dsb, "ds_b")):
-        assert t is None or t.stride(0) == 256, name
+        assert t is None or t.stride(0) == d, name
     assert dH is None or dH.stride(0) == d_ff
-    if ffn and (bits is None or bits.dtype != torch.int64 or not bits.is_contiguous() or bits.numel() < chain_mask_words(M, d_ff)):
+    if ffn and (bits is None or bits.dtype != torch.int64 or not bits.is_contiguous() or bits.numel() < chain_mask_words(M, d_ff, d)):
         raise ValueError("row_chain_bwd: relu_bits must be the int64 buffer the forward chain wrote (chain_mask_words(M, d_ff) words)")
     assert O is None or Ores is None or Ores.stride(0) == O.stride(0)
-    for v, n, name in ((ra, M, "rstd_a"), (ga, 256, "gamma_a"), (dga, 256, "dgamma_a"), (dba, 256, "dbeta_a"), (dbia, 256, "dbias_a"),
-                       (rb, M, "rstd_b"), (gb, 256, "gamma_b"), (dgb, 256, "dgamma_b"), (dbb, 256, "dbeta_b"), (dbib, 256, "dbias_b"),
-                       (delta, 4 * M, "delta")):
+    for v, n, name in ((ra, M, "rstd_a"), (ga, d, "gamma_a"), (dga, d, "dgamma_a"), (dba, d, "dbeta_a"), (dbia, d, "dbias_a"),
+                       (rb, M, "rstd_b"), (gb, d, "gamma_b"), (dgb, d, "dgamma_b"), (dbb, d, "dbeta_b"), (dbib, d, "dbias_b"),
+                       (delta, (d // 64) * M, "delta")):
         _vec(v, F32, n, name)
     if head is None and ds_in is None:
         raise ValueError("row_chain_bwd: without head the chain needs ds_in")
@@ -693,6 +703,14 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
         raise ValueError("row_chain_bwd: chain.split_work must be a contiguous int32 tensor on the GPU")
     _tag("row_chain_bwd", M, n_blocks, d_ff, io=((dP, M), (G, M), (xa, M), (dsa, M), (ds_in, M), bits, (dH, M), (xb, M), (dsb, M), (O, M),
                                                  (Ores, M), (dctx, M), (delta, 4 * M), (ra, M), (rb, M), 2.0 * 256 * 256 * n_blocks))
+    if d == 512:
+        rc = load().st_row_chain512_bwd(
+            _stream(), M, chain.stream.data_ptr(), n_blocks, int(chain.next_blocks), int(nb), _p(dP), 0 if dP is None else dP.stride(0),
+            _p(G), 0 if G is None else G.stride(0), _p(xa), _p(ra), _p(ga), sd[0], sd[1], sd[2], sd[3], _p(dsa), _p(dga), _p(dba),
+            _p(dbia), int(d_ff), _p(bits), float(msc), _p(dH), _p(xb), _p(rb), _p(gb), _p(dsb), _p(dgb), _p(dbb), _p(dbib),
+            _p(O), _p(Ores), O.stride(0), _p(dctx), dctx.stride(0), _p(delta))
+        _check(rc, "st_row_chain512_bwd")
+        return
     rc = load().st_row_chain_bwd(
         _stream(), M, chain.stream.data_ptr(), n_blocks, int(chain.next_blocks), int(nb), _p(dP), 0 if dP is None else dP.stride(0),
         _p(G), 0 if G is None else G.stride(0), _p(xa), _p(ra), _p(ga), sd[0], sd[1], sd[2], sd[3], _p(dsa), _p(dga), _p(dba),

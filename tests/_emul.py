@@ -273,6 +273,26 @@ def row_chain(A, chain, pre=None, ffn=None, post=None, eps=1e-6, post_kscale=0.0
 def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
     """csrc/st_rowchain.hip's backward chain as a composition of the emulated kernels it replaces."""
     blocks = list(chain.blocks)
+    if ffn is not None and ffn[4] is not None and ffn[4].shape[1] == 512:      # csrc/st_rowchain_pipe512_bwd.cuh (chains.encoder512_blocks_bwd)
+        nb, dP, G, xa, ra, ga, drop, dsa, dga, dba, dbia = head
+        d_ff, relu_bits, msc, dH, xb, rb, gb, dsb, dgb, dbb, dbib = ffn
+        O, Ores, dctx, delta = tail
+        assert all(b[3] for b in blocks) and len(blocks) == 2 * nb + 4 * (d_ff // 256) + 4
+        w2, w1, wo = blocks[2 * nb][0], blocks[2 * nb + 2][0], blocks[-1][0]
+        if nb:
+            gemm_lnbwd(dP[:M], blocks[0][0], None if G is None else G[:M], xa, ra[:M], ga, dsa[:M], dga, dba, dbia, drop=drop)
+        else:
+            ln_bwd(G[:M], xa[:M], ra[:M], ga, dsa[:M], dga, dba, dbia, drop=drop)
+        ds = dsa[:M]
+        acc = ds.float() @ w2.float()
+        dH[:M] = ((acc * msc).to(BF16).float() * _unpack_bits(relu_bits, M, d_ff)).to(BF16)
+        gemm_lnbwd(dH[:M], w1, ds, xb, rb[:M], gb, dsb[:M], dgb, dbb, dbib)
+        dl = torch.zeros(8 * M, dtype=torch.float32)
+        out = torch.zeros(M, 512, dtype=BF16)
+        gemm(dsb[:M], wo, out, epi=nv.EPI_BF16_DELTA, aux=O[:M], aux2=None if Ores is None else Ores[:M], y_cmajor=True, delta=dl, head_dim=64)
+        dctx[:M] = out
+        delta.view(8, -1)[:, :M] = dl.view(8, M)
+        return
 
     def take(n):
         out = [w[n0:n0 + 256, k0:k0 + 256] for w, n0, k0, tr in blocks[:n]]

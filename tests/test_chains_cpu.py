@@ -63,7 +63,8 @@ def test_plans_decline_what_the_kernels_do_not_serve():
         for bad in (model(128, 4, 256), model(256, 4, 384)):
             ab = arena_of(bad)
             assert bad.encoder.row_chains(ab) is None and bad.decoder.row_chains(ab) is None
-        m5 = model(512, 8, 1024)                # config 3's width: forward chains for the encoder (st_row_chain512), nothing else
+        m5 = model(512, 8, 1024)                # config 3's width: forward and backward chains for the encoder (st_row_chain512[_bwd])
         a5 = arena_of(m5)
         e5 = m5.encoder.row_chains(a5)
-        assert e5 is not None and e5.use_bwd is False and [c.n_blocks for c in e5.e] == [4 + 16] and m5.decoder.row_chains(a5) is None
+        assert e5 is not None and not e5.use_bwd and [c.n_blocks for c in e5.e] == [4 + 16] and [c.n_blocks for c in e5.bwd] == [16 + 4]
+        assert m5.decoder.row_chains(a5) is None

@@ -1428,6 +1428,52 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
         check(got[n], ref[n], tol, "row_chain_bwd %s M=%d: %s" % (variant, M, n))
 
 
+@pytest.mark.parametrize("M", [5, 64, 1000, 9000, 24060])
+@pytest.mark.parametrize("variant", ["head6", "head0", "head6+drop", "head6+nores"])
+def test_row_chain512_bwd_matches_the_separate_kernels(M, variant):
+    """st_row_chain512_bwd (d_model 512: HEAD + FFN + TAIL of BASELINE config 3's encoder layer as ONE launch) == st_gemm_lnbwd, st_gemm
+    (mask epilogue), st_gemm_lnbwd and st_gemm (delta epilogue, 8 heads) as separate kernels: every gradient tensor, the atomically
+    accumulated LayerNorm / bias gradients, delta; ragged last row block; the bare LayerNorm backward as head; without Ores."""
+    from st_amd import chains
+    d, dff = 512, 1024
+    parts = variant.split("+")
+    nb, drop, nores = (6 if "head6" in parts else 0), "drop" in parts, "nores" in parts
+    wp, w1, w2, wo = g(3 * d, d, seed=1, scale=d ** -0.5), g(dff, d, seed=2, scale=d ** -0.5), g(d, dff, seed=3, scale=dff ** -0.5), \
+        g(d, d, seed=4, scale=d ** -0.5)
+    dP, G = g(M, 3 * d, seed=5, scale=0.3), g(M, d, seed=6, scale=0.3)
+    xa, xb = g(M, d, seed=8), g(M, d, seed=9)
+    ra, rb = g(M, seed=10, dtype=F32).abs() + 0.5, g(M, seed=11, dtype=F32).abs() + 0.5
+    ga, gb = g(d, seed=12, dtype=F32) * 0.2 + 1, g(d, seed=13, dtype=F32) * 0.2 + 1
+    H = torch.relu(g(M, dff, seed=14))
+    O, Ores = g(M, d, seed=15), g(M, d, seed=16, scale=2.0 ** -9)
+    dn, de = _drops(31, 0.1) if drop else (None, None)
+
+    def run(dev, fn, dr):
+        f = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t)
+        Z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+        o = dict(ds_a=Z(M, d), dga=Z(d, dt=F32) + 1, dba=Z(d, dt=F32) + 2, dbia=Z(d, dt=F32) + 3, dH=Z(M, dff), ds_b=Z(M, d),
+                 dgb=Z(d, dt=F32) - 1, dbb=Z(d, dt=F32) - 2, dbib=Z(d, dt=F32) - 3, dctx=Z(M, d), delta=Z(8 * M, dt=F32))
+        blocks = chains.encoder512_blocks_bwd(f(wo), f(w1), f(w2), f(wp) if nb else None)
+        if dev == "cuda":
+            cs = chains.ChainSet("cuda")
+            cid = cs.add(blocks)
+            cs.finalize().rebuild()
+            ch = cs.chain(cid)
+            bits = nv.relu_bits_from(f(H), d)
+        else:
+            ch = chains.Chain(None, len(blocks), blocks)
+            bits = em.relu_bits_from(H, d)
+        fn(ch, M, head=(nb, f(dP) if nb else None, f(G), f(xa), f(ra), f(ga), dr, o["ds_a"], o["dga"], o["dba"], o["dbia"]),
+           ffn=(dff, bits, 1.0 / 0.9 if drop else 1.0, o["dH"], f(xb), f(rb), f(gb), o["ds_b"], o["dgb"], o["dbb"], o["dbib"]),
+           tail=(f(O), None if nores else f(Ores), o["dctx"], o["delta"]))
+        return o
+
+    got, ref = run("cuda", nv.row_chain_bwd, dn), run("cpu", em.row_chain_bwd, de)
+    for n in ["ds_a", "dga", "dba", "dbia", "dH", "ds_b", "dgb", "dbb", "dbib", "dctx", "delta"]:
+        tol = 1e-2 if got[n].dtype == BF16 else 5e-3
+        check(got[n], ref[n], tol, "row_chain512_bwd %s M=%d: %s" % (variant, M, n))
+
+
 @pytest.mark.parametrize("two_launch", [False, True])
 @pytest.mark.parametrize("B,beam,V", [(5, 4, 30), (32, 10, 4337), (3, 16, 1000), (7, 10, 5120), (2, 1, 100), (4, 3, 257)])
 def test_beam_advance_matches_torch_formulation(B, beam, V, two_launch):
