@@ -31,9 +31,9 @@ extern "C" {
 typedef void* st_stream_t; /* hipStream_t */
 
 /* Library ABI version, bumped on any signature change (2: round 5's k_prescaled / dense attention / grad_scale arguments;
- * 3: round 6).  A host binding must refuse a library whose st_version() differs from the header it was written against:
+ * 3, 4: round 6 - 4 added the column-sum workspace of st_row_chain_bwd).  A host binding must refuse a library whose st_version() differs from the header it was written against:
  * through ctypes / dlsym a stale libst_hip.so would be called with shifted arguments (st_amd/native.py: ABI_VERSION). */
-#define ST_ABI_VERSION 3
+#define ST_ABI_VERSION 4
 int st_version(void);
 
 /* Re-read the development switches that choose between a specialised attention kernel and the general one
@@ -251,7 +251,14 @@ int st_row_chain_bwd(st_stream_t stream, int M, const void* wfrag, int n_blocks,
                      void* ds_a, float* dgamma_a, float* dbeta_a, float* dbias_a, const void* DS, int d_ff,
                      const unsigned long long* relu_bits, float mask_scale, void* dH, const void* xhat_b, const float* rstd_b, const float* gamma_b, void* ds_b,
                      float* dgamma_b, float* dbeta_b, float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx,
-                     int lddc, float* delta, void* split_work, long long split_bytes);
+                     int lddc, float* delta, void* split_work, long long split_bytes, float* colsum_ws, long long colsum_bytes);
+/* colsum_ws (optional; ABI 4): encoder-sized launches (HEAD + FFN + TAIL at M > 8192: st_row_chain_bwd_colsum_rows(..) > 0 workgroups) write
+ * their six column sums per workgroup - [rows][dgamma_a, dbeta_a, dbias_a, dgamma_b, dbeta_b, dbias_b][256] floats, every float of
+ * it - instead of adding them atomically (251 workgroups adding to the same 768 floats queue for ~4 us per LayerNorm: 66 -> 58 us per
+ * launch at 24,060 rows); the d* pointers are then left alone and st_colsum_fold adds the rows to them: any time before the
+ * gradients are read, several workspaces per launch.  Other launches ignore colsum_ws and add atomically. */
+int st_row_chain_bwd_colsum_rows(int M, int has_head, int d_ff, int has_tail);
+int st_colsum_fold(st_stream_t stream, int n, const float* const* ws, const int* rows, float* const* dst /* 6 n, NULL = skip */);
 
 /* LayerNorm backward: dx, and atomically accumulated dgamma / dbeta / dbias
  * (dbias = column sum of dx = bias gradient of the Linear feeding the LN).

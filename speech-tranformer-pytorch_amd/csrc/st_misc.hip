@@ -1526,4 +1526,4 @@ extern "C" int st_clock_probe(hipStream_t stream, long long* out, int n_wg, int 
   return 0;
 }
 
-extern "C" int st_version(void) { return 3; }      // == ST_ABI_VERSION (include/st_hip.h) == native.ABI_VERSION
+extern "C" int st_version(void) { return 4; }      // == ST_ABI_VERSION (include/st_hip.h) == native.ABI_VERSION

@@ -377,6 +377,8 @@ struct ChainBwdArgs {
   const bf16* O; const bf16* Ores; int ldo; bf16* dctx; int lddc; float* delta;
   // split feed-forward (row_chain_bwd_split_kernel): as ChainArgs
   float* split_ws; unsigned* split_tickets; int split_parts;
+  // pipelined kernel (st_rowchain_pipe_bwd.cuh): [workgroups][a: dgamma, dbeta, dbias | b: ..][256] column sums instead of atomics
+  float* colsum_ws;
 };
 
 // LayerNorm backward over the 256 columns held by the 8 waves.  acc = the GEMM result; t_aux holds the addend and receives
@@ -1106,7 +1108,7 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
                                 const void* xhat_b,
                                 const float* rstd_b, const float* gamma_b, void* ds_b, float* dgamma_b, float* dbeta_b,
                                 float* dbias_b, const void* O, const void* Ores, int ldo, void* dctx, int lddc, float* delta,
-                                void* split_work, long long split_bytes) {
+                                void* split_work, long long split_bytes, float* colsum_ws, long long colsum_bytes) {
   if (M <= 0) return 0;
   // HEAD is present iff xhat_a is given; with head_blocks == 0 it is the bare LayerNorm backward of G (the gradient that
   // reaches the LAST sublayer of a stack from outside)
@@ -1135,7 +1137,7 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   a.O = (const bf16*)O; a.Ores = (const bf16*)Ores; a.ldo = ldo; a.dctx = (bf16*)dctx; a.lddc = lddc; a.delta = delta;
   const int mt = row_tiles(M);
   const dim3 grid((M + 32 * mt - 1) / (32 * mt)), blk(512);
-  a.split_ws = nullptr; a.split_tickets = nullptr; a.split_parts = 0;
+  a.split_ws = nullptr; a.split_tickets = nullptr; a.split_parts = 0; a.colsum_ws = nullptr;
   const int sp = split_parts_for((int)grid.x, a.nc);
   if (split_work && ffn && mt == 1 && sp >= 2) {      // see st_row_chain
     const size_t words = (size_t)grid.x * sp * 512 * 16;
@@ -1159,6 +1161,10 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
   }
   static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();      // development switch
   if (pipe_on && mt >= 2 && head && ffn && tail) {      // the encoder's shape: st_rowchain_pipe_bwd.cuh
+    if (colsum_ws) {
+      if (colsum_bytes < (long long)grid.x * 1536 * 4) return -6;
+      a.colsum_ws = colsum_ws;
+    }
     if (mt == 3) {
       if (drop) hipLaunchKernelGGL((row_chain_bwd_pipe_kernel<true, 3>), grid, blk, 0, stream, a);
       else hipLaunchKernelGGL((row_chain_bwd_pipe_kernel<false, 3>), grid, blk, 0, stream, a);
@@ -1228,5 +1234,68 @@ extern "C" int st_row_chain512_bwd(hipStream_t stream, int M, const void* wfrag,
   if (drop) hipLaunchKernelGGL((row_chain512_bwd_kernel<true>), grid, blk, 0, stream, a);
   else hipLaunchKernelGGL((row_chain512_bwd_kernel<false>), grid, blk, 0, stream, a);
   ST_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- column sums of the pipelined backward chain: workspace rows -> gradients
+// st_row_chain_bwd_colsum_rows: workgroups (= workspace rows of 6 x 256 floats) of the launch st_row_chain_bwd would make for this
+// shape if it takes a column-sum workspace, 0 if that launch adds its column sums atomically (decoder-sized M, chains without
+// HEAD / FFN / TAIL).
+extern "C" int st_row_chain_bwd_colsum_rows(int M, int has_head, int d_ff, int has_tail) {
+  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();
+  static const bool ws_on = [] { const char* e = getenv("ST_COLSUM_WS"); return !(e && e[0] == '0'); }();      // development switch
+  if (M <= 0 || !pipe_on || !ws_on || !has_head || d_ff <= 0 || !has_tail) return 0;
+  const int mt = row_tiles(M);
+  return mt >= 2 ? (M + 32 * mt - 1) / (32 * mt) : 0;
+}
+
+namespace {
+constexpr int FOLD_MAX = 16;
+struct FoldItem { const float* ws; int rows; float* dst[6]; };
+struct FoldArgs { int n; FoldItem it[FOLD_MAX]; };
+// block = (item, vector v, 32-column eighth): 8 row groups x 32 columns, dst[v][col] += sum over the workspace rows
+__global__ __launch_bounds__(256) void colsum_fold_kernel(FoldArgs g) {
+  __shared__ float part[7][32];
+  const int b = blockIdx.x, i = b / 48, v = (b % 48) >> 3, q = b & 7;
+  const FoldItem& it = g.it[i];
+  float* dst = it.dst[v];
+  if (dst == nullptr) return;
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const float* p = it.ws + (size_t)v * 256 + q * 32 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // (fixed order: the result does not depend on the launch)
+  int w = rg;
+  for (; w + 24 < it.rows; w += 32) {
+    s0 += p[(size_t)w * 1536]; s1 += p[(size_t)(w + 8) * 1536]; s2 += p[(size_t)(w + 16) * 1536]; s3 += p[(size_t)(w + 24) * 1536];
+  }
+  for (; w < it.rows; w += 8) s0 += p[(size_t)w * 1536];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (rg) part[rg - 1][c] = s;
+  __syncthreads();
+  if (rg == 0) {
+    float t = s;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) t += part[k][c];
+    atomicAdd(dst + q * 32 + c, t);
+  }
+}
+}  // namespace
+
+// dst[i][v][0..255] += sum over the `rows[i]` workspace rows of ws[i] ([rows][6][256] floats, written by st_row_chain_bwd), for n
+// workspaces; dst: 6 n pointers (dgamma_a, dbeta_a, dbias_a, dgamma_b, dbeta_b, dbias_b per workspace; NULL entries are skipped).
+// Deterministic (fixed summation order; one atomic per destination float, which nothing else writes at that time).
+extern "C" int st_colsum_fold(hipStream_t stream, int n, const float* const* ws, const int* rows, float* const* dst) {
+  for (int base = 0; base < n; base += FOLD_MAX) {
+    FoldArgs g;
+    g.n = 0;
+    for (int i = base; i < n && i < base + FOLD_MAX; ++i) {
+      if (ws[i] == nullptr || rows[i] <= 0) continue;
+      FoldItem& it = g.it[g.n++];
+      it.ws = ws[i]; it.rows = rows[i];
+      for (int v = 0; v < 6; ++v) it.dst[v] = dst[6 * i + v];
+    }
+    if (g.n == 0) continue;
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(g.n * 48), dim3(256), 0, stream, g);
+    ST_CHECK_LAUNCH();
+  }
   return 0;
 }

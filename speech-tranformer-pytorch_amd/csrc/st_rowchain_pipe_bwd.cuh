@@ -44,12 +44,11 @@ template <int MT, int PT = AS> struct MaskSide {
 };
 
 // LayerNorm backward as epi_lnbwd (st_rowchain.hip), gamma and the rows' rstd handed in as registers; dx is left in t_dx (the
-// caller copies it out beside its next block).  One barrier for the row sums, one before the column pass (which uses red2 as
-// its exchange buffer: one more barrier inside); the caller needs one more before t_aux / t_xhat are rewritten.
+// caller copies it out beside its next block).  One barrier for the row sums, one behind the dx stores; the column sums are
+// ColSide's (t_aux - now dy -, t_xhat and t_dx stay as they are until it has run).
 template <bool DROP, int MT>
 __device__ __forceinline__ void epi_lnbwd_p(const Ctx<MT>& c, f32x16 (&acc)[MT], bf16* t_aux, const bf16* t_xhat, bf16* t_dx,
-                                            const float (&rs)[MT], const BiasRegs& gamma, const Drop& d, float* red2, float* dgamma,
-                                            float* dbeta, float* dbias) {
+                                            const float (&rs)[MT], const BiasRegs& gamma, const Drop& d, float* red2, int trb = 0) {
   const int j0 = c.wave * 32;
   bf16x4 xh[MT][4], ad[MT][4];
 #pragma unroll
@@ -94,6 +93,7 @@ __device__ __forceinline__ void epi_lnbwd_p(const Ctx<MT>& c, f32x16 (&acc)[MT],
   for (int mt = 0; mt < MT; ++mt)
     *reinterpret_cast<f32x2*>(red2 + (mt * 32 + c.r) * RED2_PITCH + 2 * c.wave) = f32x2{s1[mt], s2[mt]};
   __syncthreads();
+  TRP(trb);
   f32x4 pp[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -118,29 +118,88 @@ __device__ __forceinline__ void epi_lnbwd_p(const Ctx<MT>& c, f32x16 (&acc)[MT],
     }
   }
   __syncthreads();
-  // column sums: thread = (column, half of the rows), the upper half hands its sums over through LDS: ONE atomic per column,
-  // quantity and workgroup (see epi_lnbwd)
-  {
-    const int col = c.tid & 255, half = c.tid >> 8, rows = 16 * MT;
-    float cg = 0.f, cb = 0.f, cx = 0.f;
-    for (int i = 0; i < rows; ++i) {
-      const int row = half * rows + i;
-      float v = (float)t_aux[row * AS + col];
+  TRP(trb + 1);
+}
+
+// The three column sums of a LayerNorm backward (dgamma = sum dy xhat, dbeta = sum dy, dbias = sum dx over the workgroup's rows) as
+// SIDE WORK of the block behind it (round 6: exposed, the pass and its atomics were 4.1 + 2.8 us of a 62 us workgroup).  Thread =
+// (column pair, quarter of the rows): 4-byte LDS reads, packed fp32 adds; the two lane halves of a wave hold two quarters and are
+// folded with one v_permlane32_swap per value, the two wave halves of the workgroup through `xch` (768 floats): ONE atomic per
+// column, quantity and workgroup, as before.  The tiles must stay untouched until finish_a(); finish_b() needs a barrier in front.
+template <bool DROP, int MT> struct ColSide {
+  const Ctx<MT>& c;
+  const bf16* t_aux; const bf16* t_xhat; const bf16* t_dx;
+  const Drop& d;
+  f32x2 cg = {0.f, 0.f}, cb = {0.f, 0.f}, cx = {0.f, 0.f};
+  static constexpr int RQ = 8 * MT;        // rows per quarter; MT of them per group
+  __device__ __forceinline__ int cp() const { return (c.wave & 3) * 32 + c.r; }
+  __device__ __forceinline__ static f32x2 unpack(uint32_t w) {
+    return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+  }
+  __device__ __forceinline__ void a(int) {}
+  __device__ __forceinline__ void b(int k2) {
+    const int q = (c.wave >> 2) * 2 + c.hi, col = 2 * cp();
+    uint32_t wa[MT], wx[MT], wd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int at = (q * RQ + k2 * MT + i) * AS + col;
+      wa[i] = *reinterpret_cast<const uint32_t*>(t_aux + at);
+      wx[i] = *reinterpret_cast<const uint32_t*>(t_xhat + at);
+      wd[i] = *reinterpret_cast<const uint32_t*>(t_dx + at);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      f32x2 v = unpack(wa[i]);
       if (DROP && d.on()) {
-        const uint32_t bits = d.bits(drop_counter_rc(c.row0 + row, col & ~3, DM));
-        v = d.keep(bits, col & 3) ? v * d.scale : 0.f;
+        const uint32_t bits = d.bits(drop_counter_rc(c.row0 + q * RQ + k2 * MT + i, col & ~3, DM));
+        v[0] = d.keep(bits, col & 3) ? v[0] * d.scale : 0.f;
+        v[1] = d.keep(bits, (col & 3) + 1) ? v[1] * d.scale : 0.f;
       }
       cb += v;
-      cg += v * (float)t_xhat[row * AS + col];
-      cx += (float)t_dx[row * AS + col];
+      cg = __builtin_elementwise_fma(v, unpack(wx[i]), cg);
+      cx += unpack(wd[i]);
     }
-    float* xch = red2;          // MT * 32 * RED2_PITCH >= 768 floats (the row sums were consumed before the barrier above)
-    if (half) { xch[col] = cg; xch[256 + col] = cb; xch[512 + col] = cx; }
-    __syncthreads();
-    if (!half) {
-      if (dgamma) atomicAdd(dgamma + col, cg + xch[col]);
-      if (dbeta) atomicAdd(dbeta + col, cb + xch[256 + col]);
-      if (dbias) atomicAdd(dbias + col, cx + xch[512 + col]);
+  }
+  // behind the block: fold the lane halves; the upper four waves hand their sums over
+  __device__ __forceinline__ void finish_a(float* xch) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { cg[e] = wave_sum32(cg[e]); cb[e] = wave_sum32(cb[e]); cx[e] = wave_sum32(cx[e]); }
+    if (c.wave >= 4 && c.hi == 0) {
+      const int col = 2 * cp();
+      *reinterpret_cast<f32x2*>(xch + col) = cg;
+      *reinterpret_cast<f32x2*>(xch + 256 + col) = cb;
+      *reinterpret_cast<f32x2*>(xch + 512 + col) = cx;
+    }
+  }
+  // behind the barrier behind finish_a: waves 0-3 leave the workgroup's sums in xch - lane (r, hi) owns column 64 (wave & 3) + 2 r + hi
+  __device__ __forceinline__ void finish_b(float* xch) {
+    if (c.wave < 4) {
+      const int col = 2 * cp() + c.hi;
+      xch[col] += c.hi ? cg[1] : cg[0];
+      xch[256 + col] += c.hi ? cb[1] : cb[0];
+      xch[512 + col] += c.hi ? cx[1] : cx[0];
+    }
+  }
+};
+// The column sums of a ColSide leave at the very end of the kernel (the same lanes read back what they wrote: no barrier) - into the
+// workgroup's own 6 x 256 floats of a workspace (st_colsum_fold adds the workgroups up), or, without one, as atomics.  251 workgroups
+// adding to the same 768 floats within the same few microseconds is a queue: requests to one line retire ~15 ns apart (3.8 us per
+// LayerNorm), and issued where the sums were ready every later vector-memory instruction of the workgroup (the ring's refills first)
+// waited behind it (round 6 phase stamps: the block behind a LayerNorm 6.3 us against 3.0 for its neighbours; the launch 66-67 us
+// with the atomics - wherever they are issued -, 58.4-59.0 without).  64 consecutive floats per instruction: two full lines per
+// request (half-filled requests double the queue).
+template <int MT>
+__device__ __forceinline__ void colsum_flush(const Ctx<MT>& c, const float* xch, float* dgamma, float* dbeta, float* dbias, float* ws) {
+  if (c.wave < 4) {
+    const int col = 2 * ((c.wave & 3) * 32 + c.r) + c.hi;
+    if (ws) {       // this workgroup's rows of the column-sum workspace: plain stores, st_colsum_fold adds them up
+      ws[col] = xch[col];
+      ws[256 + col] = xch[256 + col];
+      ws[512 + col] = xch[512 + col];
+    } else {
+      if (dgamma) atomicAdd(dgamma + col, xch[col]);
+      if (dbeta) atomicAdd(dbeta + col, xch[256 + col]);
+      if (dbias) atomicAdd(dbias + col, xch[512 + col]);
     }
   }
 }
@@ -149,8 +208,14 @@ template <bool DROP, int MT>
 __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs a) {
   static_assert(MT >= 2, "pipelined backward chain: 64- / 96-row workgroups");
   constexpr int RB = 32 * MT, TE = RB * AS;
+  // red2: the LayerNorms' row sums [0, 640 MT); behind LayerNorm b: delta parts [0, 768) and its column sums [768, 1536); the column
+  // sums of LayerNorm a wait for the end of the kernel in [1920, 2688), clear of LayerNorm b's row sums
+  constexpr int RED2_N = 2688;
+  static_assert(MT * 32 * RED2_PITCH <= 1920, "red2");
   __shared__ __attribute__((aligned(16))) bf16 tiles[3 * TE];
-  __shared__ __attribute__((aligned(16))) float red2[MT * 32 * RED2_PITCH];
+  __shared__ __attribute__((aligned(16))) float red2[RED2_N];
+  float* xch_a = red2 + 1920;
+  float* xch_b = red2 + 768;
   Ctx<MT> c;
   c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6); c.l = c.tid & 63; c.hi = c.l >> 5; c.r = c.l & 31;
   c.row0 = blockIdx.x * RB; c.nvalid = min(RB, a.M - c.row0);
@@ -174,18 +239,50 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs
   const Drop da = make_drop(a.drop_a), off = make_drop(DropArgs{nullptr, 0u, 0, 1.f});
   const int nbh = a.nb, nc = a.nc, b_tail = nbh + 2 * nc;      // stream: HEAD 0 .. | B1_c nbh + 2c, B2_c nbh + 2c + 1 | TAIL
   NoSide ns;
+  TRP(0);
   auto rows_rstd = [&](const float* g, float (&rs)[MT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rs[mt] = mt * 32 + c.r < c.nvalid ? g[c.row0 + mt * 32 + c.r] : 0.f;
   };
   auto bits_of = [&](int ch) { return a.relu_bits[((size_t)(blockIdx.x * nc + ch) * NW + c.wave) * 64 + c.l]; };
 
-  // ---- HEAD: dy = sum_u dP_u Wp_u + G, LayerNorm backward a.  T0: the dP blocks, then ds_a; T1: G -> dy; T2: xhat_a
+  // ---- HEAD: dy = sum_u dP_u Wp_u + G, LayerNorm backward a
   f32x16 acc2[MT];        // (HEAD's accumulator, then the feed-forward's dy)
   zero_acc(acc2);
   BiasRegs gam;
   float rs[MT];
-  {
+  bf16 *cur, *X, *Y;      // the running gradient ds; the two other tiles
+  if (nbh == 3) {
+    // The three dP blocks each in a tile of its own, requested in the order they are multiplied (round 6: with G and xhat_a asked
+    // for first, block 0 waited for three tiles - 37 MB chip-wide, 8 us - before its first MFMA): one barrier per block; G and
+    // xhat_a arrive under blocks 0 / 1 and are stored under the tiles of blocks 1 / 0 once every wave is past them.
+    TileRegs<MT> nxt, rg, rx;
+    tile_load(c, a.dP, a.ldp, nxt);
+    bias_load(c, a.gamma_a, gam);
+    rows_rstd(a.rstd_a, rs);
+    tile_store(c, nxt, T0);
+    tile_load(c, a.dP + 256, a.ldp, nxt);
+    tile_load(c, a.xhat_a, DM, rx);
+    if (a.G) tile_load(c, a.G, a.ldg, rg);
+    __syncthreads();
+    block_mma_p(c, blk(0), blk(1), T0, acc2, ns);
+    tile_store(c, nxt, T1);
+    tile_load(c, a.dP + 512, a.ldp, nxt);
+    __syncthreads();                             // dP_1 visible; every wave is past block 0: T0 takes xhat_a
+    tile_store(c, rx, T0);
+    block_mma_p(c, blk(1), blk(2), T1, acc2, ns);
+    tile_store(c, nxt, T2);
+    __syncthreads();                             // dP_2 visible; every wave is past block 1: T1 takes G
+    if (a.G) tile_store(c, rg, T1);
+    else {
+#pragma unroll
+      for (int p = 0; p < 2 * MT; ++p) *reinterpret_cast<bf16x8*>(T1 + ((c.tid + p * 512) >> 5) * AS + ((c.tid + p * 512) & 31) * 8) = zero_bf8();
+    }
+    block_mma_p(c, blk(2), blk(3), T2, acc2, ns);
+    __syncthreads();                             // G / xhat_a visible; every wave is past block 2: T2 takes ds_a
+    TRP(1);
+    cur = T2; X = T1; Y = T0;
+  } else {
     TileRegs<MT> nxt;
     {
       TileRegs<MT> rg, rx;
@@ -199,38 +296,45 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs
 #pragma unroll
         for (int p = 0; p < 2 * MT; ++p) *reinterpret_cast<bf16x8*>(T1 + ((c.tid + p * 512) >> 5) * AS + ((c.tid + p * 512) & 31) * 8) = zero_bf8();
       }
-      tile_store(c, rx, T2);
+      tile_store(c, rx, T0);
     }
     for (int u = 0; u < nbh; ++u) {
-      tile_store(c, nxt, T0);
+      tile_store(c, nxt, T2);
       __syncthreads();
       if (u + 1 < nbh) tile_load(c, a.dP + (u + 1) * 256, a.ldp, nxt);
-      block_mma_p(c, blk(u), blk(u + 1), T0, acc2, ns);
-      __syncthreads();                           // every wave is past its MFMAs on this block of dP: T0 may be rewritten
+      block_mma_p(c, blk(u), blk(u + 1), T2, acc2, ns);
+      __syncthreads();                           // every wave is past its MFMAs on this block of dP: T2 may be rewritten
     }
     if (nbh == 0) __syncthreads();               // (bare LayerNorm backward: the G / xhat tiles must be visible)
+    TRP(1);
+    cur = T2; X = T1; Y = T0;
   }
   unsigned long long relu = bits_of(0);          // (requested in front of the LayerNorm, used behind it)
-  epi_lnbwd_p<DROP>(c, acc2, T1, T2, T0, rs, gam, da, red2, a.dgamma_a, a.dbeta_a, a.dbias_a);
-  __syncthreads();                               // the column pass has read T1 / T2: free from here
-  bf16* cur = T0;         // the running gradient ds
-  bf16 *X = T1, *Y = T2;
+  epi_lnbwd_p<DROP>(c, acc2, X, Y, cur, rs, gam, da, red2, 16);      // dy in place over G (X), xhat_a in Y, ds_a -> cur
+  TRP(2);
 
   // ---- FFN
   const int dff = nc * 256;
   f32x16 acc1[MT];
   zero_acc(acc2);
   zero_acc(acc1);
-  {       // B1_0 with the copy of ds_a beside it
+  {       // B1_0 with the copy of ds_a and the column sums of LayerNorm a beside it
     CopySide<MT, 1> cs{c, {tile_out_desc(c, cur, a.ds_a, DM)}};
-    block_mma_p(c, blk(nbh), nc > 1 ? blk(nbh + 2) : blk(nbh + 1), cur, acc1, cs);
+    ColSide<DROP, MT> col{c, X, Y, cur, da};
+    Both<CopySide<MT, 1>, ColSide<DROP, MT>> both{cs, col};
+    block_mma_p(c, blk(nbh), nc > 1 ? blk(nbh + 2) : blk(nbh + 1), cur, acc1, both);
+    col.finish_a(xch_a);
+    __syncthreads();                             // every wave is past the column sums: X / Y are free
+    col.finish_b(xch_a);
   }
+  TRP(3);
   {       // chunk 0's mask epilogue is the one nothing hides
     MaskSide<MT> m0{c, acc1, X, a.mask_scale, (uint32_t)relu, (uint32_t)(relu >> 32)};
     m0.all();
   }
   if (nc > 1) relu = bits_of(1);
   __syncthreads();
+  TRP(4);
   // from here: dH chunk c lives in (c even ? X : Y); its copy rides under B1_(c+1)
   for (int ch = 0; ch + 1 < nc; ++ch) {
     bf16* hc = (ch & 1) ? Y : X;
@@ -240,12 +344,14 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs
       CopySide<MT, 1> cs{c, {tile_out_desc(c, hc, a.dH + ch * 256, dff)}};
       block_mma_p(c, blk(nbh + 2 * (ch + 1)), blk(nbh + 2 * ch + 1), cur, acc1, cs);
     }
+    if (ch < 3) TRP(5 + 2 * ch);
     {
       MaskSide<MT> ms{c, acc1, hn, a.mask_scale, (uint32_t)relu, (uint32_t)(relu >> 32)};
       if (ch + 2 < nc) relu = bits_of(ch + 2);
       block_mma_p(c, blk(nbh + 2 * ch + 1), ch + 2 < nc ? blk(nbh + 2 * (ch + 2)) : blk(nbh + 2 * (ch + 1) + 1), hc, acc2, ms);
     }
     __syncthreads();
+    if (ch < 3) TRP(6 + 2 * ch);
   }
   bf16* hl = ((nc - 1) & 1) ? Y : X;      // the last chunk
   bf16* tx = ((nc - 1) & 1) ? X : Y;      // free: takes xhat_b
@@ -259,25 +365,45 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs
     tile_store(c, xr, tx);
   }
   __syncthreads();                               // xhat_b visible; every wave is past its MFMAs on and its copy of the last chunk
+  TRP(11);
+#ifndef ST_BWD_O_EARLY
+#define ST_BWD_O_EARLY 0      // 1: O / Ores (2: O alone) on request in front of LayerNorm b - 36 / 20 spilled registers at MT = 3
+#endif
+  TileRegs<MT> ro, rr_;
+#if ST_BWD_O_EARLY
+  tile_load(c, a.O, a.ldo, ro);
+#if ST_BWD_O_EARLY == 1
+  if (a.Ores) tile_load(c, a.Ores, a.ldo, rr_);
+#endif
+#endif
   // dy = acc2 + ds in place over the ds tile, ds_b into the last chunk's tile
-  epi_lnbwd_p<false>(c, acc2, cur, tx, hl, rs, gam, off, red2, a.dgamma_b, a.dbeta_b, a.dbias_b);
-  __syncthreads();                               // the column pass has read cur / tx
-  bf16* fa = cur;         // takes O
-  bf16* fb = tx;          // takes Ores
+  epi_lnbwd_p<false>(c, acc2, cur, tx, hl, rs, gam, off, red2, 18);
+  TRP(12);
+  bf16* fa = cur;         // dy (the column sums read it), then O
+  bf16* fb = tx;          // xhat_b, then Ores
   cur = hl;               // ds_b
 
-  // ---- TAIL: dctx = ds_b Wo, delta; ds_b leaves beside the block
+  // ---- TAIL: dctx = ds_b Wo, delta; ds_b leaves and LayerNorm b's column sums are taken beside the block
   {
-    TileRegs<MT> ro, rr_;
+#if !ST_BWD_O_EARLY
     tile_load(c, a.O, a.ldo, ro);
+#endif
+#if ST_BWD_O_EARLY != 1
     if (a.Ores) tile_load(c, a.Ores, a.ldo, rr_);
+#endif
     zero_acc(acc1);
     CopySide<MT, 1> cs{c, {tile_out_desc(c, cur, a.ds_b, DM)}};
-    block_mma_p(c, blk(b_tail), blk(b_tail + 1), cur, acc1, cs);
+    ColSide<false, MT> col{c, fa, fb, cur, off};
+    Both<CopySide<MT, 1>, ColSide<false, MT>> both{cs, col};
+    block_mma_p(c, blk(b_tail), blk(b_tail + 1), cur, acc1, both);
+    col.finish_a(xch_b);
+    __syncthreads();                             // every wave is past the column sums and its MFMAs: fa / fb / cur may be rewritten
+    col.finish_b(xch_b);
     tile_store(c, ro, fa);
     if (a.Ores) tile_store(c, rr_, fb);
   }
   __syncthreads();
+  TRP(13);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 32 + c.r;
@@ -297,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs
       *reinterpret_cast<bf16x4*>(cur + at) = o;      // (dctx is staged in the ds_b tile: every wave is past its MFMAs and copies on it)
     }
     part = wave_sum32(part);
-    red2[(c.wave * MT + mt) * 32 + c.r] = part;      // this wave's 32 columns of the row: half a head
+    red2[(c.wave * MT + mt) * 32 + c.r] = part;      // this wave's 32 columns of the row: half a head ([0, 768): clear of xch)
   }
   __syncthreads();
   tile_out_now(c, tile_out_desc(c, cur, a.dctx, a.lddc));
@@ -306,6 +432,10 @@ __global__ __launch_bounds__(512, 1) void row_chain_bwd_pipe_kernel(ChainBwdArgs
     if (row < c.nvalid)
       a.delta[(size_t)h * a.M + c.row0 + row] = red2[((2 * h) * MT + mt) * 32 + r] + red2[((2 * h + 1) * MT + mt) * 32 + r];
   }
+  float* cws = a.colsum_ws ? a.colsum_ws + (size_t)blockIdx.x * 1536 : nullptr;
+  colsum_flush(c, xch_a, a.dgamma_a, a.dbeta_a, a.dbias_a, cws);
+  colsum_flush(c, xch_b, a.dgamma_b, a.dbeta_b, a.dbias_b, cws ? cws + 768 : nullptr);
+  TRP(14);
   if (touched == 0x5a5a5a5a && a.M < 0) red2[0] = 1.f;      // (never true: keeps the warm-up load alive)
 }
 

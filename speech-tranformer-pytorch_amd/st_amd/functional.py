@@ -372,7 +372,9 @@ def flush_deferred_wgrads(final: bool = True):
     """Encoder-sized problems go to the wide-tile kernel, decoder-sized ones to the 128 x 128 grouped launch.
     final=False (the end of the decoder's backward): the encoder-sized problems collected so far - the decoder's
     encoder-decoder key/value projections - stay pending and join the encoder's launch, which then has one workgroup
-    per CU at 3 token splits (config 2: 73 + 12 tiles); on their own they are 12 tiles at 21 splits."""
+    per CU at 3 token splits (config 2: 73 + 12 tiles); on their own they are 12 tiles at 21 splits.
+    The column sums the encoder's backward chains left in workspaces (nv.row_chain_bwd) are folded into their gradients here too."""
+    nv.flush_colsum_folds()
     if _Deferred.pending:
         wide = [p for p in _Deferred.pending if p[0].shape[0] >= _Deferred.WIDE_ROWS]
         rest = [p for p in _Deferred.pending if p[0].shape[0] < _Deferred.WIDE_ROWS]
@@ -394,11 +396,13 @@ class deferred_wgrads:
 
     def __enter__(self):
         _Deferred.active = self.enable
+        nv.fold_deferred = self.enable
         return self
 
     def __exit__(self, *exc):
         flush_deferred_wgrads()
         _Deferred.active = False
+        nv.fold_deferred = False
         return False
 
 

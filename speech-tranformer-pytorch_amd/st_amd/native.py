@@ -63,7 +63,9 @@ SIGNATURES = {
     "st_row_chain_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                          _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
-                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_ll],
+                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_ll, _c_void_p, _c_ll],
+    "st_row_chain_bwd_colsum_rows": [_c_int, _c_int, _c_int, _c_int],
+    "st_colsum_fold": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_row_chain512_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                             _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                             _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
@@ -208,7 +210,7 @@ def lib_path() -> str:
     return _build.LIB
 
 
-ABI_VERSION = 3      # == ST_ABI_VERSION in include/st_hip.h == st_version() of the library this binding was written against
+ABI_VERSION = 4      # == ST_ABI_VERSION in include/st_hip.h == st_version() of the library this binding was written against
 
 
 def load(build_if_missing: bool = True):
@@ -703,6 +705,11 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
         raise ValueError("row_chain_bwd: chain.split_work must be a contiguous int32 tensor on the GPU")
     _tag("row_chain_bwd", M, n_blocks, d_ff, io=((dP, M), (G, M), (xa, M), (dsa, M), (ds_in, M), bits, (dH, M), (xb, M), (dsb, M), (O, M),
                                                  (Ores, M), (dctx, M), (delta, 4 * M), (ra, M), (rb, M), 2.0 * 256 * 256 * n_blocks))
+    # encoder-sized HEAD + FFN + TAIL launches leave their LayerNorm column sums in a per-workgroup workspace (no atomics: 251 workgroups
+    # adding to the same 768 floats queue for ~8 us per launch); st_colsum_fold adds it to the gradients - at once, or with the deferred
+    # weight gradients (flush_colsum_folds)
+    ws_rows = 0 if d == 512 else load()._cdll.st_row_chain_bwd_colsum_rows(int(M), int(head is not None), int(d_ff), int(tail is not None))
+    cws = torch.empty(ws_rows * 1536, dtype=F32, device=xb.device) if ws_rows > 0 else None
     if d == 512:
         rc = load().st_row_chain512_bwd(
             _stream(), M, chain.stream.data_ptr(), n_blocks, int(chain.next_blocks), int(nb), _p(dP), 0 if dP is None else dP.stride(0),
@@ -716,8 +723,38 @@ def row_chain_bwd(chain, M, head=None, ds_in=None, ffn=None, tail=None):
         _p(G), 0 if G is None else G.stride(0), _p(xa), _p(ra), _p(ga), sd[0], sd[1], sd[2], sd[3], _p(dsa), _p(dga), _p(dba),
         _p(dbia), _p(ds_in), int(d_ff), _p(bits), float(msc), _p(dH), _p(xb), _p(rb), _p(gb), _p(dsb), _p(dgb), _p(dbb), _p(dbib),
         _p(O), _p(Ores), 0 if O is None else O.stride(0), _p(dctx), 0 if dctx is None else dctx.stride(0), _p(delta),
-        _p(work), 0 if work is None else work.numel() * work.element_size())
+        _p(work), 0 if work is None else work.numel() * work.element_size(), _p(cws), 0 if cws is None else cws.numel() * 4)
     _check(rc, "st_row_chain_bwd")
+    if cws is not None:
+        _fold_pending.append((cws, ws_rows, (dga, dba, dbia, dgb, dbb, dbib)))
+        if not fold_deferred:
+            flush_colsum_folds()
+
+
+_fold_pending = []        # (workspace, rows, six destination vectors) of row_chain_bwd launches whose column sums are not folded yet
+fold_deferred = False     # functional.deferred_wgrads: folds wait for flush_deferred_wgrads (they feed nothing but parameter gradients)
+
+
+def colsum_fold(items):
+    """dst[v] += column sums over the workspace rows, for every (workspace [rows, 6, 256] fp32, rows, (6 fp32 [256] vectors or None))."""
+    n = len(items)
+    if n == 0:
+        return
+    ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+    rows = (ctypes.c_int * n)(*[int(it[1]) for it in items])
+    for it in items:
+        for v in it[2]:
+            _vec(v, F32, 256, "colsum_fold dst")
+    dst = (ctypes.c_void_p * (6 * n))(*[_p(v) for it in items for v in it[2]])
+    _tag("colsum_fold", n, 0, 0, io=tuple((it[0], it[1] * 1536) for it in items))
+    _check(load().st_colsum_fold(_stream(), n, ws, rows, dst), "st_colsum_fold")
+
+
+def flush_colsum_folds():
+    if _fold_pending:
+        items = list(_fold_pending)
+        _fold_pending.clear()
+        colsum_fold(items)
 
 
 def gemm_lnbwd(dY, W, aux, xhat, rstd, gamma, dx, dgamma=None, dbeta=None, dbias=None, drop=None):

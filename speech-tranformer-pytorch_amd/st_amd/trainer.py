@@ -417,6 +417,8 @@ class TrainStep:
             self._cut = None
             _Deferred.pending.clear()
             _Deferred.active = False
+            nv._fold_pending.clear()
+            nv.fold_deferred = False
             if TailBuffers.active is not None:
                 TailBuffers.active.i = 0
             del g_all

@@ -1428,6 +1428,52 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
         check(got[n], ref[n], tol, "row_chain_bwd %s M=%d: %s" % (variant, M, n))
 
 
+@pytest.mark.parametrize("M", [9000, 24060])
+def test_row_chain_bwd_column_sums_through_the_workspace(M):
+    """Encoder-sized backward chains leave their LayerNorm column sums in a per-workgroup workspace and st_colsum_fold adds it to the
+    gradients (ABI 4): nothing reaches the gradient vectors while the fold is deferred, the deferred fold gives what the immediate
+    one gives, and - no atomics between workgroups any more - twice the same launch gives the same bits."""
+    from st_amd import chains
+    d, dff = 256, 1024
+    assert nv.load()._cdll.st_row_chain_bwd_colsum_rows(M, 1, dff, 1) == -(-M // (96 if M > 64 * 256 else 64))
+    assert nv.load()._cdll.st_row_chain_bwd_colsum_rows(1206, 1, dff, 1) == 0
+    wp, w1, w2, wo = g(768, d, seed=1, scale=d ** -0.5), g(dff, d, seed=2, scale=d ** -0.5), g(d, dff, seed=3, scale=dff ** -0.5), g(d, d, seed=4, scale=d ** -0.5)
+    c = lambda t: t.cuda()
+    cs = chains.ChainSet("cuda")
+    cid = cs.add(chains.t_blocks(chains.blocks_of(c(wp))) + chains.ffn_blocks_bwd(c(w1), c(w2)) + chains.t_blocks(chains.blocks_of(c(wo))))
+    cs.finalize().rebuild()
+    ch = cs.chain(cid)
+    dP, G, xa, xb = c(g(M, 768, seed=5, scale=0.3)), c(g(M, d, seed=6, scale=0.3)), c(g(M, d, seed=8)), c(g(M, d, seed=9))
+    ra, rb = c(g(M, seed=10, dtype=F32).abs() + 0.5), c(g(M, seed=11, dtype=F32).abs() + 0.5)
+    ga, gb = c(g(d, seed=12, dtype=F32) * 0.2 + 1), c(g(d, seed=13, dtype=F32) * 0.2 + 1)
+    bits = nv.relu_bits_from(torch.relu(c(g(M, dff, seed=14))))
+    O, Ores = c(g(M, d, seed=15)), c(g(M, d, seed=16, scale=2.0 ** -9))
+    E = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device="cuda")
+
+    def run(deferred):
+        acc = [torch.full((d,), float(i), device="cuda") for i in range(6)]
+        nv.fold_deferred = deferred
+        try:
+            nv.row_chain_bwd(ch, M, head=(3, dP, G, xa, ra, ga, None, E(M, d), acc[0], acc[1], acc[2]),
+                             ffn=(dff, bits, 1.0, E(M, dff), xb, rb, gb, E(M, d), acc[3], acc[4], acc[5]), tail=(O, Ores, E(M, d), E(4 * M, dt=F32)))
+            if deferred:
+                torch.cuda.synchronize()
+                for i in range(6):
+                    assert torch.equal(acc[i], torch.full((d,), float(i), device="cuda")), "a deferred fold reached gradient %d" % i
+                assert len(nv._fold_pending) == 1
+                nv.flush_colsum_folds()
+                assert not nv._fold_pending
+        finally:
+            nv.fold_deferred = False
+        torch.cuda.synchronize()
+        return acc
+
+    a, b, c2 = run(False), run(True), run(False)
+    for i in range(6):
+        assert torch.equal(a[i], b[i]) and torch.equal(a[i], c2[i]), "column sums not reproducible: vector %d" % i
+        assert float((a[i] - i).abs().max()) > 0
+
+
 @pytest.mark.parametrize("M", [5, 64, 1000, 9000, 24060])
 @pytest.mark.parametrize("variant", ["head6", "head0", "head6+drop", "head6+nores"])
 def test_row_chain512_bwd_matches_the_separate_kernels(M, variant):
