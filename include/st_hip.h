@@ -338,7 +338,13 @@ int st_attn_bwd(st_stream_t stream, const void* Q, int ldq, const void* K, int l
                 void* dK, int lddk, void* dV, int lddv, const int* q_off, const int* q_len, const int* k_off,
                 const int* k_len, int B, int H, int d_k, int max_q, int max_k, int q_rows_total, int causal,
                 float scale, int parts, const int* work_q, int n_work_q, const int* work_k, int n_work_k,
-                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int k_prescaled);
+                const unsigned* drop_seed, unsigned drop_salt, int drop_thresh, float drop_scale, int k_prescaled,
+                void* split_work, long long split_bytes);
+/* split_work (optional; ABI 4): st_attn_bwd_split_kib(..) KiB of scratch for the merged launch (parts = 3, O = NULL) of a few-queries /
+ * many-keys problem (max_q <= 64, max_k >= 256, not causal: the decoder-encoder attention) - every dQ item's key tiles are then cut over
+ * up to four workgroups, fp32 partials merged by the last arriver in part order (deterministic).  Its first 16 KiB (tickets) must be
+ * zero before the first launch (the kernel leaves them zero); launches on one stream may share it.  0 KiB: the shape does not split. */
+int st_attn_bwd_split_kib(int B, int H, int d_k, int max_q, int max_k, int causal);
 
 /* row_pos[off[b]+t] = t (and row_seq[...] = b if non-null), t < len[b]:
  * the per-row position the PE add needs (Embedding.py:21-29). */

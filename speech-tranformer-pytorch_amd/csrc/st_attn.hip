@@ -233,6 +233,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
   constexpr int NT = DK / 16, ND = DK / 32;
   constexpr int ROWS = TILE * KS, QROWS = WG_ROWS / KS;   // KS = 2: see attn_fwd_kernel
 
+  // KS = 2 and a.xsplit > 1: the item's key tiles are cut over `xsplit` consecutive workgroups (round 6: one workgroup streaming
+  // all ~750 keys of an utterance WAS the decoder-encoder attention's backward launch - 14 of its 21 us, and all of it at 4 utterances)
+  const int xs = (KS > 1 && a.xsplit > 1) ? a.xsplit : 1;      // workgroup-uniform
+  const int part = xs > 1 ? bid % xs : 0;
+  if (xs > 1) bid /= xs;
   int b, h, tile;
   decode_item(a, bid, b, h, tile);
   const int lq = a.q_len[b], lk = a.k_len[b];
@@ -249,6 +254,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
 
   const int k_hi = a.causal ? min(lk, q0 + QROWS) : lk;
   const int ntiles = (k_hi + ROWS - 1) / ROWS;
+  const int nparts = min(xs, max(ntiles, 1));      // (an item with fewer tiles than parts: the spare workgroups leave at once)
+  if (part >= nparts) return;
+  const int it0 = part * ntiles / nparts, it1 = (part + 1) * ntiles / nparts;
   const bf16* kbase = a.K + (size_t)a.k_off[b] * a.ldk + h * DK;
   const bf16* vbase = a.V + (size_t)a.k_off[b] * a.ldv + h * DK;
 
@@ -268,7 +276,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
       for (int e = 0; e < 8; ++e) dl += (float)dof[t][e] * (float)of[e];
     }
     dl += wave_xor32(dl);
-    if (q_ok && hi == 0 && kp == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
+    if (q_ok && hi == 0 && kp == 0 && part == 0) a.delta[(size_t)h * a.q_rows_total + qrow] = dl;
   } else {                // ... or already produced by the launch that wrote dO (st_gemm, ST_EPI_BF16_DELTA)
     dl = a.delta[(size_t)h * a.q_rows_total + qrow];
   }
@@ -284,8 +292,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
   for (int d = 0; d < ND; ++d) dq[d] = zero16();
 
   auto load = [&](int set, int it) {
-    sk[set].load(offk, kbase, a.ldk, it * ROWS, lk);
-    sv[set].load(offv, vbase, a.ldv, it * ROWS, lk);
+    sk[set].load(offk, kbase, a.ldk, (it0 + it) * ROWS, lk);
+    sv[set].load(offv, vbase, a.ldv, (it0 + it) * ROWS, lk);
   };
   auto store = [&](int set) {
     sk[set].store(smem + set * 2 * G::E);
@@ -294,7 +302,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
   auto compute = [&](int buf, int it) {
     const bf16* ks = smem + buf * 2 * G::E + kp * TILE * G::STR;
     const bf16* vs = ks + G::E;
-    const int kt = it * ROWS + kp * TILE;
+    const int kt = (it0 + it) * ROWS + kp * TILE;
     const bool full = (kt + TILE <= lk) && (!a.causal || kt + TILE - 1 <= q0 + qw * 32);   // no masks needed
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -330,7 +338,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
       }
     }
   };
-  stream_tiles(ntiles, load, store, compute);
+  stream_tiles(it1 - it0, load, store, compute);
   if (KS > 1) {   // dQ of the two key halves: waves 2,3 -> LDS -> waves 0,1
     float* xch = reinterpret_cast<float*>(smem + 2 * 32 * DK) + qw * (ND * 16) * 64 + l;
     if (kp == 1) {
@@ -340,11 +348,54 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int bid, bf1
         for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 64] = dq[d][r];
     }
     __syncthreads();
+    if (kp == 0) {
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] += xch[(d * 16 + r) * 64];
+    }
+    if (nparts > 1) {      // (workgroup-uniform) the parts of the item: fp32 partial -> scratch, ticket, the last arriver adds them in order
+      __shared__ bool last;
+      constexpr int WAVE8 = ND * 8 * 64;      // 8-byte words of one wave's 32 x DK partial
+      unsigned long long* slot = reinterpret_cast<unsigned long long*>(a.xs_ws) + (size_t)bid * xs * (2 * WAVE8);
+      const bool live = kp == 0 && q0 + qw * 32 < lq;      // (wave-uniform) this wave holds rows of the item
+      auto pack2 = [](float lo, float hi_) { return ((unsigned long long)__float_as_uint(hi_) << 32) | __float_as_uint(lo); };
+      if (live) {
+        unsigned long long* mine = slot + (size_t)(part * 2 + qw) * WAVE8 + l;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2)
+            __hip_atomic_store(mine + (d * 8 + r / 2) * 64, pack2(dq[d][r], dq[d][r + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      ST_PUBLISH_FENCE();
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned* tk = a.xs_tickets + bid;
+        last = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nparts - 1);
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (!last) return;
+      ST_MERGER_FENCE();
+      if (live) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) dq[d] = zero16();
+        for (int p = 0; p < nparts; ++p) {      // part order: the sum does not depend on who is last
+          const unsigned long long* src = slot + (size_t)(p * 2 + qw) * WAVE8 + l;
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const unsigned long long v = __hip_atomic_load(src + (d * 8 + r / 2) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              dq[d][r] += __uint_as_float((unsigned)v);
+              dq[d][r + 1] += __uint_as_float((unsigned)(v >> 32));
+            }
+        }
+      }
+    }
     if (kp == 1) return;
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dq[d][r] += xch[(d * 16 + r) * 64];
   }
   store_rows<DK>(smem + qw * 32 * DK, dq, a.dq_scale, a.dQ + (size_t)a.q_off[b] * a.lddq + h * DK, a.lddq,
                  q0 + qw * 32, min(32, lq - (q0 + qw * 32)));
@@ -532,6 +583,25 @@ bool set_drop(AttnArgs& a, const unsigned* seed, unsigned salt, int thresh, floa
 // few queries against many keys (decoder-encoder attention): split the keys over the wave pairs
 bool key_split(int max_q, int max_k, int causal) { return !causal && max_q <= 64 && max_k >= 256; }
 
+// ... and, in the merged backward launch, over up to four workgroups per (utterance, head): whole 128-key tiles each.  Scratch:
+// XS_TICKETS tickets (zero before the first launch; the kernel leaves them zero), then xs fp32 partials of 64 x d_k per item.
+constexpr int XS_TICKETS = 4096;
+int xsplit_for(int d_k, int max_q, int max_k, int causal) {
+  static const bool off = [] { const char* e = getenv("ST_ATTN_XSPLIT"); return e && e[0] == '0'; }();      // development switch
+  if (off || !key_split(max_q, max_k, causal)) return 1;
+  const int nt = (max_k + 127) / 128;
+  return nt < 4 ? nt : 4;
+}
+int device_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }();
+  return n;
+}
+long long xsplit_bytes(int items, int xs, int d_k) { return (long long)XS_TICKETS * 4 + (long long)items * xs * 64 * d_k * 4; }
+
 // grid size and enumeration mode for one family of workgroups
 int plan(AttnArgs& a, const int* work, int n_work, int B, int H, int max_rows, int wg_rows = WG_ROWS) {
   a.work = work;
@@ -702,13 +772,24 @@ extern "C" int st_attn_sf1_fwd(hipStream_t stream, const void* qkv_q, const void
                       n_work, drop_seed, drop_salt, drop_thresh, drop_scale, sa);
 }
 
+// KiB of scratch st_attn_bwd wants for this shape (0: none - it then ignores split_work): the merged launch (parts = 3, O = NULL) of a
+// few-queries / many-keys problem cuts every dQ item's keys over up to four workgroups.  The first 16 KiB (tickets) must be zero
+// before the first launch; launches on one stream may share the scratch.
+extern "C" int st_attn_bwd_split_kib(int B, int H, int d_k, int max_q, int max_k, int causal) {
+  if (B <= 0 || H <= 0) return 0;
+  const int xs = xsplit_for(d_k, max_q, max_k, causal);
+  if (xs <= 1 || (long long)B * H > XS_TICKETS) return 0;
+  return (int)((xsplit_bytes(B * H, xs, d_k) + 1023) / 1024);
+}
+
 extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                            const void* O, int ldo, const void* dO, int lddo, const float* lse, float* delta,
                            void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int* q_off,
                            const int* q_len, const int* k_off, const int* k_len, int B, int H, int d_k, int max_q,
                            int max_k, int q_rows_total, int causal, float scale, int parts, const int* work_q,
                            int n_work_q, const int* work_k, int n_work_k, const unsigned* drop_seed,
-                           unsigned drop_salt, int drop_thresh, float drop_scale, int k_prescaled) {
+                           unsigned drop_salt, int drop_thresh, float drop_scale, int k_prescaled, void* split_work,
+                           long long split_bytes) {
   if (B <= 0 || H <= 0 || max_q <= 0 || max_k <= 0) return 0;
   int rc = check_common(d_k, ldq, ldk, ldv);
   if (rc) return rc;
@@ -735,7 +816,21 @@ extern "C" int st_attn_bwd(hipStream_t stream, const void* Q, int ldq, const voi
   if (run_q && run_k && O == nullptr) {
     // delta was produced together with dO (st_gemm, ST_EPI_BF16_DELTA): the two kernels are independent -> one launch
     AttnArgs ak = a;
-    const int nq = plan(a, work_q, n_work_q, B, H, max_q), nk = plan(ak, work_k, n_work_k, B, H, max_k);
+    int nq = plan(a, work_q, n_work_q, B, H, max_q);
+    const int nk = plan(ak, work_k, n_work_k, B, H, max_k);
+    // the dQ items' keys over xs workgroups each (attn_bwd_dq_body) - as long as the whole launch still fits one round of the chip
+    // (two workgroups per CU).  Measured, round 6 (tools/dev/xattn_bwd_parts.py): 4 utterances (16 + 96 items) 14.2 -> 10.7 us with
+    // xs = 4; 32 utterances (128 + 768 items: more than a round already) 19.4 -> 27.3 us - there the launch is the sum of its items,
+    // and every part pays an item's prologue again.
+    int xs = split_work ? xsplit_for(d_k, max_q, max_k, causal) : 1;
+    while (xs > 1 && nq * xs + nk > 2 * device_cus()) xs >>= 1;
+    if (xs > 1 && nq <= XS_TICKETS) {
+      if (split_bytes < xsplit_bytes(nq, xs, d_k)) return -6;
+      a.xs_tickets = (unsigned*)split_work;
+      a.xs_ws = (float*)((char*)split_work + XS_TICKETS * 4);
+      a.xsplit = xs;
+      nq *= xs;
+    }
     dim3 grid(nq + nk);
 #define ST_BWD(DKK, DR) \
   do { if (ks2) hipLaunchKernelGGL((attn_bwd_kernel<DKK, DR, 2>), grid, block, 0, stream, a, ak, nk); \

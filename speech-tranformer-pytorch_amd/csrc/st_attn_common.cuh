@@ -44,6 +44,9 @@ struct AttnArgs {
   // UNSCALED key projection either way (d/dk = scale log2e * d/dk~, and dS_log2 = ln2 dS).
   float c2, dq_scale;
   DropArgs drop;                  // attention-probability dropout (Attention.py:89), training mode only
+  // backward, few queries against many keys (st_attn.hip, KS = 2 dQ body): the keys of an item cut over `xsplit` workgroups,
+  // fp32 partial dQ in xs_ws, one ticket per item - the last arriver adds the parts in order (st_common.cuh: last-arriver merges)
+  float* xs_ws; unsigned* xs_tickets; int xsplit;
 };
 
 inline void set_score_scales(AttnArgs& a, float scale, int k_prescaled) {

@@ -92,7 +92,8 @@ SIGNATURES = {
     "st_attn_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                    _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_int],
+                    _c_float, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_uint, _c_int, _c_float, _c_int, _c_void_p, _c_ll],
+    "st_attn_bwd_split_kib": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
     "st_row_index": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
     "st_pack_rows": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_ctc_gather": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p],
@@ -959,6 +960,9 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
             attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len, n_head, max_q, max_k, causal,
                      scale, parts=part, work_q=work_q, work_k=work_k, drop=drop, k_prescaled=k_prescaled)
         return
+    # few queries against many keys (the decoder-encoder attention): scratch for the dQ items' key split across workgroups
+    kib = load()._cdll.st_attn_bwd_split_kib(B, n_head, d_k, int(max_q), int(max_k), int(causal)) if (parts == 3 and O is None) else 0
+    swork = _attn_split_work(Q.device, kib) if kib > 0 else None
     _tag("attn_bwd", n_head, d_k, int(causal), q_len, k_len, parts, io=(Q, K, V, O, dO, dQ, dK, dV, lse, delta))
     rc = load().st_attn_bwd(_stream(), Q.data_ptr(), Q.stride(0), K.data_ptr(), K.stride(0), V.data_ptr(), V.stride(0),
                             _p(O), 0 if O is None else O.stride(0), dO.data_ptr(), dO.stride(0), lse.data_ptr(),
@@ -966,8 +970,23 @@ def attn_bwd(Q, K, V, O, dO, lse, delta, dQ, dK, dV, q_off, q_len, k_off, k_len,
                             dQ.data_ptr(), dQ.stride(0), dK.data_ptr(), dK.stride(0), dV.data_ptr(), dV.stride(0),
                             q_off.data_ptr(), q_len.data_ptr(), k_off.data_ptr(), k_len.data_ptr(), B, n_head, d_k,
                             int(max_q), int(max_k), rows, int(causal), float(scale), int(parts), *_work(work_q),
-                            *_work(work_k), *_drop(drop), int(bool(k_prescaled)))
+                            *_work(work_k), *_drop(drop), int(bool(k_prescaled)), _p(swork),
+                            0 if swork is None else swork.numel() * 4)
     _check(rc, "st_attn_bwd")
+
+
+_ATTN_SPLIT_WORK = {}
+
+
+def _attn_split_work(device, kib):
+    """The attention backward's key-split scratch (tickets + fp32 partials), one per device, grown on demand: launches are
+    stream-ordered, the kernel leaves the tickets zero, so every launch may use the same buffer."""
+    key = torch.device(device).index
+    t = _ATTN_SPLIT_WORK.get(key)
+    if t is None or t.numel() * 4 < kib * 1024:
+        t = torch.zeros(kib * 256, dtype=torch.int32, device=device)
+        _ATTN_SPLIT_WORK[key] = t
+    return t
 
 
 def ctc_gather(logits, rowmap, T, cols, lse, lp, V=None):

@@ -261,8 +261,43 @@ DELTA_CASES = [
     (2, 2, 64, None, [223, 352], False, True),
     (2, 4, 64, None, [300, 257], True, True),
     (2, 4, 32, None, [300, 131], False, True),
-    (3, 4, 64, [64, 1, 40], [700, 256, 65], False, True),
+    (3, 4, 64, [64, 1, 40], [700, 256, 65], False, True),      # few queries, many keys: the dQ items' keys over up to 4 workgroups (round 6)
+    (2, 4, 64, [50, 33], [1000, 517], False, True),
+    (5, 4, 64, [38, 20, 64, 7, 45], [900, 640, 511, 129, 384], False, True),
+    (3, 2, 128, [64, 1, 40], [700, 256, 65], False, True),
+    (3, 4, 32, [33, 64, 2], [513, 300, 256], False, False),
 ]
+
+
+def test_attention_backward_key_split_across_workgroups_is_reproducible():
+    """The merged backward launch of a few-queries / many-keys problem cuts each dQ item's key tiles over up to four workgroups and the
+    last arriver adds the fp32 partials in part order: the same bits every time (no atomics), tickets left zero, and within bf16
+    rounding of the two-launch form (parts 1, then 2), which does not split."""
+    c = _attn_case(6, 4, 64, [38, 20, 64, 7, 45, 33], [900, 640, 511, 129, 384, 1000], False, True, seed=77)
+    H, Mq, dk = c["H"], c["Mq"], c["d"] // c["H"]
+    assert nv.load()._cdll.st_attn_bwd_split_kib(6, H, dk, c["max_q"], c["max_k"], 0) > 0
+    assert nv.load()._cdll.st_attn_bwd_split_kib(6, H, dk, c["max_k"], c["max_k"], 0) == 0      # (self-attention shapes do not split)
+    meta = [cu(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
+    Q, K, V, dO = cu(c["Q"]), cu(c["K"]), cu(c["V"]), cu(c["dO"])
+    O, lse = torch.zeros(Mq, c["d"], dtype=BF16, device="cuda"), torch.zeros(H * Mq, dtype=F32, device="cuda")
+    nv.attn_fwd(Q, K, V, O, lse, *meta, H, c["max_q"], False, c["scale"], max_k=c["max_k"])
+    delta = (dO.float() * O.float()).view(Mq, H, dk).sum(-1).t().contiguous().view(-1)
+
+    def run(parts_seq):
+        out = [torch.full((Mq, c["d"]), float("nan"), dtype=BF16, device="cuda")] + \
+              [torch.full((c["Mk"], c["d"]), float("nan"), dtype=BF16, device="cuda") for _ in range(2)]
+        for parts in parts_seq:
+            nv.attn_bwd(Q, K, V, None, dO, lse, delta, *out, *meta, H, c["max_q"], c["max_k"], False, c["scale"], parts=parts)
+        torch.cuda.synchronize()
+        return out
+
+    a, b, two = run((3,)), run((3,)), run((1, 2))
+    for x, y, z, nm in zip(a, b, two, ("dQ", "dK", "dV")):
+        assert torch.isfinite(x.float()).all(), nm
+        assert torch.equal(x, y), "merged backward launch not reproducible: %s" % nm
+        check(x.cpu(), z.cpu(), 8e-3, "key split across workgroups vs the two-launch form: %s" % nm)
+    work = nv._ATTN_SPLIT_WORK[torch.device("cuda", torch.cuda.current_device()).index]
+    assert int(work[:4096].abs().sum()) == 0, "tickets not reset"
 
 
 @pytest.mark.parametrize("case", DELTA_CASES)
@@ -754,9 +789,13 @@ def test_attention_backward_single_launch(case):
                     c["causal"], c["scale"])
         outs.append((dQ, dK, dV, delta))
     streams = case[2] == 64 and not case[5] and min(c["max_q"], c["max_k"]) > 128
+    # (few queries against many keys: the one-launch form cuts the dQ items' keys over workgroups - other fp32 partial sums, round 6)
+    split = nv.load()._cdll.st_attn_bwd_split_kib(case[0], c["H"], case[2], c["max_q"], c["max_k"], int(case[5])) > 0
     for a, b, nm in zip(outs[0][:3], outs[1][:3], ("dQ", "dK", "dV")):
         if streams:
             check(b, a, 6e-3, "single-launch backward (hand-scheduled streams) %s" % nm)
+        elif split and nm == "dQ":
+            check(b, a, 6e-3, "single-launch backward (keys split across workgroups) %s" % nm)
         else:
             assert torch.equal(a, b), "single-launch backward changed %s" % nm
 
