@@ -436,6 +436,8 @@ int st_adam_clip(st_stream_t stream, long long n, float* p, float* g, float* m, 
  * int64 [n_max][4]): base address, bytes per row (% 16 == 0), capacity in rows, address of a device int32 holding the
  * number of valid rows; entries with a null base address are skipped. */
 int st_zero_tails(st_stream_t stream, const long long* table, int n_max);
+/* zero_grad of a flat buffer (train.py:37; ABI 4): `bytes` (a multiple of 16) at the 16-byte aligned `ptr` set to zero with wide stores. */
+int st_zero(st_stream_t stream, void* ptr, long long bytes);
 
 /* total_norm of clip_grad_norm_ (train.py:45) over the flat fp32 gradient buffer g [n] (n % 4 == 0) as one launch:
  * *gnorm = grad_scale * ||g||_2 (partials added in a fixed order, fp64), and - when step is not NULL - *step += 1, the optimiser's

@@ -1262,13 +1262,21 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(FoldArgs g) {
   if (dst == nullptr) return;
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const float* p = it.ws + (size_t)v * 256 + q * 32 + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // (fixed order: the result does not depend on the launch)
+  // (fixed order: the result does not depend on the launch; sixteen loads in flight per thread - the kernel is latency, not bytes)
+  float acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
   int w = rg;
-  for (; w + 24 < it.rows; w += 32) {
-    s0 += p[(size_t)w * 1536]; s1 += p[(size_t)(w + 8) * 1536]; s2 += p[(size_t)(w + 16) * 1536]; s3 += p[(size_t)(w + 24) * 1536];
+  for (; w + 8 * 15 < it.rows; w += 8 * 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] += p[(size_t)(w + 8 * u) * 1536];
   }
-  for (; w < it.rows; w += 8) s0 += p[(size_t)w * 1536];
-  const float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (w + 8 * u < it.rows) acc[u] += p[(size_t)(w + 8 * u) * 1536];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) s += acc[u];
   if (rg) part[rg - 1][c] = s;
   __syncthreads();
   if (rg == 0) {

@@ -154,7 +154,10 @@ class ParamArena:
     def zero_grads(self) -> None:
         """One memset over the whole gradient buffer, with every ``p.grad`` (re)attached -
         the arena's ``optimizer.zero_grad()`` (train.py:37)."""
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            native.zero_(self.grad)
+        else:
+            self.grad.zero_()
         base = self.grad.data_ptr()
         for p in self.params:
             if p.grad is None or p.grad.data_ptr() != base + 4 * self.offset[id(p)]:

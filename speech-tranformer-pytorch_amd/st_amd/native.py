@@ -64,6 +64,7 @@ SIGNATURES = {
                          _c_void_p, _c_void_p, _c_void_p, _c_uint, _c_int, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                          _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_ll, _c_void_p, _c_ll],
+    "st_zero": [_c_void_p, _c_void_p, _c_ll],
     "st_row_chain_bwd_colsum_rows": [_c_int, _c_int, _c_int, _c_int],
     "st_colsum_fold": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p],
     "st_row_chain512_bwd": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -1298,6 +1299,17 @@ def zero_tails(table, n_max):
         raise ValueError("zero_tails: table must be a contiguous int64 GPU tensor of 4 * n_max elements")
     _tag("zero_tails", n_max)
     _check(load().st_zero_tails(_stream(), table.data_ptr(), int(n_max)), "st_zero_tails")
+
+
+def zero_(t):
+    """t.zero_() for a contiguous fp32 / bf16 GPU buffer whose byte count and address are multiples of 16 (the flat gradient buffer);
+    anything else goes to torch."""
+    nbytes = t.numel() * t.element_size()
+    if not (t.is_cuda and t.is_contiguous()) or nbytes % 16 or t.data_ptr() % 16:
+        return t.zero_()
+    _tag("zero", nbytes, io=(float(nbytes),))
+    _check(load().st_zero(_stream(), t.data_ptr(), nbytes), "st_zero")
+    return t
 
 
 _NORM_BLOCKS = None

@@ -1467,6 +1467,19 @@ def test_row_chain_bwd_matches_the_separate_kernels(M, variant):
         check(got[n], ref[n], tol, "row_chain_bwd %s M=%d: %s" % (variant, M, n))
 
 
+@pytest.mark.parametrize("n", [4, 1000, 13_300_004, 4 * 1024 * 2048 * 4 + 12])
+def test_zero_buffer(n):
+    """st_zero (zero_grad of the flat gradient buffer): every byte of the range, nothing around it; odd sizes go to torch."""
+    buf = torch.full((n + 8,), 3.0, device="cuda")
+    nv.zero_(buf[4:4 + n])
+    torch.cuda.synchronize()
+    assert float(buf[4:4 + n].abs().sum()) == 0.0
+    assert float(buf[:4].sum()) == 12.0 and float(buf[4 + n:].sum()) == 12.0
+    odd = torch.full((7,), 2.0, device="cuda")
+    nv.zero_(odd[1:])
+    assert odd.tolist() == [2.0] + [0.0] * 6
+
+
 @pytest.mark.parametrize("M", [9000, 24060])
 def test_row_chain_bwd_column_sums_through_the_workspace(M):
     """Encoder-sized backward chains leave their LayerNorm column sums in a per-workgroup workspace and st_colsum_fold adds it to the
