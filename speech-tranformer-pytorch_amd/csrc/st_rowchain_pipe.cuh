@@ -208,12 +208,30 @@ template <class S0, class S1> struct Both {
   __device__ __forceinline__ void b(int k2) { s0.b(k2); s1.b(k2); }
 };
 
+#ifndef ST_PIPE_RING_BUF
+#define ST_PIPE_RING_BUF 1
+#endif
+// fragment f (0 .. 15) of the block at byte offset `blk_off` of the wave's stream
+__device__ __forceinline__ bf16x8 ring_load(__amdgpu_buffer_rsrc_t rs, unsigned lane16, unsigned blk_off, int f) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + (unsigned)f * 1024u, blk_off, 0));
+}
+
 // One 256 x 256 weight block as block_mma, the ring refilled from two places: the second half of THIS block (cur_blk), then the
 // first half of the block that is multiplied NEXT (nxt_blk) - the blocks are not visited in stream order.  Ring<MT>::D == 8.
 template <int PT, int MT, class Side>      // PT: row pitch of the activation tile in elements
 __device__ __forceinline__ void block_mma_pt(Ctx<MT>& c, const bf16x8* cur_blk, const bf16x8* nxt_blk, const bf16* act, f32x16 (&acc)[MT],
                                              Side&& side) {
   static_assert(Ring<MT>::D == 8, "block_mma_p: half a block on request");
+#if ST_PIPE_RING_BUF
+  // the ring's refills as buffer loads: wave-uniform stream base in the descriptor, the block's byte offset in the scalar offset, the
+  // fragment's in the immediate - no address arithmetic per load (flat loads took one v_lshl_add_u64 each: 16 VALU instructions per
+  // block in a loop that is issue-bound, and eight registers of 64-bit lane indices)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)c.ws, 0, 0x7fffffff, 0x00020000);
+  const unsigned lane16 = (unsigned)c.l * 16u;
+  const unsigned cur_off = __builtin_amdgcn_readfirstlane((unsigned)((const char*)cur_blk - (const char*)c.ws));
+  const unsigned nxt_off = __builtin_amdgcn_readfirstlane((unsigned)((const char*)nxt_blk - (const char*)c.ws));
+#endif
 #ifndef ST_PIPE_LDS_AHEAD
 #define ST_PIPE_LDS_AHEAD 0      // (1: the activation fragments of group k2 + 1 read while group k2 multiplies - measured at nothing, 24 registers)
 #endif
@@ -273,7 +291,11 @@ __device__ __forceinline__ void block_mma_pt(Ctx<MT>& c, const bf16x8* cur_blk, 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int f = 2 * k2 + u + 8;
+#if ST_PIPE_RING_BUF
+      c.ring[(2 * k2 + u) % 8] = ring_load(wrs, lane16, f < 16 ? cur_off : nxt_off, f & 15);
+#else
       c.ring[(2 * k2 + u) % 8] = f < 16 ? cur_blk[f * 64 + c.l] : nxt_blk[(f - 16) * 64 + c.l];
+#endif
     }
     side.b(k2);
     __builtin_amdgcn_sched_barrier(0);
