@@ -55,6 +55,15 @@ template <int MT> struct Ctx {
 
 // One 256 x 256 weight block: acc[mt][n = wave*32 + ...][m] (+)= W_block x act^T for the MT row tiles of the workgroup
 // (every weight fragment feeds MT MFMAs), refilling the ring DEPTH fragments ahead.
+// A weight fragment through a buffer descriptor (the pipelined chains, st_rowchain_pipe.cuh: stream base in the descriptor, block
+// offset in the scalar offset, fragment offset in the immediate - no address arithmetic per load in their issue-bound block loop;
+// the same in block_mma below measured nothing on the decoder-sized chains, which are latency, and was taken out again: round 6).
+// Fragment f (0 .. 15) of the block at byte offset `blk_off` behind the descriptor's base
+__device__ __forceinline__ bf16x8 ring_load(__amdgpu_buffer_rsrc_t rs, unsigned lane16, unsigned blk_off, int f) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + (unsigned)f * 1024u, blk_off, 0));
+}
+
 template <int MT>
 __device__ __forceinline__ void block_mma(Ctx<MT>& c, const bf16* act, f32x16 (&acc)[MT]) {
   // two k-steps per group: the 2 MT activation reads, then the 2 MT MFMAs, then the two refills (one k-step per group

@@ -209,14 +209,8 @@ template <class S0, class S1> struct Both {
 };
 
 #ifndef ST_PIPE_RING_BUF
-#define ST_PIPE_RING_BUF 1
+#define ST_PIPE_RING_BUF 1      // (ring_load: st_rowchain_common.cuh)
 #endif
-// fragment f (0 .. 15) of the block at byte offset `blk_off` of the wave's stream
-__device__ __forceinline__ bf16x8 ring_load(__amdgpu_buffer_rsrc_t rs, unsigned lane16, unsigned blk_off, int f) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + (unsigned)f * 1024u, blk_off, 0));
-}
-
 // One 256 x 256 weight block as block_mma, the ring refilled from two places: the second half of THIS block (cur_blk), then the
 // first half of the block that is multiplied NEXT (nxt_blk) - the blocks are not visited in stream order.  Ring<MT>::D == 8.
 template <int PT, int MT, class Side>      // PT: row pitch of the activation tile in elements
