@@ -995,7 +995,7 @@ extern "C" int st_row_chain(hipStream_t stream, int M, const void* wfrag, int n_
     return 0;
   }
   // 64- / 96-row workgroups, the encoder's shapes (PRE + FFN [+ POST], POST alone): the pipelined kernel (st_rowchain_pipe.cuh)
-  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();      // development switch
+  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && (e[0] == '0' || e[0] == 'b')); }();      // development switch
   if (pipe_on && mt >= 2 && ((pre && ffn && (post_blocks == 0 || post_blocks == 1 || post_blocks == 3)) || (!pre && !ffn && post_blocks == 3))) {
 #ifdef ST_DEV_CHAIN_NULL
   {       // development: which saved tensors does the launch's time hang on? (bit 0 H, 1 xhat, 2 out0, 3 P, 4 out1, 5 mask bits)
@@ -1159,7 +1159,7 @@ extern "C" int st_row_chain_bwd(hipStream_t stream, int M, const void* wfrag, in
     ST_CHECK_LAUNCH();
     return 0;
   }
-  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();      // development switch
+  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && (e[0] == '0' || e[0] == 'f')); }();      // development switch
   if (pipe_on && mt >= 2 && head && ffn && tail) {      // the encoder's shape: st_rowchain_pipe_bwd.cuh
     if (colsum_ws) {
       if (colsum_bytes < (long long)grid.x * 1536 * 4) return -6;
@@ -1242,7 +1242,7 @@ extern "C" int st_row_chain512_bwd(hipStream_t stream, int M, const void* wfrag,
 // shape if it takes a column-sum workspace, 0 if that launch adds its column sums atomically (decoder-sized M, chains without
 // HEAD / FFN / TAIL).
 extern "C" int st_row_chain_bwd_colsum_rows(int M, int has_head, int d_ff, int has_tail) {
-  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && e[0] == '0'); }();
+  static const bool pipe_on = [] { const char* e = getenv("ST_CHAIN_PIPE"); return !(e && (e[0] == '0' || e[0] == 'f')); }();
   static const bool ws_on = [] { const char* e = getenv("ST_COLSUM_WS"); return !(e && e[0] == '0'); }();      // development switch
   if (M <= 0 || !pipe_on || !ws_on || !has_head || d_ff <= 0 || !has_tail) return 0;
   const int mt = row_tiles(M);
