@@ -1276,9 +1276,9 @@ __global__ __launch_bounds__(256) void zero_kernel(f32x4* __restrict__ p, size_t
   const size_t stride = (size_t)gridDim.x * 256;
   size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
   for (; i + 3 * stride < n16; i += 4 * stride) {
-    p[i] = z; p[i + stride] = z; p[i + 2 * stride] = z; p[i + 3 * stride] = z;
+    store16<ST_ADAM_SC1>(p + i, z); store16<ST_ADAM_SC1>(p + i + stride, z); store16<ST_ADAM_SC1>(p + i + 2 * stride, z); store16<ST_ADAM_SC1>(p + i + 3 * stride, z);
   }
-  for (; i < n16; i += stride) p[i] = z;
+  for (; i < n16; i += stride) store16<ST_ADAM_SC1>(p + i, z);
 }
 }  // namespace
 

@@ -1083,6 +1083,44 @@ def test_last_arriver_merges_under_uneven_load():
         assert int(wk[:1024].abs().sum()) == 0, "split-K tickets not reset"
 
 
+def test_attention_key_split_merge_under_uneven_load():
+    """The decoder-encoder attention backward's dQ key split (round 6) publishes fp32 partials the same way (write-through stores,
+    drained vmcnt, device-scope ticket, device-scope loads): 200 launches on inputs that change every iteration, a second stream
+    pushing copies through every XCD's L2 - the merged launch must equal the two-launch form (which does not split) to bf16
+    rounding EVERY time, and two merged launches must agree bit for bit."""
+    c = _attn_case(4, 4, 64, [38, 20, 64, 45], [900, 640, 511, 384], False, True, seed=3)
+    H, Mq, dk = c["H"], c["Mq"], c["d"] // c["H"]
+    meta = [cu(c[k]) for k in ("q_off", "q_len", "k_off", "k_len")]
+    side = torch.cuda.Stream()
+    a, b = torch.empty(1 << 27, dtype=torch.float32, device="cuda"), torch.empty(1 << 27, dtype=torch.float32, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    O, lse = torch.zeros(Mq, c["d"], dtype=BF16, device="cuda"), torch.zeros(H * Mq, dtype=F32, device="cuda")
+    bad = []
+    for it in range(200):
+        if it % 4 == 0:
+            with torch.cuda.stream(side):
+                b.copy_(a)
+        Q = (torch.randn(Mq, c["d"], device="cuda", generator=gen) * 0.7).to(BF16)
+        KV = (torch.randn(c["Mk"], 2 * c["d"], device="cuda", generator=gen) * 0.7).to(BF16)
+        K, V = KV[:, :c["d"]], KV[:, c["d"]:]
+        dO = (torch.randn(Mq, c["d"], device="cuda", generator=gen) * 0.5).to(BF16)
+        nv.attn_fwd(Q, K, V, O, lse, *meta, H, c["max_q"], False, c["scale"], max_k=c["max_k"])
+        delta = (dO.float() * O.float()).view(Mq, H, dk).sum(-1).t().contiguous().view(-1)
+        outs = []
+        for parts_seq in ((3,), (3,), (1, 2)):
+            o = [torch.full((Mq, c["d"]), float("nan"), dtype=BF16, device="cuda")] + \
+                [torch.full((c["Mk"], c["d"]), float("nan"), dtype=BF16, device="cuda") for _ in range(2)]
+            for parts in parts_seq:
+                nv.attn_bwd(Q, K, V, None, dO, lse, delta, *o, *meta, H, c["max_q"], c["max_k"], False, c["scale"], parts=parts)
+            outs.append(o)
+        if not torch.equal(outs[0][0], outs[1][0]) or not bool(torch.isfinite(outs[0][0].float()).all()) or rel(outs[0][0], outs[2][0].float()) > 8e-3:
+            bad.append(it)
+    torch.cuda.synchronize()
+    assert not bad, "stale or torn dQ partials in iterations %s" % bad[:10]
+    work = nv._ATTN_SPLIT_WORK[torch.device("cuda", torch.cuda.current_device()).index]
+    assert int(work[:4096].abs().sum()) == 0, "tickets not reset"
+
+
 def test_gemm_ws_stacked_weights():
     """Stacked weights (the decoder-encoder K/V projections of all layers, read in place from the arena) == the
     gathered GEMM, and == st_gemm_stacked."""
