@@ -58,3 +58,22 @@ def test_generated_instruction_streams_are_the_generators_output(tmp_path):
     for name in made:
         with open(os.path.join(tmp_path, name), "rb") as a, open(os.path.join(csrc, name), "rb") as b:
             assert a.read() == b.read(), name
+
+
+def test_host_side_plans_of_the_round6_scratch_buffers():
+    """The pure host queries of ABI 4 (no launch, no GPU): which backward-chain launches write their column sums to a workspace and
+    how many rows it has; which attention backward launches split their dQ items over workgroups and how much scratch they want."""
+    lib = native.load()._cdll
+    # encoder-sized HEAD + FFN + TAIL launches: 96-row workgroups above 16,384 rows, 64-row above 8,192; everything else: atomics
+    assert lib.st_row_chain_bwd_colsum_rows(24060, 1, 1024, 1) == 251
+    assert lib.st_row_chain_bwd_colsum_rows(9000, 1, 1024, 1) == 141
+    assert lib.st_row_chain_bwd_colsum_rows(1206, 1, 1024, 1) == 0
+    assert lib.st_row_chain_bwd_colsum_rows(24060, 0, 1024, 1) == 0 and lib.st_row_chain_bwd_colsum_rows(24060, 1, 0, 1) == 0
+    assert lib.st_row_chain_bwd_colsum_rows(24060, 1, 1024, 0) == 0 and lib.st_row_chain_bwd_colsum_rows(0, 1, 1024, 1) == 0
+    # few queries against many keys, not causal: up to four parts of whole 128-key tiles; 16 KiB of tickets + parts x 64 x d_k fp32 per item
+    assert lib.st_attn_bwd_split_kib(32, 4, 64, 50, 1000, 0) == 16 + 32 * 4 * 4 * 16
+    assert lib.st_attn_bwd_split_kib(4, 4, 64, 50, 300, 0) == 16 + 4 * 4 * 3 * 16            # three key tiles: three parts
+    assert lib.st_attn_bwd_split_kib(32, 4, 64, 50, 1000, 1) == 0                              # causal
+    assert lib.st_attn_bwd_split_kib(32, 4, 64, 1000, 1000, 0) == 0                            # self-attention shapes
+    assert lib.st_attn_bwd_split_kib(32, 4, 64, 50, 200, 0) == 0                               # too few keys for the key-split kernels
+    assert lib.st_attn_bwd_split_kib(2000, 4, 64, 50, 1000, 0) == 0                            # more items than tickets
