@@ -346,10 +346,13 @@ def _device_cus(device) -> int:
 def _wide_plan(problems, cus: int = 0):
     """Launches of the 256 x 256-tile kernel (st_wgrad_wide): the problems in chunks of WIDE_CHUNK, each chunk with the token-split
     count that finishes first.  Items of one launch are equally long (tokens / splits) and one workgroup owns a CU, so a launch takes
-    ceil(tiles x splits / CUs) rounds of tokens / splits each, plus ~50 us per round (prologue, 256 KB of fp32 atomics per item, the
-    ragged end of a round).  Config 2 (85 tiles): 3 splits = 255 items, one round.  Config 3 (12 + 6 layers of width 512: 384
-    tiles in the first launch, 52 in the second) ran unsplit - 2 + 1 rounds of full-length items, 2.1 ms; 2 splits and 4 splits make it
-    3 half rounds + 1 quarter round.  At least 256 tokens per item.  Returns a list of argument lists for nv.wgrad_group(wide=True)."""
+    ceil(tiles x splits / CUs) rounds of tokens / splits each.  Cost model (round 6, tools/dev/wgrad_small_m.py: 12- and 85-tile
+    launches at 3,120 .. 24,060 tokens, 1 .. 21 splits, two boxes): 17.3 ns per token of an item's k-loop, 12 us per launch, and 0.25 us per item
+    for its 256 KB of fp32 atomics (the term that grows with the splits: until round 6 the model charged a flat 50 us per round and
+    took as many splits as fit one round - a DP step's per-layer launches, 12 tiles, ran 21 splits where 12 are 23 % faster, 12 where
+    4 are 28 % faster at a 4-utterance shard).  Config 2 (85 tiles): 3 splits = 255 items, one round; its 4-utterance shard: 2.
+    Config 3 (12 + 6 layers of width 512: 384 tiles in the first launch, 52 in the second): 2 and 4 splits.  At least 256 tokens
+    per item.  Returns a list of argument lists for nv.wgrad_group(wide=True)."""
     launches = []
     if cus <= 0:
         cus = _device_cus(problems[0][0].device) if problems else 256
@@ -357,11 +360,11 @@ def _wide_plan(problems, cus: int = 0):
         chunk = problems[c0:c0 + WIDE_CHUNK]
         tiles = sum(-(-p[0].shape[1] // 256) * -(-p[5] // 256) for p in chunk)
         rows = min(p[0].shape[0] for p in chunk)
-        unit_us = 800.0 * rows / 24060          # one full-length item with every CU busy (measured: 0.7-0.95 ms at 24,060 tokens)
+        loop_us = 17.3e-3 * rows                # one item over all tokens (54 us at 3,120 tokens, 416 at 24,060)
         best, best_cost = 1, None
         for sp in range(1, max(1, min(rows // 256, 4 * cus // max(tiles, 1) + 1)) + 1):
             rounds = -(-tiles * sp // cus)
-            cost = rounds * (unit_us / sp + 50.0)      # + prologue, the atomic epilogue, the ragged end of a round (72 tiles: 3 splits 307-334 us, 7 splits 350)
+            cost = rounds * loop_us / sp + 12.0 + 0.25 * tiles * sp
             if best_cost is None or cost < best_cost - 1e-9:
                 best, best_cost = sp, cost
         launches.append([p[:4] + (best, p[5]) for p in chunk])
