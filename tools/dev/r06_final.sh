@@ -1,5 +1,5 @@
 # Dev: the round's committed artefacts in one GPU call (profiles/r06_*), stamped with the product tree they were taken at.
-export TMPDIR=/tmp GIT_SHA=24308f9
+export TMPDIR=/tmp GIT_SHA=5c20b16
 cd /root/repo; mkdir -p gpurun_out
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r06_gputests.log 2>&1; grep -E "passed|failed" gpurun_out/r06_gputests.log | tail -1
 python bench.py --steps 20 --warmup 5 --pmc > gpurun_out/bench_r06.json 2> gpurun_out/bench_r06.err
