@@ -47,3 +47,12 @@ print("workgroups %d; span %.1f us; start spread %.2f us; wg duration avg %.1f (
 for a, b in zip(order[:-1], order[1:]):
     dt = t[:, b] - t[:, a]
     print("  %-48s %6.2f us avg  (min %5.2f  max %5.2f)   ends at %6.2f avg" % (names[b], dt.mean(), dt.min(), dt.max(), (t[:, b] - t0).mean()))
+dur = (t[:, 14] - t[:, 0])
+end = t[:, 14] - t0
+print("by XCD (blockIdx % 8): mean duration / latest end:", ["%.1f / %.1f" % (float(dur[x::8].mean()), float(end[x::8].max())) for x in range(8)])
+order_ = torch.argsort(end, descending=True)[:10].tolist()
+print("latest ten workgroups (index, start, end):", [(i, round(float(t[i, 0] - t0), 1), round(float(end[i]), 1)) for i in order_])
+order_ = torch.argsort(end)[:10].tolist()
+print("earliest ten workgroups (index, start, end):", [(i, round(float(t[i, 0] - t0), 1), round(float(end[i]), 1)) for i in order_])
+q = torch.tensor([float(end[i * 25:(i + 1) * 25].mean()) for i in range(10)])
+print("mean end by blockIdx decile:", [round(float(v), 1) for v in q])
